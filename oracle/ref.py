@@ -1,0 +1,81 @@
+"""TEST INFRASTRUCTURE ONLY.  ctypes loader for oracle/_ref/libdegensac_ref.so — the UNMODIFIED
+reference C sources (compiled by oracle/Makefile from /root/reference) behind oracle/ref_shim.c.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def available(flavour=""):
+    return os.path.exists(os.path.join(_HERE, "_ref", f"libdegensac_ref{flavour}.so"))
+
+
+def lib(flavour=""):
+    global _LIB
+    if _LIB is None or getattr(_LIB, "_flavour", None) != flavour:
+        os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+        os.environ.setdefault("MKL_NUM_THREADS", "1")
+        l = C.CDLL(os.path.join(_HERE, "_ref", f"libdegensac_ref{flavour}.so"))
+        dp = C.POINTER(C.c_double)
+        l.ref_find_fundamental.argtypes = [dp, dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                           C.c_int, C.c_int, C.c_double, C.c_int, C.c_uint, C.c_int,
+                                           dp, C.POINTER(C.c_ubyte), C.POINTER(C.c_int)]
+        l.ref_find_fundamental.restype = C.c_int
+        l.ref_find_homography.argtypes = [dp, dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                          C.c_int, C.c_int, C.c_double, C.c_uint, C.c_int,
+                                          dp, C.POINTER(C.c_ubyte), C.POINTER(C.c_int)]
+        l.ref_find_homography.restype = C.c_int
+        l.ref_counters_reset.argtypes = [C.c_int]
+        l.ref_counters_get.argtypes = [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
+        l._flavour = flavour
+        _LIB = l
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def find_fundamental(pts1, pts2, px_th=0.5, conf=0.9999, max_iters=100000, error_type=0,
+                     sym_check=True, laf_coef=0.0, degen=True, seed=1, count_models=False,
+                     time_passes=False, flavour=""):
+    """Reference exp_ransacFcustomLAF through the bindings.cpp-equivalent marshalling.
+    Returns (F [3,3] row-major, mask [n] bool, stats dict)."""
+    l = lib(flavour)
+    a = np.ascontiguousarray(pts1, dtype=np.float64); b = np.ascontiguousarray(pts2, dtype=np.float64)
+    n, dim = a.shape
+    F = np.zeros(9); mask = np.zeros(n, np.uint8); st = (C.c_int * 4)()
+    l.ref_counters_reset(int(time_passes))
+    l.ref_find_fundamental(_dp(a), _dp(b), n, dim, px_th, conf, max_iters, error_type, int(sym_check),
+                           max(0.0, laf_coef), int(degen), seed, int(count_models or time_passes),
+                           _dp(F), mask.ctypes.data_as(C.POINTER(C.c_ubyte)), st)
+    full = C.c_longlong(); ex = C.c_longlong(); sec = C.c_double()
+    l.ref_counters_get(C.byref(full), C.byref(ex), C.byref(sec))
+    stats = dict(samples=st[0], lo_runs=st[1], Ih=st[2], I=st[3], full_passes=full.value,
+                 ex_passes=ex.value, models=full.value + ex.value, pass_seconds=sec.value)
+    return F.reshape(3, 3), mask.astype(bool), stats
+
+
+def find_homography(pts1, pts2, px_th=1.0, conf=0.999, max_iters=50000, error_type=0,
+                    sym_check=True, laf_coef=0.0, seed=1, count_models=False, time_passes=False,
+                    flavour=""):
+    """Reference exp_ransacHcustomLAF.  Returns the RAW internal H (column-wise, image2->image1;
+    the Python wrapper applies inv(H.T), utils.py:108), mask, stats."""
+    l = lib(flavour)
+    a = np.ascontiguousarray(pts1, dtype=np.float64); b = np.ascontiguousarray(pts2, dtype=np.float64)
+    n, dim = a.shape
+    H = np.zeros(9); mask = np.zeros(n, np.uint8); st = (C.c_int * 4)()
+    l.ref_counters_reset(int(time_passes))
+    l.ref_find_homography(_dp(a), _dp(b), n, dim, px_th, conf, max_iters, error_type, int(sym_check),
+                          max(0.0, laf_coef), seed, int(count_models or time_passes),
+                          _dp(H), mask.ctypes.data_as(C.POINTER(C.c_ubyte)), st)
+    full = C.c_longlong(); ex = C.c_longlong(); sec = C.c_double()
+    l.ref_counters_get(C.byref(full), C.byref(ex), C.byref(sec))
+    stats = dict(samples=st[0], lo_runs=st[1], rejected=st[2], I=st[3], full_passes=full.value,
+                 models=full.value, pass_seconds=sec.value)
+    return H.reshape(3, 3), mask.astype(bool), stats

@@ -1,0 +1,154 @@
+/* TEST INFRASTRUCTURE ONLY — never linked into the product library.
+ *
+ * Shim that sits next to the UNMODIFIED reference sources (compiled where they lie under
+ * /root/reference by oracle/Makefile) and makes them usable as a deterministic checker:
+ *
+ *   - oracle_time(): exp_ranF.c / exp_ranH.c are compiled with -Dtime=oracle_time, so the
+ *     reference's `srand(time(NULL))` (exp_ranF.c:1277, exp_ranH.c:510) becomes
+ *     `srand(oracle_seed)`.  Nothing in the reference is edited.
+ *   - ref_find_fundamental / ref_find_homography: the marshalling that
+ *     src/pydegensac/bindings.cpp:297-435 and :64-222 do in C++ (build u[N][6] and the two LAF
+ *     point sets, pick metric function pointers, threshold conventions), restated in C so that
+ *     ctypes can call the reference without pybind11.
+ *   - counting thunks for the injected metric pointers (FDS1/EXFDS1/HDS1): number of full
+ *     N-point scoring passes ("models scored") and time spent in them.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "degensac/exp_ranF.h"
+#include "degensac/exp_ranH.h"
+#include "degensac/Htools.h"
+#include "degensac/Ftools.h"
+
+static unsigned g_seed = 1u;
+time_t oracle_time(time_t *t) { if (t) *t = (time_t)g_seed; return (time_t)g_seed; }
+void oracle_set_seed(unsigned s) { g_seed = s; }
+
+/* ---- counting thunks ---------------------------------------------------------------------- */
+static long long g_full_passes = 0;   /* FDS1 / HDS1 calls  (one model scored on all N points) */
+static long long g_ex_passes = 0;     /* EXFDS1 calls (LO iterations)                          */
+static double    g_pass_seconds = 0;
+static int       g_time_passes = 0;
+
+static double now_s(void) {
+    struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+static FDsPtr   g_FDS = 0;
+static exFDsPtr g_EXFDS = 0;
+static HDsPtr   g_HDS = 0;
+
+static void thunk_FDS(const double *u, const double *F, double *p, int len) {
+    double t0 = g_time_passes ? now_s() : 0;
+    g_FDS(u, F, p, len);
+    if (g_time_passes) g_pass_seconds += now_s() - t0;
+    g_full_passes++;
+}
+static void thunk_EXFDS(const double *u, const double *F, double *p, double *w, int len) {
+    double t0 = g_time_passes ? now_s() : 0;
+    g_EXFDS(u, F, p, w, len);
+    if (g_time_passes) g_pass_seconds += now_s() - t0;
+    g_ex_passes++;
+}
+static void thunk_HDS(const double *lin, const double *u, const double *H, double *p, int len) {
+    double t0 = g_time_passes ? now_s() : 0;
+    g_HDS(lin, u, H, p, len);
+    if (g_time_passes) g_pass_seconds += now_s() - t0;
+    g_full_passes++;
+}
+
+void ref_counters_reset(int time_passes) {
+    g_full_passes = 0; g_ex_passes = 0; g_pass_seconds = 0; g_time_passes = time_passes;
+}
+void ref_counters_get(long long *full, long long *ex, double *seconds) {
+    *full = g_full_passes; *ex = g_ex_passes; *seconds = g_pass_seconds;
+}
+
+/* ---- marshalling (bindings.cpp:126-198 / :337-409) ----------------------------------------- */
+static void build_u(const double *x1, const double *x2, int n, int dim, int laf,
+                    double *u, double *ulaf1, double *ulaf2) {
+    int i;
+    for (i = 0; i < n; i++) {
+        const double *a = x1 + (size_t)dim * i, *b = x2 + (size_t)dim * i;
+        u[6*i+0] = a[0]; u[6*i+1] = a[1]; u[6*i+2] = 1.;
+        u[6*i+3] = b[0]; u[6*i+4] = b[1]; u[6*i+5] = 1.;
+        if (laf) {
+            /* (x + a12, y + a22) */
+            ulaf1[6*i+0] = a[0] + a[3]; ulaf1[6*i+1] = a[1] + a[5]; ulaf1[6*i+2] = 1.;
+            ulaf1[6*i+3] = b[0] + b[3]; ulaf1[6*i+4] = b[1] + b[5]; ulaf1[6*i+5] = 1.;
+            /* (x + a11, y + a21) */
+            ulaf2[6*i+0] = a[0] + a[2]; ulaf2[6*i+1] = a[1] + a[4]; ulaf2[6*i+2] = 1.;
+            ulaf2[6*i+3] = b[0] + b[2]; ulaf2[6*i+4] = b[1] + b[4]; ulaf2[6*i+5] = 1.;
+        }
+    }
+}
+
+/* stats: [0]=samples drawn, [1]=LO runs, [2]=(H) rejected samples, [3]=returned inlier count I */
+int ref_find_fundamental(const double *x1, const double *x2, int n, int dim,
+                         double px_th, double conf, int max_iters, int error_type,
+                         int sym_check, double laf_coef, int degen, unsigned seed,
+                         int count_models, double *F, unsigned char *mask, int *stats)
+{
+    FDsPtr FDS1; exFDsPtr EXFDS1; FDsidxPtr FDSidx1;
+    double th = px_th * px_th, sym_th = px_th * px_th * 3.0 * (sym_check ? 1 : 0);
+    int laf = laf_coef > 0, ret, I_H = 0, i;
+    double *u, *ulaf1, *ulaf2, *resids = 0, HinF[9];
+    int *data_out;
+
+    if (error_type == 1) { FDS1 = &FDsSym; EXFDS1 = &exFDsSym; FDSidx1 = &FDsSymidx; }
+    else                 { FDS1 = &FDs;    EXFDS1 = &exFDs;    FDSidx1 = &FDsidx;    }
+    if (count_models) { g_FDS = FDS1; g_EXFDS = EXFDS1; FDS1 = &thunk_FDS; EXFDS1 = &thunk_EXFDS; }
+
+    u  = (double *)malloc(sizeof(double) * 6 * (size_t)n);
+    ulaf1 = (double *)malloc(sizeof(double) * 6 * (size_t)(laf ? n : 1));
+    ulaf2 = (double *)malloc(sizeof(double) * 6 * (size_t)(laf ? n : 1));
+    data_out = (int *)calloc((size_t)n * 18 + 8, sizeof(int));
+    build_u(x1, x2, n, dim, laf, u, ulaf1, ulaf2);
+    for (i = 0; i < 9; i++) F[i] = 0;
+
+    oracle_set_seed(seed);
+    ret = exp_ransacFcustomLAF(u, ulaf1, ulaf2, n, th, laf_coef, conf, max_iters, F, mask, data_out,
+                               1, 0, &resids, HinF, &I_H, EXFDS1, FDS1, FDSidx1, sym_th, degen);
+    if (stats) { stats[0] = data_out[0]; stats[1] = data_out[1]; stats[2] = I_H; stats[3] = ret; }
+    free(resids); free(data_out); free(u); free(ulaf1); free(ulaf2);
+    return ret;
+}
+
+int ref_find_homography(const double *x1, const double *x2, int n, int dim,
+                        double px_th, double conf, int max_iters, int error_type,
+                        int sym_check, double laf_coef, unsigned seed,
+                        int count_models, double *H, unsigned char *mask, int *stats)
+{
+    HDsPtr HDS1; HDsiPtr HDSi1; HDsidxPtr HDSidx1;
+    double th, sym_th, coef = 3.0 * (sym_check ? 1 : 0);
+    int laf = laf_coef > 0, i;
+    double *u, *ulaf1, *ulaf2, *resids = 0;
+    int *data_out;
+    Score S;
+
+    switch (error_type) {
+    case 1:  HDS1 = &HDsSymMaxSq; HDSi1 = &HDsiSymMaxSq; HDSidx1 = &HDsSymMaxSqidx; th = px_th*px_th; sym_th = 0; break;
+    case 2:  HDS1 = &HDsSymMax;   HDSi1 = &HDsiSymMax;   HDSidx1 = &HDsSymMaxidx;   th = px_th;       sym_th = 0; break;
+    case 3:  HDS1 = &HDsSymSumSq; HDSi1 = &HDsiSymSumSq; HDSidx1 = &HDsSymSumSqidx; th = px_th*px_th; sym_th = px_th*coef; break;
+    case 4:  HDS1 = &HDsSymSum;   HDSi1 = &HDsiSymSum;   HDSidx1 = &HDsSymSumidx;   th = px_th;       sym_th = px_th*coef; break;
+    default: HDS1 = &HDs;         HDSi1 = &HDsi;         HDSidx1 = &HDsidx;         th = px_th*px_th; sym_th = px_th*coef; break;
+    }
+    if (count_models) { g_HDS = HDS1; HDS1 = &thunk_HDS; }
+
+    u  = (double *)malloc(sizeof(double) * 6 * (size_t)n);
+    ulaf1 = (double *)malloc(sizeof(double) * 6 * (size_t)(laf ? n : 1));
+    ulaf2 = (double *)malloc(sizeof(double) * 6 * (size_t)(laf ? n : 1));
+    data_out = (int *)calloc((size_t)n * 18 + 8, sizeof(int));
+    build_u(x1, x2, n, dim, laf, u, ulaf1, ulaf2);
+    for (i = 0; i < 9; i++) H[i] = 0;
+
+    oracle_set_seed(seed);
+    S = exp_ransacHcustomLAF(u, ulaf1, ulaf2, n, th, laf_coef, conf, max_iters, H, mask, 4, data_out,
+                             1, 0, &resids, HDS1, HDSi1, HDSidx1, sym_th);
+    if (stats) { stats[0] = data_out[0]; stats[1] = data_out[1]; stats[2] = data_out[2]; stats[3] = (int)S.I; }
+    free(resids); free(data_out); free(u); free(ulaf1); free(ulaf2);
+    return (int)S.I;
+}

@@ -1,0 +1,83 @@
+"""Synthetic correspondence generators for the BASELINE.json configs.
+
+numpy only.  The same generators feed the tests, bench.py and the golden-fixture script, so a
+(config, data seed) pair names one exact input everywhere.
+"""
+import numpy as np
+
+IMG_W, IMG_H, FOCAL = 1000.0, 750.0, 800.0
+
+# v_dogman H_1_6 ground truth of the reference's bundled example pair
+# (values of /root/reference/examples/img/v_dogman/H_1_6, the scene fixture named by BASELINE C1/C3)
+H_1_6 = np.array([[-0.036838, -0.012358, 166.5],
+                  [-0.28304, 0.70203, 61.488],
+                  [-0.0011124, -1.7983e-05, 0.99335]], dtype=np.float64)
+
+
+def _project(K, R, t, X):
+    x = (K @ (R @ X.T + t[:, None])).T
+    return x[:, :2] / x[:, 2:3]
+
+
+def two_view_fundamental(n=2000, inlier_ratio=0.4, sigma=0.1, seed=0, plane_fraction=0.0):
+    """C2 / C2b / C5 generator: two pinhole views of a random 3-D cloud + uniform outliers.
+
+    Returns (pts1 [n,2], pts2 [n,2], is_inlier [n] bool, F_gt [3,3]) with x2^T F_gt x1 = 0.
+    plane_fraction > 0 puts that share of the inlier 3-D points on the plane z = 6 + 0.1 x (C2b).
+    """
+    rng = np.random.default_rng(seed)
+    n_in = int(round(n * inlier_ratio))
+    X = np.stack([rng.uniform(-2, 2, n_in), rng.uniform(-1.5, 1.5, n_in), rng.uniform(4, 8, n_in)], 1)
+    if plane_fraction > 0:
+        k = int(round(n_in * plane_fraction))
+        X[:k, 2] = 6.0 + 0.1 * X[:k, 0]
+    K = np.array([[FOCAL, 0, IMG_W / 2], [0, FOCAL, IMG_H / 2], [0, 0, 1.0]])
+    a = 0.2
+    R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    t = np.array([1.0, 0.1, 0.2])
+    p1 = _project(K, np.eye(3), np.zeros(3), X) + rng.normal(0, sigma, (n_in, 2))
+    p2 = _project(K, R, t, X) + rng.normal(0, sigma, (n_in, 2))
+    n_out = n - n_in
+    o1 = np.stack([rng.uniform(0, IMG_W, n_out), rng.uniform(0, IMG_H, n_out)], 1)
+    o2 = np.stack([rng.uniform(0, IMG_W, n_out), rng.uniform(0, IMG_H, n_out)], 1)
+    pts1 = np.concatenate([p1, o1]); pts2 = np.concatenate([p2, o2])
+    lab = np.concatenate([np.ones(n_in, bool), np.zeros(n_out, bool)])
+    perm = rng.permutation(n)
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    Kinv = np.linalg.inv(K)
+    F = Kinv.T @ tx @ R @ Kinv
+    return (np.ascontiguousarray(pts1[perm]), np.ascontiguousarray(pts2[perm]), lab[perm], F)
+
+
+def homography_pairs(n=5000, inlier_ratio=0.4, sigma=0.5, seed=0, laf=False, H=None, w=788.0, h=522.0):
+    """C1 / C3 generator: points mapped through a ground-truth homography + uniform outliers.
+
+    With laf=True the arrays are [n,6] = (x, y, a11, a12, a21, a22) with an isotropic 5 px frame
+    in image 1 and the frame mapped by the local affine approximation of H in image 2.
+    """
+    rng = np.random.default_rng(seed)
+    H = H_1_6 if H is None else H
+    n_in = int(round(n * inlier_ratio))
+    p1 = np.stack([rng.uniform(0, w, n_in), rng.uniform(0, h, n_in)], 1)
+    ph = np.concatenate([p1, np.ones((n_in, 1))], 1) @ H.T
+    p2 = ph[:, :2] / ph[:, 2:3] + rng.normal(0, sigma, (n_in, 2))
+    p1 = p1 + rng.normal(0, sigma, (n_in, 2))
+    n_out = n - n_in
+    o1 = np.stack([rng.uniform(0, w, n_out), rng.uniform(0, h, n_out)], 1)
+    o2 = np.stack([rng.uniform(0, w, n_out), rng.uniform(0, h, n_out)], 1)
+    pts1 = np.concatenate([p1, o1]); pts2 = np.concatenate([p2, o2])
+    lab = np.concatenate([np.ones(n_in, bool), np.zeros(n_out, bool)])
+    if laf:
+        A1 = np.tile(np.array([5.0, 0.0, 0.0, 5.0]), (n, 1))
+        # local affine of H at each image-1 point (Jacobian of the projective map)
+        q = np.concatenate([pts1, np.ones((n, 1))], 1) @ H.T
+        wz = q[:, 2]
+        J = np.empty((n, 2, 2))
+        for r in range(2):
+            for c in range(2):
+                J[:, r, c] = (H[r, c] * wz - q[:, r] * H[2, c]) / (wz * wz)
+        A2 = np.einsum('nij,njk->nik', J, A1.reshape(n, 2, 2)).reshape(n, 4)
+        A2[~lab] = rng.normal(0, 5.0, (n_out, 4))
+        pts1 = np.concatenate([pts1, A1], 1); pts2 = np.concatenate([pts2, A2], 1)
+    perm = rng.permutation(n)
+    return np.ascontiguousarray(pts1[perm]), np.ascontiguousarray(pts2[perm]), lab[perm], H
