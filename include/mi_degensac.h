@@ -1,0 +1,136 @@
+/* mi_degensac — C-ABI of the MI355X-native LO-RANSAC / DEGENSAC estimator (libmi_degensac.so).
+ *
+ * Drop-in boundary for the reference's pybind11 FFI (src/pydegensac/bindings.cpp):
+ *   findFundamentalMatrix_  bindings.cpp:253-467  -> mi_degensac_find_fundamental[_batch|_batch_dev]
+ *   findHomography_         bindings.cpp:19-251   -> mi_degensac_find_homography[_batch|_batch_dev]
+ * which in turn replace the two C drivers those bindings call:
+ *   exp_ransacFcustomLAF    degensac/exp_ranF.h:72-74 (exp_ranF.c:1244-1767)
+ *   exp_ransacHcustomLAF    degensac/exp_ranH.h:27-33 (exp_ranH.c:470-930)
+ *
+ * Plain pointers and sizes only; no exceptions cross the boundary; every entry point returns 0 or a
+ * negative MI_DEGENSAC_E* code.  Host-pointer entry points stage through device memory themselves;
+ * the *_dev entry points take device pointers (HBM-resident inputs/outputs) and a hipStream_t.
+ * The whole estimation (sampling, minimal solver, scoring, DEGENSAC test, local optimisation,
+ * adaptive termination, final mask) runs in one persistent HIP kernel, one workgroup per image pair.
+ * There is NO CPU fallback: without a usable gfx950 device every call fails with MI_DEGENSAC_ENODEV.
+ */
+#ifndef MI_DEGENSAC_H
+#define MI_DEGENSAC_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_DEGENSAC_OK        0
+#define MI_DEGENSAC_EINVAL   -1   /* bad shape / argument (bindings.cpp:32-47, :267-282 -> ValueError) */
+#define MI_DEGENSAC_ENODEV   -2   /* no HIP device / wrong architecture */
+#define MI_DEGENSAC_EHIP     -3   /* HIP runtime error (see mi_degensac_last_error) */
+#define MI_DEGENSAC_ENOMEM   -4
+
+/* error_type values: utils.py:15-22, bindings.cpp:10-17 */
+#define MI_DEGENSAC_F_SAMPSON        0
+#define MI_DEGENSAC_F_SYMM_EPIPOLAR  1
+#define MI_DEGENSAC_H_SAMPSON        0
+#define MI_DEGENSAC_H_SYMM_SQ_MAX    1
+#define MI_DEGENSAC_H_SYMM_MAX       2
+#define MI_DEGENSAC_H_SYMM_SQ_SUM    3
+#define MI_DEGENSAC_H_SYMM_SUM       4
+
+/* flags */
+#define MI_DEGENSAC_FLAG_FINAL_LAF_FILTER 1u  /* apply the F driver's final LAF filter, which the reference
+                                                 guards with an uninitialised variable (exp_ranF.c:1254,1725) */
+
+typedef struct mi_degensac_params {
+    double   px_th;                    /* pixel threshold (utils.py:76,113)                         */
+    double   conf;                     /* confidence for adaptive termination                       */
+    int32_t  max_iters;                /* hard cap on minimal samples                               */
+    int32_t  error_type;               /* MI_DEGENSAC_F_* / MI_DEGENSAC_H_*                          */
+    int32_t  symmetric_error_check;    /* bool                                                      */
+    int32_t  enable_degeneracy_check;  /* bool, fundamental only (utils.py:119)                     */
+    double   laf_consistensy_coef;     /* <=0: off; needs dim == 6                                  */
+    uint32_t flags;
+    uint32_t reserved;
+} mi_degensac_params;
+
+/* per-pair int32 statistics block (the reference computes most of these and drops them:
+ * bindings.cpp:242-243, exp_ranF.c:1758-1759, exp_ranH.c:922-927) */
+#define MI_DEGENSAC_STATS_LEN 16
+enum {
+    MI_ST_SAMPLES = 0,      /* minimal samples drawn (data_out[0])                                  */
+    MI_ST_LO_RUNS = 1,      /* local optimisations run (data_out[1])                                */
+    MI_ST_REJECTED = 2,     /* H: samples rejected before scoring (data_out[2])                     */
+    MI_ST_I = 3,            /* inlier count of the returned model (driver return value)             */
+    MI_ST_MODELS = 4,       /* models scored against all N points through the metric pointers       */
+    MI_ST_DEGEN = 5,        /* F: DEGENSAC plane-and-parallax completions                           */
+    MI_ST_IH = 6,           /* F: largest H-inlier count seen (exp_ranF.c *Ih)                      */
+    MI_ST_BEST_SAMPLE = 7,  /* sample number at which the returned model was committed              */
+    MI_ST_FULL_PASSES = 8, MI_ST_EX_PASSES = 9, MI_ST_H_PASSES = 10, MI_ST_AUX_PASSES = 11,
+    MI_ST_TICKS_BEST = 12,  /* 100 MHz device wall-clock ticks from kernel entry to that commit     */
+    MI_ST_TICKS_TOTAL = 13, /* ... to kernel exit                                                   */
+    MI_ST_RESERVED0 = 14, MI_ST_RESERVED1 = 15
+};
+
+/* ---- host-pointer entry points (mirror the pybind signatures) -------------------------------- */
+/* pts1, pts2: [n, dim] row-major float64, dim in {2, 6}; F/H: 9 doubles row-major as the reference's C
+ * driver returns them (H is the internal image2->image1 column-wise form; the Python layer applies
+ * inv(H.T), utils.py:108); mask: n bytes (0/1); stats: MI_DEGENSAC_STATS_LEN int32 or NULL. */
+int mi_degensac_find_fundamental(const double *pts1, const double *pts2, int n, int dim,
+                                 const mi_degensac_params *prm, uint32_t seed, int device,
+                                 double *F, uint8_t *mask, int32_t *stats);
+int mi_degensac_find_homography(const double *pts1, const double *pts2, int n, int dim,
+                                const mi_degensac_params *prm, uint32_t seed, int device,
+                                double *H, uint8_t *mask, int32_t *stats);
+
+/* ---- batches of independent pairs (ragged): pair p owns rows offsets[p] .. offsets[p+1] ------- */
+int mi_degensac_find_fundamental_batch(const double *pts1, const double *pts2, const int64_t *offsets,
+                                       int n_pairs, int dim, const mi_degensac_params *prm,
+                                       const uint32_t *seeds, int device,
+                                       double *F /*[n_pairs*9]*/, uint8_t *mask /*[offsets[n_pairs]]*/,
+                                       int32_t *stats /*[n_pairs*16] or NULL*/);
+int mi_degensac_find_homography_batch(const double *pts1, const double *pts2, const int64_t *offsets,
+                                      int n_pairs, int dim, const mi_degensac_params *prm,
+                                      const uint32_t *seeds, int device,
+                                      double *H, uint8_t *mask, int32_t *stats);
+
+/* ---- device-pointer entry points: everything except `offsets_host` and `prm` lives in HBM ----- */
+/* `stream` is a hipStream_t (NULL = default stream).  Asynchronous: returns after enqueueing. */
+int mi_degensac_find_fundamental_batch_dev(const double *d_pts1, const double *d_pts2,
+                                           const int64_t *d_offsets, const int64_t *offsets_host,
+                                           int n_pairs, int dim, const mi_degensac_params *prm,
+                                           const uint32_t *d_seeds, int device, void *stream,
+                                           double *d_F, uint8_t *d_mask, int32_t *d_stats);
+int mi_degensac_find_homography_batch_dev(const double *d_pts1, const double *d_pts2,
+                                          const int64_t *d_offsets, const int64_t *offsets_host,
+                                          int n_pairs, int dim, const mi_degensac_params *prm,
+                                          const uint32_t *d_seeds, int device, void *stream,
+                                          double *d_H, uint8_t *d_mask, int32_t *d_stats);
+
+/* ---- unit-level device entry points (parity tests of the kernels' building blocks) ------------ */
+/* score n_models fundamental (kind 0: Sampson, 1: symmetric epipolar) or homography (kind 10..14:
+ * H Sampson, symm_sq_max, symm_max, symm_sq_sum, symm_sum) models against all n points: I (<= th)
+ * and MSAC J per model, optionally the residual vectors [n_models*n]. Host pointers. */
+int mi_degensac_score_models(const double *pts1, const double *pts2, int n, int dim,
+                             const double *models, int n_models, int kind, double th, int device,
+                             uint32_t *I, double *J, double *resid /*nullable*/);
+/* the main-loop sample stream: for `iters` iterations the 7 (or 4) drawn ids in draw order. */
+int mi_degensac_sample_stream(uint32_t seed, int n, int sample_size, int iters, int device,
+                              int32_t *samples /*[iters*sample_size]*/);
+/* the 7-point solver + oriented-epipolar test on given samples: for each of n_samples 7-tuples of
+ * ids (draw order) nsol[i] in 0..3 valid models and up to 3 models (27 doubles per sample). */
+int mi_degensac_solve7(const double *pts1, const double *pts2, int n, int dim,
+                       const int32_t *samples, int n_samples, int device,
+                       int32_t *nsol, int32_t *root_idx /*[3*n_samples]*/, double *models /*[27*n_samples]*/);
+
+/* ---- misc -------------------------------------------------------------------------------------- */
+int         mi_degensac_device_count(void);
+const char *mi_degensac_last_error(void);
+const char *mi_degensac_version(void);
+/* name of the dominant kernel for profiling and the algorithmic bytes it processed in the last
+ * batch call on this thread (32*N per model scored) */
+const char *mi_degensac_kernel_name(int homography);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_DEGENSAC_H */

@@ -1,0 +1,79 @@
+"""ctypes binding of libmi_degensac.so (include/mi_degensac.h).  No CPU fallback: if the HIP
+library is missing or no gfx950 device is usable, every call raises."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi_degensac.so")
+STATS_LEN = 16
+STAT_NAMES = ["samples", "lo_runs", "rejected", "I", "models", "degen", "Ih", "best_sample",
+              "full_passes", "ex_passes", "h_passes", "aux_passes", "ticks_best", "ticks_total", "r0", "r1"]
+FLAG_FINAL_LAF_FILTER = 1
+
+
+class Params(C.Structure):
+    _fields_ = [("px_th", C.c_double), ("conf", C.c_double), ("max_iters", C.c_int32), ("error_type", C.c_int32),
+                ("symmetric_error_check", C.c_int32), ("enable_degeneracy_check", C.c_int32),
+                ("laf_consistensy_coef", C.c_double), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class MiDegensacError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MiDegensacError(f"{LIB_PATH} is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                                  "there is no CPU fallback")
+        l = C.CDLL(LIB_PATH)
+        dp = C.POINTER(C.c_double); ip = C.POINTER(C.c_int32); up = C.POINTER(C.c_uint32); bp = C.POINTER(C.c_uint8)
+        lp = C.POINTER(C.c_int64); pp = C.POINTER(Params)
+        for name in ("mi_degensac_find_fundamental", "mi_degensac_find_homography"):
+            f = getattr(l, name); f.restype = C.c_int
+            f.argtypes = [dp, dp, C.c_int, C.c_int, pp, C.c_uint32, C.c_int, dp, bp, ip]
+        for name in ("mi_degensac_find_fundamental_batch", "mi_degensac_find_homography_batch"):
+            f = getattr(l, name); f.restype = C.c_int
+            f.argtypes = [dp, dp, lp, C.c_int, C.c_int, pp, up, C.c_int, dp, bp, ip]
+        for name in ("mi_degensac_find_fundamental_batch_dev", "mi_degensac_find_homography_batch_dev"):
+            f = getattr(l, name); f.restype = C.c_int
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, lp, C.c_int, C.c_int, pp, C.c_void_p, C.c_int, C.c_void_p,
+                          C.c_void_p, C.c_void_p, C.c_void_p]
+        l.mi_degensac_score_models.restype = C.c_int
+        l.mi_degensac_score_models.argtypes = [dp, dp, C.c_int, C.c_int, dp, C.c_int, C.c_int, C.c_double, C.c_int, up, dp, dp]
+        l.mi_degensac_sample_stream.restype = C.c_int
+        l.mi_degensac_sample_stream.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, ip]
+        l.mi_degensac_solve7.restype = C.c_int
+        l.mi_degensac_solve7.argtypes = [dp, dp, C.c_int, C.c_int, ip, C.c_int, C.c_int, ip, ip, dp]
+        l.mi_degensac_last_error.restype = C.c_char_p
+        l.mi_degensac_version.restype = C.c_char_p
+        l.mi_degensac_kernel_name.restype = C.c_char_p
+        l.mi_degensac_device_count.restype = C.c_int
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().mi_degensac_last_error().decode()
+        if rc == -1:
+            raise ValueError(msg)          # std::invalid_argument -> ValueError in the reference binding
+        raise MiDegensacError(f"mi_degensac error {rc}: {msg}")
+
+
+def dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def make_params(px_th, conf, max_iters, error_type, sym_check, laf_coef, degen=True, flags=0):
+    return Params(float(px_th), float(conf), int(max_iters), int(error_type), int(bool(sym_check)), int(bool(degen)),
+                  float(laf_coef), int(flags), 0)
+
+
+def stats_dict(st):
+    return {k: int(v) for k, v in zip(STAT_NAMES, st)}

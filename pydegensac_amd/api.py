@@ -1,0 +1,226 @@
+"""Host-side mirror of the reference's Python layer (src/pydegensac/utils.py) over the C-ABI.
+
+Argument names, positional order, defaults, error-type strings, exception classes and return
+types follow utils.py:74-146; the two private functions mirror the pybind signatures
+(bindings.cpp:484-503).  Differences, all additive:
+  * `seed` (default: time-based, like the reference's srand(time(NULL))) and `device` keywords;
+  * inputs are forced C-contiguous (the reference silently mis-reads F-ordered arrays);
+  * a model that was never found is returned as zeros (the reference returns uninitialised stack
+    memory, bindings.cpp:110,321) so that the "no model -> all-False list" rule is deterministic.
+"""
+import ctypes as C
+import math
+import time
+import warnings
+
+import numpy as np
+
+from . import _lib
+
+try:  # utils.py:7-11
+    import cv2
+    OPENCV_HERE = True
+except Exception:  # pragma: no cover
+    OPENCV_HERE = False
+
+error_type_dict_homography = {"sampson": 0, "symm_sq_max": 1, "symm_max": 2, "symm_sq_sum": 3, "symm_sum": 4}
+error_type_dict_fundamental = {"sampson": 0, "symm_epipolar": 1}
+
+_last_stats = None
+
+
+def last_stats():
+    """Statistics of the most recent call in this process (dict, or list of dicts for a batch)."""
+    return _last_stats
+
+
+def convert_cv2_kpts_to_xyA(kps):
+    """cv2.KeyPoint list -> [N,6] (x, y, a11, a12, a21, a22)   (utils.py:24-41)"""
+    num = len(kps)
+    out = np.zeros((num, 6)).astype(np.float64)
+    for i, kp in enumerate(kps):
+        out[i, :2] = kp.pt
+        s = kp.size
+        a = kp.angle
+        cos = math.cos(a * math.pi / 180.0)
+        sin = math.sin(a * math.pi / 180.0)
+        out[i, 2] = s * cos
+        out[i, 3] = s * sin
+        out[i, 4] = -s * sin
+        out[i, 5] = s * cos
+    return out
+
+
+def convert_and_check(kps1):
+    """utils.py:43-71"""
+    if type(kps1) is np.ndarray:
+        sh = kps1.shape
+        err_message = ValueError("Keypoints should be list of cv2.KeyPoint \
+                             or numpy.array [Nx2] or [Nx6]. N>=4  \
+                             Got shape of {} with shape instead".format(str(sh)))
+        if len(sh) != 2:
+            raise err_message
+        num, dim = sh
+        if (dim != 2) and (dim != 6):
+            raise err_message
+        if num < 4:
+            raise err_message
+        out = np.ascontiguousarray(kps1.astype(np.float64))
+    elif type(kps1) is list:
+        if OPENCV_HERE:
+            if type(kps1[0]) is not cv2.KeyPoint:
+                raise ValueError("Keypoints should be list of cv2.KeyPoint \
+                                or numpy.array [Nx2] or [Nx6]. N>=4  \
+                                Got input of list of type {}".format(str(type(kps1[0]))))
+            else:
+                out = convert_cv2_kpts_to_xyA(kps1)
+        else:
+            raise ValueError("Cannot import cv2. Please, install or pass np.arrays instead")
+    else:
+        raise ValueError("Keypoints should be list of cv2.KeyPoint \
+                             or numpy.array [Nx2] or [Nx6]. N>=4  \
+                             Got input of type {}".format(str(type(kps1))))
+    return out
+
+
+def _time_seed():
+    return int(time.time()) & 0xFFFFFFFF
+
+
+def _call_single(which, x1y1, x2y2, px_th, conf, max_iters, error_type, sym_check_enable, laf_coef, degen, seed, device,
+                 flags=0):
+    global _last_stats
+    a = np.ascontiguousarray(x1y1, dtype=np.float64)
+    b = np.ascontiguousarray(x2y2, dtype=np.float64)
+    if a.ndim != 2 or b.ndim != 2:
+        raise ValueError("x1y1 should be an array with dims [n,2] or [n,6]")
+    n, dim = a.shape
+    if b.shape[0] != n:
+        raise ValueError("x1y1 and x2y2 should be the same size")          # bindings.cpp:45-47, :280-282
+    if b.shape[1] != dim:
+        raise ValueError("x1y1 and x2y2 should have the same number of columns")
+    prm = _lib.make_params(px_th, conf, max_iters, error_type, sym_check_enable, laf_coef, degen, flags)
+    model = np.zeros(9, np.float64)
+    mask = np.zeros(n, np.uint8)
+    st = np.zeros(_lib.STATS_LEN, np.int32)
+    fn = _lib.lib().mi_degensac_find_fundamental if which == "F" else _lib.lib().mi_degensac_find_homography
+    rc = fn(_lib.dptr(a), _lib.dptr(b), n, dim, C.byref(prm), int(seed) & 0xFFFFFFFF, int(device), _lib.dptr(model),
+            mask.ctypes.data_as(C.POINTER(C.c_uint8)), st.ctypes.data_as(C.POINTER(C.c_int32)))
+    _lib.check(rc)
+    _last_stats = _lib.stats_dict(st)
+    return model.reshape(3, 3), mask.astype(bool)
+
+
+def findHomography_(x1y1, x2y2, px_th=1.0, conf=0.999, max_iters=10000, error_type=0, sym_check_enable=True,
+                    laf_coef=0.0, seed=None, device=0):
+    """bindings.cpp:19-251 / :484-492.  Returns the driver's raw H (column-wise, image2->image1) and the mask."""
+    return _call_single("H", x1y1, x2y2, px_th, conf, max_iters, error_type, sym_check_enable, laf_coef, True,
+                        _time_seed() if seed is None else seed, device)
+
+
+def findFundamentalMatrix_(x1y1, x2y2, px_th=1.0, conf=0.999, max_iters=200000, error_type=0, sym_check_enable=True,
+                           laf_coef=0.0, enable_degeneracy_check=True, seed=None, device=0, flags=0):
+    """bindings.cpp:253-467 / :494-503."""
+    return _call_single("F", x1y1, x2y2, px_th, conf, max_iters, error_type, sym_check_enable, laf_coef,
+                        enable_degeneracy_check, _time_seed() if seed is None else seed, device, flags)
+
+
+def findHomography(pts1_, pts2_, px_th=1.0, conf=0.999, max_iters=50000, laf_consistensy_coef=-1.0,
+                   error_type="sampson", symmetric_error_check=True, seed=None, device=0):
+    """utils.py:74-109"""
+    pts1 = convert_and_check(pts1_)
+    pts2 = convert_and_check(pts2_)
+    n, dim = pts1.shape
+    n2, dim2 = pts2.shape
+    assert (n == n2) and (dim == dim2)
+    if dim == 2 and laf_consistensy_coef > 0:
+        warnings.warn('You set laf_consistensy_coef, but provided only (x,y) keypoints. Skipping LAF check')
+        laf_consistensy_coef = 0
+    try:
+        error_type_int = error_type_dict_homography[error_type.lower()]
+    except Exception:
+        raise ValueError("Error type should be on of {}. Got {} instead".format(list(error_type_dict_homography.keys()),
+                                                                           error_type))
+    laf_consistensy_coef = max(0, laf_consistensy_coef)
+    H, mask = findHomography_(pts1, pts2, px_th, conf, max_iters, error_type_int, symmetric_error_check,
+                              laf_consistensy_coef, seed=seed, device=device)
+    if np.abs(H).sum() == 0:
+        mask = [False] * len(mask)
+        return H, mask
+    H_out = np.linalg.inv(H.T)
+    return H_out, mask
+
+
+def findFundamentalMatrix(pts1_, pts2_, px_th=0.5, conf=0.9999, max_iters=100000, laf_consistensy_coef=-1.0,
+                          error_type="sampson", symmetric_error_check=True, enable_degeneracy_check=True,
+                          seed=None, device=0):
+    """utils.py:111-146"""
+    pts1 = convert_and_check(pts1_)
+    pts2 = convert_and_check(pts2_)
+    n, dim = pts1.shape
+    n2, dim2 = pts2.shape
+    assert (n == n2) and (dim == dim2)
+    if dim == 2 and laf_consistensy_coef > 0:
+        warnings.warn('You set laf_consistensy_coef, but provided only (x,y) keypoints. Skipping LAF check')
+        laf_consistensy_coef = 0
+    try:
+        error_type_int = error_type_dict_fundamental[error_type.lower()]
+    except Exception:
+        raise ValueError("Error type should be on of {}. Got {} instead".format(list(error_type_dict_fundamental.keys()),
+                                                                           error_type))
+    laf_consistensy_coef = max(0, laf_consistensy_coef)
+    if n < 8:
+        raise ValueError("x1y1 should be an array with dims [n,2], n>=8")     # bindings.cpp:270-272
+    F, mask = findFundamentalMatrix_(pts1, pts2, px_th, conf, max_iters, error_type_int, symmetric_error_check,
+                                     laf_consistensy_coef, enable_degeneracy_check, seed=seed, device=device)
+    if np.abs(F).sum() == 0:
+        mask = [False] * n
+    return F, mask
+
+
+def _batch(which, pts1_list, pts2_list, px_th, conf, max_iters, error_type_int, sym, laf, degen, seeds, device):
+    global _last_stats
+    n_pairs = len(pts1_list)
+    a = [np.ascontiguousarray(p, dtype=np.float64) for p in pts1_list]
+    b = [np.ascontiguousarray(p, dtype=np.float64) for p in pts2_list]
+    dim = a[0].shape[1]
+    offs = np.zeros(n_pairs + 1, np.int64)
+    offs[1:] = np.cumsum([x.shape[0] for x in a])
+    A = np.ascontiguousarray(np.concatenate(a, 0)); B = np.ascontiguousarray(np.concatenate(b, 0))
+    prm = _lib.make_params(px_th, conf, max_iters, error_type_int, sym, laf, degen)
+    model = np.zeros((n_pairs, 9)); mask = np.zeros(int(offs[-1]), np.uint8); st = np.zeros((n_pairs, 16), np.int32)
+    sd = np.ascontiguousarray(seeds, dtype=np.uint32)
+    fn = _lib.lib().mi_degensac_find_fundamental_batch if which == "F" else _lib.lib().mi_degensac_find_homography_batch
+    rc = fn(_lib.dptr(A), _lib.dptr(B), offs.ctypes.data_as(C.POINTER(C.c_int64)), n_pairs, dim, C.byref(prm),
+            sd.ctypes.data_as(C.POINTER(C.c_uint32)), int(device), _lib.dptr(model),
+            mask.ctypes.data_as(C.POINTER(C.c_uint8)), st.ctypes.data_as(C.POINTER(C.c_int32)))
+    _lib.check(rc)
+    _last_stats = [_lib.stats_dict(s) for s in st]
+    masks = [mask[offs[i]:offs[i + 1]].astype(bool) for i in range(n_pairs)]
+    return model.reshape(n_pairs, 3, 3), masks
+
+
+def findFundamentalMatrixBatch(pts1_list, pts2_list, px_th=0.5, conf=0.9999, max_iters=100000,
+                               laf_consistensy_coef=-1.0, error_type="sampson", symmetric_error_check=True,
+                               enable_degeneracy_check=True, seeds=None, device=0):
+    """Independent image pairs in one launch (one workgroup per pair).  Returns (F [P,3,3], [mask_p])."""
+    et = error_type_dict_fundamental[error_type.lower()]
+    if seeds is None:
+        seeds = (_time_seed() + np.arange(len(pts1_list))) & 0xFFFFFFFF
+    return _batch("F", pts1_list, pts2_list, px_th, conf, max_iters, et, symmetric_error_check,
+                  max(0, laf_consistensy_coef), enable_degeneracy_check, seeds, device)
+
+
+def findHomographyBatch(pts1_list, pts2_list, px_th=1.0, conf=0.999, max_iters=50000, laf_consistensy_coef=-1.0,
+                        error_type="sampson", symmetric_error_check=True, seeds=None, device=0):
+    """Batch homographies; returns the user-facing H_out = inv(H.T) per pair (zeros when none found)."""
+    et = error_type_dict_homography[error_type.lower()]
+    if seeds is None:
+        seeds = (_time_seed() + np.arange(len(pts1_list))) & 0xFFFFFFFF
+    H, masks = _batch("H", pts1_list, pts2_list, px_th, conf, max_iters, et, symmetric_error_check,
+                      max(0, laf_consistensy_coef), True, seeds, device)
+    out = np.zeros_like(H)
+    for i in range(len(H)):
+        if np.abs(H[i]).sum() != 0:
+            out[i] = np.linalg.inv(H[i].T)
+    return out, masks

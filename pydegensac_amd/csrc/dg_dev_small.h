@@ -1,0 +1,908 @@
+/* Device-side small dense fp64 routines of the LO-RANSAC / DEGENSAC hot path (gfx950).
+ *
+ * Same arithmetic, statement for statement, as the reference's scalar code (file:line cited per
+ * function, paths relative to /root/reference/src/pydegensac) so that a wave-uniform "lane 0"
+ * section reproduces the reference's rounding exactly (compile with -ffp-contract=off).  LAPACK
+ * dsyev is restated from the published netlib 3.12 algorithm (dsytd2/dorg2l/dsteqr), dgesvd 3x3 by a
+ * one-sided Jacobi SVD, glibc rand() by its TYPE_3 additive-feedback generator.
+ *
+ * Execution model: these run on ONE lane of a workgroup (all other lanes wait at a barrier), so the
+ * larger temporaries are function-local __shared__ arrays (LDS, statically indexed by the compiler
+ * as ds_read/ds_write) instead of per-lane scratch memory.  They must therefore never be entered by
+ * two lanes of the same workgroup at once.
+ */
+#ifndef DG_DEV_SMALL_H
+#define DG_DEV_SMALL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DG_FN static __device__ __forceinline__
+#define DG_BIG static __device__ __noinline__
+#define DG_LDS __shared__
+
+/* ------------------------------------------------------------------------------------------------
+ * glibc TYPE_3 random()/srandom() (r[i] = r[i-31] + r[i-3], 310 outputs discarded after seeding).
+ * rand() == random(), srand() == srandom() share this one state.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { int32_t r[34]; int f, b; } dg_rng;   /* ring of 31 words: r[0..30] */
+
+DG_FN void dg_srand(dg_rng *g, unsigned seed)
+{
+    int i; int32_t word; long hi, lo;
+    if (seed == 0) seed = 1;
+    g->r[0] = (int32_t)seed;
+    for (i = 1; i < 31; i++) {
+        word = g->r[i - 1];
+        hi = word / 127773; lo = word % 127773;
+        word = (int32_t)(16807 * lo - 2836 * hi);
+        if (word < 0) word += 2147483647;
+        g->r[i] = word;
+    }
+    g->f = 3; g->b = 0;
+    for (i = 0; i < 310; i++) {
+        g->r[g->f] = (int32_t)((uint32_t)g->r[g->f] + (uint32_t)g->r[g->b]);
+        if (++g->f >= 31) g->f = 0;
+        if (++g->b >= 31) g->b = 0;
+    }
+}
+
+DG_FN int dg_rand(dg_rng *g)
+{
+    uint32_t v = (uint32_t)g->r[g->f] + (uint32_t)g->r[g->b];
+    g->r[g->f] = (int32_t)v;
+    if (++g->f >= 31) g->f = 0;
+    if (++g->b >= 31) g->b = 0;
+    return (int)(v >> 1);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * CCMATH helpers (matutls/trnm.c, mmul.c, mattr.c, rmmult.c, minv.c)
+ * ---------------------------------------------------------------------------------------------- */
+DG_FN void dg_trnm(double *a, int n)                      /* matutls/trnm.c: in-place transpose */
+{
+    int i, j; double s;
+    for (i = 0; i < n - 1; i++)
+        for (j = i + 1; j < n; j++) { s = a[i*n+j]; a[i*n+j] = a[j*n+i]; a[j*n+i] = s; }
+}
+
+DG_FN void dg_mmul(double *c, const double *a, const double *b, int n)   /* matutls/mmul.c: c = a*b */
+{
+    int i, j, k; double s;
+    for (i = 0; i < n; i++)
+        for (j = 0; j < n; j++) {
+            for (k = 0, s = 0.; k < n; k++) s += a[i*n+k] * b[k*n+j];
+            c[i*n+j] = s;
+        }
+}
+
+DG_FN void dg_mattr(double *a, const double *b, int m, int n)   /* matutls/mattr.c: a[n x m] = b[m x n]^T */
+{
+    int i, j;
+    for (i = 0; i < n; i++)
+        for (j = 0; j < m; j++) *a++ = b[j*n + i];
+}
+
+DG_FN void dg_rmmult(double *rm, const double *a, const double *b, int n, int m, int l)
+{                                                        /* matutls/rmmult.c: rm[n x l] = a[n x m] b[m x l] */
+    int i, j, k; double z;
+    for (i = 0; i < l; i++)
+        for (j = 0; j < n; j++) {
+            for (k = 0, z = 0.; k < m; k++) z += a[j*m+k] * b[k*l+i];
+            rm[j*l+i] = z;
+        }
+}
+
+/* matutls/minv.c restricted to n<=3 usage: in-place inverse by LU with partial pivoting
+ * (Crout, pivot tolerance zr=1e-15 relative to the largest pivot seen).  Returns -1 if singular. */
+DG_BIG int dg_minv(double *a, int n)
+{
+    DG_LDS int le[9]; DG_LDS double q0[9];
+    int lc; double s, t, tq = 0., zr = 1.e-15;
+    double *pa, *pd, *ps, *p, *q;
+    int i, j, k, m, nle = 0;
+    for (j = 0, pa = pd = a; j < n; ++j, ++pa, pd += n + 1) {
+        if (j > 0) {
+            for (i = 0, q = q0, p = pa; i < n; ++i, p += n) *q++ = *p;
+            for (i = 1; i < n; ++i) {
+                lc = i < j ? i : j;
+                for (k = 0, p = pa + i*n - j, q = q0, t = 0.; k < lc; ++k) t += *p++ * *q++;
+                q0[i] -= t;
+            }
+            for (i = 0, q = q0, p = pa; i < n; ++i, p += n) *p = *q++;
+        }
+        s = fabs(*pd); lc = j;
+        for (k = j + 1, ps = pd; k < n; ++k) {
+            if ((t = fabs(*(ps += n))) > s) { s = t; lc = k; }
+        }
+        tq = tq > s ? tq : s;
+        if (s < zr * tq) return -1;
+        le[nle++] = lc;
+        if (lc != j) {
+            for (k = 0, p = a + n*j, q = a + n*lc; k < n; ++k) { t = *p; *p++ = *q; *q++ = t; }
+        }
+        for (k = j + 1, ps = pd, t = 1. / *pd; k < n; ++k) *(ps += n) *= t;
+        *pd = t;
+    }
+    for (j = 1, pd = ps = a; j < n; ++j) {
+        for (k = 0, pd += n + 1, q = ++ps; k < j; ++k, q += n) *q *= *pd;
+    }
+    for (j = 1, pa = a; j < n; ++j) {
+        ++pa;
+        for (i = 0, q = q0, p = pa; i < j; ++i, p += n) *q++ = *p;
+        for (k = 0; k < j; ++k) {
+            t = 0.;
+            for (i = k, p = pa + k*n + k - j, q = q0 + k; i < j; ++i) t -= *p++ * *q++;
+            q0[k] = t;
+        }
+        for (i = 0, q = q0, p = pa; i < j; ++i, p += n) *p = *q++;
+    }
+    for (j = n - 2, pd = pa = a + n*n - 1; j >= 0; --j) {
+        --pa; pd -= n + 1;
+        for (i = 0, m = n - j - 1, q = q0, p = pd + n; i < m; ++i, p += n) *q++ = *p;
+        for (k = n - 1, ps = pa; k > j; --k, ps -= n) {
+            t = -(*ps);
+            for (i = j + 1, p = ps, q = q0; i < k; ++i) t -= *++p * *q++;
+            q0[--m] = t;
+        }
+        for (i = 0, m = n - j - 1, q = q0, p = pd + n; i < m; ++i, p += n) *p = *q++;
+    }
+    for (k = 0, pa = a; k < n - 1; ++k, ++pa) {
+        for (i = 0, q = q0, p = pa; i < n; ++i, p += n) *q++ = *p;
+        for (j = 0, ps = a; j < n; ++j, ps += n) {
+            if (j > k) { t = 0.; p = ps + j; i = j; }
+            else { t = q0[j]; p = ps + k + 1; i = k + 1; }
+            for (; i < n;) t += *p++ * q0[i++];
+            q0[j] = t;
+        }
+        for (i = 0, q = q0, p = pa; i < n; ++i, p += n) *p = *q++;
+    }
+    for (j = n - 2, nle--; j >= 0; --j) {
+        --nle;
+        for (k = 0, p = a + j, q = a + le[nle]; k < n; ++k, p += n, q += n) { t = *p; *p = *q; *q = t; }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * CCMATH svduv (matutls/svduv.c + ldvmat.c + ldumat.c + qrbdv.c): a[m x n] (row-major, m>=n,
+ * destroyed) = u[m x m] * diag(d) * v[n x n]^T.  Singular values are NOT sorted.  m<=9, n<=8.
+ * ---------------------------------------------------------------------------------------------- */
+DG_FN void dg_ldvmat(double *a, double *v, int n)        /* matutls/ldvmat.c */
+{
+    double *p0, *q0, *p, *q, *qq; double h, s; int i, j, k, mm;
+    for (i = 0, mm = n*n, q = v; i < mm; ++i) *q++ = 0.;
+    *v = 1.; q0 = v + n*n - 1; *q0 = 1.; q0 -= n + 1;
+    p0 = a + n*n - n - n - 1;
+    for (i = n - 2, mm = 1; i > 0; --i, p0 -= n + 1, q0 -= n + 1, ++mm) {
+        if (*(p0 - 1) != 0.) {
+            h = *(p0 - 1); *q0 = 1. - h;
+            for (j = 0, q = q0 + n, p = p0; j < mm; ++j, q += n) *q = -h * *p++;
+            for (k = i + 1, q = q0 + 1; k < n; ++k) {
+                for (j = 0, qq = q + n, p = p0, s = 0.; j < mm; ++j, qq += n) s += *qq * *p++;
+                s *= h;
+                for (j = 0, qq = q + n, p = p0; j < mm; ++j, qq += n) *qq -= s * *p++;
+                *q++ = -s;
+            }
+        } else {
+            *q0 = 1.;
+            for (j = 0, p = q0 + 1, q = q0 + n; j < mm; ++j, q += n) *q = *p++ = 0.;
+        }
+    }
+}
+
+DG_FN void dg_ldumat(double *a, double *u, int m, int n)  /* matutls/ldumat.c */
+{
+    DG_LDS double w[9];
+    double *p0, *q0, *p, *q; int i, j, k, mm; double s, h;
+    for (i = 0; i < m; i++) w[i] = 0.;
+    for (i = 0, mm = m*m, q = u; i < mm; ++i) *q++ = 0.;
+    p0 = a + n*n - 1; q0 = u + m*m - 1; mm = m - n; i = n - 1;
+    for (j = 0; j < mm; ++j, q0 -= m + 1) *q0 = 1.;
+    if (mm == 0) { p0 -= n + 1; *q0 = 1.; q0 -= m + 1; --i; ++mm; }
+    for (; i >= 0; --i, ++mm, p0 -= n + 1, q0 -= m + 1) {
+        if (*p0 != 0.) {
+            for (j = 0, p = p0 + n; j < mm; p += n) w[j++] = *p;
+            h = *p0; *q0 = 1. - h;
+            for (j = 0, q = q0 + m; j < mm; q += m) *q = -h * w[j++];
+            for (k = i + 1, q = q0 + 1; k < m; ++k) {
+                for (j = 0, p = q + m, s = 0.; j < mm; p += m) s += w[j++] * *p;
+                s *= h;
+                for (j = 0, p = q + m; j < mm; p += m) *p -= s * w[j++];
+                *q++ = -s;
+            }
+        } else {
+            *q0 = 1.;
+            for (j = 0, p = q0 + 1, q = q0 + m; j < mm; ++j, q += m) *q = *p++ = 0.;
+        }
+    }
+}
+
+DG_FN int dg_qrbdv(double *dm, double *em, double *um, int mm, double *vm, int m)  /* matutls/qrbdv.c */
+{
+    int i, j, k, n, jj, nm;
+    double u, x, y, a, b, c, s, t, w, *p, *q;
+    for (j = 1, t = fabs(dm[0]); j < m; ++j)
+        if ((s = fabs(dm[j]) + fabs(em[j-1])) > t) t = s;
+    t *= 1.e-15; n = 100*m; nm = m;
+    for (j = 0; m > 1 && j < n; ++j) {
+        for (k = m - 1; k > 0; --k) {
+            if (fabs(em[k-1]) < t) break;
+            if (fabs(dm[k-1]) < t) {
+                for (i = k, s = 1., c = 0.; i < m; ++i) {
+                    a = s*em[i-1]; b = dm[i]; em[i-1] *= c;
+                    dm[i] = u = sqrt(a*a + b*b); s = -a/u; c = b/u;
+                    for (jj = 0, p = um + k - 1; jj < mm; ++jj, p += mm) {
+                        q = p + i - k + 1;
+                        w = c * *p + s * *q; *q = c * *q - s * *p; *p = w;
+                    }
+                }
+                break;
+            }
+        }
+        y = dm[k]; x = dm[m-1]; u = em[m-2];
+        a = (y + x)*(y - x) - u*u; s = y*em[k]; b = s + s;
+        u = sqrt(a*a + b*b);
+        if (u != 0.) {
+            c = sqrt((u + a)/(u + u));
+            if (c != 0.) s /= (c*u); else s = 1.;
+            for (i = k; i < m - 1; ++i) {
+                b = em[i];
+                if (i > k) {
+                    a = s*em[i]; b *= c;
+                    em[i-1] = u = sqrt(x*x + a*a);
+                    c = x/u; s = a/u;
+                }
+                a = c*y + s*b; b = c*b - s*y;
+                for (jj = 0, p = vm + i; jj < nm; ++jj, p += nm) {
+                    w = c * *p + s * *(p+1); *(p+1) = c * *(p+1) - s * *p; *p = w;
+                }
+                s *= dm[i+1]; dm[i] = u = sqrt(a*a + s*s);
+                y = c*dm[i+1]; c = a/u; s /= u;
+                x = c*b + s*y; y = c*y - s*b;
+                for (jj = 0, p = um + i; jj < mm; ++jj, p += mm) {
+                    w = c * *p + s * *(p+1); *(p+1) = c * *(p+1) - s * *p; *p = w;
+                }
+            }
+        }
+        em[m-2] = x; dm[m-1] = y;
+        if (fabs(x) < t) --m;
+        if (m == k + 1) --m;
+    }
+    return j;
+}
+
+DG_BIG int dg_svduv(double *d, double *a, double *u, int m, double *v, int n)   /* matutls/svduv.c */
+{
+    DG_LDS double w[20];
+    double *p, *p1, *q, *pp, *e;
+    double s, h, r, t, sv;
+    int i, j, k, mm, nm, ms;
+    if (m < n) return -1;
+    for (i = 0; i < m + n; i++) w[i] = 0.;
+    e = w + m;
+    for (i = 0, mm = m, nm = n - 1, p = a; i < n; ++i, --mm, --nm, p += n + 1) {
+        if (mm > 1) {
+            sv = h = 0.;
+            for (j = 0, q = p, s = 0.; j < mm; ++j, q += n) { w[j] = *q; s += *q * *q; }
+            if (s > 0.) {
+                h = sqrt(s); if (*p < 0.) h = -h;
+                s += *p * h; s = 1./s; t = 1./(w[0] += h);
+                sv = 1. + fabs(*p/h);
+                for (k = 1, ms = n - i; k < ms; ++k) {
+                    for (j = 0, q = p + k, r = 0.; j < mm; q += n) r += w[j++] * *q;
+                    r *= s;
+                    for (j = 0, q = p + k; j < mm; q += n) *q -= r * w[j++];
+                }
+                for (j = 1, q = p; j < mm;) *(q += n) = t * w[j++];
+            }
+            *p = sv; d[i] = -h;
+        }
+        if (mm == 1) d[i] = *p;
+        p1 = p + 1; sv = h = 0.;
+        if (nm > 1) {
+            for (j = 0, q = p1, s = 0.; j < nm; ++j, ++q) s += *q * *q;
+            if (s > 0.) {
+                h = sqrt(s); if (*p1 < 0.) h = -h;
+                sv = 1. + fabs(*p1/h);
+                s += *p1 * h; s = 1./s; t = 1./(*p1 += h);
+                for (k = n, ms = n*(m - i); k < ms; k += n) {
+                    for (j = 0, q = p1, pp = p1 + k, r = 0.; j < nm; ++j) r += *q++ * *pp++;
+                    r *= s;
+                    for (j = 0, q = p1, pp = p1 + k; j < nm; ++j) *pp++ -= r * *q++;
+                }
+                for (j = 1, q = p1 + 1; j < nm; ++j) *q++ *= t;
+            }
+            *p1 = sv; e[i] = -h;
+        }
+        if (nm == 1) e[i] = *p1;
+    }
+    dg_ldvmat(a, v, n); dg_ldumat(a, u, m, n);
+    dg_qrbdv(d, e, u, m, v, n);
+    for (i = 0; i < n; ++i) {
+        if (d[i] < 0.) {
+            d[i] = -d[i];
+            for (j = 0, p = v + i; j < n; ++j, p += n) *p = -*p;
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Symmetric 9x9 eigensolver = LAPACK dsyev("V","U") as called by lap_eig (degensac/lapwrap.c:67-96).
+ * a: n x n symmetric, column-major (== row-major); on exit the columns (column-major: a[j*n+i] is
+ * component i of eigenvector j) are the eigenvectors, w ascending.  n <= 9.  Returns 0 on success.
+ * ---------------------------------------------------------------------------------------------- */
+#define DG_EPS    1.1102230246251565e-16      /* dlamch('E') */
+#define DG_SAFMIN 2.2250738585072014e-308     /* dlamch('S') */
+
+DG_FN double dg_sign(double a, double b) { a = fabs(a); return (b >= 0. && !(b == 0. && signbit(b))) ? a : -a; }
+
+DG_FN double dg_lapy2(double x, double y)
+{
+    double xa = fabs(x), ya = fabs(y), w = xa > ya ? xa : ya, z = xa > ya ? ya : xa, q;
+    if (z == 0.) return w;
+    q = z / w; return w * sqrt(1. + q*q);
+}
+
+DG_FN void dg_lartg(double f, double g, double *c, double *s, double *r)   /* LAPACK 3.10+ dlartg (unscaled range) */
+{
+    double f1 = fabs(f), g1 = fabs(g), d;
+    if (g == 0.) { *c = 1.; *s = 0.; *r = f; }
+    else if (f == 0.) { *c = 0.; *s = dg_sign(1., g); *r = g1; }
+    else { d = sqrt(f*f + g*g); *c = f1 / d; *r = dg_sign(d, f); *s = g / *r; }
+}
+
+DG_FN void dg_laev2(double a, double b, double c, double *rt1, double *rt2, double *cs1, double *sn1)
+{
+    double sm = a + c, df = a - c, adf = fabs(df), tb = b + b, ab = fabs(tb);
+    double acmx, acmn, rt, cs, ct, tn, acs; int sgn1, sgn2;
+    if (fabs(a) > fabs(c)) { acmx = a; acmn = c; } else { acmx = c; acmn = a; }
+    if (adf > ab) { double q = ab/adf; rt = adf * sqrt(1. + q*q); }
+    else if (adf < ab) { double q = adf/ab; rt = ab * sqrt(1. + q*q); }
+    else rt = ab * sqrt(2.);
+    if (sm < 0.) { *rt1 = .5*(sm - rt); sgn1 = -1; *rt2 = (acmx / *rt1)*acmn - (b / *rt1)*b; }
+    else if (sm > 0.) { *rt1 = .5*(sm + rt); sgn1 = 1; *rt2 = (acmx / *rt1)*acmn - (b / *rt1)*b; }
+    else { *rt1 = .5*rt; *rt2 = -.5*rt; sgn1 = 1; }
+    if (df >= 0.) { cs = df + rt; sgn2 = 1; } else { cs = df - rt; sgn2 = -1; }
+    acs = fabs(cs);
+    if (acs > ab) { ct = -tb/cs; *sn1 = 1./sqrt(1. + ct*ct); *cs1 = ct * *sn1; }
+    else {
+        if (ab == 0.) { *cs1 = 1.; *sn1 = 0.; }
+        else { tn = -cs/tb; *cs1 = 1./sqrt(1. + tn*tn); *sn1 = tn * *cs1; }
+    }
+    if (sgn1 == sgn2) { tn = *cs1; *cs1 = -*sn1; *sn1 = tn; }
+}
+
+/* z is n x n column-major (z[j*n+i] = Z(i,j)); applies rotations to columns j0..j0+cnt-1 */
+DG_FN void dg_lasr_rv(double *z, int n, int j0, int cnt, const double *c, const double *s, int backward)
+{
+    int j, i, jj; double ct, st, temp;
+    for (jj = 0; jj < cnt - 1; jj++) {
+        j = backward ? (cnt - 2 - jj) : jj;
+        ct = c[j]; st = s[j];
+        if (ct != 1. || st != 0.) {
+            double *zj = z + (size_t)(j0 + j) * n, *zj1 = zj + n;
+            for (i = 0; i < n; i++) {
+                temp = zj1[i];
+                zj1[i] = ct*temp - st*zj[i];
+                zj[i] = st*temp + ct*zj[i];
+            }
+        }
+    }
+}
+
+DG_BIG int dg_eig_sym(double *a, double *w, int n)
+{
+    DG_LDS double d[9], e[9], tau[9], work[18];
+    int i, j, k, l, m, ii;
+#define A_(r,c) a[(size_t)(c)*n + (r)]
+    /* ---- dsytd2, UPLO='U' ---- */
+    for (i = n - 2; i >= 0; i--) {
+        /* reflector H(i) annihilates A(0:i-1, i+1); alpha = A(i,i+1) */
+        double alpha = A_(i, i+1), xnorm = 0., taui, beta;
+        for (k = 0; k < i; k++) xnorm += A_(k, i+1) * A_(k, i+1);
+        xnorm = sqrt(xnorm);
+        if (xnorm == 0.) taui = 0.;
+        else {
+            beta = -dg_sign(dg_lapy2(alpha, xnorm), alpha);
+            taui = (beta - alpha) / beta;
+            { double sc = 1. / (alpha - beta); for (k = 0; k < i; k++) A_(k, i+1) *= sc; }
+            alpha = beta;
+        }
+        e[i] = alpha;
+        if (taui != 0.) {
+            double dot, al;
+            A_(i, i+1) = 1.;
+            /* tau(0:i) = taui * A(0:i,0:i) * v   (dsymv, upper) */
+            for (k = 0; k <= i; k++) {
+                double sum = 0.;
+                for (j = 0; j <= i; j++) sum += (j >= k ? A_(k, j) : A_(j, k)) * A_(j, i+1);
+                tau[k] = taui * sum;
+            }
+            dot = 0.; for (k = 0; k <= i; k++) dot += tau[k] * A_(k, i+1);
+            al = -.5 * taui * dot;
+            for (k = 0; k <= i; k++) tau[k] += al * A_(k, i+1);
+            /* dsyr2: A := A - v w' - w v' on the upper triangle */
+            for (j = 0; j <= i; j++)
+                for (k = 0; k <= j; k++)
+                    A_(k, j) = A_(k, j) - A_(k, i+1) * tau[j] - tau[k] * A_(j, i+1);
+            A_(i, i+1) = e[i];
+        }
+        d[i+1] = A_(i+1, i+1);
+        tau[i] = taui;
+    }
+    d[0] = A_(0, 0);
+    /* ---- dorgtr 'U' -> dorg2l(n-1,n-1,n-1) ---- */
+    for (j = 0; j < n - 1; j++) {
+        for (i = 0; i < j; i++) A_(i, j) = A_(i, j+1);
+        A_(n-1, j) = 0.;
+    }
+    for (i = 0; i < n - 1; i++) A_(i, n-1) = 0.;
+    A_(n-1, n-1) = 1.;
+    {
+        int mq = n - 1;              /* Q is mq x mq, k = mq reflectors */
+        for (i = 0; i < mq; i++) {
+            ii = i;                  /* column ii, reflector length ii+1 (rows 0..ii) */
+            A_(ii, ii) = 1.;
+            /* apply H(i) to A(0:ii, 0:ii-1) from the left */
+            for (j = 0; j < ii; j++) {
+                double sum = 0.;
+                for (k = 0; k <= ii; k++) sum += A_(k, j) * A_(k, ii);
+                sum *= tau[i];
+                for (k = 0; k <= ii; k++) A_(k, j) -= sum * A_(k, ii);
+            }
+            for (k = 0; k < ii; k++) A_(k, ii) *= -tau[i];
+            A_(ii, ii) = 1. - tau[i];
+            for (l = ii + 1; l < mq; l++) A_(l, ii) = 0.;
+        }
+    }
+    /* ---- dsteqr 'V' ---- */
+    {
+        const double eps = DG_EPS, eps2 = eps*eps, safmin = DG_SAFMIN;
+        int nmaxit = n * 30, jtot = 0, l1 = 0, lsv, lend, lendsv, mm;
+        double p, g, r, c, s, f, b, rt1, rt2, tst;
+        while (l1 < n) {
+            if (l1 > 0) e[l1-1] = 0.;
+            for (m = l1; m < n - 1; m++) {
+                tst = fabs(e[m]);
+                if (tst == 0.) break;
+                if (tst <= (sqrt(fabs(d[m])) * sqrt(fabs(d[m+1]))) * eps) { e[m] = 0.; break; }
+            }
+            /* m == n-1 if no break */
+            l = l1; lsv = l; lend = m; lendsv = lend; l1 = m + 1;
+            if (lend == l) continue;
+            if (fabs(d[lend]) < fabs(d[l])) { lend = lsv; l = lendsv; }
+            if (lend > l) {
+                /* QL iteration */
+                for (;;) {
+                    if (l != lend) {
+                        for (m = l; m < lend; m++) {
+                            tst = fabs(e[m]); tst *= tst;
+                            if (tst <= (eps2 * fabs(d[m])) * fabs(d[m+1]) + safmin) break;
+                        }
+                    } else m = lend;
+                    if (m < lend) e[m] = 0.;
+                    p = d[l];
+                    if (m == l) { d[l] = p; l++; if (l <= lend) continue; break; }
+                    if (m == l + 1) {
+                        dg_laev2(d[l], e[l], d[l+1], &rt1, &rt2, &c, &s);
+                        work[l] = c; work[n-1+l] = s;
+                        dg_lasr_rv(a, n, l, 2, work + l, work + n - 1 + l, 1);
+                        d[l] = rt1; d[l+1] = rt2; e[l] = 0.;
+                        l += 2; if (l <= lend) continue; break;
+                    }
+                    if (jtot == nmaxit) break;
+                    jtot++;
+                    g = (d[l+1] - p) / (2. * e[l]);
+                    r = dg_lapy2(g, 1.);
+                    g = d[m] - p + (e[l] / (g + dg_sign(r, g)));
+                    s = 1.; c = 1.; p = 0.;
+                    for (i = m - 1; i >= l; i--) {
+                        f = s * e[i]; b = c * e[i];
+                        dg_lartg(g, f, &c, &s, &r);
+                        if (i != m - 1) e[i+1] = r;
+                        g = d[i+1] - p;
+                        r = (d[i] - g)*s + 2.*c*b;
+                        p = s * r;
+                        d[i+1] = g + p;
+                        g = c*r - b;
+                        work[i] = c; work[n-1+i] = -s;
+                    }
+                    mm = m - l + 1;
+                    dg_lasr_rv(a, n, l, mm, work + l, work + n - 1 + l, 1);
+                    d[l] = d[l] - p; e[l] = g;
+                }
+            } else {
+                /* QR iteration */
+                for (;;) {
+                    if (l != lend) {
+                        for (m = l; m > lend; m--) {
+                            tst = fabs(e[m-1]); tst *= tst;
+                            if (tst <= (eps2 * fabs(d[m])) * fabs(d[m-1]) + safmin) break;
+                        }
+                    } else m = lend;
+                    if (m > lend) e[m-1] = 0.;
+                    p = d[l];
+                    if (m == l) { d[l] = p; l--; if (l >= lend) continue; break; }
+                    if (m == l - 1) {
+                        dg_laev2(d[l-1], e[l-1], d[l], &rt1, &rt2, &c, &s);
+                        work[m] = c; work[n-1+m] = s;
+                        dg_lasr_rv(a, n, l - 1, 2, work + m, work + n - 1 + m, 0);
+                        d[l-1] = rt1; d[l] = rt2; e[l-1] = 0.;
+                        l -= 2; if (l >= lend) continue; break;
+                    }
+                    if (jtot == nmaxit) break;
+                    jtot++;
+                    g = (d[l-1] - p) / (2. * e[l-1]);
+                    r = dg_lapy2(g, 1.);
+                    g = d[m] - p + (e[l-1] / (g + dg_sign(r, g)));
+                    s = 1.; c = 1.; p = 0.;
+                    for (i = m; i <= l - 1; i++) {
+                        f = s * e[i]; b = c * e[i];
+                        dg_lartg(g, f, &c, &s, &r);
+                        if (i != m) e[i-1] = r;
+                        g = d[i] - p;
+                        r = (d[i+1] - g)*s + 2.*c*b;
+                        p = s * r;
+                        d[i] = g + p;
+                        g = c*r - b;
+                        work[i] = c; work[n-1+i] = s;
+                    }
+                    mm = l - m + 1;
+                    dg_lasr_rv(a, n, m, mm, work + m, work + n - 1 + m, 0);
+                    d[l] = d[l] - p; e[l-1] = g;
+                }
+            }
+            if (jtot >= nmaxit) break;
+        }
+        /* selection sort, ascending */
+        for (ii = 1; ii < n; ii++) {
+            i = ii - 1; k = i; p = d[i];
+            for (j = ii; j < n; j++) if (d[j] < p) { k = j; p = d[j]; }
+            if (k != i) {
+                d[k] = d[i]; d[i] = p;
+                for (j = 0; j < n; j++) { double t = A_(j, i); A_(j, i) = A_(j, k); A_(j, k) = t; }
+            }
+        }
+        for (i = 0; i < n; i++) w[i] = d[i];
+        return jtot >= nmaxit ? 1 : 0;
+    }
+#undef A_
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * degensac/utools.c
+ * ---------------------------------------------------------------------------------------------- */
+/* utools.c:97-167  Gauss-Jordan null space of an n x n row-major matrix, tol 1e-12; buffer 2n ints */
+DG_BIG int dg_nullspace(double *matrix, double *nullspace, int n, int *buffer)
+{
+    int *pnopivot = buffer, nonpivot = 0;
+    int *ppivot = buffer + n;
+    int i, j, k, l, max;
+    double pivot, t, tol = 1e-12;
+    i = 0;
+    for (j = 0; j < n; j++) {
+        pivot = fabs(matrix[n*i+j]); max = i;
+        for (k = i + 1; k < n; k++) {
+            t = fabs(matrix[n*k+j]);
+            if (pivot < t) { pivot = t; max = k; }
+        }
+        if (pivot < tol) {
+            *(pnopivot++) = j; nonpivot++;
+            for (k = i; k < n; k++) matrix[n*k+j] = 0;
+        } else {
+            *(ppivot++) = j;
+            for (k = j; k < n; k++) { t = matrix[i*n+k]; matrix[i*n+k] = matrix[max*n+k]; matrix[max*n+k] = t; }
+            pivot = matrix[i*n+j];
+            for (k = j; k < n; k++) matrix[i*n+k] /= pivot;
+            for (k = 0; k < i; k++) {
+                pivot = -matrix[k*n+j];
+                for (l = j; l < n; l++) matrix[k*n+l] += pivot*matrix[i*n+l];
+            }
+            for (k = i + 1; k < n; k++) {
+                pivot = matrix[k*n+j];
+                for (l = j; l < n; l++) matrix[k*n+l] -= pivot*matrix[i*n+l];
+            }
+            i++;
+        }
+    }
+    for (k = 0; k < nonpivot; k++) {
+        j = buffer[k];
+        for (l = 0; l < n - nonpivot; l++) nullspace[k*n + buffer[n+l]] = -matrix[l*n+j];
+        for (l = 0; l < nonpivot; l++) nullspace[k*n + buffer[l]] = (j == buffer[l]) ? 1 : 0;
+    }
+    return nonpivot;
+}
+
+DG_FN double dg_det3(const double *A)                      /* utools.c:196-202 */
+{
+    double r;
+    r = (A[0]*A[4]*A[8] + A[2]*A[3]*A[7] + A[1]*A[5]*A[6]);
+    r -= (A[2]*A[4]*A[6] + A[0]*A[5]*A[7] + A[1]*A[3]*A[8]);
+    return r;
+}
+
+DG_FN void dg_denormF(double *F, const double *A1, const double *A2)   /* utools.c:53-70 */
+{
+    double r, x, y;
+    r = A2[0]; x = A2[1]; y = A2[2];
+    F[6] += x * F[0] + y * F[3];
+    F[7] += x * F[1] + y * F[4];
+    F[8] += x * F[2] + y * F[5];
+    F[0] *= r; F[1] *= r; F[2] *= r;
+    F[3] *= r; F[4] *= r; F[5] *= r;
+    r = A1[0]; x = A1[1]; y = A1[2];
+    F[2] += x * F[0] + y * F[1];
+    F[5] += x * F[3] + y * F[4];
+    F[8] += x * F[6] + y * F[7];
+    F[0] *= r; F[3] *= r; F[6] *= r;
+    F[1] *= r; F[4] *= r; F[7] *= r;
+}
+
+DG_FN void dg_denormH(double *F, const double *A1, const double *A2)   /* utools.c:72-92 */
+{
+    double r, x, y; int i;
+    r = A2[0]; x = A2[1]; y = A2[2];
+    F[6] += x * F[0] + y * F[3];
+    F[7] += x * F[1] + y * F[4];
+    F[8] += x * F[2] + y * F[5];
+    F[0] *= r; F[1] *= r; F[2] *= r;
+    F[3] *= r; F[4] *= r; F[5] *= r;
+    r = 1 / A1[0]; x = -A1[1] * r; y = -A1[2] * r;
+    for (i = 0; i < 9; i += 3) {
+        F[i]   = r * F[i]   + x * F[i+2];
+        F[i+1] = r * F[i+1] + y * F[i+2];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * degensac/Ftools.c (7-point solver pieces, rank-2 projection, orientation test)
+ * ---------------------------------------------------------------------------------------------- */
+/* Ftools.c:39-81  cubic det(x A + (1-x) B); B is overwritten with A-B.  The expression trees are
+ * written out exactly as in the reference so every rounding matches. */
+DG_FN void dg_slcm(const double *A, double *B, double *p)
+{
+#define a11 A[0]
+#define a12 A[1]
+#define a13 A[2]
+#define a21 A[3]
+#define a22 A[4]
+#define a23 A[5]
+#define a31 A[6]
+#define a32 A[7]
+#define a33 A[8]
+#define b11 B[0]
+#define b12 B[1]
+#define b13 B[2]
+#define b21 B[3]
+#define b22 B[4]
+#define b23 B[5]
+#define b31 B[6]
+#define b32 B[7]
+#define b33 B[8]
+    int i;
+    p[0] = -(b13*b22*b31) + b12*b23*b31 + b13*b21*b32 -
+            b11*b23*b32 - b12*b21*b33 + b11*b22*b33;
+
+    p[1] = -(a33*b12*b21) + a32*b13*b21 + a33*b11*b22 -
+            a31*b13*b22 - a32*b11*b23 + a31*b12*b23 +
+            a23*b12*b31 - a22*b13*b31 - a13*b22*b31 +
+            3*b13*b22*b31 + a12*b23*b31 - 3*b12*b23*b31 -
+            a23*b11*b32 + a21*b13*b32 + a13*b21*b32 -
+            3*b13*b21*b32 - a11*b23*b32 + 3*b11*b23*b32 +
+            (a22*b11 - a21*b12 - a12*b21 + 3*b12*b21 + a11*b22 -
+             3*b11*b22)*b33;
+
+    p[2] = -(a21*a33*b12) + a21*a32*b13 +
+            a13*a32*b21 - a12*a33*b21 + 2*a33*b12*b21 -
+            2*a32*b13*b21 - a13*a31*b22 + a11*a33*b22 -
+            2*a33*b11*b22 + 2*a31*b13*b22 + a12*a31*b23 -
+            a11*a32*b23 + 2*a32*b11*b23 - 2*a31*b12*b23 +
+            2*a13*b22*b31 - 3*b13*b22*b31 - 2*a12*b23*b31 +
+            3*b12*b23*b31 + a13*a21*b32 - 2*a21*b13*b32 -
+            2*a13*b21*b32 + 3*b13*b21*b32 + 2*a11*b23*b32 -
+            3*b11*b23*b32 + a23*
+            (-(a32*b11) + a31*b12 + a12*b31 - 2*b12*b31 -
+             a11*b32 + 2*b11*b32) +
+            (-(a12*a21) + 2*a21*b12 + 2*a12*b21 - 3*b12*b21 -
+             2*a11*b22 + 3*b11*b22)*b33 +
+            a22*(a33*b11 - a31*b13 - a13*b31 + 2*b13*b31 +
+                 a11*b33 - 2*b11*b33);
+
+    for (i = 0; i < 9; i++) B[i] = A[i] - B[i];
+
+    p[3] = -(b13*b22*b31) + b12*b23*b31 + b13*b21*b32 -
+            b11*b23*b32 - b12*b21*b33 + b11*b22*b33;
+#undef a11
+#undef a12
+#undef a13
+#undef a21
+#undef a22
+#undef a23
+#undef a31
+#undef a32
+#undef a33
+#undef b11
+#undef b12
+#undef b13
+#undef b21
+#undef b22
+#undef b23
+#undef b31
+#undef b32
+#undef b33
+}
+
+#define DG_PIT 1.0471975511965967             /* Ftools.c:14 */
+
+DG_FN int dg_rroots3(const double *po, double *r)         /* Ftools.c:251-298 */
+{
+    double b, c, b2, bt, v, e;
+    double p, q, D, A, cosphi, phit, R, _2R;
+    b = po[1] / po[0];
+    c = po[2] / po[0];
+    b2 = b*b;
+    bt = b/3;
+    p = (3*c - b2) / 9;
+    q = ((2 * b2 * b)/27 - b*c/3 + po[3]/po[0]) / 2;
+    D = q*q + p*p*p;
+    if (D > 0) {
+        A = sqrt(D) - q;
+        if (A > 0) { v = pow(A, 1.0/3); *r = v - p/v - bt; }
+        else       { v = pow(-A, 1.0/3); *r = p/v - v - bt; }
+        return 1;
+    } else {
+        if (q > 0) e = 1; else e = -1;
+        R = e * sqrt(-p);
+        _2R = R * 2;
+        cosphi = q / (R*R*R);
+        if (cosphi > 1) cosphi = 1; else if (cosphi < -1) cosphi = -1;
+        phit = acos(cosphi) / 3;
+        r[0] = -_2R * cos(phit) - bt;
+        r[1] =  _2R * cos(DG_PIT - phit) - bt;
+        r[2] =  _2R * cos(DG_PIT + phit) - bt;
+        return 3;
+    }
+}
+
+/* Ftools.c:330-348 singulF: project F onto rank 2 (zero the smallest singular value).  The
+ * reference calls LAPACK dgesvd on the 3x3; U*diag(s1,s2,0)*V^T does not depend on any SVD sign or
+ * ordering convention, so any accurate SVD gives the same matrix to rounding.  Here: one-sided
+ * (Hestenes) Jacobi on the columns of F, which is accurate also for the tiny singular values
+ * (CCMATH svduv is not: absolute 1e-15 deflation threshold).  F = sum_k a_k v_k^T after rotation;
+ * drop the term with the smallest |a_k|. */
+DG_BIG void dg_singulF(double *F)
+{
+    DG_LDS double A[9], V[9];
+    double nrm[3]; int sweep, p, q, i, k, rotated;
+    for (i = 0; i < 9; i++) V[i] = (i % 4 == 0) ? 1. : 0.;
+    for (i = 0; i < 9; i++) { if (isnan(F[i]) || isinf(F[i])) { for (k = 0; k < 9; k++) F[k] = (k % 4 == 0) ? 1. : 0.; return; } A[i] = F[i]; }
+    for (sweep = 0; sweep < 40; sweep++) {
+        rotated = 0;
+        for (p = 0; p < 2; p++)
+            for (q = p + 1; q < 3; q++) {
+                double alpha = 0., beta = 0., gamma = 0., zeta, t, c, sn;
+                for (i = 0; i < 3; i++) { alpha += A[3*i+p]*A[3*i+p]; beta += A[3*i+q]*A[3*i+q]; gamma += A[3*i+p]*A[3*i+q]; }
+                if (gamma == 0. || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
+                rotated = 1;
+                zeta = (beta - alpha) / (2. * gamma);
+                t = (zeta >= 0. ? 1. : -1.) / (fabs(zeta) + sqrt(1. + zeta*zeta));
+                c = 1. / sqrt(1. + t*t); sn = c * t;
+                for (i = 0; i < 3; i++) {
+                    double ap = A[3*i+p], aq = A[3*i+q], vp = V[3*i+p], vq = V[3*i+q];
+                    A[3*i+p] = c*ap - sn*aq; A[3*i+q] = sn*ap + c*aq;
+                    V[3*i+p] = c*vp - sn*vq; V[3*i+q] = sn*vp + c*vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    for (k = 0; k < 3; k++) nrm[k] = A[k]*A[k] + A[3+k]*A[3+k] + A[6+k]*A[6+k];
+    k = 0; if (nrm[1] < nrm[k]) k = 1; if (nrm[2] < nrm[k]) k = 2;
+    for (i = 0; i < 3; i++)
+        for (p = 0; p < 3; p++) {
+            double acc = 0.;
+            for (q = 0; q < 3; q++) if (q != k) acc += A[3*i+q] * V[3*p+q];
+            F[3*i+p] = acc;
+        }
+}
+
+#define DG_XEPS 1.9984e-15                    /* Ftools.c:461 */
+
+DG_FN void dg_crossprod_st(double *out, const double *a, const double *b, int st)   /* utools.c:187-193 */
+{
+    int st2 = 2 * st;
+    out[0] = a[st]*b[st2] - a[st2]*b[st];
+    out[1] = a[st2]*b[0]  - a[0]*b[st2];
+    out[2] = a[0]*b[st]   - a[st]*b[0];
+}
+
+DG_FN void dg_epipole(double *ec, const double *F)        /* Ftools.c:463-470; crossprod = crossprod_st(...,1) */
+{
+    int i;
+    dg_crossprod_st(ec, F, F + 6, 1);
+    for (i = 0; i < 3; i++)
+        if ((ec[i] > DG_XEPS) || (ec[i] < -DG_XEPS)) return;
+    dg_crossprod_st(ec, F + 3, F + 6, 1);
+}
+
+DG_FN double dg_getorisig(const double *F, const double *ec, const double *u)   /* Ftools.c:472-479 */
+{
+    double s1, s2;
+    s1 = F[0]*u[3] + F[3]*u[4] + F[6]*u[5];
+    s2 = ec[1]*u[2] - ec[2]*u[1];
+    return s1 * s2;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * degensac/Htools.c pinvJ (:135-159)
+ * ---------------------------------------------------------------------------------------------- */
+DG_FN void dg_pinvJ(double a, double b, double c, double d, double e, double *pJ)
+{
+    double a2 = a*a, b2 = b*b, c2 = c*c, d2 = d*d, e2 = e*e;
+    double c2pd2 = c2 + d2, ab = a*b, de = d*e;
+    double Q = c * (c2pd2 + e2);
+    double N; int i;
+    pJ[0] = -b * de + a * (c2 + e2);
+    pJ[1] = b * c2pd2 - a * de;
+    pJ[2] = Q;
+    pJ[3] = -c * (a*d + b*e);
+    pJ[4] = d * (b2 + c2) - ab * e;
+    pJ[5] = -ab * d + e * (a2 + c2);
+    pJ[6] = pJ[3];
+    pJ[7] = c * (a2 + b2 + c2);
+    N = a * pJ[0] + b * pJ[1] + c * pJ[2];
+    for (i = 0; i < 8; i++) pJ[i] /= N;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * degensac/hash.c:4-47  Hsieh SuperFastHash over the bytes of the int inlier list
+ * ---------------------------------------------------------------------------------------------- */
+DG_FN uint32_t dg_superfasthash(const unsigned char *data, int len)
+{
+    uint32_t hash = (uint32_t)len, tmp; int rem;
+#define DG_GET16(d) ((((uint32_t)((d)[1])) << 8) + (uint32_t)((d)[0]))
+    if (len <= 0 || data == 0) return 0;
+    rem = len & 3; len >>= 2;
+    for (; len > 0; len--) {
+        hash += DG_GET16(data);
+        tmp = (DG_GET16(data + 2) << 11) ^ hash;
+        hash = (hash << 16) ^ tmp;
+        data += 4;
+        hash += hash >> 11;
+    }
+    switch (rem) {   /* never taken: the list is ints (len % 4 == 0) */
+    case 3: hash += DG_GET16(data); hash ^= hash << 16; hash ^= ((uint32_t)(int32_t)(signed char)data[2]) << 18; hash += hash >> 11; break;
+    case 2: hash += DG_GET16(data); hash ^= hash << 11; hash += hash >> 17; break;
+    case 1: hash += (uint32_t)(int32_t)(signed char)*data; hash ^= hash << 10; hash += hash >> 1;
+    }
+#undef DG_GET16
+    hash ^= hash << 3;  hash += hash >> 5;
+    hash ^= hash << 4;  hash += hash >> 17;
+    hash ^= hash << 25; hash += hash >> 6;
+    return hash;
+}
+
+/* degensac/rtools.c:202-225 */
+DG_FN int dg_nsamples(int ninl, int ptNum, int samsiz, double conf)
+{
+    double a = 1, b = 1; int i;
+    for (i = 0; i < samsiz; i++) { a *= ninl - i; b *= ptNum - i; }
+    a = a / b;
+    if (a < 2.2204e-16) return 1000000;
+    a = 1 - a;
+    if (a < 2.2204e-16) return 1;
+    b = log(1 - conf) / log(a);
+    if (b > 1000000) return 1000000;
+    return (int)ceil(b);
+}
+
+/* degensac/rtools.c:228-236 */
+DG_FN double dg_truncQuad(double epsilon, double thr)
+{
+    if (thr == 0) return 0;
+    if (epsilon >= thr*9/4) return 0;
+    return 1 - (epsilon / (thr*9/4));
+}
+
+#endif /* DG_DEV_SMALL_H */

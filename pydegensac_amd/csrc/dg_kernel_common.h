@@ -1,0 +1,139 @@
+/* Shared definitions of the persistent kernels: kernel arguments, per-pair workspace layout,
+ * the device RNG fast path, the sampler and the lane-0 small LSQ solvers. */
+#ifndef DG_KERNEL_COMMON_H
+#define DG_KERNEL_COMMON_H
+#include "dg_geom.h"
+
+#define DG_CHUNK   DG_T        /* minimal samples speculated per round (one per lane)            */
+#define DG_MCAP    96          /* models scored per LDS sub-batch                                  */
+#define DG_HT_CAP  4096        /* LO inlier-set hash entries per pair                              */
+
+/* rtools.h:4-15 */
+#define DG_ITER_SAM 50
+#define DG_RAN_REP 10
+#define DG_ILSQ_ITERS 4
+#define DG_TC 4
+#define DG_MWM (9/4)
+
+struct dg_params {
+    double th;            /* squared / linear threshold as the C driver receives it               */
+    double sym_th;        /* SymCheck_th                                                          */
+    double laf_coef;
+    double conf;
+    int    max_iters;
+    int    error_type;
+    int    degen;
+    int    final_laf_filter;
+};
+
+/* per-pair global scratch (L2-resident), sized for the pair's n */
+struct dg_ws_layout {
+    size_t stride;        /* bytes per pair                                                       */
+    size_t off_lists;     /* 6 int lists of n_max                                                 */
+    size_t off_flags;     /* 4 byte-flag vectors of n_max                                         */
+    size_t off_ht;        /* hash table: heads[64] + entries[DG_HT_CAP][4] ints                    */
+    size_t off_models;    /* chunk models: [3*DG_CHUNK][9] doubles + tags                          */
+    size_t off_pts;       /* dg_pt[n_max] when the points do not fit LDS                          */
+    size_t off_pool;      /* int[n_max]   ditto                                                   */
+    int    n_max;
+};
+
+struct dg_args {
+    const double *pts1, *pts2;       /* [total, dim] */
+    const long long *offsets;        /* [n_pairs + 1] */
+    const unsigned *seeds;           /* [n_pairs] */
+    double *model_out;               /* [n_pairs, 9] */
+    unsigned char *mask_out;         /* [total] */
+    int *stats_out;                  /* [n_pairs, 16] or null */
+    char *ws;
+    dg_ws_layout wl;
+    dg_params prm;
+    int dim, n_pairs, pts_in_lds;
+};
+
+/* ---- glibc TYPE_3 fast path ----------------------------------------------------------------------
+ * After srandom(seed) the k-th output is ((sum_j C[k][j] * r_j) mod 2^32) >> 1 with r_0 = seed,
+ * r_j = 16807 * r_{j-1} mod (2^31-1): the 310 discarded steps of r[i] = r[i-31] + r[i-3] are linear
+ * over Z/2^32, so they collapse into the constant 8 x 31 matrix C (filled by the host at load time
+ * by running the generator on unit vectors).  G[j] = 16807^j mod (2^31-1). */
+__constant__ unsigned dg_rng_C[8][32];
+__constant__ unsigned dg_rng_G[32];
+
+__device__ __forceinline__ unsigned dg_mulmod31(unsigned a, unsigned b)
+{
+    unsigned long long x = (unsigned long long)a * b;
+    x = (x & 0x7fffffffull) + (x >> 31);
+    x = (x & 0x7fffffffull) + (x >> 31);
+    if (x >= 0x7fffffffull) x -= 0x7fffffffull;
+    return (unsigned)x;
+}
+/* first LCG step exactly as glibc does it (handles seeds >= 2^31, i.e. negative int32) */
+__device__ __forceinline__ unsigned dg_lcg_first(int r0)
+{
+    long long hi = r0 / 127773, lo = r0 % 127773;
+    long long word = 16807 * lo - 2836 * hi;
+    if (word < 0) word += 2147483647;
+    return (unsigned)word;
+}
+/* all 8 outputs after srand(seed): o[0..6] raw draws, o[7] the next seed */
+__device__ __forceinline__ void dg_rng_outputs(unsigned seed, unsigned *o)
+{
+    if (seed == 0) seed = 1;
+    unsigned r1 = dg_lcg_first((int)seed);
+    unsigned acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = dg_rng_C[k][0] * seed;
+    for (int j = 1; j < 31; j++) {
+        unsigned rj = dg_mulmod31(r1, dg_rng_G[j - 1]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] += dg_rng_C[k][j] * rj;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) o[k] = acc[k] >> 1;
+}
+/* wave-cooperative: next seed only (lanes 0..30 carry one term each) */
+__device__ __forceinline__ unsigned dg_rng_next_seed_wave(unsigned seed, int lane)
+{
+    if (seed == 0) seed = 1;
+    unsigned r1 = dg_lcg_first((int)seed);
+    unsigned rj = (lane == 0) ? seed : ((lane < 31) ? dg_mulmod31(r1, dg_rng_G[(lane - 1) & 31]) : 0u);
+    unsigned term = (lane < 31) ? dg_rng_C[7][lane & 31] * rj : 0u;
+    return dg_wave_sum_u(term) >> 1;
+}
+
+/* ---- LO hash table: the reference's 64 chained buckets (hash.c:49-96, hash.h:21-32) ------------ */
+struct dg_ht { int *heads; int *ent; int *count; };     /* ent: [cap][4] = hash, length, iterID, next */
+__device__ __forceinline__ void dg_ht_init(dg_ht &h, int tid)
+{
+    if (tid < 64) h.heads[tid] = -1;
+    if (tid == 0) *h.count = 0;
+}
+__device__ __forceinline__ int dg_ht_contains(const dg_ht &h, unsigned hash, int length, int iterID)
+{
+    int e = h.heads[hash % 64];
+    while (e >= 0) { if ((unsigned)h.ent[4*e] == hash && h.ent[4*e+1] == length && h.ent[4*e+2] == iterID) return iterID; e = h.ent[4*e+3]; }
+    e = h.heads[hash % 64];
+    while (e >= 0) { if ((unsigned)h.ent[4*e] == hash && h.ent[4*e+1] == length) return h.ent[4*e+2]; e = h.ent[4*e+3]; }
+    return -1;
+}
+__device__ __forceinline__ void dg_ht_insert(dg_ht &h, unsigned hash, int length, int iterID)
+{
+    int e = *h.count;
+    if (e >= DG_HT_CAP) return;
+    h.ent[4*e] = (int)hash; h.ent[4*e+1] = length; h.ent[4*e+2] = iterID; h.ent[4*e+3] = h.heads[hash % 64];
+    h.heads[hash % 64] = e; *h.count = e + 1;
+}
+
+/* ---- lane-0 helpers on global int lists --------------------------------------------------------- */
+/* rtools.c:25-39 randsubset on a list in global memory; returns the offset of the subset (max_sz - siz) */
+__device__ __forceinline__ int dg_randsubset(dg_rng *g, int *pool, int max_sz, int siz)
+{
+    for (int i = 0; i < siz; i++) {
+        int s = dg_rand(g) % (max_sz - i);
+        int j = max_sz - i - 1;
+        int q = pool[s]; pool[s] = pool[j]; pool[j] = q;
+    }
+    return max_sz - siz;
+}
+
+#endif /* DG_KERNEL_COMMON_H */

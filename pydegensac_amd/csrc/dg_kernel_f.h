@@ -1,0 +1,487 @@
+/* Persistent fundamental-matrix kernel: one workgroup runs the whole reference driver
+ * exp_ransacFcustomLAF (degensac/exp_ranF.c:1244-1767) for one image pair.
+ *
+ * Main loop = speculate-then-commit: the sample stream does not depend on scoring
+ * outcomes, so DG_CHUNK minimal samples are drawn (lane-parallel glibc replay + sequential pool
+ * swaps), solved (one 7-point problem per lane, registers only) and scored (one wave per model, the
+ * point set resident in LDS), then a workgroup-uniform commit scan replays exp_ranF.c:1365-1577 in
+ * order and fires the rare heavy branches (symmetric/LAF checks, DEGENSAC, local optimisation) as
+ * cooperative passes.  Residual vectors are never materialised: every `errs[k]` buffer of the
+ * reference is tracked as "the model whose residuals it would hold" and recomputed on demand.
+ */
+#ifndef DG_KERNEL_F_H
+#define DG_KERNEL_F_H
+#include "dg_lsq.h"
+
+struct dg_score { unsigned I; double J; unsigned Is; unsigned Ilafs; };
+
+struct dg_f_shared {
+    dg_red red;
+    dg_lsq_scratch lsq;
+    dg_rng rng;
+    unsigned seeds[DG_CHUNK];
+    int      draws[DG_CHUNK][8];        /* raw draws, then drawn ids (draw order) */
+    double   models[DG_MCAP][9];
+    unsigned res_I[3 * DG_CHUNK];
+    double   res_J[3 * DG_CHUNK];
+    unsigned short moff[DG_CHUNK + 1];  /* first model slot of each sample */
+    unsigned char  nv[DG_CHUNK];        /* valid models per sample; 255 = nullspace dimension != 2 */
+    unsigned char  ridx[DG_CHUNK][4];   /* root index i (= errs[] slot) of each valid model */
+    unsigned wave_cnt[DG_NW];
+    double   f[9], F[9], FBest[9], H[9], Hx[9], fLO[9], ftmp[9];
+    double   bufF[4][9]; int bufKind[4]; /* model whose residuals each physical errs[] buffer holds */
+    double   u7[7][4];
+    int      samidxBest[7];
+    int      itmp[32];
+    double   dtmp[32];
+};
+
+/* ------------------------------------------------------------------------------------------------ */
+template <bool LDSPTS>
+struct dg_f_ctx {
+    dg_f_shared *S;
+    const dg_pt *P;          /* correspondences (LDS or global) */
+    int *pool;               /* sampler permutation pool (LDS or global) */
+    int n, tid;
+    const dg_args *A;
+    long long off;           /* first row of this pair in the input arrays */
+    int *L[10];              /* global int lists: 0 inliers, 1 intbuff, 2 intbuff_best (LO); 3 inliersH, 4 intbuffH (innerH);
+                                5 idxN, 6 idxH, 7 idxV, 8 ptr (rFtH); 9 inlI (u2Fit) */
+    unsigned char *Fl[5];    /* global flag vectors: 0 hinl, 1 nhinl, 2 vN, 3 v (innerFH), 4 inl (innerFH result) */
+    dg_ht ht;
+    double *gmodels;         /* [3*DG_CHUNK][9] chunk models */
+    /* counters */
+    int n_fds, n_exfds, n_hds, n_aux;
+
+    __device__ __forceinline__ dg_pt pt(int i) const { return P[i]; }
+    /* LAF point sets u_1 (which=1: +a12,+a22) and u_2 (which=2: +a11,+a21): bindings.cpp:337-409 */
+    __device__ __forceinline__ dg_pt laf_pt(int i, int which) const {
+        const double *a = A->pts1 + (size_t)(off + i) * 6, *b = A->pts2 + (size_t)(off + i) * 6;
+        dg_pt p;
+        if (which == 1) { p.x1 = a[0] + a[3]; p.y1 = a[1] + a[5]; p.x2 = b[0] + b[3]; p.y2 = b[1] + b[5]; }
+        else            { p.x1 = a[0] + a[2]; p.y1 = a[1] + a[4]; p.x2 = b[0] + b[2]; p.y2 = b[1] + b[4]; }
+        return p;
+    }
+};
+
+#define CTX dg_f_ctx<LDSPTS>
+
+/* a full scoring pass of model F (kind) with optional list/flags; counts as FDS1/EXFDS1/aux */
+template <bool LDSPTS>
+__device__ __forceinline__ dg_pass_res dg_f_pass(CTX &c, const double *Fm /* LDS */, int kind, dg_pass_cfg cfg)
+{
+    double F[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) F[i] = Fm[i];
+    const dg_pt *P = c.P;
+    return dg_pass(&c.S->red, cfg, [&](int pid, int) { return dg_Ferr(kind, F, P[pid]); }, c.tid);
+}
+template <bool LDSPTS>
+__device__ __forceinline__ dg_pass_res dg_h_pass(CTX &c, const double *Hm /* LDS */, dg_pass_cfg cfg)
+{
+    double H[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) H[i] = Hm[i];
+    const dg_pt *P = c.P;
+    return dg_pass(&c.S->red, cfg, [&](int pid, int) { dg_pt p = P[pid]; return dg_HDs(H, p.x1, p.y1, p.x2, p.y2); }, c.tid);
+}
+__device__ __forceinline__ dg_pass_cfg dg_cfg0(int n)
+{
+    dg_pass_cfg c; c.n = n; c.src = 0; c.wantJ = 0; c.thJ = 0; c.wantC = 0; c.thC = 0; c.list = 0; c.thL = 0; c.flags = 0; c.thF = 0;
+    return c;
+}
+
+/* gather `len` points of a global id list into the lane-0 scratch (coordinates x1,y1,x2,y2) */
+template <bool LDSPTS>
+__device__ __forceinline__ void dg_gather(CTX &c, const int *ids, int len, double *px)
+{
+    for (int i = 0; i < len; i++) { dg_pt p = c.P[ids[i]]; px[4*i] = p.x1; px[4*i+1] = p.y1; px[4*i+2] = p.x2; px[4*i+3] = p.y2; }
+}
+
+/* u2f on a global id list of any length -> S->f  (exp_ranF.c's u2f(u, inliers, n, f, buffer) calls) */
+template <bool LDSPTS>
+__device__ __forceinline__ void dg_u2f_list(CTX &c, const int *list, int len, const double *wmodel, int wkind, double *Fout)
+{
+    dg_f_shared *S = c.S;
+    if (len <= 16) {
+        __syncthreads();
+        if (c.tid == 0) {
+            dg_gather(c, list, len, S->lsq.px);
+            double wts[16];
+            if (wmodel) {
+                for (int i = 0; i < len; i++) {
+                    double *q = S->lsq.px + 4*i;
+                    if (wkind == DG_K_FDS) wts[i] = dg_exFDs_w(wmodel, q[0], q[1], q[2], q[3]);
+                    else { double w; dg_exFDsSym(wmodel, q[0], q[1], q[2], q[3], &w); wts[i] = w; }
+                }
+            }
+            dg_u2f_small(&S->lsq, S->lsq.px, wmodel ? wts : 0, len, Fout);
+        }
+        __syncthreads();
+    } else {
+        const dg_pt *P = c.P;
+        dg_u2f_big(&S->red, &S->lsq, [&](int i) { return P[i]; }, list, len, c.tid, Fout);
+    }
+}
+
+/* symmetric + LAF consistency of candidate f over the ids list[0..cnt) (exp_ranF.c:1383-1411,
+ * :1526-1556, :1654-1682).  Returns 0 when the candidate must be rejected. */
+template <bool LDSPTS>
+__device__ __forceinline__ int dg_f_checks(CTX &c, const double *f, const int *list, int cnt, dg_score &S, const dg_score &maxS, int mkind)
+{
+    const dg_params &pr = c.A->prm;
+    if (pr.sym_th > 0) {
+        dg_pass_cfg cfg = dg_cfg0(cnt); cfg.src = list; cfg.wantC = 1; cfg.thC = pr.sym_th;
+        dg_pass_res r = dg_f_pass(c, f, DG_K_FSYM, cfg);
+        S.Is = r.C;
+        if (S.Is < maxS.Is) return 0;
+    }
+    if (pr.laf_coef > 0) {
+        double thl = pr.laf_coef * pr.th;
+        double F[9];
+        for (int i = 0; i < 9; i++) F[i] = f[i];
+        dg_pass_cfg cfg = dg_cfg0(cnt); cfg.src = list; cfg.wantC = 1; cfg.thC = thl;
+        dg_pass_res r1 = dg_pass(&c.S->red, cfg, [&](int pid, int) { return dg_Ferr(mkind, F, c.laf_pt(pid, 1)); }, c.tid);
+        dg_pass_res r2 = dg_pass(&c.S->red, cfg, [&](int pid, int) { return dg_Ferr(mkind, F, c.laf_pt(pid, 2)); }, c.tid);
+        S.Ilafs = r2.C < r1.C ? r2.C : r1.C;
+        if (S.Ilafs < maxS.Ilafs) return 0;
+    }
+    return 1;
+}
+
+/* ---- DegUtils.c:42-161 checksample / Hdetect on lane 0 ----------------------------------------- */
+__device__ __noinline__ void dg_Hdetect(const double *F, const double (*u7)[4], const unsigned char *IDXS, double *H)
+{
+    DG_LDS double D[3], U[9], V[9], ec[3], Ex[9], A[9], u3a[9], u3b[9], u3aT[9], u3bT[9], Au3b[9], Ft[9], F1[9], p1[9], p1T[9], p2[9], b[3];
+    int i, j, sing;
+    dg_mattr(Ft, F, 3, 3);
+    for (i = 0; i < 9; i++) F1[i] = F[i];
+    dg_svduv(D, F1, U, 3, V, 3);
+    ec[0] = V[2]; ec[1] = V[5]; ec[2] = V[8];
+    Ex[0] = 0; Ex[1] = -ec[2]; Ex[2] = ec[1]; Ex[3] = ec[2]; Ex[4] = 0; Ex[5] = -ec[0]; Ex[6] = -ec[1]; Ex[7] = ec[0]; Ex[8] = 0;
+    dg_mmul(A, Ex, Ft, 3);
+    for (i = 0; i < 3; ++i) {
+        const double *q = u7[IDXS[i]];
+        double ua[3] = {q[0], q[1], 1.0}, ub[3] = {q[2], q[3], 1.0};
+        for (j = 0; j < 3; ++j) { u3a[i+j*3] = ua[j]; u3b[i+j*3] = ub[j]; }
+    }
+    dg_mmul(Au3b, A, u3b, 3);
+    dg_mattr(u3aT, u3a, 3, 3);
+    dg_mattr(u3bT, Au3b, 3, 3);
+    for (i = 0; i < 3; i++) {
+        const double *u = u3aT + 3*i, *v = u3bT + 3*i; double *h = p1T + 3*i;
+        h[0] = u[1]*v[2] - u[2]*v[1]; h[1] = u[2]*v[0] - u[0]*v[2]; h[2] = u[0]*v[1] - u[1]*v[0];
+    }
+    dg_mattr(p1, p1T, 3, 3);
+    for (i = 0; i < 9; ++i) Ex[i] *= -1;
+    dg_mmul(p2, Ex, u3a, 3);
+    b[0] = (p1[0]*p2[0] + p1[3]*p2[3] + p1[6]*p2[6]) / (p2[0]*p2[0] + p2[3]*p2[3] + p2[6]*p2[6]);
+    b[1] = (p1[1]*p2[1] + p1[4]*p2[4] + p1[7]*p2[7]) / (p2[1]*p2[1] + p2[4]*p2[4] + p2[7]*p2[7]);
+    b[2] = (p1[2]*p2[2] + p1[5]*p2[5] + p1[8]*p2[8]) / (p2[2]*p2[2] + p2[5]*p2[5] + p2[8]*p2[8]);
+    dg_mattr(u3bT, u3b, 3, 3);
+    sing = dg_minv(u3bT, 3);
+    dg_rmmult(u3b, u3bT, b, 3, 3, 1);
+    dg_mattr(u3bT, u3b, 3, 1);
+    dg_rmmult(u3b, ec, u3bT, 3, 1, 3);
+    for (i = 0; i < 3; ++i) for (j = 0; j < 3; ++j) H[i+j*3] = A[i*3+j] - u3b[i*3+j];
+    if (isnan(*H) || isinf(*H) || sing) { H[1] = H[2] = H[3] = H[5] = H[6] = H[7] = 0; H[0] = H[4] = H[8] = 1; }
+}
+
+__device__ __noinline__ int dg_checksample(dg_lsq_scratch *ls, const double *F, const double (*u7)[4], double th, double *H)
+{
+    const unsigned char IDXS[5][3] = {{0,1,2}, {3,4,5}, {0,1,6}, {3,4,6}, {2,5,6}};
+    DG_LDS double Ds[7], sDs[7], px[20];
+    DG_LDS int idx[7];
+    for (int i = 0; i < 5; ++i) {
+        dg_Hdetect(F, u7, IDXS[i], H);
+        for (int j = 0; j < 7; j++) Ds[j] = dg_HDs(H, u7[j][0], u7[j][1], u7[j][2], u7[j][3]);
+        for (int j = 0; j < 7; j++) { sDs[j] = Ds[j]; idx[j] = j; }          /* sortDs, DegUtils.c:164-183 */
+        for (int a = 0; a < 7; ++a)
+            for (int b = a + 1; b < 7; ++b)
+                if (sDs[b] < sDs[a]) { double t = sDs[b]; sDs[b] = sDs[a]; sDs[a] = t; int ti = idx[b]; idx[b] = idx[a]; idx[a] = ti; }
+        for (int j = 0; j < 5; ++j) { px[4*j] = u7[idx[j]][0]; px[4*j+1] = u7[idx[j]][1]; px[4*j+2] = u7[idx[j]][2]; px[4*j+3] = u7[idx[j]][3]; }
+        dg_u2h_small(ls, px, 5, H);
+        int inlCount = 0;
+        for (int j = 0; j < 7; ++j) if (dg_HDs(H, u7[j][0], u7[j][1], u7[j][2], u7[j][3]) < th) ++inlCount;
+        if (inlCount > 4) return 1;
+    }
+    return 0;
+}
+
+/* ---- ranH.c:18-135 + DegUtils.c:693-731: LO of the plane homography (innerH) -------------------- */
+template <bool LDSPTS>
+__device__ __forceinline__ unsigned dg_innerH(CTX &c, double *H /* LDS, in/out */, double th, unsigned inlLimit, unsigned char *inl_flags)
+{
+    dg_f_shared *S = c.S; const int n = c.n, tid = c.tid;
+    int *inliers = c.L[3], *intbuff = c.L[4];
+    double *h = S->Hx, *hbest = S->ftmp;            /* hbest = model in errs[0]-chain; H itself is the running best */
+    /* d = HDs(H); S = inlidxs(d, th, inliers) */
+    dg_pass_cfg cfg = dg_cfg0(n); cfg.list = inliers; cfg.thL = th;
+    dg_pass_res r0 = dg_h_pass(c, H, cfg); c.n_hds++;
+    int ninl = (int)r0.nL;
+    if (ninl >= 8) {                                  /* inHrani, ranH.c:88-135 */
+        int ssiz = ninl / 2; if (ssiz > 12) ssiz = 12;
+        double maxJ = 0;                               /* maxS = {0,0} */
+        for (int rep = 0; rep < DG_RAN_REP; ++rep) {
+            __syncthreads();
+            if (tid == 0) {
+                int o = dg_randsubset(&S->rng, inliers, ninl, ssiz);
+                dg_gather(c, inliers + o, ssiz, S->lsq.px);
+                dg_u2h_small(&S->lsq, S->lsq.px, ssiz, h);
+            }
+            __syncthreads();
+            /* errs[0] = HDs(h); errs[4] = errs[0]; iterH */
+            double itJ = 0; int itValid = 0;            /* iterH's maxS and whether H-out was updated */
+            {
+                double ths = DG_TC * th, dth = (ths - th) / DG_ILSQ_ITERS;
+                dg_pass_cfg c1 = dg_cfg0(n); c1.wantJ = 1; c1.thJ = th; c1.list = intbuff; c1.thL = th;
+                dg_pass_res r1 = dg_h_pass(c, h, c1); c.n_hds++;
+                double mJ = r1.J; unsigned mI = r1.I;   /* maxS = inlidxs(errs[4], th) */
+                /* hloc (= S->dtmp[0..8]) : the h being iterated; h (S->Hx) : iterH's output parameter */
+                if (mI >= 4) {
+                    double *hl = S->dtmp;
+                    __syncthreads();
+                    if (tid == 0) {
+                        int cnt = (int)mI, o = 0;
+                        if (mI > inlLimit) { o = dg_randsubset(&S->rng, intbuff, (int)mI, (int)inlLimit); cnt = (int)inlLimit; }
+                        dg_gather(c, intbuff + o, cnt, S->lsq.px);
+                        dg_u2h_small(&S->lsq, S->lsq.px, cnt, hl);
+                    }
+                    __syncthreads();
+                    int early = 0;
+                    for (int it = 0; it < DG_ILSQ_ITERS; ++it) {
+                        dg_pass_cfg c2 = dg_cfg0(n); c2.wantJ = 1; c2.thJ = th; c2.list = intbuff; c2.thL = ths;
+                        dg_pass_res r2 = dg_h_pass(c, hl, c2); c.n_hds++;
+                        if (mJ < r2.J) { mJ = r2.J; mI = r2.I; __syncthreads(); if (tid < 9) h[tid] = hl[tid]; __syncthreads(); }
+                        if (r2.nL < 4) { early = 1; break; }
+                        __syncthreads();
+                        if (tid == 0) {
+                            int cnt = (int)r2.nL, o = 0;
+                            if (r2.nL > inlLimit) { o = dg_randsubset(&S->rng, intbuff, (int)r2.nL, (int)inlLimit); cnt = (int)inlLimit; }
+                            dg_gather(c, intbuff + o, cnt, S->lsq.px);
+                            dg_u2h_small(&S->lsq, S->lsq.px, cnt, hl);
+                        }
+                        __syncthreads();
+                        ths -= dth;
+                    }
+                    if (!early) {
+                        dg_pass_cfg c3 = dg_cfg0(n); c3.wantJ = 1; c3.thJ = th; c3.list = intbuff; c3.thL = th;
+                        dg_pass_res r3 = dg_h_pass(c, hl, c3); c.n_hds++;
+                        if (mJ < r3.J) { mJ = r3.J; mI = r3.I; __syncthreads(); if (tid < 9) h[tid] = hl[tid]; __syncthreads(); }
+                    }
+                    itJ = mJ; itValid = 1;
+                } else { itJ = 0; itValid = 1; }         /* returns S = {0,0}: h untouched */
+            }
+            (void)itValid; (void)hbest;
+            if (maxJ < itJ) { maxJ = itJ; __syncthreads(); if (tid < 9) H[tid] = h[tid]; __syncthreads(); }
+        }
+    }
+    /* inl[j] = (errs[0][j] <= th) with errs[0] = residuals of the (possibly refined) H */
+    dg_pass_cfg cf = dg_cfg0(n); cf.wantC = 1; cf.thC = th;
+    {
+        double Hr[9]; for (int i = 0; i < 9; i++) Hr[i] = H[i];
+        const dg_pt *P = c.P;
+        unsigned cnt = 0;
+        for (int base = 0; base < n; base += DG_T) {
+            int j = base + tid; bool in = false;
+            if (j < n) { dg_pt p = P[j]; in = dg_HDs(Hr, p.x1, p.y1, p.x2, p.y2) <= th; inl_flags[j] = in ? 1 : 0; }
+            cnt += in ? 1u : 0u;
+        }
+        cnt = dg_block_sum_u(&c.S->red, cnt, tid);
+        __syncthreads();
+        return cnt;
+    }
+}
+
+/* ---- DegUtils.c:635-690 u2Fit ------------------------------------------------------------------- */
+template <bool LDSPTS>
+__device__ __forceinline__ unsigned dg_u2Fit(CTX &c, double *F /* LDS in/out */, unsigned char *inl, double th, double ths, unsigned iters)
+{
+    const int n = c.n;
+    double dth = (ths - th) / (iters - 1);
+    int *inlI = c.L[9];
+    for (unsigned iter = 0; iter < iters; ++iter) {
+        /* flags: d < ths (strict); the id list is the same set in index order */
+        dg_pass_cfg cfg = dg_cfg0(n); cfg.flags = inl; cfg.thF = ths;
+        dg_pass_res r = dg_f_pass(c, F, DG_K_FDS, cfg); c.n_aux++;
+        if (r.nF < 8) return r.nF;
+        /* list from flags */
+        {
+            dg_pass_cfg c2 = dg_cfg0(n); c2.list = inlI; c2.thL = 0.5;
+            const unsigned char *fl = inl;
+            dg_pass(&c.S->red, c2, [&](int pid, int) { return fl[pid] ? 0.0 : 1.0; }, c.tid);
+        }
+        dg_u2f_list(c, inlI, (int)r.nF, 0, 0, F);
+        ths -= dth;
+    }
+    dg_pass_cfg cfg = dg_cfg0(n); cfg.flags = inl; cfg.thF = th;
+    dg_pass_res r = dg_f_pass(c, F, DG_K_FDS, cfg); c.n_aux++;
+    return r.nF;
+}
+
+/* ---- DegUtils.c:488-632 innerFH + dual_sample ---------------------------------------------------- */
+/* dual_sample draws on freshly initialised identity permutations; only the first sA (sB) entries are
+ * read afterwards, so the permutation is tracked sparsely on lane 0. */
+__device__ __forceinline__ void dg_dual_pick(dg_rng *g, unsigned len, unsigned s, int *out /* s entries */)
+{
+    int pos_key[16], pos_val[16], np = 0;
+    for (unsigned pos = 0; pos < s; ++pos) {
+        unsigned idx = (unsigned)dg_rand(g) % len;
+        /* swap ptr[pos] <-> ptr[idx] on a sparse identity map */
+        int vp = (int)pos, vi = (int)idx, ip = -1, ii = -1;
+        for (int k = 0; k < np; k++) { if (pos_key[k] == (int)pos) { vp = pos_val[k]; ip = k; } if (pos_key[k] == (int)idx) { vi = pos_val[k]; ii = k; } }
+        if (ip < 0) { ip = np; pos_key[np++] = (int)pos; }
+        pos_val[ip] = vi;
+        if ((int)idx != (int)pos) { if (ii < 0) { ii = np; pos_key[np++] = (int)idx; } pos_val[ii] = vp; }
+        else pos_val[ip] = vp;
+    }
+    for (unsigned i = 0; i < s; i++) {
+        int v = (int)i;
+        for (int k = 0; k < np; k++) if (pos_key[k] == (int)i) v = pos_val[k];
+        out[i] = v;
+    }
+}
+
+template <bool LDSPTS>
+__device__ __forceinline__ void dg_innerFH(CTX &c, const int *idxH, unsigned lenH, const int *idxO, unsigned lenO,
+                                           double th, unsigned repCount, double *F /* LDS out */, unsigned char *inl /* out flags */)
+{
+    dg_f_shared *S = c.S; const int n = c.n, tid = c.tid;
+    unsigned char *v = c.Fl[3];
+    double *aF = S->fLO;
+    unsigned max_i = 0, max_s = 0;
+    __syncthreads();
+    if (tid < 9) F[tid] = 1;
+    for (int j = tid; j < n; j += DG_T) inl[j] = 0;
+    __syncthreads();
+    for (unsigned rep = 0; rep < repCount; ++rep) {
+        __syncthreads();
+        if (tid == 0) {
+            int pick[16];
+            dg_dual_pick(&S->rng, lenH, 6, pick);
+            dg_dual_pick(&S->rng, lenO, 4, pick + 6);
+            for (int i = 0; i < 6; i++) S->itmp[i] = idxH[pick[i]];
+            for (int i = 0; i < 4; i++) S->itmp[6+i] = idxO[pick[6+i]];
+            dg_gather(c, S->itmp, 10, S->lsq.px);
+            dg_u2f_small(&S->lsq, S->lsq.px, 0, 10, aF);
+        }
+        __syncthreads();
+        dg_pass_cfg cfg = dg_cfg0(n); cfg.flags = v; cfg.thF = th;
+        dg_pass_res r = dg_f_pass(c, aF, DG_K_FDS, cfg); c.n_aux++;
+        unsigned no_i = r.nF;
+        if (max_i < no_i) {
+            for (int j = tid; j < n; j += DG_T) inl[j] = v[j];
+            if (tid < 9) F[tid] = aF[tid];
+            __syncthreads();
+            max_i = no_i;
+        }
+        if (no_i > max_s) {
+            max_s = no_i;
+            no_i = dg_u2Fit(c, aF, v, th, th*3, 4);
+            if (max_i < no_i) {
+                for (int j = tid; j < n; j += DG_T) inl[j] = v[j];
+                if (tid < 9) F[tid] = aF[tid];
+                __syncthreads();
+                max_i = no_i;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+/* ---- DegUtils.c:254-444 rFtH: plane-and-parallax completion ------------------------------------- */
+template <bool LDSPTS>
+__device__ __forceinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, double th, const double *H /* LDS */, double *F /* LDS out */)
+{
+    dg_f_shared *S = c.S; const int n = c.n, tid = c.tid;
+    unsigned char *nhinl = c.Fl[1], *vN = c.Fl[2], *inl = c.Fl[4];
+    int *idxN = c.L[5], *idxH = c.L[6], *idxV = c.L[7], *ptr = c.L[8];
+    const unsigned MAX_SAM = 10000; const double conf = .999;
+    /* nhinl = HDs(H) > 100*th ; lists */
+    double Hr[9]; for (int i = 0; i < 9; i++) Hr[i] = H[i];
+    {
+        const dg_pt *P = c.P;
+        dg_pass_cfg cfg = dg_cfg0(n); cfg.list = idxN; cfg.thL = 0.5; cfg.flags = nhinl; cfg.thF = 0.5;
+        /* err = 0 when off-plane (d > 100 th) so that list/flags collect exactly those */
+        dg_pass(&S->red, cfg, [&](int pid, int) { dg_pt p = P[pid]; return dg_HDs(Hr, p.x1, p.y1, p.x2, p.y2) > 100*th ? 0.0 : 1.0; }, tid);
+        c.n_hds++;
+    }
+    /* recount (dg_pass returned counts are discarded above for clarity) */
+    unsigned nhinlCount, hinlCount;
+    {
+        dg_pass_cfg cfg = dg_cfg0(n); cfg.list = idxH; cfg.thL = 0.5; cfg.wantC = 1; cfg.thC = 0.5;
+        dg_pass_res r = dg_pass(&S->red, cfg, [&](int pid, int) { return hinl[pid] ? 0.0 : 1.0; }, tid);
+        hinlCount = r.nL;
+        dg_pass_cfg cfg2 = dg_cfg0(n); cfg2.wantC = 1; cfg2.thC = 0.5;
+        const unsigned char *nf = nhinl;
+        dg_pass_res r2 = dg_pass(&S->red, cfg2, [&](int pid, int) { return nf[pid] ? 0.0 : 1.0; }, tid);
+        nhinlCount = r2.C;
+    }
+    for (int j = tid; j < (int)nhinlCount; j += DG_T) ptr[j] = j;
+    __syncthreads();
+    unsigned max_i = 3, m_i = 4, max_sam = MAX_SAM;
+    if (nhinlCount < 4 || hinlCount < 6) return 0;
+    for (unsigned no_sam = 1; no_sam < 2*max_sam; ++no_sam) {
+        __syncthreads();
+        if (tid == 0) {
+            for (unsigned pos = 0; pos < 2; ++pos) {
+                unsigned idx = pos + 1 + (unsigned)dg_rand(&S->rng) % (nhinlCount - pos - 1);
+                int aux = ptr[pos]; ptr[pos] = ptr[idx]; ptr[idx] = aux;
+            }
+            S->itmp[0] = idxN[ptr[0]]; S->itmp[1] = idxN[ptr[1]];
+        }
+        __syncthreads();
+        /* epipole from the two off-plane points: every lane repeats the same scalar arithmetic */
+        double aFt[9];
+        {
+            dg_pt p0 = c.P[S->itmp[0]], p1 = c.P[S->itmp[1]];
+            double a0[3] = {p0.x1, p0.y1, 1.0}, a1[3] = {p1.x1, p1.y1, 1.0}, b0[3], b1[3], c1[3], c2[3], ec[3];
+            b0[0] = Hr[0]*p0.x2 + Hr[3]*p0.y2 + Hr[6]*1.0; b0[1] = Hr[1]*p0.x2 + Hr[4]*p0.y2 + Hr[7]*1.0; b0[2] = Hr[2]*p0.x2 + Hr[5]*p0.y2 + Hr[8]*1.0;
+            b1[0] = Hr[0]*p1.x2 + Hr[3]*p1.y2 + Hr[6]*1.0; b1[1] = Hr[1]*p1.x2 + Hr[4]*p1.y2 + Hr[7]*1.0; b1[2] = Hr[2]*p1.x2 + Hr[5]*p1.y2 + Hr[8]*1.0;
+            c1[0] = a0[1]*b0[2] - a0[2]*b0[1]; c1[1] = a0[2]*b0[0] - a0[0]*b0[2]; c1[2] = a0[0]*b0[1] - a0[1]*b0[0];
+            c2[0] = a1[1]*b1[2] - a1[2]*b1[1]; c2[1] = a1[2]*b1[0] - a1[0]*b1[2]; c2[2] = a1[0]*b1[1] - a1[1]*b1[0];
+            ec[0] = c1[1]*c2[2] - c1[2]*c2[1]; ec[1] = c1[2]*c2[0] - c1[0]*c2[2]; ec[2] = c1[0]*c2[1] - c1[1]*c2[0];
+            double ecNorm = sqrt(ec[0]*ec[0] + ec[1]*ec[1] + ec[2]*ec[2]);
+            ec[0] = ec[0]/ecNorm; ec[1] = ec[1]/ecNorm; ec[2] = ec[2]/ecNorm;
+            double sk[9] = {0, -ec[2], ec[1], ec[2], 0, -ec[0], -ec[1], ec[0], 0}, Ht[9], aFtH[9];
+            dg_mattr(Ht, Hr, 3, 3);
+            dg_mmul(aFtH, sk, Ht, 3);
+            dg_mattr(aFt, aFtH, 3, 3);
+        }
+        /* Ds = FDs(uN, aFt); v = Ds < 2 th */
+        unsigned no_i;
+        {
+            const dg_pt *P = c.P;
+            dg_pass_cfg cfg = dg_cfg0((int)nhinlCount); cfg.src = idxN; cfg.flags = vN; cfg.thF = th*2;
+            dg_pass_res r = dg_pass(&S->red, cfg, [&](int pid, int) { dg_pt p = P[pid]; return dg_FDs(aFt, p.x1, p.y1, p.x2, p.y2); }, tid);
+            c.n_aux++;
+            no_i = r.nF;
+        }
+        if (no_i > m_i) {
+            /* uV = uN(:, v): ordered compaction of the off-plane ids by their position flags */
+            {
+                const unsigned char *vf = vN;
+                dg_pass_cfg cfg = dg_cfg0((int)nhinlCount); cfg.src = idxN; cfg.list = idxV; cfg.thL = 0.5;
+                dg_pass_res r = dg_pass(&S->red, cfg, [&](int, int pos) { return vf[pos] ? 0.0 : 1.0; }, tid);
+                no_i = r.nL;
+            }
+            m_i = no_i;
+            dg_innerFH(c, idxH, hinlCount, idxV, no_i, th, 15, S->ftmp, inl);
+            unsigned ninl = 0, maxni = 0;
+            for (int j = tid; j < n; j += DG_T) { if (inl[j]) { ninl++; if (nhinl[j]) maxni++; } }
+            ninl = dg_block_sum_u(&S->red, ninl, tid);
+            maxni = dg_block_sum_u(&S->red, maxni, tid);
+            if (ninl > max_i) {
+                max_i = ninl;
+                __syncthreads();
+                if (tid < 9) F[tid] = S->ftmp[tid];
+                __syncthreads();
+                unsigned ns = (unsigned)dg_nsamples((int)maxni, (int)nhinlCount, 2, conf);
+                max_sam = max_sam > ns ? ns : max_sam;
+            }
+        }
+    }
+    return max_i;
+}
+
+#endif /* DG_KERNEL_F_H */

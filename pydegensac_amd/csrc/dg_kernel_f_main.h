@@ -1,0 +1,570 @@
+/* Local optimisation (exp_ranF.c:621-806) and the persistent F kernel body (exp_ranF.c:1244-1767). */
+#ifndef DG_KERNEL_F_MAIN_H
+#define DG_KERNEL_F_MAIN_H
+#include "dg_kernel_f.h"
+
+/* lane 0: hash of an id list in global memory (hash.c:4-47 over the ints' bytes) */
+__device__ __forceinline__ unsigned dg_hash_list(const int *list, int count)
+{
+    unsigned hash = (unsigned)(count * 4), tmp;
+    if (count <= 0) return 0;
+    for (int k = 0; k < count; k++) {
+        unsigned v = (unsigned)list[k];
+        hash += v & 0xffffu;
+        tmp = ((v >> 16) << 11) ^ hash;
+        hash = (hash << 16) ^ tmp;
+        hash += hash >> 11;
+    }
+    hash ^= hash << 3;  hash += hash >> 5;
+    hash ^= hash << 4;  hash += hash >> 17;
+    hash ^= hash << 25; hash += hash >> 6;
+    return hash;
+}
+
+/* exp_ranF.c:621-743 exp_iterFcustom.  f (LDS) is the in/out model parameter `F`; on return *kind0 is the
+ * metric variant (FDS1 / EXFDS1) whose residuals the reference would hold in errs[0] for that model. */
+template <bool LDSPTS>
+__device__ __forceinline__ dg_score dg_iterF(CTX &c, int *inliers, double th, double ths, double *f, int iterID,
+                                             int mk_full, int mk_ex, int *kind0)
+{
+    dg_f_shared *S = c.S; const int n = c.n, tid = c.tid;
+    double *fl = S->fLO;
+    dg_score zero = {0, 0, 0, 0}, maxS = zero, Sc = zero;
+    double dth = (ths - th) / DG_ILSQ_ITERS;
+    /* errs[4] = errs[0] = FDS1(f): one pass gives inlidxs(.., th) and the list at th*MWM */
+    dg_pass_cfg c0 = dg_cfg0(n); c0.wantJ = 1; c0.thJ = th; c0.list = inliers; c0.thL = th * DG_MWM;
+    dg_pass_res r0 = dg_f_pass(c, f, mk_full, c0); c.n_fds++;
+    maxS.I = r0.I; maxS.J = r0.J;
+    *kind0 = mk_full;
+    if (maxS.I < 8) {
+        dg_pass_cfg c1 = dg_cfg0(n); c1.list = inliers; c1.thL = th;      /* the list the reference leaves behind */
+        dg_f_pass(c, f, mk_full, c1);
+        return zero;
+    }
+    {
+        int cnt = (int)r0.nL;                                              /* S.I at th*MWM */
+        int o = 0, use = cnt;
+        __syncthreads();
+        if (8 < cnt) { if (tid == 0) o = dg_randsubset(&S->rng, inliers, cnt, 8); use = 8; o = cnt - 8; }
+        __syncthreads();
+        dg_u2f_list(c, inliers + o, use, 0, 0, fl);
+    }
+    for (int it = 0; it < DG_ILSQ_ITERS; it++) {
+        dg_pass_cfg c1 = dg_cfg0(n); c1.wantJ = 1; c1.thJ = th; c1.list = inliers; c1.thL = th;
+        dg_pass_res r1 = dg_f_pass(c, fl, mk_ex, c1); c.n_exfds++;
+        Sc = zero; Sc.I = r1.I; Sc.J = r1.J;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned hash = dg_hash_list(inliers, (int)Sc.I);
+            int ret = dg_ht_contains(c.ht, hash, (int)Sc.I, iterID);
+            if (ret == -1) dg_ht_insert(c.ht, hash, (int)Sc.I, iterID);
+            S->itmp[0] = (ret != -1 && ret != iterID) ? 1 : 0;
+        }
+        __syncthreads();
+        if (S->itmp[0]) return zero;
+        if (maxS.J < Sc.J) {
+            maxS = Sc; *kind0 = mk_ex;
+            __syncthreads();
+            if (tid < 9) f[tid] = fl[tid];
+            __syncthreads();
+        }
+        dg_pass_cfg c2 = dg_cfg0(n); c2.list = inliers; c2.thL = ths * DG_MWM;
+        dg_pass_res r2 = dg_f_pass(c, fl, mk_ex, c2);
+        if (r2.nL < 8) return maxS;
+        {
+            int cnt = (int)r2.nL, o = 0, use = cnt;
+            __syncthreads();
+            if (8 < cnt) { if (tid == 0) dg_randsubset(&S->rng, inliers, cnt, 8); use = 8; o = cnt - 8; }
+            __syncthreads();
+            /* u2fw: weights are exFDs' w of the current model at the subset points */
+            __syncthreads();
+            if (tid < 9) S->ftmp[tid] = fl[tid];
+            __syncthreads();
+            dg_u2f_list(c, inliers + o, use, S->ftmp, mk_ex == DG_K_FDS ? DG_K_FDS : DG_K_EXFSYM, fl);
+        }
+        ths -= dth;
+    }
+    dg_pass_cfg c3 = dg_cfg0(n); c3.wantJ = 1; c3.thJ = th; c3.list = inliers; c3.thL = th;
+    dg_pass_res r3 = dg_f_pass(c, fl, mk_full, c3); c.n_fds++;
+    if (maxS.J < r3.J) {
+        maxS = zero; maxS.I = r3.I; maxS.J = r3.J; *kind0 = mk_full;
+        __syncthreads();
+        if (tid < 9) f[tid] = fl[tid];
+        __syncthreads();
+    }
+    return maxS;
+}
+
+/* exp_ranF.c:745-806 exp_inFranicustom.  inliers = L[0] (in/out), result model -> Fout (LDS). */
+template <bool LDSPTS>
+__device__ __forceinline__ dg_score dg_inFrani(CTX &c, int ninl, double th, double *Fout, int *iterID,
+                                               int mk_full, int mk_ex, int *kindBest)
+{
+    dg_f_shared *S = c.S; const int tid = c.tid;
+    int *inliers = c.L[0], *intbuff = c.L[1], *intbuff_best = c.L[2];
+    dg_score maxS = {0, 0, 0, 0};
+    *kindBest = mk_full;
+    if (ninl < 16) return maxS;
+    int ssiz = ninl / 2; if (ssiz > 14) ssiz = 14;
+    for (int i = 0; i < DG_RAN_REP; i++) {
+        __syncthreads();
+        if (tid == 0) {
+            int o = dg_randsubset(&S->rng, inliers, ninl, ssiz);
+            dg_gather(c, inliers + o, ssiz, S->lsq.px);
+            dg_u2f_small(&S->lsq, S->lsq.px, 0, ssiz, S->f);
+        }
+        __syncthreads();
+        int k0;
+        ++*iterID;
+        dg_score Sc = dg_iterF(c, intbuff, th, DG_TC * th, S->f, *iterID, mk_full, mk_ex, &k0);
+        if (maxS.J < Sc.J) {
+            maxS = Sc; *kindBest = k0;
+            __syncthreads();
+            if (tid < 9) Fout[tid] = S->f[tid];
+            for (int j = tid; j < (int)maxS.I; j += DG_T) intbuff_best[j] = intbuff[j];
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < (int)maxS.I; j += DG_T) inliers[j] = intbuff_best[j];
+    __syncthreads();
+    return maxS;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+template <bool LDSPTS>
+__global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+    __shared__ dg_f_shared Sh;
+    dg_f_shared *S = &Sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pair = blockIdx.x;
+    const long long off = A.offsets[pair];
+    const int n = (int)(A.offsets[pair + 1] - off);
+    const dg_params &pr = A.prm;
+    const double th = pr.th;
+    long long t_start = wall_clock64();
+
+    char *ws = A.ws + (size_t)pair * A.wl.stride;
+    CTX c;
+    c.S = S; c.n = n; c.tid = tid; c.A = &A; c.off = off;
+    for (int i = 0; i < 10; i++) c.L[i] = (int *)(ws + A.wl.off_lists) + (size_t)i * A.wl.n_max;
+    for (int i = 0; i < 5; i++) c.Fl[i] = (unsigned char *)(ws + A.wl.off_flags) + (size_t)i * A.wl.n_max;
+    c.ht.heads = (int *)(ws + A.wl.off_ht); c.ht.count = c.ht.heads + 64; c.ht.ent = c.ht.heads + 80;
+    c.gmodels = (double *)(ws + A.wl.off_models);
+    c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0;
+    dg_pt *Pw; int *pool;
+    if (LDSPTS) { Pw = (dg_pt *)dyn_smem; pool = (int *)(dyn_smem + (size_t)n * sizeof(dg_pt)); }
+    else        { Pw = (dg_pt *)(ws + A.wl.off_pts); pool = (int *)(ws + A.wl.off_pool); }
+    c.P = Pw; c.pool = pool;
+    const dg_pt *P = Pw;
+
+    /* ---- stage the correspondences (bindings.cpp:337-409: only x,y of each row are geometry) ---- */
+    for (int i = tid; i < n; i += DG_T) {
+        const double *a = A.pts1 + (size_t)(off + i) * A.dim, *b = A.pts2 + (size_t)(off + i) * A.dim;
+        dg_pt p; p.x1 = a[0]; p.y1 = a[1]; p.x2 = b[0]; p.y2 = b[1];
+        Pw[i] = p; pool[i] = i;
+    }
+    dg_ht_init(c.ht, tid);
+    if (tid < 9) { S->F[tid] = 0; S->FBest[tid] = 0; }
+    __syncthreads();
+
+    const int mk_full = pr.error_type == 1 ? DG_K_FSYM : DG_K_FDS;
+    const int mk_ex   = pr.error_type == 1 ? DG_K_EXFSYM : DG_K_FDS;
+    const int doSym = pr.sym_th > 0, doLaf = pr.laf_coef > 0;
+
+    /* ---- driver state (workgroup-uniform, replicated in every lane) ---- */
+    dg_score maxS = {8, 0, 0, 0}, maxSs = {8, 0, 0, 0};
+    int no_sam = 0, max_sam = pr.max_iters, iter_cnt = 0, degen_cnt = 0, iterID = 0, Ihmax = 0;
+    unsigned non_degen = 0;
+    int best_sample = 0; long long t_best = t_start;
+    int finKind = mk_full, accepted = 0;              /* errs[3] = residuals of S->F under finKind */
+    int perm[4] = {0, 1, 2, 3}, p4 = 3, e4kind = mk_full, track = 1;   /* errs[] pointer bookkeeping */
+    double *e4F = S->bufF[0];                         /* model whose residuals errs[4] points at */
+    int done = 0;
+
+    /* srand(seed0); seed = rand() */
+    if (tid == 0) { dg_srand(&S->rng, A.seeds[pair]); S->seeds[0] = (unsigned)dg_rand(&S->rng); }
+    __syncthreads();
+    unsigned seed = S->seeds[0];
+    __syncthreads();
+
+    while (!done && no_sam < max_sam) {
+        /* ================= speculate: DG_CHUNK samples ================= */
+        int chunk = max_sam - no_sam; if (chunk > DG_CHUNK) chunk = DG_CHUNK;
+        if (wave == 0) {
+            unsigned sd = seed;
+            for (int k = 0; k < chunk; k++) { if (lane == 0) S->seeds[k] = sd; sd = dg_rng_next_seed_wave(sd, lane); }
+            if (lane == 0) S->itmp[31] = (int)sd;
+        }
+        __syncthreads();
+        seed = (unsigned)S->itmp[31];
+        if (tid < chunk) {
+            unsigned o[8];
+            dg_rng_outputs(S->seeds[tid], o);
+#pragma unroll
+            for (int i = 0; i < 7; i++) S->draws[tid][i] = (int)(o[i] % (unsigned)(n - i));
+        }
+        __syncthreads();
+        if (wave == 0) {
+            /* rtools.c:12-23 pool swaps: lanes 0..6 own one draw each; the 7 tail slots live in registers */
+            volatile int *vp = pool;
+            int t = (lane < 7) ? vp[n - 1 - lane] : 0;
+            for (int k = 0; k < chunk; k++) {
+                int s = (lane < 7) ? S->draws[k][lane] : (-1 - lane);
+                bool alias = (lane < 7) && (s >= n - 7);
+#pragma unroll
+                for (int d = 1; d < 7; d++) { int so = __shfl(s, (lane + d) % 7, 64); alias = alias || (lane < 7 && so == s); }
+                if (__any(alias)) {
+                    if (lane < 7) vp[n - 1 - lane] = t;
+                    if (!LDSPTS) __threadfence_block();
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) {
+                        for (int i = 0; i < 7; i++) {
+                            int si = S->draws[k][i], j = n - 1 - i, q = vp[si];
+                            vp[si] = vp[j]; vp[j] = q; S->draws[k][i] = q;
+                        }
+                    }
+                    if (!LDSPTS) __threadfence_block();
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < 7) t = vp[n - 1 - lane];
+                } else if (lane < 7) {
+                    int q = vp[s]; vp[s] = t; t = q; S->draws[k][lane] = q;
+                    if (!LDSPTS) __threadfence_block();
+                }
+            }
+            if (lane < 7) vp[n - 1 - lane] = t;
+        }
+        __syncthreads();
+
+        /* ================= solve: one 7-point problem per lane ================= */
+        double fm[3][9]; int nvalid = 0; unsigned char rix[3] = {0, 0, 0}; int nullbad = 0;
+        if (tid < chunk) {
+            dg_pt sp[7];
+            double m[7][9];
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                sp[i] = P[S->draws[tid][i]];
+                double a[3] = {sp[i].x1, sp[i].y1, 1.0}, b[3] = {sp[i].x2, sp[i].y2, 1.0};
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+#pragma unroll
+                    for (int l = 0; l < 3; l++) m[i][3*k+l] = b[k] * a[l];
+            }
+            double f1[9], f2[9];
+            int ok = dg_gj7(m, f1, f2);
+            if (!ok) {
+                /* general utools.c:97-167 path on a private 9x9 copy (degenerate samples only) */
+                double Ag[81], sol[81]; int nb[18];
+                for (int i = 0; i < 7; i++) {
+                    double a[3] = {sp[i].x1, sp[i].y1, 1.0}, b[3] = {sp[i].x2, sp[i].y2, 1.0};
+                    for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) Ag[9*i+3*k+l] = b[k] * a[l];
+                }
+                for (int i = 63; i < 81; i++) Ag[i] = 0;
+                for (int i = 0; i < 81; i++) sol[i] = 0;
+                int ns = dg_nullspace(Ag, sol, 9, nb);
+                if (ns == 2) { for (int i = 0; i < 9; i++) { f1[i] = sol[i]; f2[i] = sol[9+i]; } ok = 1; }
+                else nullbad = 1;
+            }
+            if (ok) {
+                double poly[4], roots[3];
+                dg_slcm(f1, f2, poly);
+                int nsol = dg_rroots3(poly, roots);
+                for (int i = 0; i < nsol; i++) {
+                    double f[9];
+#pragma unroll
+                    for (int j = 0; j < 9; j++) f[j] = f1[j] * roots[i] + f2[j] * (1 - roots[i]);
+                    if (!dg_ori_valid7(f, sp)) continue;
+#pragma unroll
+                    for (int j = 0; j < 9; j++) fm[nvalid][j] = f[j];
+                    rix[nvalid] = (unsigned char)i; nvalid++;
+                }
+            }
+        }
+        /* ordered slots: exclusive scan of nvalid over the lanes of the chunk */
+        {
+            unsigned v = (unsigned)nvalid, incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            if (lane == 63) S->wave_cnt[wave] = incl;
+            __syncthreads();
+            unsigned wbase = 0;
+            for (int w = 0; w < wave; w++) wbase += S->wave_cnt[w];
+            unsigned excl = wbase + incl - v;
+            if (tid < chunk) {
+                S->moff[tid] = (unsigned short)excl;
+                S->nv[tid] = nullbad ? 255 : (unsigned char)nvalid;
+                for (int r = 0; r < nvalid; r++) {
+                    S->ridx[tid][r] = rix[r];
+                    double *g = c.gmodels + (size_t)(excl + r) * 9;
+#pragma unroll
+                    for (int j = 0; j < 9; j++) g[j] = fm[r][j];
+                }
+            }
+            if (tid == DG_T - 1) S->moff[DG_CHUNK] = (unsigned short)(excl + v);
+            __syncthreads();
+        }
+        const int Mtot = S->moff[DG_CHUNK];
+
+        /* ================= score: one wave per model, points streamed from LDS ================= */
+        for (int mi = wave; mi < Mtot; mi += DG_NW) {
+            double F[9];
+            const double *g = c.gmodels + (size_t)mi * 9;
+#pragma unroll
+            for (int j = 0; j < 9; j++) F[j] = g[j];
+            unsigned I = 0; double J = 0; const double t94 = th * 9 / 4;
+            for (int base = 0; base < n; base += 64) {
+                int p = base + lane; bool act = p < n;
+                double d = 0;
+                if (act) { dg_pt q = P[p]; d = dg_Ferr(mk_full, F, q); }
+                double term = 0.0;
+                if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
+                J += dg_tile_sum(term);
+                I += (unsigned)__popcll(__ballot(act && d <= th));
+            }
+            if (lane == 0) { S->res_I[mi] = I; S->res_J[mi] = J; }
+        }
+        c.n_fds += Mtot;   /* provisional: models past the termination point are subtracted below */
+        __syncthreads();
+
+        /* ================= commit: replay exp_ranF.c:1334-1577 in order ================= */
+        int k;
+        for (k = 0; k < chunk; k++) {
+            if (no_sam >= max_sam) break;
+            no_sam++;
+            const int nvk = S->nv[k];
+            if (nvk == 255) continue;                              /* nullsize != 2 */
+            int new_max = 0, do_iterate = 0, rng_ready = 0, brk = 0;
+            for (int r = 0; r < nvk && !brk; r++) {
+                const int mi = S->moff[k] + r, ri = S->ridx[k][r];
+                dg_score Sc = {S->res_I[mi], S->res_J[mi], 0, 0};
+                const int phys = perm[ri];
+                const bool ev1 = maxS.J < Sc.J, ev2 = maxSs.J < Sc.J;
+                if (!(ev1 || ev2)) {
+                    if (track && phys == p4) { __syncthreads(); if (tid < 9) e4F[tid] = c.gmodels[(size_t)mi*9 + tid]; e4kind = mk_full; __syncthreads(); }
+                    continue;
+                }
+                __syncthreads();
+                if (tid < 9) S->f[tid] = c.gmodels[(size_t)mi*9 + tid];
+                __syncthreads();
+                if (track && phys == p4) { if (tid < 9) e4F[tid] = S->f[tid]; e4kind = mk_full; __syncthreads(); }
+                if (ev1) {
+                    int pass = 1;
+                    if (doSym || doLaf) {
+                        /* `inliers` = exact th-list of this model */
+                        dg_pass_cfg cl = dg_cfg0(n); cl.list = c.L[0]; cl.thL = th;
+                        dg_pass_res rl = dg_f_pass(c, S->f, mk_full, cl);
+                        pass = dg_f_checks(c, S->f, c.L[0], (int)rl.nL, Sc, maxS, mk_full);
+                    }
+                    if (!pass) continue;
+                    { int t = perm[ri]; perm[ri] = perm[3]; perm[3] = t; }
+                    maxS = Sc;
+                    __syncthreads();
+                    if (tid < 9) S->F[tid] = S->f[tid];
+                    __syncthreads();
+                    new_max = 1; accepted = 1; finKind = mk_full; best_sample = no_sam; t_best = wall_clock64();
+                }
+                if (maxSs.J < Sc.J) {
+                    maxSs = Sc;
+                    int degenerate = 0;
+                    if (pr.degen) {
+                        __syncthreads();
+                        if (tid == 0) {
+                            for (int i = 0; i < 7; i++) {              /* u7 in samidx order = reverse draw order */
+                                dg_pt q = P[S->draws[k][6 - i]];
+                                S->u7[i][0] = q.x1; S->u7[i][1] = q.y1; S->u7[i][2] = q.x2; S->u7[i][3] = q.y2;
+                            }
+                            S->itmp[1] = dg_checksample(&S->lsq, S->f, S->u7, 3*th, S->H);
+                        }
+                        __syncthreads();
+                        degenerate = S->itmp[1];
+                    }
+                    if (degenerate) {
+                        if (!rng_ready) {
+                            __syncthreads();
+                            if (tid == 0) { dg_srand(&S->rng, S->seeds[k]); for (int i = 0; i < 8; i++) dg_rand(&S->rng); }
+                            __syncthreads();
+                            rng_ready = 1;
+                        }
+                        dg_pass_cfg ch = dg_cfg0(n); ch.flags = c.Fl[1]; ch.thF = th*3;
+                        dg_pass_res rh = dg_h_pass(c, S->H, ch); c.n_hds++;
+                        unsigned I = rh.nF;
+                        if (I < 8) { brk = 1; c.n_fds -= (nvk - 1 - r); break; }   /* exp_ranF.c:1437-1439: later roots are never scored */
+                        I = dg_innerH(c, S->H, 16*th, 10, c.Fl[0]);
+                        if ((int)I > Ihmax) Ihmax = (int)I;
+                        if (I > 6) {
+                            I = dg_rFtH(c, c.Fl[0], th, S->H, S->f);
+                            int dphys;
+                            if (I > maxS.I) {
+                                maxS.I = I;
+                                __syncthreads();
+                                if (tid < 9) S->F[tid] = S->f[tid];
+                                __syncthreads();
+                                new_max = 1; accepted = 1; finKind = mk_full; best_sample = no_sam; t_best = wall_clock64();
+                                dphys = perm[3];
+                            } else dphys = perm[ri];
+                            /* FDS1(u, f, errs[..]) + the I/J recount (exp_ranF.c:1456-1480) */
+                            dg_pass_cfg cj = dg_cfg0(n); cj.wantJ = 1; cj.thJ = th;
+                            dg_pass_res rj = dg_f_pass(c, S->f, mk_full, cj); c.n_fds++;
+                            if (new_max) maxS.J = rj.J;
+                            if (track && dphys == p4) { __syncthreads(); if (tid < 9) e4F[tid] = S->f[tid]; e4kind = mk_full; __syncthreads(); }
+                            ++degen_cnt;
+                        }
+                    } else {
+                        do_iterate = (no_sam > DG_ITER_SAM);
+                        p4 = phys;                                  /* errs[4] = d */
+                        __syncthreads();
+                        if (tid < 9) { e4F[tid] = S->f[tid]; S->FBest[tid] = S->f[tid]; }
+                        if (tid < 7) S->samidxBest[tid] = S->draws[k][6 - tid];
+                        e4kind = mk_full;
+                        __syncthreads();
+                        non_degen++;
+                    }
+                }
+            }
+            if (no_sam == DG_ITER_SAM && non_degen) do_iterate = 1;
+
+            if (do_iterate) {
+                if (!rng_ready) {
+                    __syncthreads();
+                    if (tid == 0) { dg_srand(&S->rng, S->seeds[k]); for (int i = 0; i < 8; i++) dg_rand(&S->rng); }
+                    __syncthreads();
+                    rng_ready = 1;
+                }
+                iter_cnt++; track = 0;
+                /* LSQ before LO: S = inlidxs(errs[4], TC*th*MWM); u2f; FDS1; inlidxs(th)  (:1506-1511) */
+                dg_pass_cfg ca = dg_cfg0(n); ca.list = c.L[0]; ca.thL = DG_TC * th * DG_MWM;
+                dg_pass_res ra = dg_f_pass(c, e4F, e4kind, ca);
+                dg_u2f_list(c, c.L[0], (int)ra.nL, 0, 0, S->f);
+                dg_pass_cfg cb = dg_cfg0(n); cb.list = c.L[0]; cb.thL = th;
+                dg_pass_res rb = dg_f_pass(c, S->f, mk_full, cb); c.n_fds++;
+                int kb;
+                dg_score Sl = dg_inFrani(c, (int)rb.nL, th, S->Hx /* LO result model */, &iterID, mk_full, mk_ex, &kb);
+                if (maxS.J < Sl.J) {
+                    if (dg_f_checks(c, S->Hx, c.L[0], (int)Sl.I, Sl, maxS, mk_full)) {
+                        maxS = Sl;
+                        __syncthreads();
+                        if (tid < 9) S->F[tid] = S->Hx[tid];
+                        __syncthreads();
+                        new_max = 1; accepted = 1; finKind = kb; best_sample = no_sam; t_best = wall_clock64();
+                    }
+                }
+                if (new_max) {
+                    int new_sam = dg_nsamples((int)maxS.I + 1, n, 7, pr.conf);
+                    if (new_sam < max_sam) max_sam = new_sam;
+                }
+            }
+        }
+        /* models of samples that were never committed do not count as scored */
+        if (k < chunk) { c.n_fds -= (Mtot - (int)S->moff[k]); done = 1; }
+        __syncthreads();
+    }
+
+    /* ---- "If there were no LOs, do at least one NOW!"  exp_ranF.c:1580-1697 ---- */
+    if (!iter_cnt && !degen_cnt && non_degen) {
+        int degenerate = 0;
+        /* the libc stream continues from wherever the last iteration left it: after its seed draw */
+        __syncthreads();
+        if (tid == 0) {
+            if (pr.degen) {
+                for (int i = 0; i < 7; i++) { dg_pt q = P[S->samidxBest[i]]; S->u7[i][0] = q.x1; S->u7[i][1] = q.y1; S->u7[i][2] = q.x2; S->u7[i][3] = q.y2; }
+                S->itmp[1] = dg_checksample(&S->lsq, S->FBest, S->u7, 3*th, S->H);
+            } else S->itmp[1] = 0;
+            /* state after the last executed iteration: srand(prev seed) + 8 outputs == srand(prev), so replay it */
+            S->itmp[2] = 0;
+        }
+        __syncthreads();
+        degenerate = S->itmp[1];
+        /* RNG: re-create the state the reference has here (last iteration's srand + 7 draws + seed draw) */
+        __syncthreads();
+        if (tid == 0) {
+            /* S->seeds[] of the last chunk still holds the per-iteration seeds; the last executed
+             * iteration is no_sam (1-based) => index (no_sam-1) % DG_CHUNK within its chunk */
+            int li = (no_sam - 1) % DG_CHUNK;
+            dg_srand(&S->rng, S->seeds[li]); for (int i = 0; i < 8; i++) dg_rand(&S->rng);
+        }
+        __syncthreads();
+        if (degenerate) {
+            dg_pass_cfg ch = dg_cfg0(n); ch.flags = c.Fl[1]; ch.thF = th*3;
+            dg_pass_res rh = dg_h_pass(c, S->H, ch); c.n_hds++;
+            unsigned I = rh.nF;
+            if (I >= 8) I = dg_innerH(c, S->H, 16*th, 10, c.Fl[0]);
+            else { for (int j = tid; j < n; j += DG_T) c.Fl[0][j] = 0; __syncthreads(); }
+            if ((int)I > Ihmax) Ihmax = (int)I;
+            if (I > 6) {
+                __syncthreads();
+                if (tid < 9) S->f[tid] = S->FBest[tid];
+                __syncthreads();
+                I = dg_rFtH(c, c.Fl[0], th, S->H, S->f);
+                int nm = 0;
+                if (I > maxS.I) {
+                    maxS.I = I;
+                    __syncthreads();
+                    if (tid < 9) S->F[tid] = S->f[tid];
+                    __syncthreads();
+                    nm = 1; accepted = 1; finKind = mk_full; best_sample = no_sam; t_best = wall_clock64();
+                }
+                dg_pass_cfg cj = dg_cfg0(n); cj.wantJ = 1; cj.thJ = th;
+                dg_pass_res rj = dg_f_pass(c, S->f, mk_full, cj); c.n_fds++;
+                if (nm) maxS.J = rj.J;
+                ++degen_cnt;
+            }
+        } else {
+            iter_cnt++;
+            dg_pass_cfg ca = dg_cfg0(n); ca.list = c.L[0]; ca.thL = DG_TC * th * DG_MWM;
+            dg_pass_res ra = dg_f_pass(c, S->FBest, mk_full, ca);
+            dg_u2f_list(c, c.L[0], (int)ra.nL, 0, 0, S->f);
+            dg_pass_cfg cb = dg_cfg0(n); cb.list = c.L[0]; cb.thL = th;
+            dg_pass_res rb = dg_f_pass(c, S->f, mk_full, cb); c.n_fds++;
+            int kb;
+            dg_score Sl = dg_inFrani(c, (int)rb.nL, th, S->Hx, &iterID, mk_full, mk_ex, &kb);
+            if (maxS.J < Sl.J) {
+                if (dg_f_checks(c, S->Hx, c.L[0], (int)Sl.I, Sl, maxS, mk_full)) {
+                    maxS = Sl;
+                    __syncthreads();
+                    if (tid < 9) S->F[tid] = S->Hx[tid];
+                    __syncthreads();
+                    accepted = 1; finKind = kb; best_sample = no_sam; t_best = wall_clock64();
+                }
+            }
+        }
+    }
+
+    /* ---- final mask: exp_ranF.c:1699-1740 ---- */
+    unsigned char *mask = A.mask_out + off;
+    if (!accepted) {
+        for (int j = tid; j < n; j += DG_T) mask[j] = 0;
+    } else {
+        double F[9];
+        for (int i = 0; i < 9; i++) F[i] = S->F[i];
+        for (int j = tid; j < n; j += DG_T) mask[j] = dg_Ferr(finKind, F, P[j]) <= th ? 1 : 0;
+        __syncthreads();
+        if (doSym || (doLaf && pr.final_laf_filter)) {
+            dg_pass_cfg cl = dg_cfg0(n); cl.list = c.L[0]; cl.thL = th;
+            dg_pass_res rl = dg_f_pass(c, S->F, finKind, cl);
+            const int cnt = (int)rl.nL; const int *lst = c.L[0];
+            /* clears list POSITION j, not lst[j]: exp_ranF.c:1719-1721 */
+            if (doSym)
+                for (int j = tid; j < cnt; j += DG_T) if (dg_Ferr(DG_K_FSYM, F, P[lst[j]]) > pr.sym_th) mask[j] = 0;
+            if (doLaf && pr.final_laf_filter) {
+                double thl = pr.laf_coef * th;
+                for (int j = tid; j < cnt; j += DG_T) {
+                    if (dg_Ferr(mk_full, F, c.laf_pt(lst[j], 1)) > thl) mask[j] = 0;
+                    if (dg_Ferr(mk_full, F, c.laf_pt(lst[j], 2)) > thl) mask[j] = 0;
+                }
+            }
+        }
+    }
+    if (tid < 9) A.model_out[(size_t)pair * 9 + tid] = accepted ? S->F[tid] : 0.0;
+    if (A.stats_out && tid == 0) {
+        int *st = A.stats_out + (size_t)pair * 16;
+        long long t_end = wall_clock64();
+        st[0] = no_sam; st[1] = iter_cnt; st[2] = 0; st[3] = (int)maxS.I; st[4] = c.n_fds + c.n_exfds;
+        st[5] = degen_cnt; st[6] = Ihmax; st[7] = best_sample; st[8] = c.n_fds; st[9] = c.n_exfds;
+        st[10] = c.n_hds; st[11] = c.n_aux; st[12] = (int)(t_best - t_start); st[13] = (int)(t_end - t_start);
+        st[14] = 0; st[15] = 0;
+    }
+}
+
+#endif /* DG_KERNEL_F_MAIN_H */

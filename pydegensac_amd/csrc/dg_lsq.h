@@ -1,0 +1,191 @@
+/* Non-minimal solvers (normalised least squares) of the LO / DEGENSAC steps.
+ *   - "small" variants (<= 16 correspondences): lane 0, reference statement order, bit-compatible
+ *     with the scalar reference up to the restated dsyev / SVD.
+ *   - "big" variants (an inlier list of any length): the whole workgroup accumulates the Hartley
+ *     normalisation and the 9x9 normal matrix in parallel, lane 0 finishes (eig, rank-2, denorm).
+ */
+#ifndef DG_LSQ_H
+#define DG_LSQ_H
+#include "dg_kernel_common.h"
+
+struct dg_lsq_scratch {
+    double Z[24 * 9];          /* design matrix of a small problem (<= 14 F rows or 2*12 H rows) */
+    double V[81], D[9];
+    double A1[3], A2[3];
+    double Z8[72], U9[81], V8[64], D8[8];
+    double part[DG_NW][48];    /* per-wave partial sums of the big variants */
+    double out[9];
+    double px[16 * 4];         /* gathered coordinates of a small problem */
+};
+
+/* utools.c:7-51 normu over k gathered points p[4*i + {0,1,2,3}] = x1,y1,x2,y2 */
+__device__ __forceinline__ void dg_normu_small(const double *p, int len, double *A1, double *A2)
+{
+    int i, j; double a, b;
+    for (j = 0; j < 3; j++) { A1[j] = 0; A2[j] = 0; }
+    for (j = 0; j < len; j++) { A1[1] += p[4*j]; A1[2] += p[4*j+1]; A2[1] += p[4*j+2]; A2[2] += p[4*j+3]; }
+    if (len > 0) for (i = 1; i < 3; i++) { A1[i] /= len; A2[i] /= len; }
+    for (j = 0; j < len; j++) {
+        a = p[4*j] - A1[1]; b = p[4*j+1] - A1[2]; A1[0] += sqrt(a*a + b*b);
+        a = p[4*j+2] - A2[1]; b = p[4*j+3] - A2[2]; A2[0] += sqrt(a*a + b*b);
+    }
+    if (A1[0] != 0) A1[0] = len * sqrt(2.0) / A1[0];
+    if (A2[0] != 0) A2[0] = len * sqrt(2.0) / A2[0];
+    A1[1] *= -A1[0]; A1[2] *= -A1[0];
+    A2[1] *= -A2[0]; A2[2] *= -A2[0];
+}
+
+/* utools.c:170-184 cov_mat, rows x 9 */
+__device__ __forceinline__ void dg_cov9(double *Cv, const double *Z, int rows)
+{
+    for (int i = 0; i < 9; i++)
+        for (int j = 0; j <= i; j++) {
+            double val = 0;
+            for (int k = 0; k < rows; k++) val += Z[9*k+i] * Z[9*k+j];
+            Cv[9*i+j] = val; Cv[i+9*j] = val;
+        }
+}
+
+/* Ftools.c:350-458 u2f / u2fw on `len` gathered points (lane 0 only).  wts: per-point weights or 0. */
+__device__ __noinline__ void dg_u2f_small(dg_lsq_scratch *s, const double *p, const double *wts, int len, double *F)
+{
+    int i, j, k, l;
+    if (len > 8) {
+        dg_normu_small(p, len, s->A1, s->A2);
+        for (i = 0; i < len; i++) {                                   /* lin_fmN, Ftools.c:300-328 */
+            double a[3], b[3];
+            a[2] = 1; b[2] = 1;
+            a[0] = p[4*i]   * s->A1[0] + s->A1[1]; a[1] = p[4*i+1] * s->A1[0] + s->A1[2];
+            b[0] = p[4*i+2] * s->A2[0] + s->A2[1]; b[1] = p[4*i+3] * s->A2[0] + s->A2[2];
+            for (k = 0; k < 3; k++) for (l = 0; l < 3; l++) s->Z[9*i + 3*k + l] = a[l] * b[k];
+        }
+        if (wts) for (i = 0; i < len; i++) for (k = 0; k < 9; k++) s->Z[9*i+k] *= wts[i];
+        dg_cov9(s->V, s->Z, len);
+        dg_eig_sym(s->V, s->D, 9);
+        j = 0; for (i = 1; i < 9; i++) if (s->D[i] < s->D[j]) j = i;
+        for (i = 0; i < 9; i++) F[i] = s->V[j*9 + i];
+    } else {
+        for (i = 0; i < 72; i++) s->Z8[i] = 0.;
+        for (i = 0; i < len && i < 8; i++) {
+            double a[3] = {p[4*i], p[4*i+1], 1.0}, b[3] = {p[4*i+2], p[4*i+3], 1.0};
+            for (k = 0; k < 3; k++) for (l = 0; l < 3; l++) s->Z8[(k*3+l)*8 + i] = b[k] * a[l];
+        }
+        /* Ftools.c:427-432: scalmul(Z+i, w, 9, 9) strides by 9 over a row stride of 8 (reproduced) */
+        if (wts) for (i = 0; i < len && i < 8; i++) for (k = 0; k < 9; k++) if (i + 9*k < 72) s->Z8[i + 9*k] *= wts[i];
+        dg_svduv(s->D8, s->Z8, s->U9, 9, s->V8, 8);
+        for (i = 0; i < 9; i++) F[i] = s->U9[i*9 + 8];
+    }
+    dg_singulF(F);
+    if (len > 8) dg_denormF(F, s->A1, s->A2);
+}
+
+/* Htools.c:101-133 u2h on `len` gathered points (lane 0 only) */
+__device__ __noinline__ void dg_u2h_small(dg_lsq_scratch *s, const double *p, int len, double *H)
+{
+    int i, j;
+    if (len < 4) return;
+    if (len == 4) {
+        /* Htools.c:106-114 incl. the 9x8-as-9x9 transposition (never-written entries zeroed) */
+        int nb[18];
+        for (i = 0; i < 81; i++) { s->V[i] = 0.; s->U9[i] = 0.; }
+        for (i = 0; i < 4; i++) {
+            double s0 = p[4*i], s1 = p[4*i+1], s3 = p[4*i+2], s4 = p[4*i+3];
+            double z0[9] = {s3, 0, -s0*s3, s4, 0, -s0*s4, 1.0, 0, -s0*1.0};
+            double z1[9] = {0, s3, -s1*s3, 0, s4, -s1*s4, 0, 1.0, -s1*1.0};
+            for (j = 0; j < 9; j++) { s->U9[j*8 + 2*i] = z0[j]; s->U9[j*8 + 2*i + 1] = z1[j]; }
+        }
+        dg_trnm(s->U9, 9);
+        for (i = 72; i < 81; i++) s->U9[i] = 0.;
+        dg_nullspace(s->U9, s->V, 9, nb);
+        for (i = 0; i < 9; i++) H[i] = s->V[i];
+    } else {
+        dg_normu_small(p, len, s->A1, s->A2);
+        for (i = 0; i < len; i++) {                                   /* lin_hgN, Htools.c:60-99 */
+            double a0 = p[4*i]   * s->A1[0] + s->A1[1], a1 = p[4*i+1] * s->A1[0] + s->A1[2];
+            double b[3] = {p[4*i+2] * s->A2[0] + s->A2[1], p[4*i+3] * s->A2[0] + s->A2[2], 1.0};
+            double *z = s->Z + 18*i;
+            for (j = 0; j < 3; j++) { z[3*j] = b[j]; z[3*j+1] = 0; z[3*j+2] = -a0 * b[j]; }
+            for (j = 0; j < 3; j++) { z[9+3*j] = 0; z[9+3*j+1] = b[j]; z[9+3*j+2] = -a1 * b[j]; }
+        }
+        dg_cov9(s->V, s->Z, 2*len);
+        dg_eig_sym(s->V, s->D, 9);
+        for (i = 0; i < 9; i++) H[i] = s->V[i];
+        dg_denormH(H, s->A1, s->A2);
+    }
+}
+
+/* ---- workgroup-parallel normalised 8-point LSQ over a list of point ids (Ftools.c:350-398) ----- */
+template <class PtFn>
+__device__ __forceinline__ void dg_u2f_big(dg_red *r, dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, double *Fout /* LDS */)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    /* pass 1: centroids */
+    double sx1 = 0, sy1 = 0, sx2 = 0, sy2 = 0;
+    for (int j = tid; j < len; j += DG_T) { dg_pt p = pt(list[j]); sx1 += p.x1; sy1 += p.y1; sx2 += p.x2; sy2 += p.y2; }
+    sx1 = dg_wave_sum_d(sx1); sy1 = dg_wave_sum_d(sy1); sx2 = dg_wave_sum_d(sx2); sy2 = dg_wave_sum_d(sy2);
+    __syncthreads();
+    if (lane == 0) { s->part[wave][0] = sx1; s->part[wave][1] = sy1; s->part[wave][2] = sx2; s->part[wave][3] = sy2; }
+    __syncthreads();
+    double m1x = 0, m1y = 0, m2x = 0, m2y = 0;
+    for (int w = 0; w < DG_NW; w++) { m1x += s->part[w][0]; m1y += s->part[w][1]; m2x += s->part[w][2]; m2y += s->part[w][3]; }
+    m1x /= len; m1y /= len; m2x /= len; m2y /= len;
+    /* pass 2: mean distances */
+    double d1 = 0, d2 = 0;
+    for (int j = tid; j < len; j += DG_T) {
+        dg_pt p = pt(list[j]);
+        double a = p.x1 - m1x, b = p.y1 - m1y; d1 += sqrt(a*a + b*b);
+        a = p.x2 - m2x; b = p.y2 - m2y; d2 += sqrt(a*a + b*b);
+    }
+    d1 = dg_wave_sum_d(d1); d2 = dg_wave_sum_d(d2);
+    __syncthreads();
+    if (lane == 0) { s->part[wave][0] = d1; s->part[wave][1] = d2; }
+    __syncthreads();
+    double A1[3], A2[3];
+    A1[0] = 0; A2[0] = 0;
+    for (int w = 0; w < DG_NW; w++) { A1[0] += s->part[w][0]; A2[0] += s->part[w][1]; }
+    if (A1[0] != 0) A1[0] = len * sqrt(2.0) / A1[0];
+    if (A2[0] != 0) A2[0] = len * sqrt(2.0) / A2[0];
+    A1[1] = m1x * -A1[0]; A1[2] = m1y * -A1[0];
+    A2[1] = m2x * -A2[0]; A2[2] = m2y * -A2[0];
+    /* pass 3: normal matrix, 45 unique entries */
+    double acc[45];
+#pragma unroll
+    for (int e = 0; e < 45; e++) acc[e] = 0;
+    for (int j = tid; j < len; j += DG_T) {
+        dg_pt p = pt(list[j]);
+        double a[3], b[3], z[9];
+        a[2] = 1; b[2] = 1;
+        a[0] = p.x1 * A1[0] + A1[1]; a[1] = p.y1 * A1[0] + A1[2];
+        b[0] = p.x2 * A2[0] + A2[1]; b[1] = p.y2 * A2[0] + A2[2];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int l = 0; l < 3; l++) z[3*k+l] = a[l] * b[k];
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+#pragma unroll
+            for (int q = 0; q <= i; q++) { acc[e] += z[i] * z[q]; e++; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 45; e++) { double v = dg_wave_sum_d(acc[e]); if (lane == 0) s->part[wave][e] = v; }
+    __syncthreads();
+    if (tid == 0) {
+        int e = 0;
+        for (int i = 0; i < 9; i++)
+            for (int q = 0; q <= i; q++) {
+                double v = 0;
+                for (int w = 0; w < DG_NW; w++) v += s->part[w][e];
+                s->V[9*i+q] = v; s->V[i+9*q] = v; e++;
+            }
+        dg_eig_sym(s->V, s->D, 9);
+        int jm = 0; for (int i = 1; i < 9; i++) if (s->D[i] < s->D[jm]) jm = i;
+        for (int i = 0; i < 9; i++) Fout[i] = s->V[jm*9 + i];
+        dg_singulF(Fout);
+        dg_denormF(Fout, A1, A2);
+    }
+    __syncthreads();
+}
+
+#endif /* DG_LSQ_H */
