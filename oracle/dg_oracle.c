@@ -41,6 +41,11 @@ typedef void (*dg_trace_fn)(int kind, const double *f);
 static dg_trace_fn g_trace = 0;
 void dg_oracle_set_trace(dg_trace_fn fn) { g_trace = fn; }
 #define TRACE(kind, f) do { if (g_trace) g_trace(kind, f); } while (0)
+/* second hook: (tag, I, J) checkpoints inside the local optimisation, mirrored by the device's debug trace */
+typedef void (*dg_trace2_fn)(int tag, int I, double J);
+static dg_trace2_fn g_trace2 = 0;
+void dg_oracle_set_trace2(dg_trace2_fn fn) { g_trace2 = fn; }
+#define TRACE2(tag, I, J) do { if (g_trace2) g_trace2(tag, (int)(I), (double)(J)); } while (0)
 
 typedef struct {
     dg_rng rng;
@@ -627,8 +632,10 @@ static dg_score exp_iterFcustom(dg_ctx *c, const double *u, int len, int *inlier
     w = (double *)malloc(len * sizeof(double));
     dth = (ths - th) / ILSQ_ITERS;
     maxS = inlidxs(errs[4], len, th, inliers);
+    TRACE2(10, maxS.I, maxS.J);
     if (maxS.I < 8) { free(w); return S; }
     S = inlidxs(errs[4], len, th*MWM, inliers);
+    TRACE2(15, S.I, 0);
     detachedCount = (unsigned)(int)(S.I * 1);              /* D3_F_RATIO=1, D3_F_MIN=0: exp_ranF.h:15-16 */
     if (detachedCount > inlLimit) detachedCount = inlLimit;
     if (detachedCount < 8) detachedCount = 8;
@@ -637,15 +644,17 @@ static dg_score exp_iterFcustom(dg_ctx *c, const double *u, int len, int *inlier
     for (it = 0; it < iters; it++) {
         EXFDS1(u, f, d, w, len); c->n_exfds++; TRACE(1, f);
         S = inlidxs(d, len, th, inliers);
+        TRACE2(11, S.I, S.J);
         hash = dg_superfasthash((const unsigned char *)inliers, (int)(S.I * sizeof(*inliers)));
         iterIDret = htContains(c, hash, S.I, iterID);
-        if (iterIDret != -1 && iterIDret != iterID) { S.I = 0; S.J = 0; free(w); return S; }
+        if (iterIDret != -1 && iterIDret != iterID) { TRACE2(13, iterIDret, 0); S.I = 0; S.J = 0; free(w); return S; }
         if (iterIDret == -1) htInsert(c, hash, S.I, iterID);
         if (scoreLess(maxS, S)) {
             maxS = S; errs[1] = errs[0]; errs[0] = d; d = errs[1];
             memcpy(F, f, 9 * sizeof(double));
         }
         Ss = inlidxs(d, len, ths*MWM, inliers);
+        TRACE2(14, Ss.I, 0);
         if (Ss.I < 8) { free(w); return maxS; }
         detachedCount = (unsigned)(int)(Ss.I * 1);
         if (detachedCount > inlLimit) detachedCount = inlLimit;
@@ -656,6 +665,7 @@ static dg_score exp_iterFcustom(dg_ctx *c, const double *u, int len, int *inlier
     }
     FDS1(u, f, d, len); c->n_fds++; TRACE(0, f);
     S = inlidxs(d, len, th, inliers);
+    TRACE2(12, S.I, S.J);
     if (scoreLess(maxS, S)) {
         maxS = S; errs[1] = errs[0]; errs[0] = d;
         memcpy(F, f, 9 * sizeof(double));
@@ -835,9 +845,11 @@ static int exp_ransacFcustomLAF(dg_ctx *c, const double *u, const double *u_1, c
             iter_cnt++;
             d = errs[0];
             S = inlidxs(errs[4], len, TC*th*MWM, inliers);
+            TRACE2(1, S.I, no_sam);
             u2f(u, inliers, S.I, f);
             FDS1(u, f, d, len); c->n_fds++; TRACE(0, f);
             S = inlidxs(d, len, th, inliers);
+            TRACE2(2, S.I, S.J);
             S = exp_inFranicustom(c, u, len, inliers, S.I, th, errs, f, &iterID, inlLimit, EXFDS1, FDS1);
             if (scoreLess(maxS, S)) {
                 if (f_checks(u, u_1, u_2, len, f, inliers, &S, &maxS, doSymCheck, SymCheck_th, DO_LAF_CHECK,

@@ -49,6 +49,8 @@ struct dg_args {
     dg_ws_layout wl;
     dg_params prm;
     int dim, n_pairs, pts_in_lds;
+    int *trace;                      /* debug: [0] = count, then (tag, I, J lo, J hi) records; null = off */
+    int trace_cap;
 };
 
 /* ---- glibc TYPE_3 fast path ----------------------------------------------------------------------

@@ -66,6 +66,11 @@ struct dg_f_ctx {
 
 #define CTX dg_f_ctx<LDSPTS>
 
+/* debug checkpoints (tag, I, J), mirrored by the oracle's TRACE2 hook; active only when A.trace != 0 */
+#define DG_TRACE(c, tag, I, J) do { if ((c).A->trace && (c).tid == 0) { int *t_ = (c).A->trace; int k_ = t_[0]; \
+    if (k_ < (c).A->trace_cap) { long long jb_ = __double_as_longlong((double)(J)); t_[1+4*k_] = (tag); t_[2+4*k_] = (int)(I); \
+    t_[3+4*k_] = (int)(jb_ & 0xffffffffll); t_[4+4*k_] = (int)(jb_ >> 32); t_[0] = k_ + 1; } } } while (0)
+
 /* a full scoring pass of model F (kind) with optional list/flags; counts as FDS1/EXFDS1/aux */
 template <bool LDSPTS>
 __device__ __forceinline__ dg_pass_res dg_f_pass(CTX &c, const double *Fm /* LDS */, int kind, dg_pass_cfg cfg)

@@ -36,6 +36,7 @@ __device__ __forceinline__ dg_score dg_iterF(CTX &c, int *inliers, double th, do
     dg_pass_res r0 = dg_f_pass(c, f, mk_full, c0); c.n_fds++;
     maxS.I = r0.I; maxS.J = r0.J;
     *kind0 = mk_full;
+    DG_TRACE(c, 10, maxS.I, maxS.J);
     if (maxS.I < 8) {
         dg_pass_cfg c1 = dg_cfg0(n); c1.list = inliers; c1.thL = th;      /* the list the reference leaves behind */
         dg_f_pass(c, f, mk_full, c1);
@@ -43,6 +44,7 @@ __device__ __forceinline__ dg_score dg_iterF(CTX &c, int *inliers, double th, do
     }
     {
         int cnt = (int)r0.nL;                                              /* S.I at th*MWM */
+        DG_TRACE(c, 15, cnt, 0);
         int o = 0, use = cnt;
         __syncthreads();
         if (8 < cnt) { if (tid == 0) o = dg_randsubset(&S->rng, inliers, cnt, 8); use = 8; o = cnt - 8; }
@@ -53,6 +55,7 @@ __device__ __forceinline__ dg_score dg_iterF(CTX &c, int *inliers, double th, do
         dg_pass_cfg c1 = dg_cfg0(n); c1.wantJ = 1; c1.thJ = th; c1.list = inliers; c1.thL = th;
         dg_pass_res r1 = dg_f_pass(c, fl, mk_ex, c1); c.n_exfds++;
         Sc = zero; Sc.I = r1.I; Sc.J = r1.J;
+        DG_TRACE(c, 11, Sc.I, Sc.J);
         __syncthreads();
         if (tid == 0) {
             unsigned hash = dg_hash_list(inliers, (int)Sc.I);
@@ -61,15 +64,20 @@ __device__ __forceinline__ dg_score dg_iterF(CTX &c, int *inliers, double th, do
             S->itmp[0] = (ret != -1 && ret != iterID) ? 1 : 0;
         }
         __syncthreads();
-        if (S->itmp[0]) return zero;
+        if (S->itmp[0]) { DG_TRACE(c, 13, 0, 0); return zero; }
+        /* exp_ranF.c:687-696: on improvement the buffers rotate and `d` becomes the OLD errs[0], so the
+         * following inlidxs(d, ths*MWM) runs on the residuals of the previous best model of this chain
+         * (= the previous value of the out-parameter F), not on the current one.  Reproduced. */
+        int stale = 0, stale_kind = *kind0;
         if (maxS.J < Sc.J) {
-            maxS = Sc; *kind0 = mk_ex;
+            maxS = Sc; stale = 1; *kind0 = mk_ex;
             __syncthreads();
-            if (tid < 9) f[tid] = fl[tid];
+            if (tid < 9) { S->dtmp[16 + tid] = f[tid]; f[tid] = fl[tid]; }
             __syncthreads();
         }
         dg_pass_cfg c2 = dg_cfg0(n); c2.list = inliers; c2.thL = ths * DG_MWM;
-        dg_pass_res r2 = dg_f_pass(c, fl, mk_ex, c2);
+        dg_pass_res r2 = stale ? dg_f_pass(c, S->dtmp + 16, stale_kind, c2) : dg_f_pass(c, fl, mk_ex, c2);
+        DG_TRACE(c, 14, r2.nL, 0);
         if (r2.nL < 8) return maxS;
         {
             int cnt = (int)r2.nL, o = 0, use = cnt;
@@ -86,6 +94,7 @@ __device__ __forceinline__ dg_score dg_iterF(CTX &c, int *inliers, double th, do
     }
     dg_pass_cfg c3 = dg_cfg0(n); c3.wantJ = 1; c3.thJ = th; c3.list = inliers; c3.thL = th;
     dg_pass_res r3 = dg_f_pass(c, fl, mk_full, c3); c.n_fds++;
+    DG_TRACE(c, 12, r3.I, r3.J);
     if (maxS.J < r3.J) {
         maxS = zero; maxS.I = r3.I; maxS.J = r3.J; *kind0 = mk_full;
         __syncthreads();
@@ -436,9 +445,11 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
                 /* LSQ before LO: S = inlidxs(errs[4], TC*th*MWM); u2f; FDS1; inlidxs(th)  (:1506-1511) */
                 dg_pass_cfg ca = dg_cfg0(n); ca.list = c.L[0]; ca.thL = DG_TC * th * DG_MWM;
                 dg_pass_res ra = dg_f_pass(c, e4F, e4kind, ca);
+                DG_TRACE(c, 1, ra.nL, no_sam);
                 dg_u2f_list(c, c.L[0], (int)ra.nL, 0, 0, S->f);
-                dg_pass_cfg cb = dg_cfg0(n); cb.list = c.L[0]; cb.thL = th;
+                dg_pass_cfg cb = dg_cfg0(n); cb.wantJ = 1; cb.thJ = th; cb.list = c.L[0]; cb.thL = th;
                 dg_pass_res rb = dg_f_pass(c, S->f, mk_full, cb); c.n_fds++;
+                DG_TRACE(c, 2, rb.nL, rb.J);
                 int kb;
                 dg_score Sl = dg_inFrani(c, (int)rb.nL, th, S->Hx /* LO result model */, &iterID, mk_full, mk_ex, &kb);
                 if (maxS.J < Sl.J) {

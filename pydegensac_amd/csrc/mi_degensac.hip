@@ -14,6 +14,22 @@ static void set_err(const char *fmt, const char *a = "", const char *b = "") { s
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err("%s failed: %s", #x, hipGetErrorString(e_)); return MI_DEGENSAC_EHIP; } } while (0)
 
 extern "C" const char *mi_degensac_last_error(void) { return g_err; }
+/* debug trace (device buffer owned by the caller of mi_degensac_debug_trace); not part of the public header */
+static int *g_trace_dev = nullptr; static int g_trace_cap = 0;
+extern "C" int mi_degensac_debug_trace(int cap, int *host_out)
+{
+    if (cap > 0 && !host_out) {           /* arm */
+        if (g_trace_dev) hipFree(g_trace_dev);
+        if (hipMalloc((void **)&g_trace_dev, (size_t)(1 + 4 * cap) * sizeof(int)) != hipSuccess) return -1;
+        hipMemset(g_trace_dev, 0, sizeof(int)); g_trace_cap = cap; return 0;
+    }
+    if (host_out && g_trace_dev) {        /* fetch and disarm */
+        hipDeviceSynchronize();
+        hipMemcpy(host_out, g_trace_dev, (size_t)(1 + 4 * g_trace_cap) * sizeof(int), hipMemcpyDeviceToHost);
+        hipFree(g_trace_dev); g_trace_dev = nullptr; g_trace_cap = 0; return 0;
+    }
+    return -1;
+}
 extern "C" const char *mi_degensac_version(void) { return "mi_degensac 0.1 (gfx950)"; }
 extern "C" const char *mi_degensac_kernel_name(int homography) { return homography ? "dg_find_homography_kernel" : "dg_find_fundamental_kernel"; }
 extern "C" int mi_degensac_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
@@ -143,6 +159,7 @@ static int launch_batch(int homography, const double *d_p1, const double *d_p2, 
     A.wl = make_layout(n_max, !in_lds);
     char *ws; rc = ensure_ws(device, A.wl.stride * (size_t)n_pairs, &ws); if (rc) return rc;
     A.ws = ws; A.pts1 = d_p1; A.pts2 = d_p2; A.offsets = (const long long *)d_off; A.seeds = d_seeds;
+    A.trace = g_trace_dev; A.trace_cap = g_trace_cap;
     A.model_out = d_model; A.mask_out = d_mask; A.stats_out = d_stats; A.dim = dim; A.n_pairs = n_pairs; A.pts_in_lds = in_lds;
     if (in_lds) hipLaunchKernelGGL(dg_find_fundamental_kernel<true>, dim3(n_pairs), dim3(DG_T), dyn, stream, A);
     else        hipLaunchKernelGGL(dg_find_fundamental_kernel<false>, dim3(n_pairs), dim3(DG_T), 0, stream, A);

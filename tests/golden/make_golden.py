@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the UNMODIFIED reference (oracle/_ref, built from /root/reference by
+oracle/Makefile).  Run in the build container only (the GPU box has no /root/reference):
+
+    make -C oracle ref && python tests/golden/make_golden.py
+
+Each fixture stores the generator arguments (inputs are re-created from pydegensac_amd.synthetic), the call
+parameters, the RANSAC seed and the reference outputs: model (9 doubles), mask, sample / LO / scored-model
+counts.  The reference seeds from time(NULL); the oracle build redirects it (oracle/ref_shim.c).
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import ref  # noqa: E402
+from pydegensac_amd import synthetic as syn  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+F_CASES = [
+    # name, generator kwargs, call kwargs
+    ("F_c2", dict(n=2000, inlier_ratio=0.4, sigma=0.1, seed=0), dict()),
+    ("F_c2_seed5", dict(n=2000, inlier_ratio=0.4, sigma=0.1, seed=5), dict()),
+    ("F_c2b_plane", dict(n=2000, inlier_ratio=0.4, sigma=0.1, seed=1, plane_fraction=0.7), dict(max_iters=3000)),
+    ("F_c2b_plane_nodegen", dict(n=2000, inlier_ratio=0.4, sigma=0.1, seed=1, plane_fraction=0.7), dict(degen=False)),
+    ("F_symm_epipolar", dict(n=1000, inlier_ratio=0.4, sigma=0.1, seed=2), dict(error_type=1)),
+    ("F_nosym", dict(n=1000, inlier_ratio=0.4, sigma=0.3, seed=2), dict(sym_check=False)),
+    ("F_n100", dict(n=100, inlier_ratio=0.3, sigma=0.3, seed=4), dict(max_iters=5000)),
+    ("F_n8", dict(n=8, inlier_ratio=1.0, sigma=0.1, seed=4), dict(max_iters=200)),
+    ("F_all_outliers", dict(n=300, inlier_ratio=0.0, sigma=0.5, seed=6), dict(max_iters=3000)),
+    ("F_c5_small", dict(n=5000, inlier_ratio=0.1, sigma=0.1, seed=7), dict(max_iters=4000)),
+]
+H_CASES = [
+    ("H_c3_sampson", dict(n=5000, inlier_ratio=0.4, sigma=0.5, seed=0), dict(px_th=2.0, error_type=0)),
+    ("H_c3_symm_max", dict(n=5000, inlier_ratio=0.4, sigma=0.5, seed=0), dict(px_th=2.0, error_type=2)),
+    ("H_c3_symm_sq_max", dict(n=2000, inlier_ratio=0.4, sigma=0.5, seed=1), dict(px_th=2.0, error_type=1)),
+    ("H_c3_symm_sq_sum", dict(n=2000, inlier_ratio=0.4, sigma=0.5, seed=1), dict(px_th=2.0, error_type=3)),
+    ("H_c3_symm_sum", dict(n=2000, inlier_ratio=0.4, sigma=0.5, seed=1), dict(px_th=2.0, error_type=4)),
+    ("H_c3_laf", dict(n=2000, inlier_ratio=0.4, sigma=0.5, seed=2, laf=True), dict(px_th=2.0, error_type=0, laf_coef=3.0)),
+    ("H_c1_plumbing", dict(n=400, inlier_ratio=0.4, sigma=0.5, seed=3), dict(px_th=4.0, conf=0.99, max_iters=2000)),
+    ("H_n4", dict(n=4, inlier_ratio=1.0, sigma=0.0, seed=3), dict(px_th=1.0, max_iters=100)),
+    ("H_all_outliers", dict(n=200, inlier_ratio=0.0, sigma=0.5, seed=5), dict(px_th=1.0, max_iters=2000)),
+]
+SEEDS = [1, 7]
+
+
+def main():
+    for name, g, kw in F_CASES:
+        p1, p2, _, _ = syn.two_view_fundamental(**g)
+        for s in SEEDS:
+            F, m, st = ref.find_fundamental(p1, p2, seed=s, count_models=True, **kw)
+            np.savez_compressed(os.path.join(HERE, f"{name}_s{s}.npz"), kind="F", gen=repr(g), call=repr(kw), seed=s,
+                                model=F, mask=np.packbits(m), n=len(m), samples=st["samples"], lo_runs=st["lo_runs"],
+                                full_passes=st["full_passes"], ex_passes=st["ex_passes"], I=st["I"])
+    for name, g, kw in H_CASES:
+        p1, p2, _, _ = syn.homography_pairs(**g)
+        for s in SEEDS:
+            H, m, st = ref.find_homography(p1, p2, seed=s, count_models=True, **kw)
+            np.savez_compressed(os.path.join(HERE, f"{name}_s{s}.npz"), kind="H", gen=repr(g), call=repr(kw), seed=s,
+                                model=H, mask=np.packbits(m), n=len(m), samples=st["samples"], lo_runs=st["lo_runs"],
+                                full_passes=st["full_passes"], rejected=st["rejected"], I=st["I"])
+    print("wrote", len(F_CASES) * len(SEEDS) + len(H_CASES) * len(SEEDS), "fixtures")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,26 @@
+"""GPU: the HIP path against the committed golden fixtures produced by the unmodified reference."""
+import os
+
+import numpy as np
+import pytest
+
+import pydegensac_amd as pd
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("path", gu.fixtures("F"), ids=lambda p: os.path.basename(p)[:-4])
+def test_fundamental_matches_reference_golden(path):
+    g = gu.load(path); kw = g["call"]
+    F, m = pd.findFundamentalMatrix_(g["p1"], g["p2"], kw.get("px_th", 0.5), kw.get("conf", 0.9999), kw.get("max_iters", 100000),
+                                     kw.get("error_type", 0), kw.get("sym_check", True), kw.get("laf_coef", 0.0),
+                                     kw.get("degen", True), seed=g["seed"])
+    st = pd.last_stats()
+    assert st["samples"] == g["samples"] and st["lo_runs"] == g["lo_runs"]
+    assert st["full_passes"] == g["full_passes"] and st["ex_passes"] == g["ex_passes"]
+    if np.abs(g["model"]).sum() == 0:
+        assert np.abs(F).sum() == 0 and not np.asarray(m).any()
+    else:
+        assert np.array_equal(np.asarray(m), g["mask"])
+        assert gu.rel(F, g["model"]) < 1e-6

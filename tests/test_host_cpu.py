@@ -1,0 +1,122 @@
+"""CPU suite: host logic of the drop-in layer, the C-ABI library's exported symbols, and the
+pair-sharding / result gather over a world_size-2 gloo group."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    from pydegensac_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    hdr = open(os.path.join(ROOT, "include", "mi_degensac.h")).read()
+    names = sorted(set(re.findall(r"\b(mi_degensac_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(names) >= 12
+    lib = C.CDLL(_lib.LIB_PATH)          # loads without a GPU; no compute is called
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/mi_degensac.h but not exported"
+    lib.mi_degensac_version.restype = C.c_char_p
+    assert b"gfx950" in lib.mi_degensac_version()
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import pydegensac_amd as pd
+    from pydegensac_amd import _lib
+    p = np.random.default_rng(0).uniform(0, 100, (50, 2))
+    with pytest.raises(_lib.MiDegensacError):
+        pd.findFundamentalMatrix(p, p + 1.0, seed=1)
+
+
+def test_python_surface_matches_reference_signatures():
+    import inspect
+    import pydegensac_amd as pd
+    s = inspect.signature(pd.findHomography)
+    assert list(s.parameters)[:8] == ["pts1_", "pts2_", "px_th", "conf", "max_iters", "laf_consistensy_coef", "error_type",
+                                      "symmetric_error_check"]
+    assert [s.parameters[k].default for k in list(s.parameters)[2:8]] == [1.0, 0.999, 50000, -1.0, "sampson", True]
+    s = inspect.signature(pd.findFundamentalMatrix)
+    assert list(s.parameters)[:9] == ["pts1_", "pts2_", "px_th", "conf", "max_iters", "laf_consistensy_coef", "error_type",
+                                      "symmetric_error_check", "enable_degeneracy_check"]
+    assert [s.parameters[k].default for k in list(s.parameters)[2:9]] == [0.5, 0.9999, 100000, -1.0, "sampson", True, True]
+    assert pd.api.error_type_dict_homography == {"sampson": 0, "symm_sq_max": 1, "symm_max": 2, "symm_sq_sum": 3, "symm_sum": 4}
+    assert pd.api.error_type_dict_fundamental == {"sampson": 0, "symm_epipolar": 1}
+
+
+def test_input_validation_errors_like_reference():
+    import pydegensac_amd as pd
+    good = np.zeros((10, 2))
+    with pytest.raises(ValueError):
+        pd.findHomography(np.zeros((10, 3)), good)          # utils.py:50-52
+    with pytest.raises(ValueError):
+        pd.findHomography(np.zeros((3, 2)), np.zeros((3, 2)))   # utils.py:53-54
+    with pytest.raises(ValueError):
+        pd.findHomography("nope", good)                      # utils.py:68-70
+    with pytest.raises(AssertionError):
+        pd.findHomography(np.zeros((10, 2)), np.zeros((11, 2)))  # utils.py:86
+    with pytest.raises(ValueError):
+        pd.findHomography(good, good, error_type="bogus")    # utils.py:93
+    with pytest.raises(ValueError):
+        pd.findFundamentalMatrix(good, good, error_type="symm_max")
+    with pytest.raises(ValueError):
+        pd.findFundamentalMatrix(np.zeros((5, 2)), np.zeros((5, 2)))   # bindings.cpp:270-272 (N >= 8)
+
+
+def test_shard_ranges_cover_everything():
+    from pydegensac_amd import parallel
+    for n in [1, 7, 8, 4096, 4099]:
+        for w in [1, 2, 3, 8]:
+            r = [parallel.shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+    assert parallel.pair_seed(5) == parallel.pair_seeds(5, 6)[0]
+
+
+GLOO_WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from pydegensac_amd import parallel, synthetic
+from oracle import port            # the CPU oracle stands in for the GPU kernel in this CPU-only test
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+NP, N = 5, 200
+lo, hi = parallel.shard_range(NP, rank, world)
+F = np.zeros((hi - lo, 9)); st = np.zeros((hi - lo, 16), np.int32); mk = np.zeros(((hi - lo) * N,), np.uint8)
+for i, pid in enumerate(range(lo, hi)):
+    p1, p2, _, _ = synthetic.two_view_fundamental(N, 0.6, 0.1, seed=pid)
+    f, m, s = port.find_fundamental(p1, p2, max_iters=2000, seed=parallel.pair_seed(pid))
+    F[i] = f.ravel(); mk[i * N:(i + 1) * N] = m; st[i, 0] = s["samples"]; st[i, 3] = s["I"]
+gm, gs, gk = parallel.gather_results(torch.from_numpy(F), torch.from_numpy(st), torch.from_numpy(mk), N, NP)
+if rank == 0:
+    np.savez(sys.argv[2], F=gm.numpy(), st=gs.numpy(), mk=gk.numpy())
+dist.destroy_process_group()
+'''
+
+
+def test_gather_invariant_to_world_size(tmp_path):
+    from oracle import port
+    port.lib()
+    script = tmp_path / "w.py"; script.write_text(GLOO_WORKER)
+    outs = []
+    for world in [1, 2]:
+        out = str(tmp_path / f"o{world}.npz")
+        port_no = 29500 + os.getpid() % 1000 + world
+        if world == 1:
+            env = dict(os.environ, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_no))
+            subprocess.check_call([sys.executable, str(script), ROOT, out], env=env)
+        else:
+            subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                                   "--master-addr", "127.0.0.1", "--master-port", str(port_no), str(script), ROOT, out])
+        outs.append(np.load(out))
+    for k in ["F", "st", "mk"]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    assert outs[0]["st"][:, 0].min() > 0

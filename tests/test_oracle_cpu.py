@@ -1,0 +1,101 @@
+"""CPU suite (-m "not gpu"): pins the oracle.
+
+  * the restatement (oracle/dg_oracle.c) against the golden fixtures generated from the unmodified
+    reference (tests/golden, made by tests/golden/make_golden.py) — trajectory counters and mask exact,
+    model <= 1e-9 relative;
+  * the restatement against oracle/_ref live, when that build is present (this container);
+  * unit pieces against libc / the reference's own functions.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from pydegensac_amd import synthetic as syn
+from tests import golden_util as gu
+
+
+@pytest.mark.parametrize("path", gu.fixtures("F"), ids=lambda p: os.path.basename(p)[:-4])
+def test_port_matches_golden_fundamental(oracle_port, path):
+    g = gu.load(path)
+    F, m, st = oracle_port.find_fundamental(g["p1"], g["p2"], seed=g["seed"], **g["call"])
+    assert st["samples"] == g["samples"] and st["lo_runs"] == g["lo_runs"]
+    assert st["full_passes"] == g["full_passes"] and st["ex_passes"] == g["ex_passes"]
+    assert np.array_equal(m, g["mask"]) or np.abs(g["model"]).sum() == 0
+    assert gu.rel(F, g["model"]) < 1e-9
+
+
+def test_rng_matches_libc(oracle_port):
+    libc = C.CDLL("libc.so.6")
+    libc.srand.argtypes = [C.c_uint]; libc.rand.restype = C.c_int
+    for seed in [0, 1, 2, 12345, 2**31 - 1, 2**31, 2**32 - 1, 987654321]:
+        libc.srand(seed)
+        want = [libc.rand() for _ in range(50)]
+        got = np.zeros(50, np.int32)
+        oracle_port.lib().dg_oracle_rand_stream(C.c_uint(seed), 50, oracle_port.ip(got))
+        assert list(got) == want, seed
+
+
+def test_units_match_reference(oracle_port, oracle_ref):
+    R = oracle_ref.lib(); P = oracle_port.lib(); dp = oracle_port.dp; ip = oracle_port.ip
+    rng = np.random.default_rng(0)
+    p1, p2, lab, _ = syn.two_view_fundamental(800, 0.5, 0.1, seed=1)
+    n = 800
+    u = np.ones((n, 6)); u[:, 0:2] = p1; u[:, 3:5] = p2
+    F = rng.normal(size=9)
+    for name_r, name_p in [("FDs", "dg_oracle_FDs"), ("FDsSym", "dg_oracle_FDsSym")]:
+        d1 = np.zeros(n); d2 = np.zeros(n)
+        getattr(R, name_r)(dp(u), dp(F), dp(d1), n); getattr(P, name_p)(dp(u), dp(F), dp(d2), n)
+        assert np.array_equal(d1, d2)
+    # nullspace / slcm / rroots3 on real samples
+    for t in range(50):
+        ids = rng.choice(n, 7, replace=False)
+        A = np.zeros(81)
+        for i, q in enumerate(ids):
+            A[9 * i:9 * i + 9] = np.outer(u[q, 3:6], u[q, 0:3]).ravel()
+        A1 = A.copy(); A2 = A.copy(); s1 = np.zeros(81); s2 = np.zeros(81); buf = np.zeros(18, np.int32)
+        r1 = R.nullspace(dp(A1), dp(s1), 9, ip(buf)); r2 = P.dg_oracle_nullspace(dp(A2), dp(s2), 9)
+        assert r1 == r2 == 2 and np.array_equal(s1[:18], s2[:18])
+        pa = np.zeros(4); pb = np.zeros(4); b1 = s1[9:18].copy(); b2 = s2[9:18].copy()
+        R.slcm(dp(s1), dp(b1), dp(pa)); P.dg_oracle_slcm(dp(s2), dp(b2), dp(pb))
+        assert np.array_equal(pa, pb) and np.array_equal(b1, b2)
+        ra = np.zeros(3); rb = np.zeros(3)
+        assert R.rroots3(dp(pa), dp(ra)) == P.dg_oracle_rroots3(dp(pb), dp(rb)) and np.array_equal(ra, rb)
+    # svduv bit-exact, eig / u2f / u2h to rounding (external LAPACK in the reference)
+    for shape in [(9, 8), (3, 3)]:
+        A = rng.normal(size=shape)
+        a1 = A.copy().ravel(); a2 = A.copy().ravel()
+        d1 = np.zeros(9); d2 = np.zeros(9); u1 = np.zeros(81); u2 = np.zeros(81); v1 = np.zeros(64); v2 = np.zeros(64)
+        R.svduv(dp(d1), dp(a1), dp(u1), shape[0], dp(v1), shape[1]); P.dg_oracle_svduv(dp(d2), dp(a2), dp(u2), shape[0], dp(v2), shape[1])
+        assert np.array_equal(u1, u2) and np.array_equal(v1, v2) and np.array_equal(d1, d2)
+    inl = np.nonzero(lab)[0].astype(np.int32)
+    buf = np.zeros(18 * n)
+    for ln in [8, 10, 14, 300]:
+        sel = np.ascontiguousarray(rng.choice(inl, ln, replace=False).astype(np.int32))
+        F1 = np.zeros(9); F2 = np.zeros(9)
+        R.u2f(dp(u), ip(sel), ln, dp(F1), dp(buf)); P.dg_oracle_u2f(dp(u), ip(sel), ln, dp(F2))
+        assert np.linalg.norm(F1 - F2) < 1e-8 * np.linalg.norm(F1)          # same sign, same scale
+    for ln in [5, 10, 12, 200]:
+        sel = np.ascontiguousarray(rng.choice(inl, ln, replace=False).astype(np.int32))
+        H1 = np.zeros(9); H2 = np.zeros(9)
+        R.u2h(dp(u), ip(sel), ln, dp(H1), dp(buf)); P.dg_oracle_u2h(dp(u), ip(sel), ln, dp(H2))
+        assert np.linalg.norm(H1 - H2) < 1e-7 * np.linalg.norm(H1)
+    # hash
+    lst = np.ascontiguousarray(rng.choice(5000, 321, replace=False).astype(np.int32))
+    R.SuperFastHash.restype = C.c_uint32
+    assert R.SuperFastHash(lst.ctypes.data_as(C.c_char_p), 321 * 4) == P.dg_oracle_hash(ip(lst), 321)
+    for a in [(801, 2000, 7, 0.9999), (10, 2000, 7, 0.99), (2000, 2000, 4, 0.999), (3, 100, 7, 0.5)]:
+        assert R.nsamples(*[C.c_int(x) for x in a[:3]], C.c_double(a[3])) == P.dg_oracle_nsamples(*[C.c_int(x) for x in a[:3]], C.c_double(a[3]))
+
+
+@pytest.mark.parametrize("dseed,plane", [(0, 0.0), (1, 0.7), (2, 0.0)])
+def test_port_matches_reference_live(oracle_port, oracle_ref, dseed, plane):
+    p1, p2, _, _ = syn.two_view_fundamental(1200, 0.4, 0.1, seed=dseed, plane_fraction=plane)
+    mi = 100000 if plane == 0 else 2000
+    for seed in [3, 11]:
+        F, m, st = oracle_ref.find_fundamental(p1, p2, seed=seed, count_models=True, max_iters=mi)
+        F2, m2, st2 = oracle_port.find_fundamental(p1, p2, seed=seed, max_iters=mi)
+        assert (st["samples"], st["lo_runs"], st["full_passes"], st["ex_passes"]) == \
+               (st2["samples"], st2["lo_runs"], st2["full_passes"], st2["ex_passes"])
+        assert np.array_equal(m, m2) and gu.rel(F, F2) < 1e-9
