@@ -1027,12 +1027,383 @@ uint32_t dg_oracle_hash(const int *list, int count) { return dg_superfasthash((c
 int  dg_oracle_checksample(const double *F, const double *u7, double th, double *H) { return checksample(F, u7, th, H); }
 int  dg_oracle_all_ori_valid(const double *F, const double *u, const int *idx, int N) { return all_ori_valid(F, u, idx, N); }
 
+
+/* ================================================================================================
+ * Homography path: exp_ranH.c:29-44, :291-467, :470-930 ; Htools.c:202-370, :428-605, :649-848
+ * ============================================================================================== */
+/* the four symmetric transfer errors.  Hinv = transpose of the stored H, H1 = minv(Hinv).
+ * kind: 1 SymMaxSq, 2 SymMax, 3 SymSumSq, 4 SymSum.  eps: the +1e-10 on the denominators, present in the
+ * Sum* metrics and in every i/idx variant but NOT in the plain HDsSymMax / HDsSymMaxSq (Htools.c:310-311,352-353). */
+typedef struct { double Hinv[9], H1[9]; } hsym_t;
+static void hsym_prepare(const double *H, hsym_t *t)
+{
+    int i;
+    t->Hinv[0] = H[0]; t->Hinv[1] = H[3]; t->Hinv[2] = H[6];
+    t->Hinv[3] = H[1]; t->Hinv[4] = H[4]; t->Hinv[5] = H[7];
+    t->Hinv[6] = H[2]; t->Hinv[7] = H[5]; t->Hinv[8] = H[8];
+    for (i = 0; i < 9; i++) t->H1[i] = t->Hinv[i];
+    dg_minv(t->H1, 3);
+}
+#define HMAX(i,j) ( (i)<(j) ? (j):(i) )
+static double hsym_one(const hsym_t *t, const double *u, int kind, int eps)
+{
+    const double *H1 = t->H1, *Hinv = t->Hinv;
+    double a, b, xa, ya, d1, d2, xdiff, ydiff;
+    a = H1[6]*u[0] + H1[7]*u[1] + H1[8];
+    b = Hinv[6]*u[3] + Hinv[7]*u[4] + Hinv[8];
+    if (eps) { a = a + 1e-10; b = b + 1e-10; }
+    xa = (H1[0]*u[0] + H1[1]*u[1] + H1[2]) / a;
+    ya = (H1[3]*u[0] + H1[4]*u[1] + H1[5]) / a;
+    xdiff = u[3] - xa; ydiff = u[4] - ya;
+    d1 = xdiff*xdiff + ydiff*ydiff;
+    xa = (Hinv[0]*u[3] + Hinv[1]*u[4] + Hinv[2]) / b;
+    ya = (Hinv[3]*u[3] + Hinv[4]*u[4] + Hinv[5]) / b;
+    xdiff = u[0] - xa; ydiff = u[1] - ya;
+    d2 = xdiff*xdiff + ydiff*ydiff;
+    switch (kind) {
+    case 1: return HMAX(d1, d2);
+    case 2: return sqrt(HMAX(d1, d2));
+    case 3: return d1 + d2;
+    default: return sqrt(d1) + sqrt(d2);
+    }
+}
+/* HDsi / HDsidx (Htools.c:372-410, :607-647): residual rows from the DLT of the ORIGINAL points (lin),
+ * Jacobian terms from the point set passed as u6 (the LAF-shifted points in the LAF checks) */
+static double HDs_mixed(const double *uo, const double *ul, const double *H)
+{
+    double z0[9], z1[9], pJ[8], r1 = 0, r2 = 0, a, b, c, d, e, p; int j;
+    dlt_rows(uo, z0, z1);
+    for (j = 0; j < 9; j++) { r1 += H[j] * z0[j]; r2 += H[j] * z1[j]; }
+    a = H[0] - H[2] * ul[0];
+    b = H[3] - H[5] * ul[0];
+    c = -H[8] - H[2] * ul[3] - H[5] * ul[4];
+    d = H[1] - H[2] * ul[1];
+    e = H[4] - H[5] * ul[1];
+    dg_pinvJ(a, b, c, d, e, pJ);
+    p = 0;
+    for (j = 0; j < 4; j++) { a = pJ[j] * r1 + pJ[j+4] * r2; p += a * a; }
+    return p;
+}
+/* metric selected by bindings.cpp:64-107: full pass over all points (HDS1) */
+static void HDS_full(int kind, const double *u, const double *H, double *p, int len)
+{
+    int i;
+    if (kind == 0) { HDs(u, H, p, len); return; }
+    { hsym_t t; hsym_prepare(H, &t); for (i = 0; i < len; i++) p[i] = hsym_one(&t, u + 6*i, kind, kind >= 3); }
+}
+/* HDSi1 / HDSidx1 value for point id on point set ul (original points uo) */
+static double HDS_sub(int kind, const hsym_t *t, const double *uo, const double *ul, const double *H)
+{
+    if (kind == 0) return HDs_mixed(uo, ul, H);
+    return hsym_one(t, ul, kind, 1);
+}
+
+static int HcloseToSingular(const double *h)               /* exp_ranH.c:29-44 */
+{
+    double v, tol; int i;
+    v = dg_det3(h);
+    tol = h[8];
+    if (tol == 0) { for (i = 0; i < 9; ++i) tol += h[i]*h[i]; tol = sqrt(tol); tol *= 0.001; }
+    tol = tol*tol*tol;
+    return (fabs(v/tol) < 1e-2);
+}
+
+static int all_Hori_valid(const double *us, const int *idx)   /* Htools.c:821-848; crossprod = crossprod_st(..,1) */
+{
+    double p[3], q[3]; const double *a, *b, *c, *d;
+    a = us + 6*idx[0]; b = us + 6*idx[1]; c = us + 6*idx[2]; d = us + 6*idx[3];
+    dg_crossprod_st(p, a, b, 1); dg_crossprod_st(q, a+3, b+3, 1);
+    if ((p[0]*c[0]+p[1]*c[1]+p[2]*c[2])*(q[0]*c[3]+q[1]*c[4]+q[2]*c[5]) < 0) return 0;
+    if ((p[0]*d[0]+p[1]*d[1]+p[2]*d[2])*(q[0]*d[3]+q[1]*d[4]+q[2]*d[5]) < 0) return 0;
+    dg_crossprod_st(p, c, d, 1); dg_crossprod_st(q, c+3, d+3, 1);
+    if ((p[0]*a[0]+p[1]*a[1]+p[2]*a[2])*(q[0]*a[3]+q[1]*a[4]+q[2]*a[5]) < 0) return 0;
+    if ((p[0]*b[0]+p[1]*b[1]+p[2]*b[2])*(q[0]*b[3]+q[1]*b[4]+q[2]*b[5]) < 0) return 0;
+    return 1;
+}
+
+/* exp_ranH.c:291-412 */
+static dg_score exp_iterHcustom(dg_ctx *c, const double *u, int len, int *inliers, double th, double ths, int steps,
+                                double *H, double **errs, int iterID, unsigned inlLimit, int kind)
+{
+    double *d = errs[1], h[9], dth; int it;
+    dg_score maxS = {0,0,0,0}, S = {0,0,0,0}, Ss; int *detachedInl; unsigned detachedCount;
+    int iterIDret; uint32_t hash;
+    dth = (ths - th) / (steps);
+    maxS = inlidxs(errs[4], len, th, inliers);
+    TRACE2(20, maxS.I, maxS.J);
+    if (maxS.I < 4) return S;
+    S = inlidxs(errs[4], len, th*MWM, inliers);
+    detachedCount = (unsigned)(int)(S.I * 1);
+    if (detachedCount > inlLimit) detachedCount = inlLimit;
+    if (detachedCount < 4) detachedCount = 4;
+    if (detachedCount >= S.I) u2h(u, inliers, S.I, h);
+    else { detachedInl = randsubset(c, inliers, S.I, detachedCount); u2h(u, detachedInl, detachedCount, h); }
+    for (it = 0; it < steps; it++) {
+        HDS_full(kind, u, h, d, len); c->n_hds++; TRACE(2, h);
+        Ss = inlidxs(d, len, th, inliers);
+        TRACE2(21, Ss.I, Ss.J);
+        hash = dg_superfasthash((const unsigned char *)inliers, (int)(Ss.I * sizeof(*inliers)));
+        iterIDret = htContains(c, hash, Ss.I, iterID);
+        if (iterIDret != -1 && iterIDret != iterID) { TRACE2(23, iterIDret, 0); S.I = 0; S.J = 0; return S; }
+        if (iterIDret == -1) htInsert(c, hash, Ss.I, iterID);
+        S = inlidxs(d, len, ths*MWM, inliers);
+        TRACE2(24, S.I, 0);
+        if (scoreLess(maxS, Ss)) {
+            maxS = Ss; errs[1] = errs[0]; errs[0] = d; d = errs[1];
+            memcpy(H, h, 9 * sizeof(double));
+        }
+        if (S.I < 4) return maxS;
+        detachedCount = (unsigned)(int)(S.I * 1);
+        if (detachedCount > inlLimit) detachedCount = inlLimit;
+        if (detachedCount < 4) detachedCount = 4;
+        if (detachedCount >= S.I) u2h(u, inliers, S.I, h);
+        else { detachedInl = randsubset(c, inliers, S.I, detachedCount); u2h(u, detachedInl, detachedCount, h); }
+        ths -= dth;
+    }
+    HDS_full(kind, u, h, d, len); c->n_hds++; TRACE(2, h);
+    S = inlidxs(d, len, th, inliers);
+    TRACE2(22, S.I, S.J);
+    if (scoreLess(maxS, S)) {
+        maxS = S; errs[1] = errs[0]; errs[0] = d;
+        memcpy(H, h, 9 * sizeof(double));
+    }
+    return maxS;
+}
+
+/* exp_ranH.c:415-467 */
+static dg_score exp_inHranicustom(dg_ctx *c, const double *u, int len, int *inliers, int ninl, double th, double **errs,
+                                  double *H, int rep, int *iterID, unsigned inlLimit, int kind)
+{
+    int ssiz, i; dg_score S, maxS = {0,0,0,0}; double *d, h[9]; int *sample, *intbuff;
+    if (ninl < 8) return maxS;
+    intbuff = (int *)malloc(sizeof(int) * len);
+    ssiz = ninl / 2; if (ssiz > 12) ssiz = 12;
+    d = errs[2]; errs[2] = errs[0]; errs[0] = d;
+    for (i = 0; i < rep; i++) {
+        sample = randsubset(c, inliers, ninl, ssiz);
+        u2h(u, sample, ssiz, h);
+        HDS_full(kind, u, h, errs[0], len); c->n_hds++; TRACE(2, h);
+        errs[4] = errs[0];
+        S = exp_iterHcustom(c, u, len, intbuff, th, TC*th, ILSQ_ITERS, h, errs, ++*iterID, inlLimit, kind);
+        if (scoreLess(maxS, S)) {
+            maxS = S; d = errs[2]; errs[2] = errs[0]; errs[0] = d;
+            memcpy(H, h, 9 * sizeof(double));
+        }
+    }
+    d = errs[2]; errs[2] = errs[0]; errs[0] = d;
+    free(intbuff);
+    return maxS;
+}
+
+/* exp_ranH.c:470-930 with iter_type = 4, oriented_constraint = 1, inlLimit = 0 (bindings.cpp:206-222) */
+static dg_score exp_ransacHcustomLAF(dg_ctx *c, const double *u, const double *u_1, const double *u_2, int len, double th,
+                                     double laf_coef, double conf, int max_sam, double *H, unsigned char *inl,
+                                     unsigned inlLimit, int kind, double SymCheck_th, unsigned seed0, int *stats)
+{
+    int *pool, no_sam, new_sam, *samidx, bestsamidx[4];
+    double M[81], sol[81], *h, *err, *d, *d_check, *errs[5];
+    int i, j, *inliers, *inliersS; char do_update = 0;
+    dg_score maxS = {0,0,0,0}, maxSs = {0,0,0,0}, S = {0,0,0,0}, Scheck = {0,0,0,0};
+    unsigned seed; int do_iterate, iter_cnt = 0, no_rej = 0, iterID = 0; char new_max = 0;
+    const int doSymCheck = SymCheck_th > 0, DO_LAF_CHECK = laf_coef > 0; const double th_laf_check = laf_coef * th;
+    int p1_inliers = 0, nullspace_buff[18], nullsize, best_sample = 0, accepted = 0;
+    hsym_t hs;
+    if (inlLimit == 0) inlLimit = 1000000;
+    h = sol;
+    dg_srand(&c->rng, seed0);
+    c->ht_n = 0;
+    pool = (int *)malloc(len * sizeof(int));
+    for (i = 0; i < len; i++) pool[i] = i;
+    err = (double *)calloc((size_t)len * 4, sizeof(double));
+    d_check = (double *)malloc(len * sizeof(double));
+    for (i = 0; i < 4; i++) errs[i] = err + (size_t)i * len;
+    errs[4] = errs[3];
+    inliers = (int *)malloc(sizeof(int) * len);
+    inliersS = (int *)malloc(sizeof(int) * len);
+    no_sam = 0;
+    seed = (unsigned)dg_rand(&c->rng);
+    samidx = pool + len - 4;
+    for (i = 0; i < 81; i++) sol[i] = 0;
+
+    while (no_sam < max_sam) {
+        no_sam++;
+        dg_srand(&c->rng, seed);
+        /* multirsampleT(Z,9,2,pool,4,len,M) (rtools.c:136-156): rows 2i,2i+1 = DLT rows of the i-th drawn point */
+        for (i = 0; i < 4; i++) {
+            int s = dg_rand(&c->rng) % (len - i), jx = len - i - 1, q = pool[s];
+            pool[s] = pool[jx]; pool[jx] = q;
+            dlt_rows(u + 6*q, M + 18*i, M + 18*i + 9);
+        }
+        seed = (unsigned)dg_rand(&c->rng);
+        if (!all_Hori_valid(u, samidx)) { no_rej++; continue; }
+        for (i = 72; i < 81; ++i) M[i] = 0.0;
+        nullsize = dg_nullspace(M, sol, 9, nullspace_buff);
+        if (nullsize != 1) { no_rej++; continue; }
+        if (HcloseToSingular(h)) { no_rej++; continue; }
+
+        d = errs[0];
+        HDS_full(kind, u, h, d, len); c->n_hds++; TRACE(2, h);
+        S = inlidxs(d, len, th, inliersS);
+        if (scoreLess(maxS, S)) {
+            if (doSymCheck) {
+                hsym_prepare(h, &hs);
+                S.Is = 0;
+                for (j = 0; j < (int)S.I; j++) if (hsym_one(&hs, u + 6*inliersS[j], 2, 1) <= SymCheck_th) S.Is++;   /* HDsSymMaxidx */
+                if (S.Is < maxS.Is) continue;
+            }
+            if (DO_LAF_CHECK) {
+                Scheck = inlidxs(d, len, th, inliersS);
+                hsym_prepare(h, &hs);
+                for (j = 0; j < (int)Scheck.I; j++)
+                    if (HDS_sub(kind, &hs, u + 6*inliersS[j], u_1 + 6*inliersS[j], h) <= th_laf_check) p1_inliers++;   /* never reset: exp_ranH.c:501,605 */
+                if (p1_inliers < (int)maxS.Ilafs) continue;
+                S.Ilafs = 0;
+                for (j = 0; j < (int)Scheck.I; j++)
+                    if (HDS_sub(kind, &hs, u + 6*inliersS[j], u_2 + 6*inliersS[j], h) <= th_laf_check) S.Ilafs++;
+                S.Ilafs = (int)S.Ilafs < p1_inliers ? S.Ilafs : (unsigned)p1_inliers;
+                if (S.Ilafs < maxS.Ilafs) continue;
+            }
+            errs[0] = errs[3]; errs[3] = d;
+            maxS = S; new_max = 1; accepted = 1; best_sample = no_sam;
+            memcpy(H, h, 9 * sizeof(double));
+        }
+        if (scoreLess(maxSs, S)) {
+            do_iterate = no_sam > ITER_SAM;
+            maxSs = S; errs[4] = d;
+            memcpy(bestsamidx, samidx, 4 * sizeof(int));
+        } else do_iterate = 0;
+        if ((no_sam >= ITER_SAM) && (iter_cnt == 0) && (maxSs.I > 4)) do_iterate = 1;
+
+        if (do_iterate) {
+            iter_cnt++;
+            d = errs[0];
+            S = inlidxs(errs[4], len, TC*th*MWM, inliers);
+            TRACE2(1, S.I, no_sam);
+            u2h(u, inliers, S.I, h);
+            HDS_full(kind, u, h, d, len); c->n_hds++; TRACE(2, h);
+            S = inlidxs(d, len, th, inliers);
+            TRACE2(2, S.I, S.J);
+            S = exp_inHranicustom(c, u, len, inliers, S.I, th, errs, h, RAN_REP, &iterID, inlLimit, kind);
+            TRACE2(3, S.I, S.J);
+            if (scoreLess(maxS, S) && !HcloseToSingular(h)) {
+                do_update = 1;
+                if (doSymCheck) {
+                    /* `d` still is the buffer that was errs[0] before the LO rotated the pointers: whatever
+                     * residuals were written there last define the "current inliers" (exp_ranH.c:708) */
+                    Scheck = inlidxs(d, len, th, inliersS);
+                    TRACE2(4, Scheck.I, Scheck.J);
+                    hsym_prepare(h, &hs);
+                    S.Is = 0;
+                    for (j = 0; j < (int)Scheck.I; j++) if (hsym_one(&hs, u + 6*inliersS[j], 2, 1) <= SymCheck_th) S.Is++;
+                    if (S.Is < maxS.Is) do_update = 0;
+                }
+                if (do_update && DO_LAF_CHECK) {
+                    Scheck = inlidxs(d, len, th, inliersS);
+                    hsym_prepare(h, &hs);
+                    for (j = 0; j < (int)Scheck.I; j++)
+                        if (HDS_sub(kind, &hs, u + 6*inliersS[j], u_1 + 6*inliersS[j], h) <= th_laf_check) p1_inliers++;
+                    S.Ilafs = 0;
+                    for (j = 0; j < (int)Scheck.I; j++)
+                        if (HDS_sub(kind, &hs, u + 6*inliersS[j], u_2 + 6*inliersS[j], h) <= th_laf_check) S.Ilafs++;
+                    S.Ilafs = (int)S.Ilafs < p1_inliers ? S.Ilafs : (unsigned)p1_inliers;
+                    if (S.Ilafs < maxS.Ilafs) do_update = 0;
+                }
+                if (do_update) {
+                    d = errs[0]; errs[0] = errs[3]; errs[3] = d;
+                    maxS = S; new_max = 1; accepted = 1; best_sample = no_sam;
+                    memcpy(H, h, 9 * sizeof(double));
+                }
+            }
+        }
+        if (new_max) {
+            new_sam = dg_nsamples(maxS.I + 1, len, 4, conf);
+            if (new_sam < max_sam) max_sam = new_sam;
+            new_max = 0;
+        }
+    }
+    if (iter_cnt == 0) {                                     /* exp_ranH.c:759-862 */
+        iter_cnt++;
+        d = errs[0];
+        S = inlidxs(errs[4], len, TC*th*MWM, inliers);
+        u2h(u, inliers, S.I, h);
+        HDS_full(kind, u, h, d, len); c->n_hds++; TRACE(2, h);
+        S = inlidxs(d, len, th, inliers);
+        S = exp_inHranicustom(c, u, len, inliers, S.I, th, errs, h, RAN_REP, &iterID, inlLimit, kind);
+        if (scoreLess(maxS, S) && !HcloseToSingular(h)) {
+            do_update = 1;
+            if (doSymCheck) {
+                Scheck = inlidxs(d, len, th, inliersS);
+                hsym_prepare(h, &hs);
+                S.Is = 0;
+                for (j = 0; j < (int)Scheck.I; j++) if (hsym_one(&hs, u + 6*inliersS[j], 2, 1) <= SymCheck_th) S.Is++;   /* HDsiSymMax */
+                if (S.Is < maxS.Is) do_update = 0;
+            }
+            if (do_update && DO_LAF_CHECK) {
+                Scheck = inlidxs(d, len, th, inliersS);
+                hsym_prepare(h, &hs);
+                for (j = 0; j < (int)Scheck.I; j++)
+                    if (HDS_sub(kind, &hs, u + 6*inliersS[j], u_1 + 6*inliersS[j], h) <= th_laf_check) p1_inliers++;
+                S.Ilafs = 0;
+                for (j = 0; j < (int)Scheck.I; j++)
+                    if (HDS_sub(kind, &hs, u + 6*inliersS[j], u_2 + 6*inliersS[j], h) <= th_laf_check) S.Ilafs++;
+                S.Ilafs = (int)S.Ilafs < p1_inliers ? S.Ilafs : (unsigned)p1_inliers;
+                if (S.Ilafs < maxS.Ilafs) do_update = 0;
+            }
+            if (do_update) {
+                d = errs[0]; errs[0] = errs[3]; errs[3] = d;
+                maxS = S; accepted = 1; best_sample = no_sam;
+                memcpy(H, h, 9 * sizeof(double));
+            }
+        }
+    }
+    d = errs[3];
+    if (!accepted) { for (j = 0; j < len; j++) inl[j] = 0; }
+    else {
+        for (j = 0; j < len; j++) inl[j] = (d[j] <= th) ? 1 : 0;
+        if (doSymCheck) {
+            Scheck = inlidxs(d, len, th, inliersS);
+            hsym_prepare(H, &hs);
+            for (j = 0; j < (int)Scheck.I; j++) if (hsym_one(&hs, u + 6*inliersS[j], 2, 1) > SymCheck_th) inl[inliersS[j]] = 0;
+        }
+        if (DO_LAF_CHECK) {
+            Scheck = inlidxs(d, len, th, inliersS);
+            hsym_prepare(H, &hs);
+            for (j = 0; j < (int)Scheck.I; j++) if (HDS_sub(kind, &hs, u + 6*inliersS[j], u_1 + 6*inliersS[j], H) > th_laf_check) inl[inliersS[j]] = 0;
+            for (j = 0; j < (int)Scheck.I; j++) if (HDS_sub(kind, &hs, u + 6*inliersS[j], u_2 + 6*inliersS[j], H) > th_laf_check) inl[inliersS[j]] = 0;
+        }
+    }
+    free(pool); free(err); free(inliers); free(inliersS); free(d_check);
+    (void)bestsamidx;
+    if (stats) {
+        stats[DG_ST_SAMPLES] = no_sam; stats[DG_ST_LO_RUNS] = iter_cnt; stats[DG_ST_REJECTED] = no_rej;
+        stats[DG_ST_I] = (int)maxS.I; stats[DG_ST_MODELS] = (int)c->n_hds; stats[DG_ST_DEGEN] = 0; stats[DG_ST_IH] = 0;
+        stats[DG_ST_BEST_SAMPLE] = best_sample; stats[8] = (int)c->n_hds; stats[9] = 0; stats[10] = 0; stats[11] = 0;
+    }
+    return maxS;
+}
+
 int dg_oracle_find_homography(const double *x1, const double *x2, int n, int dim,
                               double px_th, double conf, int max_iters, int error_type,
                               int sym_check, double laf_coef, unsigned seed,
                               double *H, unsigned char *mask, int *stats)
 {
-    (void)x1; (void)x2; (void)n; (void)dim; (void)px_th; (void)conf; (void)max_iters; (void)error_type;
-    (void)sym_check; (void)laf_coef; (void)seed; (void)H; (void)mask; (void)stats;
-    return -100;   /* H driver restatement: see dg_oracle_h.c (next milestone) */
+    dg_ctx c; int laf = laf_coef > 0 && dim == 6, i; double th, sym_th, coef = 3.0 * (sym_check ? 1 : 0);
+    double *u, *ua, *ub; dg_score S;
+    if ((dim != 2 && dim != 6) || n < 4) return -1;          /* bindings.cpp:32-37 */
+    switch (error_type) {                                    /* bindings.cpp:64-107 */
+    case 1:  th = px_th*px_th; sym_th = 0; break;
+    case 2:  th = px_th;       sym_th = 0; break;
+    case 3:  th = px_th*px_th; sym_th = px_th*coef; break;
+    case 4:  th = px_th;       sym_th = px_th*coef; break;
+    default: th = px_th*px_th; sym_th = px_th*coef; error_type = 0; break;
+    }
+    memset(&c, 0, sizeof c);
+    u = (double *)malloc(sizeof(double) * 6 * (size_t)n);
+    ua = (double *)malloc(sizeof(double) * 6 * (size_t)(laf ? n : 1));
+    ub = (double *)malloc(sizeof(double) * 6 * (size_t)(laf ? n : 1));
+    build_u(x1, x2, n, dim, laf, u, ua, ub);
+    for (i = 0; i < 9; i++) H[i] = 0;
+    S = exp_ransacHcustomLAF(&c, u, ua, ub, n, th, laf ? laf_coef : 0.0, conf, max_iters, H, mask, 0, error_type, sym_th, seed, stats);
+    free(u); free(ua); free(ub); free(c.ht);
+    return (int)S.I;
 }
