@@ -142,4 +142,178 @@ __device__ __forceinline__ int dg_ori_valid7(const double *F, const dg_pt *s /* 
     return ok;
 }
 
+
+/* ---- Htools.c:202-370 / :428-605 / :649-816: the four symmetric transfer errors --------------------
+ * Hinv = transpose of the stored H, H1 = minv(Hinv) (prepared once per model).  kind: 1 SymMaxSq,
+ * 2 SymMax, 3 SymSumSq, 4 SymSum.  eps = the +1e-10 on the denominators: always for the Sum metrics and
+ * for every i/idx variant, never for the plain HDsSymMax / HDsSymMaxSq (Htools.c:310-311, :352-353). */
+struct dg_hsym { double Hinv[9], H1[9]; };
+#define DG_HMAX(i,j) ( (i)<(j) ? (j):(i) )
+__device__ __forceinline__ double dg_Hsym(const double *Hinv, const double *H1, double u0, double u1, double u3, double u4, int kind, int eps)
+{
+    double a = H1[6]*u0 + H1[7]*u1 + H1[8];
+    double b = Hinv[6]*u3 + Hinv[7]*u4 + Hinv[8];
+    if (eps) { a = a + 1e-10; b = b + 1e-10; }
+    double xa = (H1[0]*u0 + H1[1]*u1 + H1[2]) / a;
+    double ya = (H1[3]*u0 + H1[4]*u1 + H1[5]) / a;
+    double xdiff = u3 - xa, ydiff = u4 - ya;
+    double d1 = xdiff*xdiff + ydiff*ydiff;
+    xa = (Hinv[0]*u3 + Hinv[1]*u4 + Hinv[2]) / b;
+    ya = (Hinv[3]*u3 + Hinv[4]*u4 + Hinv[5]) / b;
+    xdiff = u0 - xa; ydiff = u1 - ya;
+    double d2 = xdiff*xdiff + ydiff*ydiff;
+    if (kind == 1) return DG_HMAX(d1, d2);
+    if (kind == 2) return sqrt(DG_HMAX(d1, d2));
+    if (kind == 3) return d1 + d2;
+    return sqrt(d1) + sqrt(d2);
+}
+/* HDsi / HDsidx (Htools.c:372-410, :607-647): residual rows from the ORIGINAL point's DLT rows, Jacobian
+ * terms from the point set passed as u6 (the LAF-shifted points in the LAF checks) */
+__device__ __forceinline__ double dg_HDs_mixed(const double *H, double o0, double o1, double o3, double o4,
+                                               double u0, double u1, double u3, double u4)
+{
+    double r1 = 0, r2 = 0;
+    r1 += H[0] * o3;  r2 += H[0] * 0.0;
+    r1 += H[1] * 0.0; r2 += H[1] * o3;
+    r1 += H[2] * (-o0 * o3); r2 += H[2] * (-o1 * o3);
+    r1 += H[3] * o4;  r2 += H[3] * 0.0;
+    r1 += H[4] * 0.0; r2 += H[4] * o4;
+    r1 += H[5] * (-o0 * o4); r2 += H[5] * (-o1 * o4);
+    r1 += H[6] * 1.0; r2 += H[6] * 0.0;
+    r1 += H[7] * 0.0; r2 += H[7] * 1.0;
+    r1 += H[8] * (-o0 * 1.0); r2 += H[8] * (-o1 * 1.0);
+    double a = H[0] - H[2] * u0;
+    double b = H[3] - H[5] * u0;
+    double c = -H[8] - H[2] * u3 - H[5] * u4;
+    double d = H[1] - H[2] * u1;
+    double e = H[4] - H[5] * u1;
+    double pJ[8];
+    dg_pinvJ(a, b, c, d, e, pJ);
+    double p = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { double t = pJ[j] * r1 + pJ[j+4] * r2; p += t * t; }
+    return p;
+}
+/* the metric selected by bindings.cpp:64-107 as a full pass (HDS1): kind 0 Sampson, 1..4 symmetric */
+__device__ __forceinline__ double dg_Herr(int kind, const double *H, const double *Hinv, const double *H1, const dg_pt &p)
+{
+    if (kind == 0) return dg_HDs(H, p.x1, p.y1, p.x2, p.y2);
+    return dg_Hsym(Hinv, H1, p.x1, p.y1, p.x2, p.y2, kind, kind >= 3);
+}
+
+/* exp_ranH.c:29-44 */
+__device__ __forceinline__ int dg_HcloseToSingular(const double *h)
+{
+    double v = dg_det3(h), tol = h[8];
+    if (tol == 0) { for (int i = 0; i < 9; ++i) tol += h[i]*h[i]; tol = sqrt(tol); tol *= 0.001; }
+    tol = tol*tol*tol;
+    return (fabs(v/tol) < 1e-2);
+}
+
+/* Htools.c:821-848 all_Hori_valid on the 4 sample points; s[] in DRAW order, samidx = reverse draw order */
+__device__ __forceinline__ int dg_Hori_valid4(const dg_pt *s)
+{
+    const dg_pt &A = s[3], &B = s[2], &Cc = s[1], &D = s[0];
+    double a[6] = {A.x1, A.y1, 1.0, A.x2, A.y2, 1.0}, b[6] = {B.x1, B.y1, 1.0, B.x2, B.y2, 1.0};
+    double c[6] = {Cc.x1, Cc.y1, 1.0, Cc.x2, Cc.y2, 1.0}, d[6] = {D.x1, D.y1, 1.0, D.x2, D.y2, 1.0};
+    double p[3], q[3];
+    dg_crossprod_st(p, a, b, 1); dg_crossprod_st(q, a+3, b+3, 1);
+    if ((p[0]*c[0]+p[1]*c[1]+p[2]*c[2])*(q[0]*c[3]+q[1]*c[4]+q[2]*c[5]) < 0) return 0;
+    if ((p[0]*d[0]+p[1]*d[1]+p[2]*d[2])*(q[0]*d[3]+q[1]*d[4]+q[2]*d[5]) < 0) return 0;
+    dg_crossprod_st(p, c, d, 1); dg_crossprod_st(q, c+3, d+3, 1);
+    if ((p[0]*a[0]+p[1]*a[1]+p[2]*a[2])*(q[0]*a[3]+q[1]*a[4]+q[2]*a[5]) < 0) return 0;
+    if ((p[0]*b[0]+p[1]*b[1]+p[2]*b[2])*(q[0]*b[3]+q[1]*b[4]+q[2]*b[5]) < 0) return 0;
+    return 1;
+}
+
+/* 4-point DLT null vector, one sample per lane (utools.c:97-167 on the 8x9 system of multirsampleT,
+ * rtools.c:136-156: rows 2i, 2i+1 = DLT rows of the i-th DRAWN point).  Generic case: pivots in
+ * columns 0..7, column 8 free.  Returns 0 when some column j<8 has no pivot >= 1e-12. */
+__device__ __forceinline__ int dg_gj8(double (&m)[8][9], double *h)
+{
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        double pivot = fabs(m[j][j]); int mx = j;
+#pragma unroll
+        for (int k = j + 1; k < 8; k++) { double t = fabs(m[k][j]); if (pivot < t) { pivot = t; mx = k; } }
+        if (pivot < 1e-12) return 0;
+#pragma unroll
+        for (int k = j + 1; k < 8; k++) {
+            if (mx == k) {
+#pragma unroll
+                for (int l = j; l < 9; l++) { double t = m[j][l]; m[j][l] = m[k][l]; m[k][l] = t; }
+            }
+        }
+        double pv = m[j][j];
+#pragma unroll
+        for (int l = j; l < 9; l++) m[j][l] /= pv;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (k == j) continue;
+            double pk = m[k][j];
+#pragma unroll
+            for (int l = j; l < 9; l++) m[k][l] -= pk * m[j][l];
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < 8; l++) h[l] = -m[l][8];
+    h[8] = 1;
+    return 1;
+}
+
+/* matutls/minv.c for n = 3 with private temporaries (re-entrant: one call per lane) */
+__device__ __noinline__ int dg_minv3(double *a)
+{
+    const int n = 3;
+    int lc, le[3]; double s, t, tq = 0., zr = 1.e-15, q0[3];
+    double *pa, *pd, *ps, *p, *q; int i, j, k, m, nle = 0;
+    for (j = 0, pa = pd = a; j < n; ++j, ++pa, pd += n + 1) {
+        if (j > 0) {
+            for (i = 0, q = q0, p = pa; i < n; ++i, p += n) *q++ = *p;
+            for (i = 1; i < n; ++i) { lc = i < j ? i : j; for (k = 0, p = pa + i*n - j, q = q0, t = 0.; k < lc; ++k) t += *p++ * *q++; q0[i] -= t; }
+            for (i = 0, q = q0, p = pa; i < n; ++i, p += n) *p = *q++;
+        }
+        s = fabs(*pd); lc = j;
+        for (k = j + 1, ps = pd; k < n; ++k) { if ((t = fabs(*(ps += n))) > s) { s = t; lc = k; } }
+        tq = tq > s ? tq : s;
+        if (s < zr * tq) return -1;
+        le[nle++] = lc;
+        if (lc != j) { for (k = 0, p = a + n*j, q = a + n*lc; k < n; ++k) { t = *p; *p++ = *q; *q++ = t; } }
+        for (k = j + 1, ps = pd, t = 1. / *pd; k < n; ++k) *(ps += n) *= t;
+        *pd = t;
+    }
+    for (j = 1, pd = ps = a; j < n; ++j) { for (k = 0, pd += n + 1, q = ++ps; k < j; ++k, q += n) *q *= *pd; }
+    for (j = 1, pa = a; j < n; ++j) {
+        ++pa;
+        for (i = 0, q = q0, p = pa; i < j; ++i, p += n) *q++ = *p;
+        for (k = 0; k < j; ++k) { t = 0.; for (i = k, p = pa + k*n + k - j, q = q0 + k; i < j; ++i) t -= *p++ * *q++; q0[k] = t; }
+        for (i = 0, q = q0, p = pa; i < j; ++i, p += n) *p = *q++;
+    }
+    for (j = n - 2, pd = pa = a + n*n - 1; j >= 0; --j) {
+        --pa; pd -= n + 1;
+        for (i = 0, m = n - j - 1, q = q0, p = pd + n; i < m; ++i, p += n) *q++ = *p;
+        for (k = n - 1, ps = pa; k > j; --k, ps -= n) { t = -(*ps); for (i = j + 1, p = ps, q = q0; i < k; ++i) t -= *++p * *q++; q0[--m] = t; }
+        for (i = 0, m = n - j - 1, q = q0, p = pd + n; i < m; ++i, p += n) *p = *q++;
+    }
+    for (k = 0, pa = a; k < n - 1; ++k, ++pa) {
+        for (i = 0, q = q0, p = pa; i < n; ++i, p += n) *q++ = *p;
+        for (j = 0, ps = a; j < n; ++j, ps += n) {
+            if (j > k) { t = 0.; p = ps + j; i = j; } else { t = q0[j]; p = ps + k + 1; i = k + 1; }
+            for (; i < n;) t += *p++ * q0[i++];
+            q0[j] = t;
+        }
+        for (i = 0, q = q0, p = pa; i < n; ++i, p += n) *p = *q++;
+    }
+    for (j = n - 2, nle--; j >= 0; --j) { --nle; for (k = 0, p = a + j, q = a + le[nle]; k < n; ++k, p += n, q += n) { t = *p; *p = *q; *q = t; } }
+    return 0;
+}
+__device__ __forceinline__ void dg_hsym_prepare(const double *H, double *Hinv, double *H1)
+{
+    Hinv[0] = H[0]; Hinv[1] = H[3]; Hinv[2] = H[6];
+    Hinv[3] = H[1]; Hinv[4] = H[4]; Hinv[5] = H[7];
+    Hinv[6] = H[2]; Hinv[7] = H[5]; Hinv[8] = H[8];
+    for (int i = 0; i < 9; i++) H1[i] = Hinv[i];
+    dg_minv3(H1);
+}
+
 #endif /* DG_GEOM_H */

@@ -94,12 +94,12 @@ __device__ __forceinline__ void dg_rng_outputs(unsigned seed, unsigned *o)
     for (int k = 0; k < 8; k++) o[k] = acc[k] >> 1;
 }
 /* wave-cooperative: next seed only (lanes 0..30 carry one term each) */
-__device__ __forceinline__ unsigned dg_rng_next_seed_wave(unsigned seed, int lane)
+__device__ __forceinline__ unsigned dg_rng_next_seed_wave(unsigned seed, int lane, int kout = 7)
 {
     if (seed == 0) seed = 1;
     unsigned r1 = dg_lcg_first((int)seed);
     unsigned rj = (lane == 0) ? seed : ((lane < 31) ? dg_mulmod31(r1, dg_rng_G[(lane - 1) & 31]) : 0u);
-    unsigned term = (lane < 31) ? dg_rng_C[7][lane & 31] * rj : 0u;
+    unsigned term = (lane < 31) ? dg_rng_C[kout][lane & 31] * rj : 0u;
     return dg_wave_sum_u(term) >> 1;
 }
 

@@ -1,0 +1,517 @@
+/* Persistent homography kernel: one workgroup runs the whole reference driver exp_ransacHcustomLAF
+ * (degensac/exp_ranH.c:470-930, iter_type 4, oriented constraint on, unlimited LSQ) for one pair.
+ * Same speculate-then-commit structure as the F kernel (dg_kernel_f_main.h); differences:
+ *   - 4 draws per sample (next seed = 5th output), orientation / rank / near-singularity rejects
+ *     happen in the per-lane solve, at most one model per sample;
+ *   - five selectable error metrics (Htools.c) incl. the symmetric ones that need H^-1 per model;
+ *   - LO re-fits on ALL band inliers (inlLimit = 1e6): workgroup-parallel normalised DLT.
+ */
+#ifndef DG_KERNEL_H_H
+#define DG_KERNEL_H_H
+#include "dg_kernel_f_main.h"
+
+/* u2h (Htools.c:115-131) over a list of ids, reference summation order (see dg_lsq_seq) */
+template <class PtFn>
+__device__ __forceinline__ void dg_u2h_big(dg_red *r, dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, double *Hout /* LDS */)
+{
+    (void)r;
+    dg_lsq_seq(s, pt, list, len, tid, 1, s->A1, s->A2);
+    if (tid == 0) {
+        dg_eig_sym(s->V, s->D, 9);
+        for (int i = 0; i < 9; i++) Hout[i] = s->V[i];
+        dg_denormH(Hout, s->A1, s->A2);
+    }
+    __syncthreads();
+}
+
+/* u2h over a global id list of any length (lane 0 for <= 12 points, cooperative otherwise) */
+template <bool LDSPTS>
+__device__ __forceinline__ void dg_u2h_list(CTX &c, const int *list, int len, double *Hout)
+{
+    dg_f_shared *S = c.S;
+    if (len <= 12) {
+        __syncthreads();
+        if (c.tid == 0) { dg_gather(c, list, len, S->lsq.px); dg_u2h_small(&S->lsq, S->lsq.px, len, Hout); }
+        __syncthreads();
+    } else {
+        const dg_pt *P = c.P;
+        dg_u2h_big(&S->red, &S->lsq, [&](int i) { return P[i]; }, list, len, c.tid, Hout);
+    }
+}
+
+/* a full pass of the selected H metric; counts as one HDS1 call when `count` */
+template <bool LDSPTS>
+__device__ __forceinline__ dg_pass_res dg_hm_pass(CTX &c, int kind, const double *Hm /* LDS */, dg_pass_cfg cfg)
+{
+    dg_f_shared *S = c.S;
+    double H[9], Hinv[9], H1[9];
+    if (kind != 0) {
+        __syncthreads();
+        if (c.tid == 0) dg_hsym_prepare(Hm, S->lsq.Z8, S->lsq.Z8 + 9);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) { H[i] = Hm[i]; Hinv[i] = kind ? S->lsq.Z8[i] : 0; H1[i] = kind ? S->lsq.Z8[9+i] : 0; }
+    const dg_pt *P = c.P;
+    return dg_pass(&S->red, cfg, [&](int pid, int) { return dg_Herr(kind, H, Hinv, H1, P[pid]); }, c.tid);
+}
+
+/* symmetric (HDsSymMaxidx, eps variant) and LAF (HDSi1 on u_1, u_2) consistency of model h over the ids
+ * list[0..cnt): exp_ranH.c:587-618, :706-735, :828-853.  p1_inliers is the driver's never-reset counter
+ * (exp_ranH.c:501).  early_p1: the main loop bails out after the first LAF set when p1 < maxS.Ilafs. */
+template <bool LDSPTS>
+__device__ __forceinline__ int dg_h_checks(CTX &c, int kind, const double *h /* LDS */, const int *list, int cnt, dg_score &S,
+                                           const dg_score &maxS, int *p1_inliers, int early_p1)
+{
+    const dg_params &pr = c.A->prm;
+    dg_f_shared *Sh = c.S;
+    double H[9], Hinv[9], H1[9];
+    __syncthreads();
+    if (c.tid == 0) dg_hsym_prepare(h, Sh->lsq.Z8, Sh->lsq.Z8 + 9);
+    __syncthreads();
+    for (int i = 0; i < 9; i++) { H[i] = h[i]; Hinv[i] = Sh->lsq.Z8[i]; H1[i] = Sh->lsq.Z8[9+i]; }
+    const dg_pt *P = c.P;
+    if (pr.sym_th > 0) {
+        dg_pass_cfg cfg = dg_cfg0(cnt); cfg.src = list; cfg.wantC = 1; cfg.thC = pr.sym_th;
+        dg_pass_res r = dg_pass(&Sh->red, cfg, [&](int pid, int) { dg_pt p = P[pid]; return dg_Hsym(Hinv, H1, p.x1, p.y1, p.x2, p.y2, 2, 1); }, c.tid);
+        S.Is = r.C;
+        if (S.Is < maxS.Is) return 0;
+    }
+    if (pr.laf_coef > 0) {
+        double thl = pr.laf_coef * pr.th;
+        dg_pass_cfg cfg = dg_cfg0(cnt); cfg.src = list; cfg.wantC = 1; cfg.thC = thl;
+        dg_pass_res r1 = dg_pass(&Sh->red, cfg, [&](int pid, int) {
+            dg_pt o = P[pid], l = c.laf_pt(pid, 1);
+            return kind == 0 ? dg_HDs_mixed(H, o.x1, o.y1, o.x2, o.y2, l.x1, l.y1, l.x2, l.y2) : dg_Hsym(Hinv, H1, l.x1, l.y1, l.x2, l.y2, kind, 1); }, c.tid);
+        *p1_inliers += (int)r1.C;
+        if (early_p1 && *p1_inliers < (int)maxS.Ilafs) return 0;
+        dg_pass_res r2 = dg_pass(&Sh->red, cfg, [&](int pid, int) {
+            dg_pt o = P[pid], l = c.laf_pt(pid, 2);
+            return kind == 0 ? dg_HDs_mixed(H, o.x1, o.y1, o.x2, o.y2, l.x1, l.y1, l.x2, l.y2) : dg_Hsym(Hinv, H1, l.x1, l.y1, l.x2, l.y2, kind, 1); }, c.tid);
+        S.Ilafs = (int)r2.C < *p1_inliers ? r2.C : (unsigned)*p1_inliers;
+        if (S.Ilafs < maxS.Ilafs) return 0;
+    }
+    return 1;
+}
+
+/* physical residual-buffer bookkeeping of the LO: pe[k] = physical id behind errs[k], k=0..2;
+ * bufM[b] = model whose residuals physical buffer b holds */
+struct dg_hbufs { int pe[3]; };
+#define DG_BUFSET(S, b, src) do { __syncthreads(); if (tid < 9) (S)->bufF[(b)][tid] = (src)[tid]; __syncthreads(); } while (0)
+
+/* exp_ranH.c:291-412 exp_iterHcustom; h (LDS) = in/out parameter H */
+template <bool LDSPTS>
+__device__ __forceinline__ dg_score dg_iterHc(CTX &c, int kind, int *inliers, double th, double ths, double *h, int iterID, unsigned inlLimit, dg_hbufs &B)
+{
+    dg_f_shared *S = c.S; const int n = c.n, tid = c.tid;
+    double *hl = S->fLO;
+    dg_score zero = {0, 0, 0, 0}, maxS = zero;
+    double dth = (ths - th) / DG_ILSQ_ITERS;
+    int pd = B.pe[1];                                         /* d = errs[1] */
+    /* errs[4] = errs[0] holds HDS1(h): inlidxs(th) and the list at th*MWM in one pass */
+    dg_pass_cfg c0 = dg_cfg0(n); c0.wantJ = 1; c0.thJ = th; c0.list = inliers; c0.thL = th * DG_MWM;
+    dg_pass_res r0 = dg_hm_pass(c, kind, h, c0); c.n_hds++;
+    maxS.I = r0.I; maxS.J = r0.J;
+    DG_TRACE(c, 20, maxS.I, maxS.J);
+    if (maxS.I < 4) {
+        dg_pass_cfg c1 = dg_cfg0(n); c1.list = inliers; c1.thL = th;
+        dg_hm_pass(c, kind, h, c1);
+        return zero;
+    }
+    {
+        int cnt = (int)r0.nL, o = 0, use = cnt;
+        unsigned dc = (unsigned)cnt; if (dc > inlLimit) dc = inlLimit; if (dc < 4) dc = 4;
+        __syncthreads();
+        if (dc < (unsigned)cnt) { if (tid == 0) dg_randsubset(&S->rng, inliers, cnt, (int)dc); use = (int)dc; o = cnt - (int)dc; }
+        __syncthreads();
+        dg_u2h_list(c, inliers + o, use, hl);
+    }
+    for (int it = 0; it < DG_ILSQ_ITERS; it++) {
+        dg_pass_cfg c1 = dg_cfg0(n); c1.wantJ = 1; c1.thJ = th; c1.list = inliers; c1.thL = th;
+        dg_pass_res r1 = dg_hm_pass(c, kind, hl, c1); c.n_hds++;
+        DG_BUFSET(S, pd, hl);
+        dg_score Ss = zero; Ss.I = r1.I; Ss.J = r1.J;
+        DG_TRACE(c, 21, Ss.I, Ss.J);
+        __syncthreads();
+        if (tid == 0) {
+            unsigned hash = dg_hash_list(inliers, (int)Ss.I);
+            int ret = dg_ht_contains(c.ht, hash, (int)Ss.I, iterID);
+            if (ret == -1) dg_ht_insert(c.ht, hash, (int)Ss.I, iterID);
+            S->itmp[0] = (ret != -1 && ret != iterID) ? 1 : 0;
+        }
+        __syncthreads();
+        if (S->itmp[0]) { DG_TRACE(c, 23, 0, 0); return zero; }
+        dg_pass_cfg c2 = dg_cfg0(n); c2.list = inliers; c2.thL = ths * DG_MWM;
+        dg_pass_res r2 = dg_hm_pass(c, kind, hl, c2);
+        DG_TRACE(c, 24, r2.nL, 0);
+        if (maxS.J < Ss.J) {
+            maxS = Ss;
+            { int t = B.pe[0]; B.pe[1] = t; B.pe[0] = pd; pd = B.pe[1]; }
+            __syncthreads();
+            if (tid < 9) h[tid] = hl[tid];
+            __syncthreads();
+        }
+        if (r2.nL < 4) return maxS;
+        {
+            int cnt = (int)r2.nL, o = 0, use = cnt;
+            unsigned dc = (unsigned)cnt; if (dc > inlLimit) dc = inlLimit; if (dc < 4) dc = 4;
+            __syncthreads();
+            if (dc < (unsigned)cnt) { if (tid == 0) dg_randsubset(&S->rng, inliers, cnt, (int)dc); use = (int)dc; o = cnt - (int)dc; }
+            __syncthreads();
+            dg_u2h_list(c, inliers + o, use, hl);
+        }
+        ths -= dth;
+    }
+    dg_pass_cfg c3 = dg_cfg0(n); c3.wantJ = 1; c3.thJ = th; c3.list = inliers; c3.thL = th;
+    dg_pass_res r3 = dg_hm_pass(c, kind, hl, c3); c.n_hds++;
+    DG_BUFSET(S, pd, hl);
+    DG_TRACE(c, 22, r3.I, r3.J);
+    if (maxS.J < r3.J) {
+        maxS = zero; maxS.I = r3.I; maxS.J = r3.J;
+        B.pe[1] = B.pe[0]; B.pe[0] = pd;
+        __syncthreads();
+        if (tid < 9) h[tid] = hl[tid];
+        __syncthreads();
+    }
+    return maxS;
+}
+
+/* exp_ranH.c:415-467 exp_inHranicustom; inliers = L[0]; result model -> Hout (LDS) */
+template <bool LDSPTS>
+__device__ __forceinline__ dg_score dg_inHranic(CTX &c, int kind, int ninl, double th, double *Hout, int *iterID, unsigned inlLimit, dg_hbufs &B)
+{
+    dg_f_shared *S = c.S; const int tid = c.tid;
+    int *inliers = c.L[0], *intbuff = c.L[1];
+    dg_score maxS = {0, 0, 0, 0};
+    if (ninl < 8) return maxS;
+    int ssiz = ninl / 2; if (ssiz > 12) ssiz = 12;
+    { int t = B.pe[2]; B.pe[2] = B.pe[0]; B.pe[0] = t; }
+    for (int i = 0; i < DG_RAN_REP; i++) {
+        __syncthreads();
+        if (tid == 0) {
+            int o = dg_randsubset(&S->rng, inliers, ninl, ssiz);
+            dg_gather(c, inliers + o, ssiz, S->lsq.px);
+            dg_u2h_small(&S->lsq, S->lsq.px, ssiz, S->f);
+        }
+        __syncthreads();
+        DG_BUFSET(S, B.pe[0], S->f);                          /* HDS1(h) -> errs[0] (scored inside dg_iterHc) */
+        ++*iterID;
+        dg_score Sc = dg_iterHc(c, kind, intbuff, th, DG_TC * th, S->f, *iterID, inlLimit, B);
+        if (maxS.J < Sc.J) {
+            maxS = Sc;
+            { int t = B.pe[2]; B.pe[2] = B.pe[0]; B.pe[0] = t; }
+            __syncthreads();
+            if (tid < 9) Hout[tid] = S->f[tid];
+            __syncthreads();
+        }
+    }
+    { int t = B.pe[2]; B.pe[2] = B.pe[0]; B.pe[0] = t; }
+    return maxS;
+}
+
+/* one LO run of the driver (exp_ranH.c:678-747 / :795-861).  e4 = model behind errs[4].  Returns 1 if accepted. */
+template <bool LDSPTS>
+__device__ __forceinline__ int dg_h_lo(CTX &c, int kind, const double *e4, double th, dg_score &maxS, int *iterID, int *p1_inliers, int no_sam)
+{
+    dg_f_shared *S = c.S; const int n = c.n, tid = c.tid;
+    dg_hbufs B; B.pe[0] = 0; B.pe[1] = 1; B.pe[2] = 2;
+    const int B0 = B.pe[0];                                   /* d = errs[0] */
+    dg_pass_cfg ca = dg_cfg0(n); ca.list = c.L[0]; ca.thL = DG_TC * th * DG_MWM;
+    dg_pass_res ra = dg_hm_pass(c, kind, e4, ca);
+    DG_TRACE(c, 1, ra.nL, no_sam);
+    dg_u2h_list(c, c.L[0], (int)ra.nL, S->f);
+    DG_BUFSET(S, B0, S->f);
+    dg_pass_cfg cb = dg_cfg0(n); cb.wantJ = 1; cb.thJ = th; cb.list = c.L[0]; cb.thL = th;
+    dg_pass_res rb = dg_hm_pass(c, kind, S->f, cb); c.n_hds++;
+    DG_TRACE(c, 2, rb.nL, rb.J);
+    /* h (the driver's `sol`) = S->Hx: u2h wrote the LSQ model there; inHrani overwrites it on improvement */
+    __syncthreads();
+    if (tid < 9) S->Hx[tid] = S->f[tid];
+    __syncthreads();
+    dg_score Sl = dg_inHranic(c, kind, (int)rb.nL, th, S->Hx, iterID, 1000000u, B);
+    DG_TRACE(c, 3, Sl.I, Sl.J);
+    if (!(maxS.J < Sl.J)) return 0;
+    if (dg_HcloseToSingular(S->Hx)) return 0;
+    const dg_params &pr = c.A->prm;
+    if (pr.sym_th > 0 || pr.laf_coef > 0) {
+        /* Scheck = inlidxs(d, th): `d` is the physical buffer that was errs[0] before the LO (exp_ranH.c:708) */
+        dg_pass_cfg cl = dg_cfg0(n); cl.wantJ = 1; cl.thJ = th; cl.list = c.L[2]; cl.thL = th;
+        dg_pass_res rl = dg_hm_pass(c, kind, S->bufF[B0], cl);
+        DG_TRACE(c, 4, rl.nL, rl.J);
+        if (!dg_h_checks(c, kind, S->Hx, c.L[2], (int)rl.nL, Sl, maxS, p1_inliers, 0)) return 0;
+    }
+    maxS = Sl;
+    __syncthreads();
+    if (tid < 9) S->F[tid] = S->Hx[tid];
+    __syncthreads();
+    return 1;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+template <bool LDSPTS>
+__global__ __launch_bounds__(DG_T) void dg_find_homography_kernel(dg_args A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+    __shared__ dg_f_shared Sh;
+    dg_f_shared *S = &Sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pair = blockIdx.x;
+    const long long off = A.offsets[pair];
+    const int n = (int)(A.offsets[pair + 1] - off);
+    const dg_params &pr = A.prm;
+    const double th = pr.th;
+    const int kind = pr.error_type;
+    long long t_start = wall_clock64();
+
+    char *ws = A.ws + (size_t)pair * A.wl.stride;
+    CTX c;
+    c.S = S; c.n = n; c.tid = tid; c.A = &A; c.off = off;
+    for (int i = 0; i < 10; i++) c.L[i] = (int *)(ws + A.wl.off_lists) + (size_t)i * A.wl.n_max;
+    for (int i = 0; i < 5; i++) c.Fl[i] = (unsigned char *)(ws + A.wl.off_flags) + (size_t)i * A.wl.n_max;
+    c.ht.heads = (int *)(ws + A.wl.off_ht); c.ht.count = c.ht.heads + 64; c.ht.ent = c.ht.heads + 80;
+    c.gmodels = (double *)(ws + A.wl.off_models);
+    c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0;
+    dg_pt *Pw; int *pool;
+    if (LDSPTS) { Pw = (dg_pt *)dyn_smem; pool = (int *)(dyn_smem + (size_t)n * sizeof(dg_pt)); }
+    else        { Pw = (dg_pt *)(ws + A.wl.off_pts); pool = (int *)(ws + A.wl.off_pool); }
+    c.P = Pw; c.pool = pool;
+    const dg_pt *P = Pw;
+    for (int i = tid; i < n; i += DG_T) {
+        const double *a = A.pts1 + (size_t)(off + i) * A.dim, *b = A.pts2 + (size_t)(off + i) * A.dim;
+        dg_pt p; p.x1 = a[0]; p.y1 = a[1]; p.x2 = b[0]; p.y2 = b[1];
+        Pw[i] = p; pool[i] = i;
+    }
+    dg_ht_init(c.ht, tid);
+    if (tid < 9) { S->F[tid] = 0; S->FBest[tid] = 0; }
+    __syncthreads();
+
+    dg_score maxS = {0, 0, 0, 0}, maxSs = {0, 0, 0, 0};
+    int no_sam = 0, max_sam = pr.max_iters, iter_cnt = 0, no_rej = 0, iterID = 0, p1_inliers = 0;
+    int best_sample = 0, accepted = 0, done = 0; long long t_best = t_start;
+    double *e4 = S->FBest;                                   /* model behind errs[4] (last so-far-best sample) */
+
+    if (tid == 0) { dg_srand(&S->rng, A.seeds[pair]); S->seeds[0] = (unsigned)dg_rand(&S->rng); }
+    __syncthreads();
+    unsigned seed = S->seeds[0];
+    __syncthreads();
+
+    while (!done && no_sam < max_sam) {
+        int chunk = max_sam - no_sam; if (chunk > DG_CHUNK) chunk = DG_CHUNK;
+        /* ---- speculate: seeds (5th output), 4 draws, pool swaps ---- */
+        if (wave == 0) {
+            unsigned sd = seed;
+            for (int k = 0; k < chunk; k++) { if (lane == 0) S->seeds[k] = sd; sd = dg_rng_next_seed_wave(sd, lane, 4); }
+            if (lane == 0) S->itmp[31] = (int)sd;
+        }
+        __syncthreads();
+        seed = (unsigned)S->itmp[31];
+        if (tid < chunk) {
+            unsigned o[8];
+            dg_rng_outputs(S->seeds[tid], o);
+#pragma unroll
+            for (int i = 0; i < 4; i++) S->draws[tid][i] = (int)(o[i] % (unsigned)(n - i));
+        }
+        __syncthreads();
+        if (wave == 0) {
+            volatile int *vp = pool;
+            int t = (lane < 4) ? vp[n - 1 - lane] : 0;
+            for (int k = 0; k < chunk; k++) {
+                int s = (lane < 4) ? S->draws[k][lane] : (-1 - lane);
+                bool alias = (lane < 4) && (s >= n - 4);
+#pragma unroll
+                for (int d = 1; d < 4; d++) { int so = __shfl(s, (lane + d) % 4, 64); alias = alias || (lane < 4 && so == s); }
+                if (__any(alias)) {
+                    if (lane < 4) vp[n - 1 - lane] = t;
+                    if (!LDSPTS) __threadfence_block();
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) {
+                        for (int i = 0; i < 4; i++) { int si = S->draws[k][i], j = n - 1 - i, q = vp[si]; vp[si] = vp[j]; vp[j] = q; S->draws[k][i] = q; }
+                    }
+                    if (!LDSPTS) __threadfence_block();
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < 4) t = vp[n - 1 - lane];
+                } else if (lane < 4) {
+                    int q = vp[s]; vp[s] = t; t = q; S->draws[k][lane] = q;
+                    if (!LDSPTS) __threadfence_block();
+                }
+            }
+            if (lane < 4) vp[n - 1 - lane] = t;
+        }
+        __syncthreads();
+
+        /* ---- solve: orientation test, 8x9 null vector, near-singularity test; <= 1 model per lane ---- */
+        double hm[9], H1m[9]; int valid = 0;
+        if (tid < chunk) {
+            dg_pt sp[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) sp[i] = P[S->draws[tid][i]];
+            if (dg_Hori_valid4(sp)) {
+                double m[8][9];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    double s0 = sp[i].x1, s1 = sp[i].y1, s3 = sp[i].x2, s4 = sp[i].y2;
+                    double z0[9] = {s3, 0, -s0*s3, s4, 0, -s0*s4, 1.0, 0, -s0*1.0};
+                    double z1[9] = {0, s3, -s1*s3, 0, s4, -s1*s4, 0, 1.0, -s1*1.0};
+#pragma unroll
+                    for (int j = 0; j < 9; j++) { m[2*i][j] = z0[j]; m[2*i+1][j] = z1[j]; }
+                }
+                int ok = dg_gj8(m, hm);
+                if (!ok) {
+                    double Ag[81], sol[81]; int nb[18];
+                    for (int i = 0; i < 4; i++) {
+                        double s0 = sp[i].x1, s1 = sp[i].y1, s3 = sp[i].x2, s4 = sp[i].y2;
+                        double z0[9] = {s3, 0, -s0*s3, s4, 0, -s0*s4, 1.0, 0, -s0*1.0};
+                        double z1[9] = {0, s3, -s1*s3, 0, s4, -s1*s4, 0, 1.0, -s1*1.0};
+                        for (int j = 0; j < 9; j++) { Ag[18*i+j] = z0[j]; Ag[18*i+9+j] = z1[j]; }
+                    }
+                    for (int i = 72; i < 81; i++) Ag[i] = 0;
+                    for (int i = 0; i < 81; i++) sol[i] = 0;
+                    if (dg_nullspace(Ag, sol, 9, nb) == 1) { for (int i = 0; i < 9; i++) hm[i] = sol[i]; ok = 1; }
+                }
+                if (ok && !dg_HcloseToSingular(hm)) {
+                    valid = 1;
+                    if (kind != 0) { double Hi[9]; dg_hsym_prepare(hm, Hi, H1m); }
+                }
+            }
+        }
+        {
+            unsigned v = (unsigned)valid, incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            if (lane == 63) S->wave_cnt[wave] = incl;
+            __syncthreads();
+            unsigned wbase = 0;
+            for (int w = 0; w < wave; w++) wbase += S->wave_cnt[w];
+            unsigned excl = wbase + incl - v;
+            if (tid < chunk) {
+                S->moff[tid] = (unsigned short)excl; S->nv[tid] = (unsigned char)valid;
+                if (valid) {
+                    double *g = c.gmodels + (size_t)excl * 18;
+#pragma unroll
+                    for (int j = 0; j < 9; j++) { g[j] = hm[j]; g[9+j] = kind ? H1m[j] : 0.0; }
+                }
+            }
+            if (tid == DG_T - 1) S->moff[DG_CHUNK] = (unsigned short)(excl + v);
+            __syncthreads();
+        }
+        const int Mtot = S->moff[DG_CHUNK];
+
+        /* ---- score: one wave per model ---- */
+        for (int mi = wave; mi < Mtot; mi += DG_NW) {
+            double H[9], Hinv[9], H1[9];
+            const double *g = c.gmodels + (size_t)mi * 18;
+#pragma unroll
+            for (int j = 0; j < 9; j++) { H[j] = g[j]; H1[j] = g[9+j]; }
+            Hinv[0] = H[0]; Hinv[1] = H[3]; Hinv[2] = H[6]; Hinv[3] = H[1]; Hinv[4] = H[4]; Hinv[5] = H[7]; Hinv[6] = H[2]; Hinv[7] = H[5]; Hinv[8] = H[8];
+            unsigned I = 0; double J = 0; const double t94 = th * 9 / 4;
+            for (int base = 0; base < n; base += 64) {
+                int p = base + lane; bool act = p < n;
+                double d = 0;
+                if (act) { dg_pt q = P[p]; d = dg_Herr(kind, H, Hinv, H1, q); }
+                double term = 0.0;
+                if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
+                J += dg_tile_sum(term);
+                I += (unsigned)__popcll(__ballot(act && d <= th));
+            }
+            if (lane == 0) { S->res_I[mi] = I; S->res_J[mi] = J; }
+        }
+        c.n_hds += Mtot;
+        __syncthreads();
+
+        /* ---- commit: replay exp_ranH.c:547-757 in order ---- */
+        int k;
+        for (k = 0; k < chunk; k++) {
+            if (no_sam >= max_sam) break;
+            no_sam++;
+            if (!S->nv[k]) { no_rej++; continue; }
+            const int mi = S->moff[k];
+            dg_score Sc = {S->res_I[mi], S->res_J[mi], 0, 0};
+            int new_max = 0, do_iterate = 0;
+            const bool ev1 = maxS.J < Sc.J;
+            if (ev1 || maxSs.J < Sc.J) {
+                __syncthreads();
+                if (tid < 9) S->f[tid] = c.gmodels[(size_t)mi*18 + tid];
+                __syncthreads();
+            }
+            if (ev1) {
+                int pass = 1;
+                if (pr.sym_th > 0 || pr.laf_coef > 0) {
+                    dg_pass_cfg cl = dg_cfg0(n); cl.list = c.L[2]; cl.thL = th;
+                    dg_pass_res rl = dg_hm_pass(c, kind, S->f, cl);
+                    pass = dg_h_checks(c, kind, S->f, c.L[2], (int)rl.nL, Sc, maxS, &p1_inliers, 1);
+                }
+                if (!pass) continue;
+                maxS = Sc; new_max = 1; accepted = 1; best_sample = no_sam; t_best = wall_clock64();
+                __syncthreads();
+                if (tid < 9) S->F[tid] = S->f[tid];
+                __syncthreads();
+            }
+            if (maxSs.J < Sc.J) {
+                do_iterate = no_sam > DG_ITER_SAM;
+                maxSs = Sc;
+                __syncthreads();
+                if (tid < 9) e4[tid] = S->f[tid];
+                __syncthreads();
+            } else do_iterate = 0;
+            if (no_sam >= DG_ITER_SAM && iter_cnt == 0 && maxSs.I > 4) do_iterate = 1;
+            if (do_iterate) {
+                __syncthreads();
+                if (tid == 0) { dg_srand(&S->rng, S->seeds[k]); for (int i = 0; i < 5; i++) dg_rand(&S->rng); }
+                __syncthreads();
+                iter_cnt++;
+                if (dg_h_lo(c, kind, e4, th, maxS, &iterID, &p1_inliers, no_sam)) { new_max = 1; accepted = 1; best_sample = no_sam; t_best = wall_clock64(); }
+            }
+            if (new_max) {
+                int new_sam = dg_nsamples((int)maxS.I + 1, n, 4, pr.conf);
+                if (new_sam < max_sam) max_sam = new_sam;
+            }
+        }
+        if (k < chunk) { c.n_hds -= (Mtot - (int)S->moff[k]); done = 1; }
+        __syncthreads();
+    }
+
+    /* ---- "If there were no LOs, do at least one NOW!"  exp_ranH.c:759-862 ---- */
+    if (iter_cnt == 0) {
+        __syncthreads();
+        if (tid == 0 && no_sam > 0) { int li = (no_sam - 1) % DG_CHUNK; dg_srand(&S->rng, S->seeds[li]); for (int i = 0; i < 5; i++) dg_rand(&S->rng); }
+        __syncthreads();
+        iter_cnt++;
+        if (dg_h_lo(c, kind, e4, th, maxS, &iterID, &p1_inliers, no_sam)) { accepted = 1; best_sample = no_sam; t_best = wall_clock64(); }
+    }
+
+    /* ---- final mask: exp_ranH.c:864-907 (this driver indexes the filters correctly) ---- */
+    unsigned char *mask = A.mask_out + off;
+    if (!accepted) {
+        for (int j = tid; j < n; j += DG_T) mask[j] = 0;
+    } else {
+        __syncthreads();
+        if (tid == 0) dg_hsym_prepare(S->F, S->lsq.Z8, S->lsq.Z8 + 9);
+        __syncthreads();
+        double H[9], Hinv[9], H1[9];
+        for (int i = 0; i < 9; i++) { H[i] = S->F[i]; Hinv[i] = S->lsq.Z8[i]; H1[i] = S->lsq.Z8[9+i]; }
+        const double thl = pr.laf_coef * th;
+        for (int j = tid; j < n; j += DG_T) {
+            dg_pt p = P[j];
+            int in = dg_Herr(kind, H, Hinv, H1, p) <= th;
+            if (in && pr.sym_th > 0 && dg_Hsym(Hinv, H1, p.x1, p.y1, p.x2, p.y2, 2, 1) > pr.sym_th) in = 0;
+            if (in && pr.laf_coef > 0) {
+                for (int wch = 1; wch <= 2; wch++) {
+                    dg_pt l = c.laf_pt(j, wch);
+                    double e = kind == 0 ? dg_HDs_mixed(H, p.x1, p.y1, p.x2, p.y2, l.x1, l.y1, l.x2, l.y2) : dg_Hsym(Hinv, H1, l.x1, l.y1, l.x2, l.y2, kind, 1);
+                    if (e > thl) in = 0;
+                }
+            }
+            mask[j] = (unsigned char)in;
+        }
+    }
+    if (tid < 9) A.model_out[(size_t)pair * 9 + tid] = accepted ? S->F[tid] : 0.0;
+    if (A.stats_out && tid == 0) {
+        int *st = A.stats_out + (size_t)pair * 16;
+        long long t_end = wall_clock64();
+        st[0] = no_sam; st[1] = iter_cnt; st[2] = no_rej; st[3] = (int)maxS.I; st[4] = c.n_hds;
+        st[5] = 0; st[6] = 0; st[7] = best_sample; st[8] = c.n_hds; st[9] = 0; st[10] = 0; st[11] = 0;
+        st[12] = (int)(t_best - t_start); st[13] = (int)(t_end - t_start); st[14] = 0; st[15] = 0;
+    }
+}
+
+#endif /* DG_KERNEL_H_H */

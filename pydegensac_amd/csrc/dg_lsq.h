@@ -114,76 +114,83 @@ __device__ __noinline__ void dg_u2h_small(dg_lsq_scratch *s, const double *p, in
     }
 }
 
-/* ---- workgroup-parallel normalised 8-point LSQ over a list of point ids (Ftools.c:350-398) ----- */
+/* ---- normalised LSQ over an id list of any length, in the REFERENCE'S summation order -----------------
+ * Hartley-normalised coordinates have zero mean, so several entries of the 9x9 normal matrix are "zero
+ * up to summation noise"; the sign LAPACK's dsyev gives the eigenvector depends on that noise.  To return
+ * the same model (sign included) as the scalar reference, every sum below is accumulated sequentially
+ * over the list exactly like normu (utools.c:7-51) and cov_mat (utools.c:170-184) do — but the 4 + 2 + 45
+ * independent sums run in different lanes of wave 0 (one lane per output entry).  `rows2`: 0 = fundamental
+ * (lin_fmN, Ftools.c:300-328, one row per point), 1 = homography (lin_hgN, Htools.c:60-99, two rows). */
+template <class PtFn>
+__device__ __forceinline__ void dg_lsq_seq(dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, int rows2, double *A1o, double *A2o)
+{
+    __syncthreads();
+    if (tid < 64) {
+        const int lane = tid;
+        /* centroids: lane l in 0..3 sums coordinate l */
+        double acc = 0;
+        if (lane < 4) for (int j = 0; j < len; j++) { dg_pt p = pt(list[j]); acc += lane == 0 ? p.x1 : lane == 1 ? p.y1 : lane == 2 ? p.x2 : p.y2; }
+        if (len > 0) acc /= len;
+        double m1x = __shfl(acc, 0, 64), m1y = __shfl(acc, 1, 64), m2x = __shfl(acc, 2, 64), m2y = __shfl(acc, 3, 64);
+        /* mean distances: lane 0 image 1, lane 1 image 2 */
+        double dsum = 0;
+        if (lane < 2) for (int j = 0; j < len; j++) {
+            dg_pt p = pt(list[j]);
+            double a = lane == 0 ? p.x1 - m1x : p.x2 - m2x, b = lane == 0 ? p.y1 - m1y : p.y2 - m2y;
+            dsum += sqrt(a*a + b*b);
+        }
+        double A1[3], A2[3];
+        A1[0] = __shfl(dsum, 0, 64); A2[0] = __shfl(dsum, 1, 64);
+        if (A1[0] != 0) A1[0] = len * sqrt(2.0) / A1[0];
+        if (A2[0] != 0) A2[0] = len * sqrt(2.0) / A2[0];
+        A1[1] = m1x * -A1[0]; A1[2] = m1y * -A1[0];
+        A2[1] = m2x * -A2[0]; A2[2] = m2y * -A2[0];
+        /* normal matrix: lane e < 45 owns entry (ie, je), je <= ie, in cov_mat's enumeration order */
+        int ie = 0, je = 0;
+        { int e = 0; for (int i = 0; i < 9; i++) for (int q = 0; q <= i; q++) { if (e == lane) { ie = i; je = q; } e++; } }
+        double val = 0;
+        if (lane < 45) for (int j = 0; j < len; j++) {
+            dg_pt p = pt(list[j]);
+            double a0 = p.x1 * A1[0] + A1[1], a1 = p.y1 * A1[0] + A1[2];
+            double b0 = p.x2 * A2[0] + A2[1], b1 = p.y2 * A2[0] + A2[2];
+            if (!rows2) {
+                double a[3] = {a0, a1, 1.0}, b[3] = {b0, b1, 1.0}, z[9];
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+#pragma unroll
+                    for (int l = 0; l < 3; l++) z[3*k+l] = a[l] * b[k];
+                double zi = z[0], zj = z[0];
+#pragma unroll
+                for (int q = 1; q < 9; q++) { zi = ie == q ? z[q] : zi; zj = je == q ? z[q] : zj; }
+                val += zi * zj;
+            } else {
+                double b[3] = {b0, b1, 1.0}, z0[9], z1[9];
+#pragma unroll
+                for (int q = 0; q < 3; q++) { z0[3*q] = b[q]; z0[3*q+1] = 0; z0[3*q+2] = -a0 * b[q]; z1[3*q] = 0; z1[3*q+1] = b[q]; z1[3*q+2] = -a1 * b[q]; }
+                double zi = z0[0], zj = z0[0], yi = z1[0], yj = z1[0];
+#pragma unroll
+                for (int q = 1; q < 9; q++) { zi = ie == q ? z0[q] : zi; zj = je == q ? z0[q] : zj; yi = ie == q ? z1[q] : yi; yj = je == q ? z1[q] : yj; }
+                val += zi * zj;
+                val += yi * yj;
+            }
+        }
+        if (lane < 45) { s->V[9*ie + je] = val; s->V[ie + 9*je] = val; }
+        if (lane == 0) { for (int i = 0; i < 3; i++) { A1o[i] = A1[i]; A2o[i] = A2[i]; } }
+    }
+    __syncthreads();
+}
+
 template <class PtFn>
 __device__ __forceinline__ void dg_u2f_big(dg_red *r, dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, double *Fout /* LDS */)
 {
-    const int lane = tid & 63, wave = tid >> 6;
-    /* pass 1: centroids */
-    double sx1 = 0, sy1 = 0, sx2 = 0, sy2 = 0;
-    for (int j = tid; j < len; j += DG_T) { dg_pt p = pt(list[j]); sx1 += p.x1; sy1 += p.y1; sx2 += p.x2; sy2 += p.y2; }
-    sx1 = dg_wave_sum_d(sx1); sy1 = dg_wave_sum_d(sy1); sx2 = dg_wave_sum_d(sx2); sy2 = dg_wave_sum_d(sy2);
-    __syncthreads();
-    if (lane == 0) { s->part[wave][0] = sx1; s->part[wave][1] = sy1; s->part[wave][2] = sx2; s->part[wave][3] = sy2; }
-    __syncthreads();
-    double m1x = 0, m1y = 0, m2x = 0, m2y = 0;
-    for (int w = 0; w < DG_NW; w++) { m1x += s->part[w][0]; m1y += s->part[w][1]; m2x += s->part[w][2]; m2y += s->part[w][3]; }
-    m1x /= len; m1y /= len; m2x /= len; m2y /= len;
-    /* pass 2: mean distances */
-    double d1 = 0, d2 = 0;
-    for (int j = tid; j < len; j += DG_T) {
-        dg_pt p = pt(list[j]);
-        double a = p.x1 - m1x, b = p.y1 - m1y; d1 += sqrt(a*a + b*b);
-        a = p.x2 - m2x; b = p.y2 - m2y; d2 += sqrt(a*a + b*b);
-    }
-    d1 = dg_wave_sum_d(d1); d2 = dg_wave_sum_d(d2);
-    __syncthreads();
-    if (lane == 0) { s->part[wave][0] = d1; s->part[wave][1] = d2; }
-    __syncthreads();
-    double A1[3], A2[3];
-    A1[0] = 0; A2[0] = 0;
-    for (int w = 0; w < DG_NW; w++) { A1[0] += s->part[w][0]; A2[0] += s->part[w][1]; }
-    if (A1[0] != 0) A1[0] = len * sqrt(2.0) / A1[0];
-    if (A2[0] != 0) A2[0] = len * sqrt(2.0) / A2[0];
-    A1[1] = m1x * -A1[0]; A1[2] = m1y * -A1[0];
-    A2[1] = m2x * -A2[0]; A2[2] = m2y * -A2[0];
-    /* pass 3: normal matrix, 45 unique entries */
-    double acc[45];
-#pragma unroll
-    for (int e = 0; e < 45; e++) acc[e] = 0;
-    for (int j = tid; j < len; j += DG_T) {
-        dg_pt p = pt(list[j]);
-        double a[3], b[3], z[9];
-        a[2] = 1; b[2] = 1;
-        a[0] = p.x1 * A1[0] + A1[1]; a[1] = p.y1 * A1[0] + A1[2];
-        b[0] = p.x2 * A2[0] + A2[1]; b[1] = p.y2 * A2[0] + A2[2];
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-#pragma unroll
-            for (int l = 0; l < 3; l++) z[3*k+l] = a[l] * b[k];
-        int e = 0;
-#pragma unroll
-        for (int i = 0; i < 9; i++)
-#pragma unroll
-            for (int q = 0; q <= i; q++) { acc[e] += z[i] * z[q]; e++; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 45; e++) { double v = dg_wave_sum_d(acc[e]); if (lane == 0) s->part[wave][e] = v; }
-    __syncthreads();
+    (void)r;
+    dg_lsq_seq(s, pt, list, len, tid, 0, s->A1, s->A2);
     if (tid == 0) {
-        int e = 0;
-        for (int i = 0; i < 9; i++)
-            for (int q = 0; q <= i; q++) {
-                double v = 0;
-                for (int w = 0; w < DG_NW; w++) v += s->part[w][e];
-                s->V[9*i+q] = v; s->V[i+9*q] = v; e++;
-            }
         dg_eig_sym(s->V, s->D, 9);
         int jm = 0; for (int i = 1; i < 9; i++) if (s->D[i] < s->D[jm]) jm = i;
         for (int i = 0; i < 9; i++) Fout[i] = s->V[jm*9 + i];
         dg_singulF(Fout);
-        dg_denormF(Fout, A1, A2);
+        dg_denormF(Fout, s->A1, s->A2);
     }
     __syncthreads();
 }

@@ -8,6 +8,7 @@
 #include <vector>
 #include "../../include/mi_degensac.h"
 #include "dg_kernel_f_main.h"
+#include "dg_kernel_h.h"
 
 static thread_local char g_err[512] = "";
 static void set_err(const char *fmt, const char *a = "", const char *b = "") { snprintf(g_err, sizeof g_err, fmt, a, b); }
@@ -35,7 +36,7 @@ extern "C" const char *mi_degensac_kernel_name(int homography) { return homograp
 extern "C" int mi_degensac_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
 /* ---- per-device state: RNG tables uploaded, cached workspace ---------------------------------- */
-struct DevState { bool init = false; char *ws = nullptr; size_t ws_bytes = 0; int max_lds = 0; int dyn_f = 0; };
+struct DevState { bool init = false; char *ws = nullptr; size_t ws_bytes = 0; int max_lds = 0; int dyn_f = 0; int dyn_h = 0; };
 static DevState g_dev[64];
 static std::mutex g_mu;
 
@@ -76,6 +77,9 @@ static int dev_init(int device)
         hipFuncAttributes fa; HIPCHK(hipFuncGetAttributes(&fa, (const void *)dg_find_fundamental_kernel<true>));
         d.dyn_f = d.max_lds - (int)fa.sharedSizeBytes - 256;          /* what is left of the 160 KiB after the static LDS */
         HIPCHK(hipFuncSetAttribute((const void *)dg_find_fundamental_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, d.dyn_f));
+        HIPCHK(hipFuncGetAttributes(&fa, (const void *)dg_find_homography_kernel<true>));
+        d.dyn_h = d.max_lds - (int)fa.sharedSizeBytes - 256;
+        HIPCHK(hipFuncSetAttribute((const void *)dg_find_homography_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, d.dyn_h));
         d.init = true;
     }
     return 0;
@@ -153,16 +157,20 @@ static int launch_batch(int homography, const double *d_p1, const double *d_p2, 
     for (int p = 0; p < n_pairs; p++) { long long n = h_off[p+1] - h_off[p]; if (n > n_max) n_max = (int)n; if (n < n_min) n_min = (int)n; }
     const int min_pts = homography ? 4 : 8;                      /* bindings.cpp:35,270 */
     if (n_min < min_pts) { set_err(homography ? "need n >= 4 correspondences" : "need n >= 8 correspondences"); return MI_DEGENSAC_EINVAL; }
-    if (homography) { set_err("homography kernel not built in this revision"); return MI_DEGENSAC_EINVAL; }
     size_t dyn = (size_t)n_max * (sizeof(dg_pt) + sizeof(int));
-    bool in_lds = dyn <= (size_t)g_dev[device].dyn_f;
+    bool in_lds = dyn <= (size_t)(homography ? g_dev[device].dyn_h : g_dev[device].dyn_f);
     A.wl = make_layout(n_max, !in_lds);
     char *ws; rc = ensure_ws(device, A.wl.stride * (size_t)n_pairs, &ws); if (rc) return rc;
     A.ws = ws; A.pts1 = d_p1; A.pts2 = d_p2; A.offsets = (const long long *)d_off; A.seeds = d_seeds;
     A.trace = g_trace_dev; A.trace_cap = g_trace_cap;
     A.model_out = d_model; A.mask_out = d_mask; A.stats_out = d_stats; A.dim = dim; A.n_pairs = n_pairs; A.pts_in_lds = in_lds;
-    if (in_lds) hipLaunchKernelGGL(dg_find_fundamental_kernel<true>, dim3(n_pairs), dim3(DG_T), dyn, stream, A);
-    else        hipLaunchKernelGGL(dg_find_fundamental_kernel<false>, dim3(n_pairs), dim3(DG_T), 0, stream, A);
+    if (!homography) {
+        if (in_lds) hipLaunchKernelGGL(dg_find_fundamental_kernel<true>, dim3(n_pairs), dim3(DG_T), dyn, stream, A);
+        else        hipLaunchKernelGGL(dg_find_fundamental_kernel<false>, dim3(n_pairs), dim3(DG_T), 0, stream, A);
+    } else {
+        if (in_lds) hipLaunchKernelGGL(dg_find_homography_kernel<true>, dim3(n_pairs), dim3(DG_T), dyn, stream, A);
+        else        hipLaunchKernelGGL(dg_find_homography_kernel<false>, dim3(n_pairs), dim3(DG_T), 0, stream, A);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -232,14 +240,15 @@ __global__ void dg_score_models_kernel(const double *p1, const double *p2, int n
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int mi = blockIdx.x * (blockDim.x >> 6) + wave;
     if (mi >= n_models) return;
-    double M[9];
-    for (int j = 0; j < 9; j++) M[j] = models[(size_t)mi * 9 + j];
+    double M[9], Hinv[9], H1[9];
+    for (int j = 0; j < 9; j++) { M[j] = models[(size_t)mi * 9 + j]; Hinv[j] = 0; H1[j] = 0; }
+    if (kind > 10) dg_hsym_prepare(M, Hinv, H1);
     unsigned I = 0; double J = 0; const double t94 = th * 9 / 4;
     for (int base = 0; base < n; base += 64) {
         int p = base + lane; bool act = p < n; double d = 0;
         if (act) {
             dg_pt q; q.x1 = p1[(size_t)p * dim]; q.y1 = p1[(size_t)p * dim + 1]; q.x2 = p2[(size_t)p * dim]; q.y2 = p2[(size_t)p * dim + 1];
-            if (kind < 10) d = dg_Ferr(kind, M, q); else d = dg_HDs(M, q.x1, q.y1, q.x2, q.y2);
+            if (kind < 10) d = dg_Ferr(kind, M, q); else d = dg_Herr(kind - 10, M, Hinv, H1, q);
             if (resid) resid[(size_t)mi * n + p] = d;
         }
         double term = 0.0;
@@ -254,7 +263,7 @@ extern "C" int mi_degensac_score_models(const double *pts1, const double *pts2, 
         int kind, double th, int device, uint32_t *I, double *J, double *resid)
 {
     int rc = dev_init(device); if (rc) return rc;
-    if (!(kind == 0 || kind == 1 || kind == 2 || kind == 10)) { set_err("unsupported metric kind"); return MI_DEGENSAC_EINVAL; }
+    if (!(kind == 0 || kind == 1 || kind == 2 || (kind >= 10 && kind <= 14))) { set_err("unsupported metric kind"); return MI_DEGENSAC_EINVAL; }
     DevBuf<double> d1, d2, dm, dJ, dr; DevBuf<uint32_t> dI;
     if (d1.alloc((size_t)n * dim) || d2.alloc((size_t)n * dim) || dm.alloc((size_t)n_models * 9) || dJ.alloc(n_models) || dI.alloc(n_models) ||
         (resid && dr.alloc((size_t)n_models * n))) { set_err("device allocation failed"); return MI_DEGENSAC_ENOMEM; }

@@ -24,3 +24,20 @@ def test_fundamental_matches_reference_golden(path):
     else:
         assert np.array_equal(np.asarray(m), g["mask"])
         assert gu.rel(F, g["model"]) < 1e-6
+
+
+@pytest.mark.parametrize("path", gu.fixtures("H"), ids=lambda p: os.path.basename(p)[:-4])
+def test_homography_matches_reference_golden(path):
+    g = gu.load(path); kw = g["call"]
+    H, m = pd.findHomography_(g["p1"], g["p2"], kw.get("px_th", 1.0), kw.get("conf", 0.999), kw.get("max_iters", 50000),
+                              kw.get("error_type", 0), kw.get("sym_check", True), kw.get("laf_coef", 0.0), seed=g["seed"])
+    st = pd.last_stats()
+    if g["n"] <= 10:
+        pytest.skip("n<=10 runs through the reference's 4-point u2h path, which reads uninitialised memory (Htools.c:108-114)")
+    assert (st["samples"], st["lo_runs"], st["rejected"]) == (g["samples"], g["lo_runs"], g["rejected"])
+    assert st["models"] == g["full_passes"]
+    if np.abs(g["model"]).sum() == 0:
+        assert np.abs(H).sum() == 0
+    else:
+        assert np.array_equal(np.asarray(m), g["mask"])
+        assert gu.rel(H, g["model"]) < 1e-6

@@ -26,6 +26,18 @@ def test_port_matches_golden_fundamental(oracle_port, path):
     assert gu.rel(F, g["model"]) < 1e-9
 
 
+@pytest.mark.parametrize("path", gu.fixtures("H"), ids=lambda p: os.path.basename(p)[:-4])
+def test_port_matches_golden_homography(oracle_port, path):
+    g = gu.load(path)
+    H, m, st = oracle_port.find_homography(g["p1"], g["p2"], seed=g["seed"], **g["call"])
+    if g["n"] <= 10:
+        pytest.skip("4-point u2h path of the reference reads uninitialised memory (Htools.c:108-114)")
+    assert (st["samples"], st["lo_runs"], st["rejected"], st["models"]) == (g["samples"], g["lo_runs"], g["rejected"], g["full_passes"])
+    if np.abs(g["model"]).sum() != 0:
+        assert np.array_equal(m, g["mask"])
+        assert gu.rel(H, g["model"]) < 1e-8
+
+
 def test_rng_matches_libc(oracle_port):
     libc = C.CDLL("libc.so.6")
     libc.srand.argtypes = [C.c_uint]; libc.rand.restype = C.c_int
