@@ -328,6 +328,69 @@ DG_BIG int dg_svduv(double *d, double *a, double *u, int m, double *v, int n)   
     return 0;
 }
 
+
+/* Left null vector of a 9x8 system the way Ftools.c:372-384 obtains it: svduv(D,Z,V,9,U,8) and then the
+ * LAST column of the 9x9 left factor.  That column is produced by the Householder bidiagonalisation and the
+ * backward accumulation of the left reflectors (ldumat) alone: qrbdv only rotates columns 0..7 of the left
+ * factor (and the right factor), ldvmat only builds the right factor.  So this routine runs svduv's
+ * reduction loop verbatim and accumulates just column 8 — the same floating-point operations, in the same
+ * order, as the reference performs for those nine numbers. */
+DG_BIG void dg_svd_lastcol_9x8(double *a /* 9x8 row-major, destroyed */, double *col /* 9 */)
+{
+    DG_LDS double w[20];
+    const int m = 9, n = 8;
+    double *p, *p1, *q, *pp; double s, h, r, t, sv; int i, j, k, mm, nm, ms;
+    for (i = 0; i < m + n; i++) w[i] = 0.;
+    for (i = 0, mm = m, nm = n - 1, p = a; i < n; ++i, --mm, --nm, p += n + 1) {
+        if (mm > 1) {
+            sv = h = 0.;
+            for (j = 0, q = p, s = 0.; j < mm; ++j, q += n) { w[j] = *q; s += *q * *q; }
+            if (s > 0.) {
+                h = sqrt(s); if (*p < 0.) h = -h;
+                s += *p * h; s = 1./s; t = 1./(w[0] += h);
+                sv = 1. + fabs(*p/h);
+                for (k = 1, ms = n - i; k < ms; ++k) {
+                    for (j = 0, q = p + k, r = 0.; j < mm; q += n) r += w[j++] * *q;
+                    r *= s;
+                    for (j = 0, q = p + k; j < mm; q += n) *q -= r * w[j++];
+                }
+                for (j = 1, q = p; j < mm;) *(q += n) = t * w[j++];
+            }
+            *p = sv;
+        }
+        p1 = p + 1; sv = h = 0.;
+        if (nm > 1) {
+            for (j = 0, q = p1, s = 0.; j < nm; ++j, ++q) s += *q * *q;
+            if (s > 0.) {
+                h = sqrt(s); if (*p1 < 0.) h = -h;
+                sv = 1. + fabs(*p1/h);
+                s += *p1 * h; s = 1./s; t = 1./(*p1 += h);
+                for (k = n, ms = n*(m - i); k < ms; k += n) {
+                    for (j = 0, q = p1, pp = p1 + k, r = 0.; j < nm; ++j) r += *q++ * *pp++;
+                    r *= s;
+                    for (j = 0, q = p1, pp = p1 + k; j < nm; ++j) *pp++ -= r * *q++;
+                }
+                for (j = 1, q = p1 + 1; j < nm; ++j) *q++ *= t;
+            }
+            *p1 = sv;
+        }
+    }
+    /* ldumat (matutls/ldumat.c) restricted to column 8 of u */
+    for (i = 0; i < 9; i++) col[i] = 0.;
+    col[8] = 1.;
+    for (i = n - 1, mm = 1; i >= 0; --i, ++mm) {
+        double p0 = a[i*n + i];
+        if (p0 != 0.) {
+            for (j = 0; j < mm; j++) w[j] = a[(i + 1 + j)*n + i];
+            h = p0;
+            for (j = 0, s = 0.; j < mm; j++) s += w[j] * col[i + 1 + j];
+            s *= h;
+            for (j = 0; j < mm; j++) col[i + 1 + j] -= s * w[j];
+            col[i] = -s;
+        } else col[i] = 0.;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Symmetric 9x9 eigensolver = LAPACK dsyev("V","U") as called by lap_eig (degensac/lapwrap.c:67-96).
  * a: n x n symmetric, column-major (== row-major); on exit the columns (column-major: a[j*n+i] is

@@ -51,6 +51,7 @@ struct dg_args {
     int dim, n_pairs, pts_in_lds;
     int *trace;                      /* debug: [0] = count, then (tag, I, J lo, J hi) records; null = off */
     int trace_cap;
+    long long *phase_out;            /* debug: [n_pairs][8] 100 MHz ticks per phase (sample, solve, score, commit+events, LO, degen, tail, total) */
 };
 
 /* ---- glibc TYPE_3 fast path ----------------------------------------------------------------------
@@ -72,6 +73,8 @@ __device__ __forceinline__ unsigned dg_mulmod31(unsigned a, unsigned b)
 /* first LCG step exactly as glibc does it (handles seeds >= 2^31, i.e. negative int32) */
 __device__ __forceinline__ unsigned dg_lcg_first(int r0)
 {
+    /* for 0 <= r0 < 2^31 Schrage's step equals 16807*r0 mod (2^31-1) exactly */
+    if (r0 >= 0) return dg_mulmod31((unsigned)r0, 16807u);
     long long hi = r0 / 127773, lo = r0 % 127773;
     long long word = 16807 * lo - 2836 * hi;
     if (word < 0) word += 2147483647;

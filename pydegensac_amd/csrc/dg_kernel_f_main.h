@@ -199,8 +199,11 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
     unsigned seed = S->seeds[0];
     __syncthreads();
 
+    long long ph[8] = {0,0,0,0,0,0,0,0}, tq = wall_clock64(), tq2;
+#define DG_PH(i) do { tq2 = wall_clock64(); ph[i] += tq2 - tq; tq = tq2; } while (0)
     while (!done && no_sam < max_sam) {
         /* ================= speculate: DG_CHUNK samples ================= */
+        DG_PH(3);
         int chunk = max_sam - no_sam; if (chunk > DG_CHUNK) chunk = DG_CHUNK;
         if (wave == 0) {
             unsigned sd = seed;
@@ -223,8 +226,9 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
             for (int k = 0; k < chunk; k++) {
                 int s = (lane < 7) ? S->draws[k][lane] : (-1 - lane);
                 bool alias = (lane < 7) && (s >= n - 7);
-#pragma unroll
-                for (int d = 1; d < 7; d++) { int so = __shfl(s, (lane + d) % 7, 64); alias = alias || (lane < 7 && so == s); }
+                /* duplicate draws among lanes 0..6 (idle lanes hold distinct negatives): row rotates on the VALU */
+                alias = alias || (dg_dpp<DG_DPP_ROR(1)>(s) == s) || (dg_dpp<DG_DPP_ROR(2)>(s) == s) || (dg_dpp<DG_DPP_ROR(3)>(s) == s)
+                              || (dg_dpp<DG_DPP_ROR(4)>(s) == s) || (dg_dpp<DG_DPP_ROR(5)>(s) == s) || (dg_dpp<DG_DPP_ROR(6)>(s) == s);
                 if (__any(alias)) {
                     if (lane < 7) vp[n - 1 - lane] = t;
                     if (!LDSPTS) __threadfence_block();
@@ -247,6 +251,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
         }
         __syncthreads();
 
+        DG_PH(0);
         /* ================= solve: one 7-point problem per lane ================= */
         double fm[3][9]; int nvalid = 0; unsigned char rix[3] = {0, 0, 0}; int nullbad = 0;
         if (tid < chunk) {
@@ -316,27 +321,30 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
         }
         const int Mtot = S->moff[DG_CHUNK];
 
+        DG_PH(1);
         /* ================= score: one wave per model, points streamed from LDS ================= */
         for (int mi = wave; mi < Mtot; mi += DG_NW) {
             double F[9];
             const double *g = c.gmodels + (size_t)mi * 9;
 #pragma unroll
             for (int j = 0; j < 9; j++) F[j] = g[j];
-            unsigned I = 0; double J = 0; const double t94 = th * 9 / 4;
-            for (int base = 0; base < n; base += 64) {
-                int p = base + lane; bool act = p < n;
-                double d = 0;
-                if (act) { dg_pt q = P[p]; d = dg_Ferr(mk_full, F, q); }
-                double term = 0.0;
-                if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
-                J += dg_tile_sum(term);
-                I += (unsigned)__popcll(__ballot(act && d <= th));
+            unsigned cI = 0; double a0 = 0, a1 = 0, a2 = 0, a3 = 0; const double t94 = th * 9 / 4;
+#define DG_SCORE_TILE(acc, p_) { int p = (p_); bool act = p < n; double d = 0; \
+                if (act) { dg_pt q = P[p]; d = dg_Ferr(mk_full, F, q); } \
+                double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94); \
+                acc += term; cI += (act && d <= th) ? 1u : 0u; }
+            for (int base = 0; base < n; base += 256) {
+                DG_SCORE_TILE(a0, base + lane); DG_SCORE_TILE(a1, base + 64 + lane);
+                DG_SCORE_TILE(a2, base + 128 + lane); DG_SCORE_TILE(a3, base + 192 + lane);
             }
+#undef DG_SCORE_TILE
+            unsigned I = dg_wave_sum_u(cI); double J = dg_J_combine(a0, a1, a2, a3);
             if (lane == 0) { S->res_I[mi] = I; S->res_J[mi] = J; }
         }
         c.n_fds += Mtot;   /* provisional: models past the termination point are subtracted below */
         __syncthreads();
 
+        DG_PH(2);
         /* ================= commit: replay exp_ranF.c:1334-1577 in order ================= */
         int k;
         for (k = 0; k < chunk; k++) {
@@ -390,6 +398,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
                         degenerate = S->itmp[1];
                     }
                     if (degenerate) {
+                        DG_PH(3);
                         if (!rng_ready) {
                             __syncthreads();
                             if (tid == 0) { dg_srand(&S->rng, S->seeds[k]); for (int i = 0; i < 8; i++) dg_rand(&S->rng); }
@@ -420,6 +429,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
                             if (track && dphys == p4) { __syncthreads(); if (tid < 9) e4F[tid] = S->f[tid]; e4kind = mk_full; __syncthreads(); }
                             ++degen_cnt;
                         }
+                        DG_PH(5);
                     } else {
                         do_iterate = (no_sam > DG_ITER_SAM);
                         p4 = phys;                                  /* errs[4] = d */
@@ -442,6 +452,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
                     rng_ready = 1;
                 }
                 iter_cnt++; track = 0;
+                DG_PH(3);
                 /* LSQ before LO: S = inlidxs(errs[4], TC*th*MWM); u2f; FDS1; inlidxs(th)  (:1506-1511) */
                 dg_pass_cfg ca = dg_cfg0(n); ca.list = c.L[0]; ca.thL = DG_TC * th * DG_MWM;
                 dg_pass_res ra = dg_f_pass(c, e4F, e4kind, ca);
@@ -465,6 +476,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
                     int new_sam = dg_nsamples((int)maxS.I + 1, n, 7, pr.conf);
                     if (new_sam < max_sam) max_sam = new_sam;
                 }
+                DG_PH(4);
             }
         }
         /* models of samples that were never committed do not count as scored */
@@ -542,6 +554,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
         }
     }
 
+    DG_PH(3);
     /* ---- final mask: exp_ranF.c:1699-1740 ---- */
     unsigned char *mask = A.mask_out + off;
     if (!accepted) {
@@ -576,6 +589,8 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
         st[10] = c.n_hds; st[11] = c.n_aux; st[12] = (int)(t_best - t_start); st[13] = (int)(t_end - t_start);
         st[14] = 0; st[15] = 0;
     }
+    DG_PH(6);
+    if (A.phase_out && tid == 0) { ph[7] = wall_clock64() - t_start; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 8 + i] = ph[i]; }
 }
 
 #endif /* DG_KERNEL_F_MAIN_H */

@@ -318,8 +318,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_homography_kernel(dg_args A)
             for (int k = 0; k < chunk; k++) {
                 int s = (lane < 4) ? S->draws[k][lane] : (-1 - lane);
                 bool alias = (lane < 4) && (s >= n - 4);
-#pragma unroll
-                for (int d = 1; d < 4; d++) { int so = __shfl(s, (lane + d) % 4, 64); alias = alias || (lane < 4 && so == s); }
+                alias = alias || (dg_dpp<DG_DPP_ROR(1)>(s) == s) || (dg_dpp<DG_DPP_ROR(2)>(s) == s) || (dg_dpp<DG_DPP_ROR(3)>(s) == s);
                 if (__any(alias)) {
                     if (lane < 4) vp[n - 1 - lane] = t;
                     if (!LDSPTS) __threadfence_block();
@@ -403,16 +402,17 @@ __global__ __launch_bounds__(DG_T) void dg_find_homography_kernel(dg_args A)
 #pragma unroll
             for (int j = 0; j < 9; j++) { H[j] = g[j]; H1[j] = g[9+j]; }
             Hinv[0] = H[0]; Hinv[1] = H[3]; Hinv[2] = H[6]; Hinv[3] = H[1]; Hinv[4] = H[4]; Hinv[5] = H[7]; Hinv[6] = H[2]; Hinv[7] = H[5]; Hinv[8] = H[8];
-            unsigned I = 0; double J = 0; const double t94 = th * 9 / 4;
-            for (int base = 0; base < n; base += 64) {
-                int p = base + lane; bool act = p < n;
-                double d = 0;
-                if (act) { dg_pt q = P[p]; d = dg_Herr(kind, H, Hinv, H1, q); }
-                double term = 0.0;
-                if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
-                J += dg_tile_sum(term);
-                I += (unsigned)__popcll(__ballot(act && d <= th));
+            unsigned cI = 0; double a0 = 0, a1 = 0, a2 = 0, a3 = 0; const double t94 = th * 9 / 4;
+#define DG_SCORE_TILE(acc, p_) { int p = (p_); bool act = p < n; double d = 0; \
+                if (act) { dg_pt q = P[p]; d = dg_Herr(kind, H, Hinv, H1, q); } \
+                double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94); \
+                acc += term; cI += (act && d <= th) ? 1u : 0u; }
+            for (int base = 0; base < n; base += 256) {
+                DG_SCORE_TILE(a0, base + lane); DG_SCORE_TILE(a1, base + 64 + lane);
+                DG_SCORE_TILE(a2, base + 128 + lane); DG_SCORE_TILE(a3, base + 192 + lane);
             }
+#undef DG_SCORE_TILE
+            unsigned I = dg_wave_sum_u(cI); double J = dg_J_combine(a0, a1, a2, a3);
             if (lane == 0) { S->res_I[mi] = I; S->res_J[mi] = J; }
         }
         c.n_hds += Mtot;

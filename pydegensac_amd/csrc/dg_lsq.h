@@ -72,8 +72,8 @@ __device__ __noinline__ void dg_u2f_small(dg_lsq_scratch *s, const double *p, co
         }
         /* Ftools.c:427-432: scalmul(Z+i, w, 9, 9) strides by 9 over a row stride of 8 (reproduced) */
         if (wts) for (i = 0; i < len && i < 8; i++) for (k = 0; k < 9; k++) if (i + 9*k < 72) s->Z8[i + 9*k] *= wts[i];
-        dg_svduv(s->D8, s->Z8, s->U9, 9, s->V8, 8);
-        for (i = 0; i < 9; i++) F[i] = s->U9[i*9 + 8];
+        dg_svd_lastcol_9x8(s->Z8, s->U9);   /* left null vector -> U9[0..8] */
+        for (i = 0; i < 9; i++) F[i] = s->U9[i];
     }
     dg_singulF(F);
     if (len > 8) dg_denormF(F, s->A1, s->A2);

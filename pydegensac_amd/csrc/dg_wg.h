@@ -4,9 +4,9 @@
  * workgroup-uniform: every thread executes the same branches on the same (LDS-broadcast or reduced)
  * values; scalar "reference-order" arithmetic is done by lane 0 between barriers.
  *
- * Canonical MSAC sum: J = sum over 64-point tiles, in tile order, of the xor-butterfly sum of the
- * tile (offsets 32,16,...,1).  Every scoring path (wave-per-model in the main loop, all-waves-per-
- * model in LO) uses this same association, so J of a model does not depend on which path scored it.
+ * Canonical MSAC sum: see dg_J_combine below.  Every scoring path (wave-per-model in the main loop,
+ * all-waves-per-model in LO) uses this same association, so J of a model does not depend on which
+ * path scored it.
  */
 #ifndef DG_WG_H
 #define DG_WG_H
@@ -18,24 +18,57 @@
 
 struct dg_pt { double x1, y1, x2, y2; };           /* 32 B per correspondence */
 
+/* ---- wave reductions on the VALU (DPP row rotates + 4 readlanes), no LDS traffic -------------------
+ * Row step: rotate-add by 8,4,2,1 inside each 16-lane row leaves the row total in every lane of the row
+ * (bitwise the same value in all 16 lanes: each step adds two values that are equal up to commutation).
+ * Then the four row totals are combined in row order ((r0+r1)+r2)+r3.  This is THE association of every
+ * 64-term sum in the kernels (canonical MSAC tile sum). */
+#define DG_DPP_ROR(k) (0x120 + (k))            /* DPP ctrl: row_ror:k */
+template <int CTRL> __device__ __forceinline__ int dg_dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ double dg_dpp_d(double v)
+{
+    long long b = __double_as_longlong(v);
+    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    lo = dg_dpp<CTRL>(lo); hi = dg_dpp<CTRL>(hi);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double dg_readlane_d(double v, int l)
+{
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
 __device__ __forceinline__ double dg_tile_sum(double v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dg_dpp_d<DG_DPP_ROR(8)>(v);
+    v += dg_dpp_d<DG_DPP_ROR(4)>(v);
+    v += dg_dpp_d<DG_DPP_ROR(2)>(v);
+    v += dg_dpp_d<DG_DPP_ROR(1)>(v);
+    double r0 = dg_readlane_d(v, 0), r1 = dg_readlane_d(v, 16), r2 = dg_readlane_d(v, 32), r3 = dg_readlane_d(v, 48);
+    return ((r0 + r1) + r2) + r3;
 }
 __device__ __forceinline__ unsigned dg_wave_sum_u(unsigned v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += (unsigned)dg_dpp<DG_DPP_ROR(8)>((int)v);
+    v += (unsigned)dg_dpp<DG_DPP_ROR(4)>((int)v);
+    v += (unsigned)dg_dpp<DG_DPP_ROR(2)>((int)v);
+    v += (unsigned)dg_dpp<DG_DPP_ROR(1)>((int)v);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 0) + (unsigned)__builtin_amdgcn_readlane((int)v, 16) +
+           (unsigned)__builtin_amdgcn_readlane((int)v, 32) + (unsigned)__builtin_amdgcn_readlane((int)v, 48);
 }
 __device__ __forceinline__ double dg_wave_sum_d(double v) { return dg_tile_sum(v); }
+
+/* Canonical MSAC gain J of one model over n points (DG_NW == 4 is part of the definition):
+ *   S_r[l] = sum over tiles t = r (mod 4), in tile order, of term(64 t + l)      r = 0..3, l = lane
+ *   J      = dg_tile_sum( ((S_0[l] + S_1[l]) + S_2[l]) + S_3[l] )
+ * A single wave keeps four accumulators per lane; in a 4-wave pass wave r owns residue class r. */
+__device__ __forceinline__ double dg_J_combine(double s0, double s1, double s2, double s3) { return dg_tile_sum(((s0 + s1) + s2) + s3); }
 
 /* LDS block used by the reductions below (declared once per kernel) */
 struct dg_red {
     double   d[2][DG_NW][4];
     unsigned u[2][DG_NW][4];
+    double   jp[DG_NW][64];   /* per-lane MSAC partial sums of the four residue classes */
     double   bc[96];          /* broadcast slots */
     int      bi[16];
 };
@@ -106,46 +139,43 @@ __device__ __forceinline__ dg_pass_res dg_pass(dg_red *r, const dg_pass_cfg &c, 
     const int lane = tid & 63, wave = tid >> 6;
     dg_pass_res out; out.I = 0; out.J = 0; out.C = 0; out.nL = 0; out.nF = 0;
     const double t94 = c.thJ * 9 / 4;
+    double accJ = 0; unsigned cI = 0, cC = 0, cF = 0;
     int par = 0;
-    for (int base = 0; base < c.n; base += DG_T, par ^= 1) {
+    for (int base = 0; base < c.n; base += DG_T) {
         int j = base + tid;
         bool act = j < c.n;
         int pid = act ? (c.src ? c.src[j] : j) : 0;
         double d = act ? err(pid, j) : 0.0;
-        unsigned long long bI = 0, bC = 0, bL = 0, bF = 0;
-        double tsum = 0;
         if (c.wantJ) {
             double term = 0.0;
             if (act && c.thJ != 0 && !(d >= t94)) term = 1 - (d / t94);
-            tsum = dg_tile_sum(term);
-            bI = __ballot(act && d <= c.thJ);
+            accJ += term;
+            cI += (act && d <= c.thJ) ? 1u : 0u;
         }
-        if (c.wantC) bC = __ballot(act && d <= c.thC);
-        if (c.list)  bL = __ballot(act && d <= c.thL);
-        if (c.flags) { bool f = act && d < c.thF; bF = __ballot(f); if (act) c.flags[j] = f ? 1 : 0; }
-        if (lane == 0) {
-            r->d[par][wave][0] = tsum;
-            r->u[par][wave][0] = (unsigned)__popcll(bI);
-            r->u[par][wave][1] = (unsigned)__popcll(bC);
-            r->u[par][wave][2] = (unsigned)__popcll(bL);
-            r->u[par][wave][3] = (unsigned)__popcll(bF);
-        }
-        __syncthreads();
-        unsigned lbase = out.nL;
+        if (c.wantC) cC += (act && d <= c.thC) ? 1u : 0u;
+        if (c.flags) { bool f = act && d < c.thF; cF += f ? 1u : 0u; if (act) c.flags[j] = f ? 1 : 0; }
+        if (c.list) {
+            /* ordered compaction needs the block's per-wave counts: one barrier per 256 items */
+            bool in = act && d <= c.thL;
+            unsigned long long bL = __ballot(in);
+            if (lane == 0) r->u[par][wave][2] = (unsigned)__popcll(bL);
+            __syncthreads();
+            unsigned lbase = out.nL;
 #pragma unroll
-        for (int w = 0; w < DG_NW; w++) {
-            out.J += r->d[par][w][0];
-            out.I += r->u[par][w][0];
-            out.C += r->u[par][w][1];
-            if (w < wave) lbase += r->u[par][w][2];
-            out.nL += r->u[par][w][2];
-            out.nF += r->u[par][w][3];
-        }
-        if (c.list && act && d <= c.thL) {
-            unsigned rank = (unsigned)__popcll(bL & ((1ull << lane) - 1ull));
-            c.list[lbase + rank] = pid;
+            for (int w = 0; w < DG_NW; w++) { if (w < wave) lbase += r->u[par][w][2]; out.nL += r->u[par][w][2]; }
+            if (in) c.list[lbase + (unsigned)__popcll(bL & ((1ull << lane) - 1ull))] = pid;
+            par ^= 1;
         }
     }
+    /* final reductions: counts exact, J in the canonical association */
+    cI = dg_wave_sum_u(cI); cC = dg_wave_sum_u(cC); cF = dg_wave_sum_u(cF);
+    __syncthreads();
+    r->jp[wave][lane] = accJ;
+    if (lane == 0) { r->u[0][wave][0] = cI; r->u[0][wave][1] = cC; r->u[0][wave][3] = cF; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < DG_NW; w++) { out.I += r->u[0][w][0]; out.C += r->u[0][w][1]; out.nF += r->u[0][w][3]; }
+    if (c.wantJ) out.J = dg_J_combine(r->jp[0][lane], r->jp[1][lane], r->jp[2][lane], r->jp[3][lane]);
     __syncthreads();
     return out;
 }

@@ -17,6 +17,8 @@ static void set_err(const char *fmt, const char *a = "", const char *b = "") { s
 extern "C" const char *mi_degensac_last_error(void) { return g_err; }
 /* debug trace (device buffer owned by the caller of mi_degensac_debug_trace); not part of the public header */
 static int *g_trace_dev = nullptr; static int g_trace_cap = 0;
+static long long *g_phase_dev = nullptr;
+extern "C" void mi_degensac_debug_phases(void *dev_ptr) { g_phase_dev = (long long *)dev_ptr; }
 extern "C" int mi_degensac_debug_trace(int cap, int *host_out)
 {
     if (cap > 0 && !host_out) {           /* arm */
@@ -162,7 +164,7 @@ static int launch_batch(int homography, const double *d_p1, const double *d_p2, 
     A.wl = make_layout(n_max, !in_lds);
     char *ws; rc = ensure_ws(device, A.wl.stride * (size_t)n_pairs, &ws); if (rc) return rc;
     A.ws = ws; A.pts1 = d_p1; A.pts2 = d_p2; A.offsets = (const long long *)d_off; A.seeds = d_seeds;
-    A.trace = g_trace_dev; A.trace_cap = g_trace_cap;
+    A.trace = g_trace_dev; A.trace_cap = g_trace_cap; A.phase_out = g_phase_dev;
     A.model_out = d_model; A.mask_out = d_mask; A.stats_out = d_stats; A.dim = dim; A.n_pairs = n_pairs; A.pts_in_lds = in_lds;
     if (!homography) {
         if (in_lds) hipLaunchKernelGGL(dg_find_fundamental_kernel<true>, dim3(n_pairs), dim3(DG_T), dyn, stream, A);
@@ -243,19 +245,22 @@ __global__ void dg_score_models_kernel(const double *p1, const double *p2, int n
     double M[9], Hinv[9], H1[9];
     for (int j = 0; j < 9; j++) { M[j] = models[(size_t)mi * 9 + j]; Hinv[j] = 0; H1[j] = 0; }
     if (kind > 10) dg_hsym_prepare(M, Hinv, H1);
-    unsigned I = 0; double J = 0; const double t94 = th * 9 / 4;
-    for (int base = 0; base < n; base += 64) {
-        int p = base + lane; bool act = p < n; double d = 0;
-        if (act) {
-            dg_pt q; q.x1 = p1[(size_t)p * dim]; q.y1 = p1[(size_t)p * dim + 1]; q.x2 = p2[(size_t)p * dim]; q.y2 = p2[(size_t)p * dim + 1];
-            if (kind < 10) d = dg_Ferr(kind, M, q); else d = dg_Herr(kind - 10, M, Hinv, H1, q);
-            if (resid) resid[(size_t)mi * n + p] = d;
+    unsigned cI = 0; double acc[4] = {0, 0, 0, 0}; const double t94 = th * 9 / 4;
+    for (int base = 0; base < n; base += 256) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int p = base + 64 * r + lane; bool act = p < n; double d = 0;
+            if (act) {
+                dg_pt q; q.x1 = p1[(size_t)p * dim]; q.y1 = p1[(size_t)p * dim + 1]; q.x2 = p2[(size_t)p * dim]; q.y2 = p2[(size_t)p * dim + 1];
+                if (kind < 10) d = dg_Ferr(kind, M, q); else d = dg_Herr(kind - 10, M, Hinv, H1, q);
+                if (resid) resid[(size_t)mi * n + p] = d;
+            }
+            double term = 0.0;
+            if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
+            acc[r] += term; cI += (act && d <= th) ? 1u : 0u;
         }
-        double term = 0.0;
-        if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
-        J += dg_tile_sum(term);
-        I += (unsigned)__popcll(__ballot(act && d <= th));
     }
+    unsigned I = dg_wave_sum_u(cI); double J = dg_J_combine(acc[0], acc[1], acc[2], acc[3]);
     if (lane == 0) { Iout[mi] = I; Jout[mi] = J; }
 }
 
@@ -367,5 +372,59 @@ extern "C" int mi_degensac_solve7(const double *pts1, const double *pts2, int n,
     HIPCHK(hipMemcpy(nsol, dn.p, (size_t)n_samples * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(root_idx, dr.p, (size_t)n_samples * 12, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(models, dm.p, (size_t)n_samples * 27 * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+
+/* ---- micro-benchmark of the lane-0 small dense routines (development aid) ------------------------- */
+__global__ void dg_microbench_kernel(const double *in, double *out, long long *ticks, int reps)
+{
+    __shared__ dg_lsq_scratch ls; __shared__ double F[9], H[9], u7[7][4]; __shared__ int list[800];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        for (int i = 0; i < 64; i++) ls.px[i] = in[i];
+        for (int i = 0; i < 7; i++) for (int j = 0; j < 4; j++) u7[i][j] = in[4*i + j];
+        long long t0, t1;
+        /* eig 9x9 on a normal matrix of 14 points */
+        t0 = wall_clock64();
+        for (int r = 0; r < reps; r++) { for (int i = 0; i < 14; i++) for (int k = 0; k < 9; k++) ls.Z[9*i+k] = in[64 + 9*i + k] + 1e-9 * r; dg_cov9(ls.V, ls.Z, 14); dg_eig_sym(ls.V, ls.D, 9); }
+        t1 = wall_clock64(); ticks[0] = t1 - t0;
+        t0 = wall_clock64();
+        for (int r = 0; r < reps; r++) { for (int i = 0; i < 14; i++) for (int k = 0; k < 9; k++) ls.Z[9*i+k] = in[64 + 9*i + k] + 1e-9 * r; dg_cov9(ls.V, ls.Z, 14); }
+        t1 = wall_clock64(); ticks[1] = t1 - t0;
+        t0 = wall_clock64();
+        for (int r = 0; r < reps; r++) dg_u2f_small(&ls, ls.px, 0, 14, F);
+        t1 = wall_clock64(); ticks[2] = t1 - t0;
+        t0 = wall_clock64();
+        for (int r = 0; r < reps; r++) dg_u2f_small(&ls, ls.px, 0, 8, F);
+        t1 = wall_clock64(); ticks[3] = t1 - t0;
+        t0 = wall_clock64();
+        for (int r = 0; r < reps; r++) { for (int i = 0; i < 9; i++) F[i] = in[200 + i] + 1e-9 * r; dg_singulF(F); }
+        t1 = wall_clock64(); ticks[4] = t1 - t0;
+        for (int i = 0; i < 9; i++) F[i] = in[200 + i];
+        dg_singulF(F);
+        t0 = wall_clock64();
+        for (int r = 0; r < reps; r++) out[9] = dg_checksample(&ls, F, u7, 0.75, H);
+        t1 = wall_clock64(); ticks[5] = t1 - t0;
+        t0 = wall_clock64();
+        for (int r = 0; r < reps; r++) dg_u2h_small(&ls, ls.px, 5, H);
+        t1 = wall_clock64(); ticks[6] = t1 - t0;
+        for (int i = 0; i < 800; i++) list[i] = (i * 37) % 2000;
+        t0 = wall_clock64();
+        unsigned hsum = 0;
+        for (int r = 0; r < reps; r++) hsum += dg_hash_list(list, 800 - (r & 1));
+        t1 = wall_clock64(); ticks[7] = t1 - t0; out[10] = hsum;
+        for (int i = 0; i < 9; i++) out[i] = F[i];
+    }
+}
+extern "C" int mi_degensac_microbench(const double *in_host, int reps, long long *ticks_host)
+{
+    int rc = dev_init(0); if (rc) return rc;
+    DevBuf<double> din, dout; DevBuf<long long> dt;
+    if (din.alloc(512) || dout.alloc(16) || dt.alloc(8)) return MI_DEGENSAC_ENOMEM;
+    HIPCHK(hipMemcpy(din.p, in_host, 512 * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(dg_microbench_kernel, dim3(1), dim3(64), 0, 0, din.p, dout.p, dt.p, reps);
+    HIPCHK(hipGetLastError()); HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(ticks_host, dt.p, 64, hipMemcpyDeviceToHost));
     return 0;
 }

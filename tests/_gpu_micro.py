@@ -1,0 +1,12 @@
+import sys, numpy as np, ctypes as C
+sys.path.insert(0,'.')
+from pydegensac_amd import synthetic as syn, _lib
+L=_lib.lib()
+p1,p2,lab,F=syn.two_view_fundamental(2000,1.0,0.1,seed=0)
+inp=np.zeros(512)
+inp[:64]=np.c_[p1[:16],p2[:16]].ravel()
+rng=np.random.default_rng(0); inp[64:64+14*9]=rng.normal(size=14*9); inp[200:209]=F.ravel()/np.linalg.norm(F)
+t=np.zeros(8,np.int64); reps=50
+rc=L.mi_degensac_microbench(inp.ctypes.data_as(C.POINTER(C.c_double)),reps,t.ctypes.data_as(C.POINTER(C.c_longlong)))
+names=["cov9+eig9","cov9 only","u2f_small(14)","u2f_small(8)","singulF","checksample","u2h_small(5)","hash(800)"]
+for n,v in zip(names,t): print(f"{n:16s} {v/reps/100:.1f} us")
