@@ -634,6 +634,212 @@ DG_BIG int dg_eig_sym(double *a, double *w, int n)
 #undef A_
 }
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Wave-cooperative dsyev: the same arithmetic as dg_eig_sym (same per-element operations, same
+ * summation order inside every dot product), but the independent loops run in different lanes of ONE
+ * wave: rows of dsymv, elements of the rank-2 update, columns of the reflector application, rows of the
+ * plane rotations.  Must be called by all 64 lanes of a single wave with identical arguments; the matrix
+ * lives in LDS.  n = 9.
+ * ---------------------------------------------------------------------------------------------- */
+#define DG_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+static __device__ __noinline__ int dg_eig_sym_wave(double *a, double *w, int lane)
+{
+    const int n = 9;
+    DG_LDS double d[9], e[9], tau[9], work[18];
+    int i, j, k, l, m, ii;
+#define A_(r,c) a[(c)*n + (r)]
+    /* ---- dsytd2, UPLO='U' ---- */
+    for (i = n - 2; i >= 0; i--) {
+        double alpha = A_(i, i+1), xnorm = 0., taui, beta, sc = 0.;
+        for (k = 0; k < i; k++) xnorm += A_(k, i+1) * A_(k, i+1);
+        xnorm = sqrt(xnorm);
+        if (xnorm == 0.) taui = 0.;
+        else { beta = -dg_sign(dg_lapy2(alpha, xnorm), alpha); taui = (beta - alpha) / beta; sc = 1. / (alpha - beta); alpha = beta; }
+        DG_WSYNC();
+        if (xnorm != 0. && lane < i) A_(lane, i+1) *= sc;
+        if (lane == 0) e[i] = alpha;
+        if (taui != 0.) {
+            if (lane == 0) A_(i, i+1) = 1.;
+            DG_WSYNC();
+            if (lane <= i) {
+                double sum = 0.;
+                for (j = 0; j <= i; j++) sum += (j >= lane ? A_(lane, j) : A_(j, lane)) * A_(j, i+1);
+                tau[lane] = taui * sum;
+            }
+            DG_WSYNC();
+            double dot = 0.; for (k = 0; k <= i; k++) dot += tau[k] * A_(k, i+1);
+            double al = -.5 * taui * dot;
+            DG_WSYNC();
+            if (lane <= i) tau[lane] += al * A_(lane, i+1);
+            DG_WSYNC();
+            if (lane < (i+1)*(i+2)/2) {
+                int jc = 0; while ((jc+1)*(jc+2)/2 <= lane) jc++;
+                int kr = lane - jc*(jc+1)/2;
+                A_(kr, jc) = A_(kr, jc) - A_(kr, i+1) * tau[jc] - tau[kr] * A_(jc, i+1);
+            }
+            DG_WSYNC();
+            if (lane == 0) A_(i, i+1) = alpha;
+        }
+        DG_WSYNC();
+        if (lane == 0) { d[i+1] = A_(i+1, i+1); tau[i] = taui; }
+        DG_WSYNC();
+    }
+    if (lane == 0) d[0] = A_(0, 0);
+    /* ---- dorgtr 'U': shift the reflector vectors one column left, unit last row/column ---- */
+    {
+        double v0 = 0., v1 = 0.; int e0 = lane, e1 = lane + 64;
+        { int r = e0 % n, c = e0 / n; v0 = (c < n-1 && r < c) ? A_(r, c+1) : A_(r, c); }
+        if (e1 < n*n) { int r = e1 % n, c = e1 / n; v1 = (c < n-1 && r < c) ? A_(r, c+1) : A_(r, c); }
+        DG_WSYNC();
+        { int r = e0 % n, c = e0 / n; if (r == n-1 || c == n-1) v0 = (r == n-1 && c == n-1) ? 1. : 0.; a[e0] = v0; }
+        if (e1 < n*n) { int r = e1 % n, c = e1 / n; if (r == n-1 || c == n-1) v1 = (r == n-1 && c == n-1) ? 1. : 0.; a[e1] = v1; }
+        DG_WSYNC();
+    }
+    /* ---- dorg2l(n-1, n-1, n-1) ---- */
+    {
+        const int mq = n - 1;
+        for (i = 0; i < mq; i++) {
+            ii = i;
+            if (lane == 0) A_(ii, ii) = 1.;
+            DG_WSYNC();
+            if (lane < ii) {
+                double sum = 0.;
+                for (k = 0; k <= ii; k++) sum += A_(k, lane) * A_(k, ii);
+                sum *= tau[i];
+                for (k = 0; k <= ii; k++) A_(k, lane) -= sum * A_(k, ii);
+            }
+            DG_WSYNC();
+            if (lane < ii) A_(lane, ii) *= -tau[i];
+            if (lane == 0) A_(ii, ii) = 1. - tau[i];
+            if (lane > ii && lane < mq) A_(lane, ii) = 0.;
+            DG_WSYNC();
+        }
+    }
+    /* ---- dsteqr 'V': scalar recurrences replicated in every lane (stores by lane 0), rotations by row ---- */
+    {
+        const double eps = DG_EPS, eps2 = eps*eps, safmin = DG_SAFMIN;
+        int nmaxit = n * 30, jtot = 0, l1 = 0, lsv, lend, lendsv, mm;
+        double p, g, r, c, s, f, b, rt1, rt2, tst;
+#define DG_ROT(j0, cnt, backward) do { DG_WSYNC(); if (lane < n) { \
+            for (int jj_ = 0; jj_ < (cnt) - 1; jj_++) { int j_ = (backward) ? ((cnt) - 2 - jj_) : jj_; \
+                double ct_ = work[(j0) + j_], st_ = work[n - 1 + (j0) + j_]; \
+                if (ct_ != 1. || st_ != 0.) { double *zj_ = a + (size_t)((j0) + j_) * n, *zj1_ = zj_ + n; \
+                    double temp_ = zj1_[lane]; zj1_[lane] = ct_*temp_ - st_*zj_[lane]; zj_[lane] = st_*temp_ + ct_*zj_[lane]; } } } DG_WSYNC(); } while (0)
+        DG_WSYNC();
+        while (l1 < n) {
+            if (l1 > 0 && lane == 0) e[l1-1] = 0.;
+            DG_WSYNC();
+            for (m = l1; m < n - 1; m++) {
+                tst = fabs(e[m]);
+                if (tst == 0.) break;
+                if (tst <= (sqrt(fabs(d[m])) * sqrt(fabs(d[m+1]))) * eps) { DG_WSYNC(); if (lane == 0) e[m] = 0.; DG_WSYNC(); break; }
+            }
+            l = l1; lsv = l; lend = m; lendsv = lend; l1 = m + 1;
+            if (lend == l) continue;
+            if (fabs(d[lend]) < fabs(d[l])) { lend = lsv; l = lendsv; }
+            if (lend > l) {
+                for (;;) {
+                    if (l != lend) {
+                        for (m = l; m < lend; m++) { tst = fabs(e[m]); tst *= tst; if (tst <= (eps2 * fabs(d[m])) * fabs(d[m+1]) + safmin) break; }
+                    } else m = lend;
+                    if (m < lend) { DG_WSYNC(); if (lane == 0) e[m] = 0.; DG_WSYNC(); }
+                    p = d[l];
+                    if (m == l) { l++; if (l <= lend) continue; break; }
+                    if (m == l + 1) {
+                        dg_laev2(d[l], e[l], d[l+1], &rt1, &rt2, &c, &s);
+                        DG_WSYNC();
+                        if (lane == 0) { work[l] = c; work[n-1+l] = s; d[l] = rt1; d[l+1] = rt2; e[l] = 0.; }
+                        DG_ROT(l, 2, 1);
+                        l += 2; if (l <= lend) continue; break;
+                    }
+                    if (jtot == nmaxit) break;
+                    jtot++;
+                    g = (d[l+1] - p) / (2. * e[l]);
+                    r = dg_lapy2(g, 1.);
+                    g = d[m] - p + (e[l] / (g + dg_sign(r, g)));
+                    s = 1.; c = 1.; p = 0.;
+                    DG_WSYNC();
+                    for (i = m - 1; i >= l; i--) {
+                        f = s * e[i]; b = c * e[i];
+                        dg_lartg(g, f, &c, &s, &r);
+                        double di = d[i], di1 = d[i+1];
+                        if (i != m - 1 && lane == 0) e[i+1] = r;
+                        g = di1 - p;
+                        r = (di - g)*s + 2.*c*b;
+                        p = s * r;
+                        if (lane == 0) { d[i+1] = g + p; work[i] = c; work[n-1+i] = -s; }
+                        g = c*r - b;
+                    }
+                    mm = m - l + 1;
+                    DG_WSYNC();
+                    { double dl = d[l]; DG_WSYNC(); if (lane == 0) { d[l] = dl - p; e[l] = g; } }
+                    DG_ROT(l, mm, 1);
+                }
+            } else {
+                for (;;) {
+                    if (l != lend) {
+                        for (m = l; m > lend; m--) { tst = fabs(e[m-1]); tst *= tst; if (tst <= (eps2 * fabs(d[m])) * fabs(d[m-1]) + safmin) break; }
+                    } else m = lend;
+                    if (m > lend) { DG_WSYNC(); if (lane == 0) e[m-1] = 0.; DG_WSYNC(); }
+                    p = d[l];
+                    if (m == l) { l--; if (l >= lend) continue; break; }
+                    if (m == l - 1) {
+                        dg_laev2(d[l-1], e[l-1], d[l], &rt1, &rt2, &c, &s);
+                        DG_WSYNC();
+                        if (lane == 0) { work[m] = c; work[n-1+m] = s; d[l-1] = rt1; d[l] = rt2; e[l-1] = 0.; }
+                        DG_ROT(l - 1, 2, 0);
+                        l -= 2; if (l >= lend) continue; break;
+                    }
+                    if (jtot == nmaxit) break;
+                    jtot++;
+                    g = (d[l-1] - p) / (2. * e[l-1]);
+                    r = dg_lapy2(g, 1.);
+                    g = d[m] - p + (e[l-1] / (g + dg_sign(r, g)));
+                    s = 1.; c = 1.; p = 0.;
+                    DG_WSYNC();
+                    for (i = m; i <= l - 1; i++) {
+                        f = s * e[i]; b = c * e[i];
+                        dg_lartg(g, f, &c, &s, &r);
+                        double di = d[i], di1 = d[i+1];
+                        if (i != m && lane == 0) e[i-1] = r;
+                        g = di - p;
+                        r = (di1 - g)*s + 2.*c*b;
+                        p = s * r;
+                        if (lane == 0) { d[i] = g + p; work[i] = c; work[n-1+i] = s; }
+                        g = c*r - b;
+                    }
+                    mm = l - m + 1;
+                    DG_WSYNC();
+                    { double dl = d[l]; DG_WSYNC(); if (lane == 0) { d[l] = dl - p; e[l-1] = g; } }
+                    DG_ROT(m, mm, 0);
+                }
+            }
+            if (jtot >= nmaxit) break;
+        }
+        DG_WSYNC();
+        /* selection sort, ascending (columns swapped by row lanes) */
+        for (ii = 1; ii < n; ii++) {
+            i = ii - 1; k = i; p = d[i];
+            for (j = ii; j < n; j++) if (d[j] < p) { k = j; p = d[j]; }
+            DG_WSYNC();
+            if (k != i) {
+                double dk = d[i];
+                if (lane == 0) { d[k] = dk; d[i] = p; }
+                if (lane < n) { double t = A_(lane, i); A_(lane, i) = A_(lane, k); A_(lane, k) = t; }
+            }
+            DG_WSYNC();
+        }
+        if (lane < n) w[lane] = d[lane];
+        DG_WSYNC();
+        return jtot >= nmaxit ? 1 : 0;
+    }
+#undef DG_ROT
+#undef A_
+}
+
 /* ------------------------------------------------------------------------------------------------
  * degensac/utools.c
  * ---------------------------------------------------------------------------------------------- */

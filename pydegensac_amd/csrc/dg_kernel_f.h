@@ -110,17 +110,19 @@ __device__ __forceinline__ void dg_u2f_list(CTX &c, const int *list, int len, co
     dg_f_shared *S = c.S;
     if (len <= 16) {
         __syncthreads();
-        if (c.tid == 0) {
-            dg_gather(c, list, len, S->lsq.px);
-            double wts[16];
-            if (wmodel) {
-                for (int i = 0; i < len; i++) {
-                    double *q = S->lsq.px + 4*i;
-                    if (wkind == DG_K_FDS) wts[i] = dg_exFDs_w(wmodel, q[0], q[1], q[2], q[3]);
-                    else { double w; dg_exFDsSym(wmodel, q[0], q[1], q[2], q[3], &w); wts[i] = w; }
+        if (c.tid < 64) {
+            if (c.tid == 0) {
+                dg_gather(c, list, len, S->lsq.px);
+                if (wmodel) {
+                    for (int i = 0; i < len; i++) {
+                        double *q = S->lsq.px + 4*i;
+                        if (wkind == DG_K_FDS) S->lsq.part[0][i] = dg_exFDs_w(wmodel, q[0], q[1], q[2], q[3]);
+                        else { double w; dg_exFDsSym(wmodel, q[0], q[1], q[2], q[3], &w); S->lsq.part[0][i] = w; }
+                    }
                 }
             }
-            dg_u2f_small(&S->lsq, S->lsq.px, wmodel ? wts : 0, len, Fout);
+            DG_WSYNC();
+            dg_u2f_small_w(&S->lsq, S->lsq.px, wmodel ? S->lsq.part[0] : 0, len, Fout, c.tid);
         }
         __syncthreads();
     } else {
@@ -192,23 +194,31 @@ __device__ __noinline__ void dg_Hdetect(const double *F, const double (*u7)[4], 
     if (isnan(*H) || isinf(*H) || sing) { H[1] = H[2] = H[3] = H[5] = H[6] = H[7] = 0; H[0] = H[4] = H[8] = 1; }
 }
 
-__device__ __noinline__ int dg_checksample(dg_lsq_scratch *ls, const double *F, const double (*u7)[4], double th, double *H)
+/* called by all 64 lanes of wave 0; the 5-point re-fit runs wave-cooperatively, the rest on lane 0 */
+__device__ __noinline__ int dg_checksample(dg_lsq_scratch *ls, const double *F, const double (*u7)[4], double th, double *H, int lane)
 {
     const unsigned char IDXS[5][3] = {{0,1,2}, {3,4,5}, {0,1,6}, {3,4,6}, {2,5,6}};
     DG_LDS double Ds[7], sDs[7], px[20];
-    DG_LDS int idx[7];
+    DG_LDS int idx[7], res;
     for (int i = 0; i < 5; ++i) {
-        dg_Hdetect(F, u7, IDXS[i], H);
-        for (int j = 0; j < 7; j++) Ds[j] = dg_HDs(H, u7[j][0], u7[j][1], u7[j][2], u7[j][3]);
-        for (int j = 0; j < 7; j++) { sDs[j] = Ds[j]; idx[j] = j; }          /* sortDs, DegUtils.c:164-183 */
-        for (int a = 0; a < 7; ++a)
-            for (int b = a + 1; b < 7; ++b)
-                if (sDs[b] < sDs[a]) { double t = sDs[b]; sDs[b] = sDs[a]; sDs[a] = t; int ti = idx[b]; idx[b] = idx[a]; idx[a] = ti; }
-        for (int j = 0; j < 5; ++j) { px[4*j] = u7[idx[j]][0]; px[4*j+1] = u7[idx[j]][1]; px[4*j+2] = u7[idx[j]][2]; px[4*j+3] = u7[idx[j]][3]; }
-        dg_u2h_small(ls, px, 5, H);
-        int inlCount = 0;
-        for (int j = 0; j < 7; ++j) if (dg_HDs(H, u7[j][0], u7[j][1], u7[j][2], u7[j][3]) < th) ++inlCount;
-        if (inlCount > 4) return 1;
+        if (lane == 0) {
+            dg_Hdetect(F, u7, IDXS[i], H);
+            for (int j = 0; j < 7; j++) Ds[j] = dg_HDs(H, u7[j][0], u7[j][1], u7[j][2], u7[j][3]);
+            for (int j = 0; j < 7; j++) { sDs[j] = Ds[j]; idx[j] = j; }          /* sortDs, DegUtils.c:164-183 */
+            for (int a = 0; a < 7; ++a)
+                for (int b = a + 1; b < 7; ++b)
+                    if (sDs[b] < sDs[a]) { double t = sDs[b]; sDs[b] = sDs[a]; sDs[a] = t; int ti = idx[b]; idx[b] = idx[a]; idx[a] = ti; }
+            for (int j = 0; j < 5; ++j) { px[4*j] = u7[idx[j]][0]; px[4*j+1] = u7[idx[j]][1]; px[4*j+2] = u7[idx[j]][2]; px[4*j+3] = u7[idx[j]][3]; }
+        }
+        DG_WSYNC();
+        dg_u2h_small_w(ls, px, 5, H, lane);
+        if (lane == 0) {
+            int inlCount = 0;
+            for (int j = 0; j < 7; ++j) if (dg_HDs(H, u7[j][0], u7[j][1], u7[j][2], u7[j][3]) < th) ++inlCount;
+            res = inlCount > 4;
+        }
+        DG_WSYNC();
+        if (res) return 1;
     }
     return 0;
 }
@@ -229,10 +239,10 @@ __device__ __forceinline__ unsigned dg_innerH(CTX &c, double *H /* LDS, in/out *
         double maxJ = 0;                               /* maxS = {0,0} */
         for (int rep = 0; rep < DG_RAN_REP; ++rep) {
             __syncthreads();
-            if (tid == 0) {
-                int o = dg_randsubset(&S->rng, inliers, ninl, ssiz);
-                dg_gather(c, inliers + o, ssiz, S->lsq.px);
-                dg_u2h_small(&S->lsq, S->lsq.px, ssiz, h);
+            if (tid < 64) {
+                if (tid == 0) { int o = dg_randsubset(&S->rng, inliers, ninl, ssiz); dg_gather(c, inliers + o, ssiz, S->lsq.px); }
+                DG_WSYNC();
+                dg_u2h_small_w(&S->lsq, S->lsq.px, ssiz, h, tid);
             }
             __syncthreads();
             /* errs[0] = HDs(h); errs[4] = errs[0]; iterH */
@@ -246,11 +256,11 @@ __device__ __forceinline__ unsigned dg_innerH(CTX &c, double *H /* LDS, in/out *
                 if (mI >= 4) {
                     double *hl = S->dtmp;
                     __syncthreads();
-                    if (tid == 0) {
-                        int cnt = (int)mI, o = 0;
-                        if (mI > inlLimit) { o = dg_randsubset(&S->rng, intbuff, (int)mI, (int)inlLimit); cnt = (int)inlLimit; }
-                        dg_gather(c, intbuff + o, cnt, S->lsq.px);
-                        dg_u2h_small(&S->lsq, S->lsq.px, cnt, hl);
+                    if (tid < 64) {
+                        int cnt = (int)mI > (int)inlLimit ? (int)inlLimit : (int)mI;
+                        if (tid == 0) { int o = 0; if (mI > inlLimit) o = dg_randsubset(&S->rng, intbuff, (int)mI, (int)inlLimit); dg_gather(c, intbuff + o, cnt, S->lsq.px); }
+                        DG_WSYNC();
+                        dg_u2h_small_w(&S->lsq, S->lsq.px, cnt, hl, tid);
                     }
                     __syncthreads();
                     int early = 0;
@@ -260,11 +270,11 @@ __device__ __forceinline__ unsigned dg_innerH(CTX &c, double *H /* LDS, in/out *
                         if (mJ < r2.J) { mJ = r2.J; mI = r2.I; __syncthreads(); if (tid < 9) h[tid] = hl[tid]; __syncthreads(); }
                         if (r2.nL < 4) { early = 1; break; }
                         __syncthreads();
-                        if (tid == 0) {
-                            int cnt = (int)r2.nL, o = 0;
-                            if (r2.nL > inlLimit) { o = dg_randsubset(&S->rng, intbuff, (int)r2.nL, (int)inlLimit); cnt = (int)inlLimit; }
-                            dg_gather(c, intbuff + o, cnt, S->lsq.px);
-                            dg_u2h_small(&S->lsq, S->lsq.px, cnt, hl);
+                        if (tid < 64) {
+                            int cnt = r2.nL > inlLimit ? (int)inlLimit : (int)r2.nL;
+                            if (tid == 0) { int o = 0; if (r2.nL > inlLimit) o = dg_randsubset(&S->rng, intbuff, (int)r2.nL, (int)inlLimit); dg_gather(c, intbuff + o, cnt, S->lsq.px); }
+                            DG_WSYNC();
+                            dg_u2h_small_w(&S->lsq, S->lsq.px, cnt, hl, tid);
                         }
                         __syncthreads();
                         ths -= dth;
@@ -368,8 +378,8 @@ __device__ __forceinline__ void dg_innerFH(CTX &c, const int *idxH, unsigned len
             for (int i = 0; i < 6; i++) S->itmp[i] = idxH[pick[i]];
             for (int i = 0; i < 4; i++) S->itmp[6+i] = idxO[pick[6+i]];
             dg_gather(c, S->itmp, 10, S->lsq.px);
-            dg_u2f_small(&S->lsq, S->lsq.px, 0, 10, aF);
         }
+        if (tid < 64) { DG_WSYNC(); dg_u2f_small_w(&S->lsq, S->lsq.px, 0, 10, aF, tid); }
         __syncthreads();
         dg_pass_cfg cfg = dg_cfg0(n); cfg.flags = v; cfg.thF = th;
         dg_pass_res r = dg_f_pass(c, aF, DG_K_FDS, cfg); c.n_aux++;

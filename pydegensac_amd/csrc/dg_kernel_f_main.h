@@ -117,10 +117,10 @@ __device__ __forceinline__ dg_score dg_inFrani(CTX &c, int ninl, double th, doub
     int ssiz = ninl / 2; if (ssiz > 14) ssiz = 14;
     for (int i = 0; i < DG_RAN_REP; i++) {
         __syncthreads();
-        if (tid == 0) {
-            int o = dg_randsubset(&S->rng, inliers, ninl, ssiz);
-            dg_gather(c, inliers + o, ssiz, S->lsq.px);
-            dg_u2f_small(&S->lsq, S->lsq.px, 0, ssiz, S->f);
+        if (tid < 64) {
+            if (tid == 0) { int o = dg_randsubset(&S->rng, inliers, ninl, ssiz); dg_gather(c, inliers + o, ssiz, S->lsq.px); }
+            DG_WSYNC();
+            dg_u2f_small_w(&S->lsq, S->lsq.px, 0, ssiz, S->f, tid);
         }
         __syncthreads();
         int k0;
@@ -387,12 +387,14 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
                     int degenerate = 0;
                     if (pr.degen) {
                         __syncthreads();
-                        if (tid == 0) {
-                            for (int i = 0; i < 7; i++) {              /* u7 in samidx order = reverse draw order */
-                                dg_pt q = P[S->draws[k][6 - i]];
-                                S->u7[i][0] = q.x1; S->u7[i][1] = q.y1; S->u7[i][2] = q.x2; S->u7[i][3] = q.y2;
+                        if (tid < 64) {
+                            if (tid < 7) {                             /* u7 in samidx order = reverse draw order */
+                                dg_pt q = P[S->draws[k][6 - tid]];
+                                S->u7[tid][0] = q.x1; S->u7[tid][1] = q.y1; S->u7[tid][2] = q.x2; S->u7[tid][3] = q.y2;
                             }
-                            S->itmp[1] = dg_checksample(&S->lsq, S->f, S->u7, 3*th, S->H);
+                            DG_WSYNC();
+                            int dgn = dg_checksample(&S->lsq, S->f, S->u7, 3*th, S->H, tid);
+                            if (tid == 0) S->itmp[1] = dgn;
                         }
                         __syncthreads();
                         degenerate = S->itmp[1];
@@ -489,11 +491,14 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
         int degenerate = 0;
         /* the libc stream continues from wherever the last iteration left it: after its seed draw */
         __syncthreads();
-        if (tid == 0) {
+        if (tid < 64) {
+            int dgn = 0;
             if (pr.degen) {
-                for (int i = 0; i < 7; i++) { dg_pt q = P[S->samidxBest[i]]; S->u7[i][0] = q.x1; S->u7[i][1] = q.y1; S->u7[i][2] = q.x2; S->u7[i][3] = q.y2; }
-                S->itmp[1] = dg_checksample(&S->lsq, S->FBest, S->u7, 3*th, S->H);
-            } else S->itmp[1] = 0;
+                if (tid < 7) { dg_pt q = P[S->samidxBest[tid]]; S->u7[tid][0] = q.x1; S->u7[tid][1] = q.y1; S->u7[tid][2] = q.x2; S->u7[tid][3] = q.y2; }
+                DG_WSYNC();
+                dgn = dg_checksample(&S->lsq, S->FBest, S->u7, 3*th, S->H, tid);
+            }
+            if (tid == 0) S->itmp[1] = dgn;
             /* state after the last executed iteration: srand(prev seed) + 8 outputs == srand(prev), so replay it */
             S->itmp[2] = 0;
         }

@@ -16,8 +16,8 @@ __device__ __forceinline__ void dg_u2h_big(dg_red *r, dg_lsq_scratch *s, PtFn pt
 {
     (void)r;
     dg_lsq_seq(s, pt, list, len, tid, 1, s->A1, s->A2);
+    if (tid < 64) dg_eig_sym_wave(s->V, s->D, tid);
     if (tid == 0) {
-        dg_eig_sym(s->V, s->D, 9);
         for (int i = 0; i < 9; i++) Hout[i] = s->V[i];
         dg_denormH(Hout, s->A1, s->A2);
     }
@@ -31,7 +31,7 @@ __device__ __forceinline__ void dg_u2h_list(CTX &c, const int *list, int len, do
     dg_f_shared *S = c.S;
     if (len <= 12) {
         __syncthreads();
-        if (c.tid == 0) { dg_gather(c, list, len, S->lsq.px); dg_u2h_small(&S->lsq, S->lsq.px, len, Hout); }
+        if (c.tid < 64) { if (c.tid == 0) dg_gather(c, list, len, S->lsq.px); DG_WSYNC(); dg_u2h_small_w(&S->lsq, S->lsq.px, len, Hout, c.tid); }
         __syncthreads();
     } else {
         const dg_pt *P = c.P;
@@ -188,10 +188,10 @@ __device__ __forceinline__ dg_score dg_inHranic(CTX &c, int kind, int ninl, doub
     { int t = B.pe[2]; B.pe[2] = B.pe[0]; B.pe[0] = t; }
     for (int i = 0; i < DG_RAN_REP; i++) {
         __syncthreads();
-        if (tid == 0) {
-            int o = dg_randsubset(&S->rng, inliers, ninl, ssiz);
-            dg_gather(c, inliers + o, ssiz, S->lsq.px);
-            dg_u2h_small(&S->lsq, S->lsq.px, ssiz, S->f);
+        if (tid < 64) {
+            if (tid == 0) { int o = dg_randsubset(&S->rng, inliers, ninl, ssiz); dg_gather(c, inliers + o, ssiz, S->lsq.px); }
+            DG_WSYNC();
+            dg_u2h_small_w(&S->lsq, S->lsq.px, ssiz, S->f, tid);
         }
         __syncthreads();
         DG_BUFSET(S, B.pe[0], S->f);                          /* HDS1(h) -> errs[0] (scored inside dg_iterHc) */

@@ -114,6 +114,72 @@ __device__ __noinline__ void dg_u2h_small(dg_lsq_scratch *s, const double *p, in
     }
 }
 
+/* ---- wave-cooperative variants of the small solvers (all 64 lanes of wave 0 call these) ----------------
+ * Same arithmetic as dg_u2f_small / dg_u2h_small; the design-matrix rows, the 45 normal-matrix entries and
+ * the eigen-solver's inner loops are spread over lanes.  p (gathered coordinates) is in LDS. */
+__device__ __forceinline__ void dg_cov9_wave(double *Cv, const double *Z, int rows, int lane)
+{
+    if (lane < 45) {
+        int i = 0; while ((i+1)*(i+2)/2 <= lane) i++;
+        int j = lane - i*(i+1)/2;
+        double val = 0;
+        for (int k = 0; k < rows; k++) val += Z[9*k+i] * Z[9*k+j];
+        Cv[9*i+j] = val; Cv[i+9*j] = val;
+    }
+}
+
+__device__ __noinline__ void dg_u2f_small_w(dg_lsq_scratch *s, const double *p, const double *wts /* LDS or 0 */, int len, double *F, int lane)
+{
+    if (len > 8) {
+        double A1[3], A2[3];
+        dg_normu_small(p, len, A1, A2);                       /* every lane: same LDS reads, same result */
+        if (lane < len) {
+            int i = lane; double a[3], b[3];
+            a[2] = 1; b[2] = 1;
+            a[0] = p[4*i]   * A1[0] + A1[1]; a[1] = p[4*i+1] * A1[0] + A1[2];
+            b[0] = p[4*i+2] * A2[0] + A2[1]; b[1] = p[4*i+3] * A2[0] + A2[2];
+            for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) { double z = a[l] * b[k]; if (wts) z *= wts[i]; s->Z[9*i + 3*k + l] = z; }
+        }
+        if (lane == 0) for (int i = 0; i < 3; i++) { s->A1[i] = A1[i]; s->A2[i] = A2[i]; }
+        DG_WSYNC();
+        dg_cov9_wave(s->V, s->Z, len, lane);
+        DG_WSYNC();
+        dg_eig_sym_wave(s->V, s->D, lane);
+        if (lane == 0) {
+            int j = 0; for (int i = 1; i < 9; i++) if (s->D[i] < s->D[j]) j = i;
+            for (int i = 0; i < 9; i++) F[i] = s->V[j*9 + i];
+            dg_singulF(F);
+            dg_denormF(F, s->A1, s->A2);
+        }
+        DG_WSYNC();
+    } else {
+        if (lane == 0) dg_u2f_small(s, p, wts, len, F);
+        DG_WSYNC();
+    }
+}
+
+__device__ __noinline__ void dg_u2h_small_w(dg_lsq_scratch *s, const double *p, int len, double *H, int lane)
+{
+    if (len <= 4) { if (lane == 0) dg_u2h_small(s, p, len, H); DG_WSYNC(); return; }
+    double A1[3], A2[3];
+    dg_normu_small(p, len, A1, A2);
+    if (lane < len) {
+        int i = lane;
+        double a0 = p[4*i] * A1[0] + A1[1], a1 = p[4*i+1] * A1[0] + A1[2];
+        double b[3] = {p[4*i+2] * A2[0] + A2[1], p[4*i+3] * A2[0] + A2[2], 1.0};
+        double *z = s->Z + 18*i;
+        for (int j = 0; j < 3; j++) { z[3*j] = b[j]; z[3*j+1] = 0; z[3*j+2] = -a0 * b[j]; }
+        for (int j = 0; j < 3; j++) { z[9+3*j] = 0; z[9+3*j+1] = b[j]; z[9+3*j+2] = -a1 * b[j]; }
+    }
+    if (lane == 0) for (int i = 0; i < 3; i++) { s->A1[i] = A1[i]; s->A2[i] = A2[i]; }
+    DG_WSYNC();
+    dg_cov9_wave(s->V, s->Z, 2*len, lane);
+    DG_WSYNC();
+    dg_eig_sym_wave(s->V, s->D, lane);
+    if (lane == 0) { for (int i = 0; i < 9; i++) H[i] = s->V[i]; dg_denormH(H, s->A1, s->A2); }
+    DG_WSYNC();
+}
+
 /* ---- normalised LSQ over an id list of any length, in the REFERENCE'S summation order -----------------
  * Hartley-normalised coordinates have zero mean, so several entries of the 9x9 normal matrix are "zero
  * up to summation noise"; the sign LAPACK's dsyev gives the eigenvector depends on that noise.  To return
@@ -185,8 +251,8 @@ __device__ __forceinline__ void dg_u2f_big(dg_red *r, dg_lsq_scratch *s, PtFn pt
 {
     (void)r;
     dg_lsq_seq(s, pt, list, len, tid, 0, s->A1, s->A2);
+    if (tid < 64) dg_eig_sym_wave(s->V, s->D, tid);
     if (tid == 0) {
-        dg_eig_sym(s->V, s->D, 9);
         int jm = 0; for (int i = 1; i < 9; i++) if (s->D[i] < s->D[jm]) jm = i;
         for (int i = 0; i < 9; i++) Fout[i] = s->V[jm*9 + i];
         dg_singulF(Fout);

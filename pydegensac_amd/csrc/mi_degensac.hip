@@ -384,38 +384,38 @@ __global__ void dg_microbench_kernel(const double *in, double *out, long long *t
     if (tid == 0) {
         for (int i = 0; i < 64; i++) ls.px[i] = in[i];
         for (int i = 0; i < 7; i++) for (int j = 0; j < 4; j++) u7[i][j] = in[4*i + j];
-        long long t0, t1;
-        /* eig 9x9 on a normal matrix of 14 points */
-        t0 = wall_clock64();
-        for (int r = 0; r < reps; r++) { for (int i = 0; i < 14; i++) for (int k = 0; k < 9; k++) ls.Z[9*i+k] = in[64 + 9*i + k] + 1e-9 * r; dg_cov9(ls.V, ls.Z, 14); dg_eig_sym(ls.V, ls.D, 9); }
-        t1 = wall_clock64(); ticks[0] = t1 - t0;
-        t0 = wall_clock64();
-        for (int r = 0; r < reps; r++) { for (int i = 0; i < 14; i++) for (int k = 0; k < 9; k++) ls.Z[9*i+k] = in[64 + 9*i + k] + 1e-9 * r; dg_cov9(ls.V, ls.Z, 14); }
-        t1 = wall_clock64(); ticks[1] = t1 - t0;
-        t0 = wall_clock64();
-        for (int r = 0; r < reps; r++) dg_u2f_small(&ls, ls.px, 0, 14, F);
-        t1 = wall_clock64(); ticks[2] = t1 - t0;
-        t0 = wall_clock64();
-        for (int r = 0; r < reps; r++) dg_u2f_small(&ls, ls.px, 0, 8, F);
-        t1 = wall_clock64(); ticks[3] = t1 - t0;
-        t0 = wall_clock64();
-        for (int r = 0; r < reps; r++) { for (int i = 0; i < 9; i++) F[i] = in[200 + i] + 1e-9 * r; dg_singulF(F); }
-        t1 = wall_clock64(); ticks[4] = t1 - t0;
         for (int i = 0; i < 9; i++) F[i] = in[200 + i];
         dg_singulF(F);
-        t0 = wall_clock64();
-        for (int r = 0; r < reps; r++) out[9] = dg_checksample(&ls, F, u7, 0.75, H);
-        t1 = wall_clock64(); ticks[5] = t1 - t0;
-        t0 = wall_clock64();
-        for (int r = 0; r < reps; r++) dg_u2h_small(&ls, ls.px, 5, H);
-        t1 = wall_clock64(); ticks[6] = t1 - t0;
         for (int i = 0; i < 800; i++) list[i] = (i * 37) % 2000;
-        t0 = wall_clock64();
-        unsigned hsum = 0;
-        for (int r = 0; r < reps; r++) hsum += dg_hash_list(list, 800 - (r & 1));
-        t1 = wall_clock64(); ticks[7] = t1 - t0; out[10] = hsum;
-        for (int i = 0; i < 9; i++) out[i] = F[i];
     }
+    DG_WSYNC();
+    long long t0, t1;
+    t0 = wall_clock64();
+    for (int r = 0; r < reps; r++) { if (tid == 0) { for (int i = 0; i < 14; i++) for (int k = 0; k < 9; k++) ls.Z[9*i+k] = in[64 + 9*i + k] + 1e-9 * r; } DG_WSYNC(); dg_cov9_wave(ls.V, ls.Z, 14, tid); DG_WSYNC(); dg_eig_sym_wave(ls.V, ls.D, tid); }
+    t1 = wall_clock64(); if (tid == 0) ticks[0] = t1 - t0;
+    t0 = wall_clock64();
+    for (int r = 0; r < reps; r++) { if (tid == 0) { for (int i = 0; i < 14; i++) for (int k = 0; k < 9; k++) ls.Z[9*i+k] = in[64 + 9*i + k] + 1e-9 * r; dg_cov9(ls.V, ls.Z, 14); dg_eig_sym(ls.V, ls.D, 9); } DG_WSYNC(); }
+    t1 = wall_clock64(); if (tid == 0) ticks[1] = t1 - t0;
+    t0 = wall_clock64();
+    for (int r = 0; r < reps; r++) dg_u2f_small_w(&ls, ls.px, 0, 14, F, tid);
+    t1 = wall_clock64(); if (tid == 0) ticks[2] = t1 - t0;
+    t0 = wall_clock64();
+    for (int r = 0; r < reps; r++) dg_u2f_small_w(&ls, ls.px, 0, 8, F, tid);
+    t1 = wall_clock64(); if (tid == 0) ticks[3] = t1 - t0;
+    t0 = wall_clock64();
+    for (int r = 0; r < reps; r++) { if (tid == 0) { for (int i = 0; i < 9; i++) F[i] = in[200 + i] + 1e-9 * r; dg_singulF(F); } DG_WSYNC(); }
+    t1 = wall_clock64(); if (tid == 0) ticks[4] = t1 - t0;
+    t0 = wall_clock64();
+    int cs = 0;
+    for (int r = 0; r < reps; r++) cs += dg_checksample(&ls, F, u7, 0.75, H, tid);
+    t1 = wall_clock64(); if (tid == 0) { ticks[5] = t1 - t0; out[9] = cs; }
+    t0 = wall_clock64();
+    for (int r = 0; r < reps; r++) dg_u2h_small_w(&ls, ls.px, 5, H, tid);
+    t1 = wall_clock64(); if (tid == 0) ticks[6] = t1 - t0;
+    t0 = wall_clock64();
+    if (tid == 0) { unsigned hsum = 0; for (int r = 0; r < reps; r++) hsum += dg_hash_list(list, 800 - (r & 1)); out[10] = hsum; }
+    t1 = wall_clock64(); if (tid == 0) ticks[7] = t1 - t0;
+    if (tid == 0) for (int i = 0; i < 9; i++) out[i] = F[i];
 }
 extern "C" int mi_degensac_microbench(const double *in_host, int reps, long long *ticks_host)
 {

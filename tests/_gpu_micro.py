@@ -8,5 +8,5 @@ inp[:64]=np.c_[p1[:16],p2[:16]].ravel()
 rng=np.random.default_rng(0); inp[64:64+14*9]=rng.normal(size=14*9); inp[200:209]=F.ravel()/np.linalg.norm(F)
 t=np.zeros(8,np.int64); reps=50
 rc=L.mi_degensac_microbench(inp.ctypes.data_as(C.POINTER(C.c_double)),reps,t.ctypes.data_as(C.POINTER(C.c_longlong)))
-names=["cov9+eig9","cov9 only","u2f_small(14)","u2f_small(8)","singulF","checksample","u2h_small(5)","hash(800)"]
+names=["cov9+eig9 WAVE","cov9+eig9 lane0","u2f_small(14)","u2f_small(8)","singulF","checksample","u2h_small(5)","hash(800)"]
 for n,v in zip(names,t): print(f"{n:16s} {v/reps/100:.1f} us")
