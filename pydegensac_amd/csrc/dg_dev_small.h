@@ -1041,37 +1041,49 @@ DG_FN int dg_rroots3(const double *po, double *r)         /* Ftools.c:251-298 */
  * (Hestenes) Jacobi on the columns of F, which is accurate also for the tiny singular values
  * (CCMATH svduv is not: absolute 1e-15 deflation threshold).  F = sum_k a_k v_k^T after rotation;
  * drop the term with the smallest |a_k|. */
-DG_BIG void dg_singulF(double *F)
+static __device__ __forceinline__ void dg_singulF(double *F)
 {
-    DG_LDS double A[9], V[9];
-    double nrm[3]; int sweep, p, q, i, k, rotated;
-    for (i = 0; i < 9; i++) V[i] = (i % 4 == 0) ? 1. : 0.;
-    for (i = 0; i < 9; i++) { if (isnan(F[i]) || isinf(F[i])) { for (k = 0; k < 9; k++) F[k] = (k % 4 == 0) ? 1. : 0.; return; } A[i] = F[i]; }
-    for (sweep = 0; sweep < 40; sweep++) {
-        rotated = 0;
-        for (p = 0; p < 2; p++)
-            for (q = p + 1; q < 3; q++) {
-                double alpha = 0., beta = 0., gamma = 0., zeta, t, c, sn;
-                for (i = 0; i < 3; i++) { alpha += A[3*i+p]*A[3*i+p]; beta += A[3*i+q]*A[3*i+q]; gamma += A[3*i+p]*A[3*i+q]; }
-                if (gamma == 0. || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
-                rotated = 1;
-                zeta = (beta - alpha) / (2. * gamma);
-                t = (zeta >= 0. ? 1. : -1.) / (fabs(zeta) + sqrt(1. + zeta*zeta));
-                c = 1. / sqrt(1. + t*t); sn = c * t;
-                for (i = 0; i < 3; i++) {
-                    double ap = A[3*i+p], aq = A[3*i+q], vp = V[3*i+p], vq = V[3*i+q];
-                    A[3*i+p] = c*ap - sn*aq; A[3*i+q] = sn*ap + c*aq;
-                    V[3*i+p] = c*vp - sn*vq; V[3*i+q] = sn*vp + c*vq;
+    /* fully unrolled: A, V live in registers (static indices only) */
+    double A[9], V[9] = {1,0,0, 0,1,0, 0,0,1};
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { A[i] = F[i]; bad = bad || isnan(A[i]) || isinf(A[i]); }
+    if (bad) { for (int k = 0; k < 9; k++) F[k] = (k % 4 == 0) ? 1. : 0.; return; }
+    for (int sweep = 0; sweep < 40; sweep++) {
+        int rotated = 0;
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int q = p + 1; q < 3; q++) {
+                double alpha = 0., beta = 0., gamma = 0.;
+#pragma unroll
+                for (int i = 0; i < 3; i++) { alpha += A[3*i+p]*A[3*i+p]; beta += A[3*i+q]*A[3*i+q]; gamma += A[3*i+p]*A[3*i+q]; }
+                if (!(gamma == 0. || fabs(gamma) <= 1e-17 * sqrt(alpha * beta))) {
+                    rotated = 1;
+                    double zeta = (beta - alpha) / (2. * gamma);
+                    double t = (zeta >= 0. ? 1. : -1.) / (fabs(zeta) + sqrt(1. + zeta*zeta));
+                    double c = 1. / sqrt(1. + t*t), sn = c * t;
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        double ap = A[3*i+p], aq = A[3*i+q], vp = V[3*i+p], vq = V[3*i+q];
+                        A[3*i+p] = c*ap - sn*aq; A[3*i+q] = sn*ap + c*aq;
+                        V[3*i+p] = c*vp - sn*vq; V[3*i+q] = sn*vp + c*vq;
+                    }
                 }
             }
         if (!rotated) break;
     }
-    for (k = 0; k < 3; k++) nrm[k] = A[k]*A[k] + A[3+k]*A[3+k] + A[6+k]*A[6+k];
-    k = 0; if (nrm[1] < nrm[k]) k = 1; if (nrm[2] < nrm[k]) k = 2;
-    for (i = 0; i < 3; i++)
-        for (p = 0; p < 3; p++) {
+    double n0 = A[0]*A[0] + A[3]*A[3] + A[6]*A[6], n1 = A[1]*A[1] + A[4]*A[4] + A[7]*A[7], n2 = A[2]*A[2] + A[5]*A[5] + A[8]*A[8];
+    int k = 0; double nk = n0;
+    if (n1 < nk) { k = 1; nk = n1; }
+    if (n2 < nk) { k = 2; }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
             double acc = 0.;
-            for (q = 0; q < 3; q++) if (q != k) acc += A[3*i+q] * V[3*p+q];
+#pragma unroll
+            for (int q = 0; q < 3; q++) { double term = A[3*i+q] * V[3*p+q]; acc = (q != k) ? acc + term : acc; }
             F[3*i+p] = acc;
         }
 }

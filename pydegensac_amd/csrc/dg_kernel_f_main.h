@@ -206,8 +206,15 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
         DG_PH(3);
         int chunk = max_sam - no_sam; if (chunk > DG_CHUNK) chunk = DG_CHUNK;
         if (wave == 0) {
+            /* seed chain: seed_{k+1} = output #8 after srand(seed_k); lane j carries the term C[7][j] * r_j */
+            const unsigned gk = lane < 31 ? dg_rng_G[lane] : 0u, ck = lane < 31 ? dg_rng_C[7][lane] : 0u;   /* r_j = seed * 16807^j mod (2^31-1) */
             unsigned sd = seed;
-            for (int k = 0; k < chunk; k++) { if (lane == 0) S->seeds[k] = sd; sd = dg_rng_next_seed_wave(sd, lane); }
+            for (int k = 0; k < chunk; k++) {
+                if (lane == 0) S->seeds[k] = sd;
+                unsigned s1 = sd ? sd : 1u;                      /* rand() outputs are < 2^31: Schrage == exact mulmod */
+                unsigned rj = lane == 0 ? s1 : dg_mulmod31(s1, gk);
+                sd = dg_wave_sum_u(ck * rj) >> 1;
+            }
             if (lane == 0) S->itmp[31] = (int)sd;
         }
         __syncthreads();
@@ -221,12 +228,14 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
         __syncthreads();
         if (wave == 0) {
             /* rtools.c:12-23 pool swaps: lanes 0..6 own one draw each; the 7 tail slots live in registers */
-            volatile int *vp = pool;
+            int *vp = pool;
             int t = (lane < 7) ? vp[n - 1 - lane] : 0;
+            int s_next = (lane < 7) ? S->draws[0][lane] : (-1 - lane);
             for (int k = 0; k < chunk; k++) {
-                int s = (lane < 7) ? S->draws[k][lane] : (-1 - lane);
+                const int s = s_next;
+                if (k + 1 < chunk) s_next = (lane < 7) ? S->draws[k + 1][lane] : (-1 - lane);
                 bool alias = (lane < 7) && (s >= n - 7);
-                /* duplicate draws among lanes 0..6 (idle lanes hold distinct negatives): row rotates on the VALU */
+                /* duplicate draws among the active lanes (idle lanes hold distinct negatives): row rotates on the VALU */
                 alias = alias || (dg_dpp<DG_DPP_ROR(1)>(s) == s) || (dg_dpp<DG_DPP_ROR(2)>(s) == s) || (dg_dpp<DG_DPP_ROR(3)>(s) == s)
                               || (dg_dpp<DG_DPP_ROR(4)>(s) == s) || (dg_dpp<DG_DPP_ROR(5)>(s) == s) || (dg_dpp<DG_DPP_ROR(6)>(s) == s);
                 if (__any(alias)) {
@@ -234,10 +243,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
                     if (!LDSPTS) __threadfence_block();
                     __builtin_amdgcn_wave_barrier();
                     if (lane == 0) {
-                        for (int i = 0; i < 7; i++) {
-                            int si = S->draws[k][i], j = n - 1 - i, q = vp[si];
-                            vp[si] = vp[j]; vp[j] = q; S->draws[k][i] = q;
-                        }
+                        for (int i = 0; i < 7; i++) { int si = S->draws[k][i], j = n - 1 - i, q = vp[si]; vp[si] = vp[j]; vp[j] = q; S->draws[k][i] = q; }
                     }
                     if (!LDSPTS) __threadfence_block();
                     __builtin_amdgcn_wave_barrier();
@@ -246,6 +252,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
                     int q = vp[s]; vp[s] = t; t = q; S->draws[k][lane] = q;
                     if (!LDSPTS) __threadfence_block();
                 }
+                __builtin_amdgcn_wave_barrier();
             }
             if (lane < 7) vp[n - 1 - lane] = t;
         }
@@ -349,6 +356,25 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
         int k;
         for (k = 0; k < chunk; k++) {
             if (no_sam >= max_sam) break;
+            if (no_sam >= DG_ITER_SAM) {
+                /* past sample 50 a sample without an "event" (a model beating maxS or maxSs) has no side effect
+                 * but no_sam++: jump to the next event sample, found by all lanes in parallel */
+                track = 0;
+                const double tau = maxS.J < maxSs.J ? maxS.J : maxSs.J;
+                bool ev = false;
+                if (tid >= k && tid < chunk && S->nv[tid] != 255)
+                    for (int r = 0; r < S->nv[tid]; r++) ev = ev || (tau < S->res_J[S->moff[tid] + r]);
+                unsigned long long bal = __ballot(ev);
+                __syncthreads();
+                if (lane == 0) S->wave_cnt[wave] = bal ? (unsigned)(wave * 64 + __ffsll((long long)bal) - 1) : 0xffffffffu;
+                __syncthreads();
+                unsigned kE = S->wave_cnt[0];
+                for (int w = 1; w < DG_NW; w++) kE = S->wave_cnt[w] < kE ? S->wave_cnt[w] : kE;
+                int stop = kE == 0xffffffffu ? chunk : (int)kE;
+                int skip = stop - k; if (skip > max_sam - no_sam) skip = max_sam - no_sam;
+                no_sam += skip; k += skip;
+                if (k >= chunk || no_sam >= max_sam) break;
+            }
             no_sam++;
             const int nvk = S->nv[k];
             if (nvk == 255) continue;                              /* nullsize != 2 */
@@ -483,6 +509,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
         }
         /* models of samples that were never committed do not count as scored */
         if (k < chunk) { c.n_fds -= (Mtot - (int)S->moff[k]); done = 1; }
+        else if (no_sam >= max_sam) done = 1;
         __syncthreads();
     }
 

@@ -299,8 +299,15 @@ __global__ __launch_bounds__(DG_T) void dg_find_homography_kernel(dg_args A)
         int chunk = max_sam - no_sam; if (chunk > DG_CHUNK) chunk = DG_CHUNK;
         /* ---- speculate: seeds (5th output), 4 draws, pool swaps ---- */
         if (wave == 0) {
+            /* seed chain: seed_{k+1} = output #5 after srand(seed_k); lane j carries the term C[4][j] * r_j */
+            const unsigned gk = lane < 31 ? dg_rng_G[lane] : 0u, ck = lane < 31 ? dg_rng_C[4][lane] : 0u;
             unsigned sd = seed;
-            for (int k = 0; k < chunk; k++) { if (lane == 0) S->seeds[k] = sd; sd = dg_rng_next_seed_wave(sd, lane, 4); }
+            for (int k = 0; k < chunk; k++) {
+                if (lane == 0) S->seeds[k] = sd;
+                unsigned s1 = sd ? sd : 1u;
+                unsigned rj = lane == 0 ? s1 : dg_mulmod31(s1, gk);
+                sd = dg_wave_sum_u(ck * rj) >> 1;
+            }
             if (lane == 0) S->itmp[31] = (int)sd;
         }
         __syncthreads();
@@ -313,11 +320,14 @@ __global__ __launch_bounds__(DG_T) void dg_find_homography_kernel(dg_args A)
         }
         __syncthreads();
         if (wave == 0) {
-            volatile int *vp = pool;
+            int *vp = pool;
             int t = (lane < 4) ? vp[n - 1 - lane] : 0;
+            int s_next = (lane < 4) ? S->draws[0][lane] : (-1 - lane);
             for (int k = 0; k < chunk; k++) {
-                int s = (lane < 4) ? S->draws[k][lane] : (-1 - lane);
+                const int s = s_next;
+                if (k + 1 < chunk) s_next = (lane < 4) ? S->draws[k + 1][lane] : (-1 - lane);
                 bool alias = (lane < 4) && (s >= n - 4);
+                /* duplicate draws among the active lanes (idle lanes hold distinct negatives): row rotates on the VALU */
                 alias = alias || (dg_dpp<DG_DPP_ROR(1)>(s) == s) || (dg_dpp<DG_DPP_ROR(2)>(s) == s) || (dg_dpp<DG_DPP_ROR(3)>(s) == s);
                 if (__any(alias)) {
                     if (lane < 4) vp[n - 1 - lane] = t;
@@ -333,6 +343,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_homography_kernel(dg_args A)
                     int q = vp[s]; vp[s] = t; t = q; S->draws[k][lane] = q;
                     if (!LDSPTS) __threadfence_block();
                 }
+                __builtin_amdgcn_wave_barrier();
             }
             if (lane < 4) vp[n - 1 - lane] = t;
         }
@@ -382,8 +393,9 @@ __global__ __launch_bounds__(DG_T) void dg_find_homography_kernel(dg_args A)
             unsigned wbase = 0;
             for (int w = 0; w < wave; w++) wbase += S->wave_cnt[w];
             unsigned excl = wbase + incl - v;
+            S->moff[tid] = (unsigned short)excl;             /* all lanes: moff[k] = scored samples before k, for any k <= DG_CHUNK */
             if (tid < chunk) {
-                S->moff[tid] = (unsigned short)excl; S->nv[tid] = (unsigned char)valid;
+                S->nv[tid] = (unsigned char)valid;
                 if (valid) {
                     double *g = c.gmodels + (size_t)excl * 18;
 #pragma unroll
@@ -422,6 +434,24 @@ __global__ __launch_bounds__(DG_T) void dg_find_homography_kernel(dg_args A)
         int k;
         for (k = 0; k < chunk; k++) {
             if (no_sam >= max_sam) break;
+            if (no_sam >= DG_ITER_SAM) {
+                /* jump to the next sample that can change state: a scored model beating maxS/maxSs, or (while no LO
+                 * has run yet) any scored sample, which fires the first LO (exp_ranH.c:639-640) */
+                const double tau = maxS.J < maxSs.J ? maxS.J : maxSs.J;
+                const bool first_lo = iter_cnt == 0 && maxSs.I > 4;
+                bool ev = tid >= k && tid < chunk && S->nv[tid] && (first_lo || tau < S->res_J[S->moff[tid]]);
+                unsigned long long bal = __ballot(ev);
+                __syncthreads();
+                if (lane == 0) S->wave_cnt[wave] = bal ? (unsigned)(wave * 64 + __ffsll((long long)bal) - 1) : 0xffffffffu;
+                __syncthreads();
+                unsigned kE = S->wave_cnt[0];
+                for (int w = 1; w < DG_NW; w++) kE = S->wave_cnt[w] < kE ? S->wave_cnt[w] : kE;
+                int stop = kE == 0xffffffffu ? chunk : (int)kE;
+                if (stop - k > max_sam - no_sam) stop = k + (max_sam - no_sam);
+                no_rej += (stop - k) - ((int)S->moff[stop] - (int)S->moff[k]);
+                no_sam += stop - k; k = stop;
+                if (k >= chunk || no_sam >= max_sam) break;
+            }
             no_sam++;
             if (!S->nv[k]) { no_rej++; continue; }
             const int mi = S->moff[k];
@@ -467,6 +497,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_homography_kernel(dg_args A)
             }
         }
         if (k < chunk) { c.n_hds -= (Mtot - (int)S->moff[k]); done = 1; }
+        else if (no_sam >= max_sam) done = 1;
         __syncthreads();
     }
 
