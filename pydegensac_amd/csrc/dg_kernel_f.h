@@ -18,7 +18,8 @@ struct dg_score { unsigned I; double J; unsigned Is; unsigned Ilafs; };
 struct dg_f_shared {
     dg_red red;
     dg_lsq_scratch lsq;
-    dg_rng rng;
+    dg_rng rng, rng_save;
+    int      rf[DG_CHUNK][5];            /* rFtH batch: candidate point ids (2), swap log (2), count */
     unsigned seeds[DG_CHUNK];
     int      draws[DG_CHUNK][8];        /* raw draws, then drawn ids (draw order) */
     double   models[DG_MCAP][9];
@@ -404,83 +405,111 @@ __device__ __forceinline__ void dg_innerFH(CTX &c, const int *idxH, unsigned len
     __syncthreads();
 }
 
-/* ---- DegUtils.c:254-444 rFtH: plane-and-parallax completion ------------------------------------- */
+/* ---- DegUtils.c:254-444 rFtH: plane-and-parallax completion -------------------------------------
+ * The 2-point epipole hypotheses are evaluated in batches of DG_CHUNK: lane 0 replays the draws and the
+ * ptr[] swaps for the whole batch, one wave scores each candidate on the off-plane points, and the first
+ * candidate that beats m_i (the only kind that has side effects) is then processed exactly as the
+ * sequential loop would: RNG and ptr[] are rolled back to their state right after that iteration. */
+template <bool LDSPTS>
+__device__ __forceinline__ void dg_rFtH_aFt(const double *Hr, const dg_pt &p0, const dg_pt &p1, double *aFt)
+{
+    double a0[3] = {p0.x1, p0.y1, 1.0}, a1[3] = {p1.x1, p1.y1, 1.0}, b0[3], b1[3], c1[3], c2[3], ec[3];
+    b0[0] = Hr[0]*p0.x2 + Hr[3]*p0.y2 + Hr[6]*1.0; b0[1] = Hr[1]*p0.x2 + Hr[4]*p0.y2 + Hr[7]*1.0; b0[2] = Hr[2]*p0.x2 + Hr[5]*p0.y2 + Hr[8]*1.0;
+    b1[0] = Hr[0]*p1.x2 + Hr[3]*p1.y2 + Hr[6]*1.0; b1[1] = Hr[1]*p1.x2 + Hr[4]*p1.y2 + Hr[7]*1.0; b1[2] = Hr[2]*p1.x2 + Hr[5]*p1.y2 + Hr[8]*1.0;
+    c1[0] = a0[1]*b0[2] - a0[2]*b0[1]; c1[1] = a0[2]*b0[0] - a0[0]*b0[2]; c1[2] = a0[0]*b0[1] - a0[1]*b0[0];
+    c2[0] = a1[1]*b1[2] - a1[2]*b1[1]; c2[1] = a1[2]*b1[0] - a1[0]*b1[2]; c2[2] = a1[0]*b1[1] - a1[1]*b1[0];
+    ec[0] = c1[1]*c2[2] - c1[2]*c2[1]; ec[1] = c1[2]*c2[0] - c1[0]*c2[2]; ec[2] = c1[0]*c2[1] - c1[1]*c2[0];
+    double ecNorm = sqrt(ec[0]*ec[0] + ec[1]*ec[1] + ec[2]*ec[2]);
+    ec[0] = ec[0]/ecNorm; ec[1] = ec[1]/ecNorm; ec[2] = ec[2]/ecNorm;
+    double sk[9] = {0, -ec[2], ec[1], ec[2], 0, -ec[0], -ec[1], ec[0], 0}, Ht[9], aFtH[9];
+    dg_mattr(Ht, Hr, 3, 3);
+    dg_mmul(aFtH, sk, Ht, 3);
+    dg_mattr(aFt, aFtH, 3, 3);
+}
+
 template <bool LDSPTS>
 __device__ __forceinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, double th, const double *H /* LDS */, double *F /* LDS out */)
 {
-    dg_f_shared *S = c.S; const int n = c.n, tid = c.tid;
+    dg_f_shared *S = c.S; const int n = c.n, tid = c.tid, lane = tid & 63, wave = tid >> 6;
     unsigned char *nhinl = c.Fl[1], *vN = c.Fl[2], *inl = c.Fl[4];
-    int *idxN = c.L[5], *idxH = c.L[6], *idxV = c.L[7], *ptr = c.L[8];
+    int *idxN = c.L[5], *idxH = c.L[6], *idxV = c.L[7];
     const unsigned MAX_SAM = 10000; const double conf = .999;
-    /* nhinl = HDs(H) > 100*th ; lists */
     double Hr[9]; for (int i = 0; i < 9; i++) Hr[i] = H[i];
-    {
-        const dg_pt *P = c.P;
-        dg_pass_cfg cfg = dg_cfg0(n); cfg.list = idxN; cfg.thL = 0.5; cfg.flags = nhinl; cfg.thF = 0.5;
-        /* err = 0 when off-plane (d > 100 th) so that list/flags collect exactly those */
-        dg_pass(&S->red, cfg, [&](int pid, int) { dg_pt p = P[pid]; return dg_HDs(Hr, p.x1, p.y1, p.x2, p.y2) > 100*th ? 0.0 : 1.0; }, tid);
-        c.n_hds++;
-    }
-    /* recount (dg_pass returned counts are discarded above for clarity) */
+    const dg_pt *P = c.P;
     unsigned nhinlCount, hinlCount;
     {
-        dg_pass_cfg cfg = dg_cfg0(n); cfg.list = idxH; cfg.thL = 0.5; cfg.wantC = 1; cfg.thC = 0.5;
-        dg_pass_res r = dg_pass(&S->red, cfg, [&](int pid, int) { return hinl[pid] ? 0.0 : 1.0; }, tid);
-        hinlCount = r.nL;
-        dg_pass_cfg cfg2 = dg_cfg0(n); cfg2.wantC = 1; cfg2.thC = 0.5;
-        const unsigned char *nf = nhinl;
-        dg_pass_res r2 = dg_pass(&S->red, cfg2, [&](int pid, int) { return nf[pid] ? 0.0 : 1.0; }, tid);
-        nhinlCount = r2.C;
+        dg_pass_cfg cfg = dg_cfg0(n); cfg.list = idxN; cfg.thL = 0.5; cfg.flags = nhinl; cfg.thF = 0.5;
+        dg_pass_res r = dg_pass(&S->red, cfg, [&](int pid, int) { dg_pt p = P[pid]; return dg_HDs(Hr, p.x1, p.y1, p.x2, p.y2) > 100*th ? 0.0 : 1.0; }, tid);
+        c.n_hds++;
+        nhinlCount = r.nL;
+        dg_pass_cfg cfg2 = dg_cfg0(n); cfg2.list = idxH; cfg2.thL = 0.5;
+        dg_pass_res r2 = dg_pass(&S->red, cfg2, [&](int pid, int) { return hinl[pid] ? 0.0 : 1.0; }, tid);
+        hinlCount = r2.nL;
     }
+    if (nhinlCount < 4 || hinlCount < 6) return 0;
+    /* ptr[] lives in the sampler pool's LDS for the duration (the pool is parked in global memory) */
+    int *ptr = LDSPTS ? c.pool : c.L[8];
+    if (LDSPTS) { for (int j = tid; j < n; j += DG_T) c.L[8][j] = c.pool[j]; __syncthreads(); }
     for (int j = tid; j < (int)nhinlCount; j += DG_T) ptr[j] = j;
     __syncthreads();
     unsigned max_i = 3, m_i = 4, max_sam = MAX_SAM;
-    if (nhinlCount < 4 || hinlCount < 6) return 0;
-    for (unsigned no_sam = 1; no_sam < 2*max_sam; ++no_sam) {
+    unsigned no_sam = 1;
+    while (no_sam < 2*max_sam) {
+        int B = (int)(2*max_sam - no_sam); if (B > DG_CHUNK) B = DG_CHUNK;
         __syncthreads();
         if (tid == 0) {
-            for (unsigned pos = 0; pos < 2; ++pos) {
-                unsigned idx = pos + 1 + (unsigned)dg_rand(&S->rng) % (nhinlCount - pos - 1);
-                int aux = ptr[pos]; ptr[pos] = ptr[idx]; ptr[idx] = aux;
+            S->rng_save = S->rng;
+            for (int b = 0; b < B; b++) {
+                for (unsigned pos = 0; pos < 2; ++pos) {
+                    unsigned idx = pos + 1 + (unsigned)dg_rand(&S->rng) % (nhinlCount - pos - 1);
+                    int aux = ptr[pos]; ptr[pos] = ptr[idx]; ptr[idx] = aux;
+                    S->rf[b][2 + pos] = (int)idx;
+                }
+                S->rf[b][0] = idxN[ptr[0]]; S->rf[b][1] = idxN[ptr[1]];
             }
-            S->itmp[0] = idxN[ptr[0]]; S->itmp[1] = idxN[ptr[1]];
         }
         __syncthreads();
-        /* epipole from the two off-plane points: every lane repeats the same scalar arithmetic */
-        double aFt[9];
-        {
-            dg_pt p0 = c.P[S->itmp[0]], p1 = c.P[S->itmp[1]];
-            double a0[3] = {p0.x1, p0.y1, 1.0}, a1[3] = {p1.x1, p1.y1, 1.0}, b0[3], b1[3], c1[3], c2[3], ec[3];
-            b0[0] = Hr[0]*p0.x2 + Hr[3]*p0.y2 + Hr[6]*1.0; b0[1] = Hr[1]*p0.x2 + Hr[4]*p0.y2 + Hr[7]*1.0; b0[2] = Hr[2]*p0.x2 + Hr[5]*p0.y2 + Hr[8]*1.0;
-            b1[0] = Hr[0]*p1.x2 + Hr[3]*p1.y2 + Hr[6]*1.0; b1[1] = Hr[1]*p1.x2 + Hr[4]*p1.y2 + Hr[7]*1.0; b1[2] = Hr[2]*p1.x2 + Hr[5]*p1.y2 + Hr[8]*1.0;
-            c1[0] = a0[1]*b0[2] - a0[2]*b0[1]; c1[1] = a0[2]*b0[0] - a0[0]*b0[2]; c1[2] = a0[0]*b0[1] - a0[1]*b0[0];
-            c2[0] = a1[1]*b1[2] - a1[2]*b1[1]; c2[1] = a1[2]*b1[0] - a1[0]*b1[2]; c2[2] = a1[0]*b1[1] - a1[1]*b1[0];
-            ec[0] = c1[1]*c2[2] - c1[2]*c2[1]; ec[1] = c1[2]*c2[0] - c1[0]*c2[2]; ec[2] = c1[0]*c2[1] - c1[1]*c2[0];
-            double ecNorm = sqrt(ec[0]*ec[0] + ec[1]*ec[1] + ec[2]*ec[2]);
-            ec[0] = ec[0]/ecNorm; ec[1] = ec[1]/ecNorm; ec[2] = ec[2]/ecNorm;
-            double sk[9] = {0, -ec[2], ec[1], ec[2], 0, -ec[0], -ec[1], ec[0], 0}, Ht[9], aFtH[9];
-            dg_mattr(Ht, Hr, 3, 3);
-            dg_mmul(aFtH, sk, Ht, 3);
-            dg_mattr(aFt, aFtH, 3, 3);
+        /* one wave per candidate: #off-plane points with Sampson error < 2 th */
+        for (int b = wave; b < B; b += DG_NW) {
+            double aFt[9];
+            dg_rFtH_aFt<LDSPTS>(Hr, P[S->rf[b][0]], P[S->rf[b][1]], aFt);
+            unsigned cnt = 0;
+            for (int j = lane; j < (int)nhinlCount; j += 64) { dg_pt p = P[idxN[j]]; cnt += dg_FDs(aFt, p.x1, p.y1, p.x2, p.y2) < th*2 ? 1u : 0u; }
+            cnt = dg_wave_sum_u(cnt);
+            if (lane == 0) S->rf[b][4] = (int)cnt;
         }
-        /* Ds = FDs(uN, aFt); v = Ds < 2 th */
-        unsigned no_i;
+        __syncthreads();
+        /* first candidate beating m_i */
+        bool hit = tid < B && (unsigned)S->rf[tid][4] > m_i;
+        unsigned long long bal = __ballot(hit);
+        __syncthreads();
+        if (lane == 0) S->wave_cnt[wave] = bal ? (unsigned)(wave * 64 + __ffsll((long long)bal) - 1) : 0xffffffffu;
+        __syncthreads();
+        unsigned bE = S->wave_cnt[0];
+        for (int w = 1; w < DG_NW; w++) bE = S->wave_cnt[w] < bE ? S->wave_cnt[w] : bE;
+        if (bE == 0xffffffffu) { no_sam += (unsigned)B; c.n_aux += B; continue; }
+        /* roll back to the state right after iteration bE */
+        __syncthreads();
+        if (tid == 0) {
+            for (int b = B - 1; b > (int)bE; b--)
+                for (int pos = 1; pos >= 0; --pos) { int idx = S->rf[b][2 + pos]; int aux = ptr[pos]; ptr[pos] = ptr[idx]; ptr[idx] = aux; }
+            S->rng = S->rng_save;
+            for (int q = 0; q < 2 * ((int)bE + 1); q++) dg_rand(&S->rng);
+        }
+        __syncthreads();
+        no_sam += bE + 1; c.n_aux += (int)bE + 1;
         {
-            const dg_pt *P = c.P;
+            double aFt[9];
+            dg_rFtH_aFt<LDSPTS>(Hr, P[S->rf[bE][0]], P[S->rf[bE][1]], aFt);
+            /* v = Ds < 2 th ; uV = uN(:, v) */
             dg_pass_cfg cfg = dg_cfg0((int)nhinlCount); cfg.src = idxN; cfg.flags = vN; cfg.thF = th*2;
-            dg_pass_res r = dg_pass(&S->red, cfg, [&](int pid, int) { dg_pt p = P[pid]; return dg_FDs(aFt, p.x1, p.y1, p.x2, p.y2); }, tid);
-            c.n_aux++;
-            no_i = r.nF;
-        }
-        if (no_i > m_i) {
-            /* uV = uN(:, v): ordered compaction of the off-plane ids by their position flags */
-            {
-                const unsigned char *vf = vN;
-                dg_pass_cfg cfg = dg_cfg0((int)nhinlCount); cfg.src = idxN; cfg.list = idxV; cfg.thL = 0.5;
-                dg_pass_res r = dg_pass(&S->red, cfg, [&](int, int pos) { return vf[pos] ? 0.0 : 1.0; }, tid);
-                no_i = r.nL;
-            }
+            dg_pass(&S->red, cfg, [&](int pid, int) { dg_pt p = P[pid]; return dg_FDs(aFt, p.x1, p.y1, p.x2, p.y2); }, tid);
+            const unsigned char *vf = vN;
+            dg_pass_cfg cf2 = dg_cfg0((int)nhinlCount); cf2.src = idxN; cf2.list = idxV; cf2.thL = 0.5;
+            dg_pass_res rv = dg_pass(&S->red, cf2, [&](int, int pos) { return vf[pos] ? 0.0 : 1.0; }, tid);
+            unsigned no_i = rv.nL;
             m_i = no_i;
+            /* innerFH needs the sampler pool's LDS untouched?  It does not use ptr/pool; safe. */
             dg_innerFH(c, idxH, hinlCount, idxV, no_i, th, 15, S->ftmp, inl);
             unsigned ninl = 0, maxni = 0;
             for (int j = tid; j < n; j += DG_T) { if (inl[j]) { ninl++; if (nhinl[j]) maxni++; } }
@@ -496,6 +525,8 @@ __device__ __forceinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, d
             }
         }
     }
+    __syncthreads();
+    if (LDSPTS) { for (int j = tid; j < n; j += DG_T) c.pool[j] = c.L[8][j]; __syncthreads(); }
     return max_i;
 }
 
