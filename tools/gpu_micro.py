@@ -1,5 +1,5 @@
 import sys, numpy as np, ctypes as C
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pydegensac_amd import synthetic as syn, _lib
 L=_lib.lib()
 p1,p2,lab,F=syn.two_view_fundamental(2000,1.0,0.1,seed=0)

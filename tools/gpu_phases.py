@@ -1,5 +1,5 @@
 import sys, numpy as np, ctypes as C, torch, time
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pydegensac_amd import synthetic as syn, _lib, parallel
 L=_lib.lib()
 P=int(sys.argv[1]) if len(sys.argv)>1 else 256

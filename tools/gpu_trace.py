@@ -1,5 +1,5 @@
 import sys, numpy as np, ctypes as C
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pydegensac_amd as pd
 from pydegensac_amd import synthetic as syn, _lib
 from oracle import port
