@@ -4,7 +4,7 @@
 #define DG_KERNEL_COMMON_H
 #include "dg_geom.h"
 
-#define DG_CHUNK   DG_T        /* minimal samples speculated per round (one per lane)            */
+#define DG_CHUNK   256         /* minimal samples speculated per round (one per lane of the first 256)  */
 #define DG_MCAP    96          /* models scored per LDS sub-batch                                  */
 #define DG_HT_CAP  4096        /* LO inlier-set hash entries per pair                              */
 
@@ -35,6 +35,7 @@ struct dg_ws_layout {
     size_t off_models;    /* chunk models: [3*DG_CHUNK][9] doubles + tags                          */
     size_t off_pts;       /* dg_pt[n_max] when the points do not fit LDS                          */
     size_t off_pool;      /* int[n_max]   ditto                                                   */
+    size_t off_stage;     /* dg_pt[n_max] staging of long least-squares lists                     */
     int    n_max;
 };
 

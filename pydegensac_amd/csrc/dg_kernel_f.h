@@ -25,7 +25,7 @@ struct dg_f_shared {
     double   models[DG_MCAP][9];
     unsigned res_I[3 * DG_CHUNK];
     double   res_J[3 * DG_CHUNK];
-    unsigned short moff[DG_CHUNK + 1];  /* first model slot of each sample */
+    unsigned short moff[DG_T + 1];      /* first model slot of each sample */
     unsigned char  nv[DG_CHUNK];        /* valid models per sample; 255 = nullspace dimension != 2 */
     unsigned char  ridx[DG_CHUNK][4];   /* root index i (= errs[] slot) of each valid model */
     unsigned wave_cnt[DG_NW];
@@ -51,8 +51,10 @@ struct dg_f_ctx {
     unsigned char *Fl[5];    /* global flag vectors: 0 hinl, 1 nhinl, 2 vN, 3 v (innerFH), 4 inl (innerFH result) */
     dg_ht ht;
     double *gmodels;         /* [3*DG_CHUNK][9] chunk models */
+    dg_pt *stage;            /* [n] gathered correspondences of a long least-squares list */
     /* counters */
     int n_fds, n_exfds, n_hds, n_aux;
+    long long dbg[8];        /* debug phase ticks: 0 innerH, 1 rFtH gen, 2 rFtH score, 3 rFtH trigger(innerFH), 4 checksample */
 
     __device__ __forceinline__ dg_pt pt(int i) const { return P[i]; }
     /* LAF point sets u_1 (which=1: +a12,+a22) and u_2 (which=2: +a11,+a21): bindings.cpp:337-409 */
@@ -128,7 +130,7 @@ __device__ __forceinline__ void dg_u2f_list(CTX &c, const int *list, int len, co
         __syncthreads();
     } else {
         const dg_pt *P = c.P;
-        dg_u2f_big(&S->red, &S->lsq, [&](int i) { return P[i]; }, list, len, c.tid, Fout);
+        dg_u2f_big(&S->red, &S->lsq, [&](int i) { return P[i]; }, list, len, c.tid, Fout, c.stage);
     }
 }
 
@@ -457,6 +459,7 @@ __device__ __forceinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, d
     while (no_sam < 2*max_sam) {
         int B = (int)(2*max_sam - no_sam); if (B > DG_CHUNK) B = DG_CHUNK;
         __syncthreads();
+        long long tg0 = wall_clock64();
         if (tid == 0) {
             S->rng_save = S->rng;
             for (int b = 0; b < B; b++) {
@@ -469,6 +472,7 @@ __device__ __forceinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, d
             }
         }
         __syncthreads();
+        long long tg1 = wall_clock64(); c.dbg[1] += tg1 - tg0;
         /* one wave per candidate: #off-plane points with Sampson error < 2 th */
         for (int b = wave; b < B; b += DG_NW) {
             double aFt[9];
@@ -479,6 +483,7 @@ __device__ __forceinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, d
             if (lane == 0) S->rf[b][4] = (int)cnt;
         }
         __syncthreads();
+        long long tg2 = wall_clock64(); c.dbg[2] += tg2 - tg1;
         /* first candidate beating m_i */
         bool hit = tid < B && (unsigned)S->rf[tid][4] > m_i;
         unsigned long long bal = __ballot(hit);
@@ -524,6 +529,7 @@ __device__ __forceinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, d
                 max_sam = max_sam > ns ? ns : max_sam;
             }
         }
+        c.dbg[3] += wall_clock64() - tg2;
     }
     __syncthreads();
     if (LDSPTS) { for (int j = tid; j < n; j += DG_T) c.pool[j] = c.L[8][j]; __syncthreads(); }

@@ -162,7 +162,9 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
     for (int i = 0; i < 5; i++) c.Fl[i] = (unsigned char *)(ws + A.wl.off_flags) + (size_t)i * A.wl.n_max;
     c.ht.heads = (int *)(ws + A.wl.off_ht); c.ht.count = c.ht.heads + 64; c.ht.ent = c.ht.heads + 80;
     c.gmodels = (double *)(ws + A.wl.off_models);
+    c.stage = (dg_pt *)(ws + A.wl.off_stage);
     c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0;
+    for (int i = 0; i < 8; i++) c.dbg[i] = 0;
     dg_pt *Pw; int *pool;
     if (LDSPTS) { Pw = (dg_pt *)dyn_smem; pool = (int *)(dyn_smem + (size_t)n * sizeof(dg_pt)); }
     else        { Pw = (dg_pt *)(ws + A.wl.off_pts); pool = (int *)(ws + A.wl.off_pool); }
@@ -335,17 +337,19 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
             const double *g = c.gmodels + (size_t)mi * 9;
 #pragma unroll
             for (int j = 0; j < 9; j++) F[j] = g[j];
-            unsigned cI = 0; double a0 = 0, a1 = 0, a2 = 0, a3 = 0; const double t94 = th * 9 / 4;
-#define DG_SCORE_TILE(acc, p_) { int p = (p_); bool act = p < n; double d = 0; \
-                if (act) { dg_pt q = P[p]; d = dg_Ferr(mk_full, F, q); } \
-                double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94); \
-                acc += term; cI += (act && d <= th) ? 1u : 0u; }
-            for (int base = 0; base < n; base += 256) {
-                DG_SCORE_TILE(a0, base + lane); DG_SCORE_TILE(a1, base + 64 + lane);
-                DG_SCORE_TILE(a2, base + 128 + lane); DG_SCORE_TILE(a3, base + 192 + lane);
+            unsigned cI = 0; double acc[DG_NW]; const double t94 = th * 9 / 4;
+#pragma unroll
+            for (int r = 0; r < DG_NW; r++) acc[r] = 0;
+            for (int base = 0; base < n; base += 64 * DG_NW) {
+#pragma unroll
+                for (int r = 0; r < DG_NW; r++) {
+                    int p = base + 64 * r + lane; bool act = p < n; double d = 0;
+                    if (act) { dg_pt q = P[p]; d = dg_Ferr(mk_full, F, q); }
+                    double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
+                    acc[r] += term; cI += (act && d <= th) ? 1u : 0u;
+                }
             }
-#undef DG_SCORE_TILE
-            unsigned I = dg_wave_sum_u(cI); double J = dg_J_combine(a0, a1, a2, a3);
+            unsigned I = dg_wave_sum_u(cI); double J = dg_J_combine(acc);
             if (lane == 0) { S->res_I[mi] = I; S->res_J[mi] = J; }
         }
         c.n_fds += Mtot;   /* provisional: models past the termination point are subtracted below */
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
                         dg_pass_res rh = dg_h_pass(c, S->H, ch); c.n_hds++;
                         unsigned I = rh.nF;
                         if (I < 8) { brk = 1; c.n_fds -= (nvk - 1 - r); break; }   /* exp_ranF.c:1437-1439: later roots are never scored */
-                        I = dg_innerH(c, S->H, 16*th, 10, c.Fl[0]);
+                        { long long ti0 = wall_clock64(); I = dg_innerH(c, S->H, 16*th, 10, c.Fl[0]); c.dbg[0] += wall_clock64() - ti0; }
                         if ((int)I > Ihmax) Ihmax = (int)I;
                         if (I > 6) {
                             I = dg_rFtH(c, c.Fl[0], th, S->H, S->f);
@@ -622,7 +626,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
         st[14] = 0; st[15] = 0;
     }
     DG_PH(6);
-    if (A.phase_out && tid == 0) { ph[7] = wall_clock64() - t_start; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 8 + i] = ph[i]; }
+    if (A.phase_out && tid == 0) { ph[7] = wall_clock64() - t_start; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + i] = ph[i]; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + 8 + i] = c.dbg[i]; }
 }
 
 #endif /* DG_KERNEL_F_MAIN_H */

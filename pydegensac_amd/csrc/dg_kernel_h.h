@@ -12,10 +12,10 @@
 
 /* u2h (Htools.c:115-131) over a list of ids, reference summation order (see dg_lsq_seq) */
 template <class PtFn>
-__device__ __forceinline__ void dg_u2h_big(dg_red *r, dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, double *Hout /* LDS */)
+__device__ __forceinline__ void dg_u2h_big(dg_red *r, dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, double *Hout /* LDS */, dg_pt *stage)
 {
     (void)r;
-    dg_lsq_seq(s, pt, list, len, tid, 1, s->A1, s->A2);
+    dg_lsq_seq(s, pt, list, len, tid, 1, s->A1, s->A2, stage);
     if (tid < 64) dg_eig_sym_wave(s->V, s->D, tid);
     if (tid == 0) {
         for (int i = 0; i < 9; i++) Hout[i] = s->V[i];
@@ -35,7 +35,7 @@ __device__ __forceinline__ void dg_u2h_list(CTX &c, const int *list, int len, do
         __syncthreads();
     } else {
         const dg_pt *P = c.P;
-        dg_u2h_big(&S->red, &S->lsq, [&](int i) { return P[i]; }, list, len, c.tid, Hout);
+        dg_u2h_big(&S->red, &S->lsq, [&](int i) { return P[i]; }, list, len, c.tid, Hout, c.stage);
     }
 }
 
@@ -270,6 +270,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_homography_kernel(dg_args A)
     for (int i = 0; i < 5; i++) c.Fl[i] = (unsigned char *)(ws + A.wl.off_flags) + (size_t)i * A.wl.n_max;
     c.ht.heads = (int *)(ws + A.wl.off_ht); c.ht.count = c.ht.heads + 64; c.ht.ent = c.ht.heads + 80;
     c.gmodels = (double *)(ws + A.wl.off_models);
+    c.stage = (dg_pt *)(ws + A.wl.off_stage);
     c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0;
     dg_pt *Pw; int *pool;
     if (LDSPTS) { Pw = (dg_pt *)dyn_smem; pool = (int *)(dyn_smem + (size_t)n * sizeof(dg_pt)); }
@@ -414,17 +415,19 @@ __global__ __launch_bounds__(DG_T) void dg_find_homography_kernel(dg_args A)
 #pragma unroll
             for (int j = 0; j < 9; j++) { H[j] = g[j]; H1[j] = g[9+j]; }
             Hinv[0] = H[0]; Hinv[1] = H[3]; Hinv[2] = H[6]; Hinv[3] = H[1]; Hinv[4] = H[4]; Hinv[5] = H[7]; Hinv[6] = H[2]; Hinv[7] = H[5]; Hinv[8] = H[8];
-            unsigned cI = 0; double a0 = 0, a1 = 0, a2 = 0, a3 = 0; const double t94 = th * 9 / 4;
-#define DG_SCORE_TILE(acc, p_) { int p = (p_); bool act = p < n; double d = 0; \
-                if (act) { dg_pt q = P[p]; d = dg_Herr(kind, H, Hinv, H1, q); } \
-                double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94); \
-                acc += term; cI += (act && d <= th) ? 1u : 0u; }
-            for (int base = 0; base < n; base += 256) {
-                DG_SCORE_TILE(a0, base + lane); DG_SCORE_TILE(a1, base + 64 + lane);
-                DG_SCORE_TILE(a2, base + 128 + lane); DG_SCORE_TILE(a3, base + 192 + lane);
+            unsigned cI = 0; double acc[DG_NW]; const double t94 = th * 9 / 4;
+#pragma unroll
+            for (int r = 0; r < DG_NW; r++) acc[r] = 0;
+            for (int base = 0; base < n; base += 64 * DG_NW) {
+#pragma unroll
+                for (int r = 0; r < DG_NW; r++) {
+                    int p = base + 64 * r + lane; bool act = p < n; double d = 0;
+                    if (act) { dg_pt q = P[p]; d = dg_Herr(kind, H, Hinv, H1, q); }
+                    double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
+                    acc[r] += term; cI += (act && d <= th) ? 1u : 0u;
+                }
             }
-#undef DG_SCORE_TILE
-            unsigned I = dg_wave_sum_u(cI); double J = dg_J_combine(a0, a1, a2, a3);
+            unsigned I = dg_wave_sum_u(cI); double J = dg_J_combine(acc);
             if (lane == 0) { S->res_I[mi] = I; S->res_J[mi] = J; }
         }
         c.n_hds += Mtot;

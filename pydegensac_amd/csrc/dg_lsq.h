@@ -188,22 +188,31 @@ __device__ __noinline__ void dg_u2h_small_w(dg_lsq_scratch *s, const double *p, 
  * independent sums run in different lanes of wave 0 (one lane per output entry).  `rows2`: 0 = fundamental
  * (lin_fmN, Ftools.c:300-328, one row per point), 1 = homography (lin_hgN, Htools.c:60-99, two rows). */
 template <class PtFn>
-__device__ __forceinline__ void dg_lsq_seq(dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, int rows2, double *A1o, double *A2o)
+__device__ __forceinline__ void dg_lsq_seq(dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, int rows2, double *A1o, double *A2o, dg_pt *stage)
 {
+    /* gather the listed correspondences into a contiguous staging array (all lanes), so that the sequential
+     * sums below stream uniform addresses */
+    __syncthreads();
+    for (int j = tid; j < len; j += DG_T) stage[j] = pt(list[j]);
     __syncthreads();
     if (tid < 64) {
         const int lane = tid;
-        /* centroids: lane l in 0..3 sums coordinate l */
+        /* centroids: lane l in 0..3 sums coordinate l, in list order */
         double acc = 0;
-        if (lane < 4) for (int j = 0; j < len; j++) { dg_pt p = pt(list[j]); acc += lane == 0 ? p.x1 : lane == 1 ? p.y1 : lane == 2 ? p.x2 : p.y2; }
+        {
+            const double *sp = (const double *)stage + (lane & 3);
+            int j = 0;
+            for (; j + 4 <= len; j += 4) { double v0 = sp[4*j], v1 = sp[4*j+4], v2 = sp[4*j+8], v3 = sp[4*j+12]; acc += v0; acc += v1; acc += v2; acc += v3; }
+            for (; j < len; j++) acc += sp[4*j];
+        }
         if (len > 0) acc /= len;
         double m1x = __shfl(acc, 0, 64), m1y = __shfl(acc, 1, 64), m2x = __shfl(acc, 2, 64), m2y = __shfl(acc, 3, 64);
         /* mean distances: lane 0 image 1, lane 1 image 2 */
         double dsum = 0;
-        if (lane < 2) for (int j = 0; j < len; j++) {
-            dg_pt p = pt(list[j]);
-            double a = lane == 0 ? p.x1 - m1x : p.x2 - m2x, b = lane == 0 ? p.y1 - m1y : p.y2 - m2y;
-            dsum += sqrt(a*a + b*b);
+        {
+            const double *sp = (const double *)stage + ((lane & 1) ? 2 : 0);
+            const double mx = (lane & 1) ? m2x : m1x, my = (lane & 1) ? m2y : m1y;
+            for (int j = 0; j < len; j++) { double a = sp[4*j] - mx, b = sp[4*j+1] - my; dsum += sqrt(a*a + b*b); }
         }
         double A1[3], A2[3];
         A1[0] = __shfl(dsum, 0, 64); A2[0] = __shfl(dsum, 1, 64);
@@ -211,33 +220,27 @@ __device__ __forceinline__ void dg_lsq_seq(dg_lsq_scratch *s, PtFn pt, const int
         if (A2[0] != 0) A2[0] = len * sqrt(2.0) / A2[0];
         A1[1] = m1x * -A1[0]; A1[2] = m1y * -A1[0];
         A2[1] = m2x * -A2[0]; A2[2] = m2y * -A2[0];
-        /* normal matrix: lane e < 45 owns entry (ie, je), je <= ie, in cov_mat's enumeration order */
+        /* normal matrix: lane e < 45 owns entry (ie, je), je <= ie, in cov_mat's enumeration order.  Each lane
+         * forms only its own two design-matrix entries: z[3k+l] = a[l]*b[k] (F) or the lin_hgN pattern (H). */
         int ie = 0, je = 0;
         { int e = 0; for (int i = 0; i < 9; i++) for (int q = 0; q <= i; q++) { if (e == lane) { ie = i; je = q; } e++; } }
+        const int ki = ie / 3, li = ie % 3, kj = je / 3, lj = je % 3;
         double val = 0;
         if (lane < 45) for (int j = 0; j < len; j++) {
-            dg_pt p = pt(list[j]);
+            dg_pt p = stage[j];
             double a0 = p.x1 * A1[0] + A1[1], a1 = p.y1 * A1[0] + A1[2];
             double b0 = p.x2 * A2[0] + A2[1], b1 = p.y2 * A2[0] + A2[2];
             if (!rows2) {
-                double a[3] = {a0, a1, 1.0}, b[3] = {b0, b1, 1.0}, z[9];
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-#pragma unroll
-                    for (int l = 0; l < 3; l++) z[3*k+l] = a[l] * b[k];
-                double zi = z[0], zj = z[0];
-#pragma unroll
-                for (int q = 1; q < 9; q++) { zi = ie == q ? z[q] : zi; zj = je == q ? z[q] : zj; }
-                val += zi * zj;
+                double ai = li == 0 ? a0 : li == 1 ? a1 : 1.0, bi = ki == 0 ? b0 : ki == 1 ? b1 : 1.0;
+                double aj = lj == 0 ? a0 : lj == 1 ? a1 : 1.0, bj = kj == 0 ? b0 : kj == 1 ? b1 : 1.0;
+                val += (ai * bi) * (aj * bj);
             } else {
-                double b[3] = {b0, b1, 1.0}, z0[9], z1[9];
-#pragma unroll
-                for (int q = 0; q < 3; q++) { z0[3*q] = b[q]; z0[3*q+1] = 0; z0[3*q+2] = -a0 * b[q]; z1[3*q] = 0; z1[3*q+1] = b[q]; z1[3*q+2] = -a1 * b[q]; }
-                double zi = z0[0], zj = z0[0], yi = z1[0], yj = z1[0];
-#pragma unroll
-                for (int q = 1; q < 9; q++) { zi = ie == q ? z0[q] : zi; zj = je == q ? z0[q] : zj; yi = ie == q ? z1[q] : yi; yj = je == q ? z1[q] : yj; }
-                val += zi * zj;
-                val += yi * yj;
+                /* row 0: z[3q] = b[q], z[3q+1] = 0, z[3q+2] = -a0*b[q];  row 1: z[3q] = 0, z[3q+1] = b[q], z[3q+2] = -a1*b[q] */
+                double bqi = ki == 0 ? b0 : ki == 1 ? b1 : 1.0, bqj = kj == 0 ? b0 : kj == 1 ? b1 : 1.0;
+                double z0i = li == 0 ? bqi : li == 1 ? 0.0 : -a0 * bqi, z0j = lj == 0 ? bqj : lj == 1 ? 0.0 : -a0 * bqj;
+                double z1i = li == 0 ? 0.0 : li == 1 ? bqi : -a1 * bqi, z1j = lj == 0 ? 0.0 : lj == 1 ? bqj : -a1 * bqj;
+                val += z0i * z0j;
+                val += z1i * z1j;
             }
         }
         if (lane < 45) { s->V[9*ie + je] = val; s->V[ie + 9*je] = val; }
@@ -247,10 +250,10 @@ __device__ __forceinline__ void dg_lsq_seq(dg_lsq_scratch *s, PtFn pt, const int
 }
 
 template <class PtFn>
-__device__ __forceinline__ void dg_u2f_big(dg_red *r, dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, double *Fout /* LDS */)
+__device__ __forceinline__ void dg_u2f_big(dg_red *r, dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, double *Fout /* LDS */, dg_pt *stage)
 {
     (void)r;
-    dg_lsq_seq(s, pt, list, len, tid, 0, s->A1, s->A2);
+    dg_lsq_seq(s, pt, list, len, tid, 0, s->A1, s->A2, stage);
     if (tid < 64) dg_eig_sym_wave(s->V, s->D, tid);
     if (tid == 0) {
         int jm = 0; for (int i = 1; i < 9; i++) if (s->D[i] < s->D[jm]) jm = i;

@@ -13,7 +13,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define DG_T   256
+#ifndef DG_T
+#define DG_T   512
+#endif
 #define DG_NW  (DG_T / 64)
 
 struct dg_pt { double x1, y1, x2, y2; };           /* 32 B per correspondence */
@@ -58,11 +60,17 @@ __device__ __forceinline__ unsigned dg_wave_sum_u(unsigned v)
 }
 __device__ __forceinline__ double dg_wave_sum_d(double v) { return dg_tile_sum(v); }
 
-/* Canonical MSAC gain J of one model over n points (DG_NW == 4 is part of the definition):
- *   S_r[l] = sum over tiles t = r (mod 4), in tile order, of term(64 t + l)      r = 0..3, l = lane
- *   J      = dg_tile_sum( ((S_0[l] + S_1[l]) + S_2[l]) + S_3[l] )
- * A single wave keeps four accumulators per lane; in a 4-wave pass wave r owns residue class r. */
-__device__ __forceinline__ double dg_J_combine(double s0, double s1, double s2, double s3) { return dg_tile_sum(((s0 + s1) + s2) + s3); }
+/* Canonical MSAC gain J of one model over n points (DG_NW is part of the definition):
+ *   S_r[l] = sum over tiles t = r (mod DG_NW), in tile order, of term(64 t + l)      r = 0..DG_NW-1, l = lane
+ *   J      = dg_tile_sum( (((S_0[l] + S_1[l]) + S_2[l]) + ...) + S_{NW-1}[l] )
+ * A single wave keeps DG_NW accumulators per lane; in a workgroup pass wave r owns residue class r. */
+__device__ __forceinline__ double dg_J_combine(const double *s)
+{
+    double t = s[0];
+#pragma unroll
+    for (int r = 1; r < DG_NW; r++) t += s[r];
+    return dg_tile_sum(t);
+}
 
 /* LDS block used by the reductions below (declared once per kernel) */
 struct dg_red {
@@ -155,7 +163,7 @@ __device__ __forceinline__ dg_pass_res dg_pass(dg_red *r, const dg_pass_cfg &c, 
         if (c.wantC) cC += (act && d <= c.thC) ? 1u : 0u;
         if (c.flags) { bool f = act && d < c.thF; cF += f ? 1u : 0u; if (act) c.flags[j] = f ? 1 : 0; }
         if (c.list) {
-            /* ordered compaction needs the block's per-wave counts: one barrier per 256 items */
+            /* ordered compaction needs the block's per-wave counts: one barrier per DG_T items */
             bool in = act && d <= c.thL;
             unsigned long long bL = __ballot(in);
             if (lane == 0) r->u[par][wave][2] = (unsigned)__popcll(bL);
@@ -175,7 +183,10 @@ __device__ __forceinline__ dg_pass_res dg_pass(dg_red *r, const dg_pass_cfg &c, 
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < DG_NW; w++) { out.I += r->u[0][w][0]; out.C += r->u[0][w][1]; out.nF += r->u[0][w][3]; }
-    if (c.wantJ) out.J = dg_J_combine(r->jp[0][lane], r->jp[1][lane], r->jp[2][lane], r->jp[3][lane]);
+    if (c.wantJ) { double sp[DG_NW];
+#pragma unroll
+        for (int w = 0; w < DG_NW; w++) sp[w] = r->jp[w][lane];
+        out.J = dg_J_combine(sp); }
     __syncthreads();
     return out;
 }

@@ -98,6 +98,7 @@ static dg_ws_layout make_layout(int n_max, bool pts_in_ws)
     w.off_flags = o;  o += align_up((size_t)5 * n_max, 256);
     w.off_ht = o;     o += align_up((size_t)(80 + 4 * DG_HT_CAP) * sizeof(int), 256);
     w.off_models = o; o += align_up((size_t)3 * DG_CHUNK * 9 * sizeof(double), 256);
+    w.off_stage = o;  o += align_up((size_t)n_max * sizeof(dg_pt), 256);
     w.off_pts = o;    if (pts_in_ws) o += align_up((size_t)n_max * sizeof(dg_pt), 256);
     w.off_pool = o;   if (pts_in_ws) o += align_up((size_t)n_max * sizeof(int), 256);
     w.stride = align_up(o, 4096);
@@ -245,10 +246,12 @@ __global__ void dg_score_models_kernel(const double *p1, const double *p2, int n
     double M[9], Hinv[9], H1[9];
     for (int j = 0; j < 9; j++) { M[j] = models[(size_t)mi * 9 + j]; Hinv[j] = 0; H1[j] = 0; }
     if (kind > 10) dg_hsym_prepare(M, Hinv, H1);
-    unsigned cI = 0; double acc[4] = {0, 0, 0, 0}; const double t94 = th * 9 / 4;
-    for (int base = 0; base < n; base += 256) {
+    unsigned cI = 0; double acc[DG_NW]; const double t94 = th * 9 / 4;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < DG_NW; r++) acc[r] = 0;
+    for (int base = 0; base < n; base += 64 * DG_NW) {
+#pragma unroll
+        for (int r = 0; r < DG_NW; r++) {
             int p = base + 64 * r + lane; bool act = p < n; double d = 0;
             if (act) {
                 dg_pt q; q.x1 = p1[(size_t)p * dim]; q.y1 = p1[(size_t)p * dim + 1]; q.x2 = p2[(size_t)p * dim]; q.y2 = p2[(size_t)p * dim + 1];
@@ -260,7 +263,7 @@ __global__ void dg_score_models_kernel(const double *p1, const double *p2, int n
             acc[r] += term; cI += (act && d <= th) ? 1u : 0u;
         }
     }
-    unsigned I = dg_wave_sum_u(cI); double J = dg_J_combine(acc[0], acc[1], acc[2], acc[3]);
+    unsigned I = dg_wave_sum_u(cI); double J = dg_J_combine(acc);
     if (lane == 0) { Iout[mi] = I; Jout[mi] = J; }
 }
 

@@ -12,7 +12,7 @@ dev=torch.device('cuda',0)
 d_a=torch.from_numpy(a).to(dev); d_b=torch.from_numpy(b).to(dev); d_off=torch.from_numpy(offs).to(dev)
 d_seeds=torch.from_numpy(parallel.pair_seeds(0,P).astype(np.int64)).to(dev).to(torch.int32)
 d_F=torch.zeros((P,9),dtype=torch.float64,device=dev); d_mask=torch.zeros(P*N,dtype=torch.uint8,device=dev); d_st=torch.zeros((P,16),dtype=torch.int32,device=dev)
-d_ph=torch.zeros((P,8),dtype=torch.int64,device=dev)
+d_ph=torch.zeros((P,16),dtype=torch.int64,device=dev)
 L.mi_degensac_debug_phases(C.c_void_p(d_ph.data_ptr()))
 prm=_lib.make_params(0.5,0.9999,100000,0,True,0.0,True)
 for it in range(2):
@@ -22,7 +22,7 @@ for it in range(2):
 print("rc",rc,"batch ms",dt*1e3)
 ph=d_ph.cpu().numpy().astype(np.float64)/1e5  # ms
 st=d_st.cpu().numpy()
-names=["sample","solve","score","commit+misc","LO","degen","tail","total"]
+names=["sample","solve","score","commit+misc","LO","degen","tail","total","innerH","rFtH_gen","rFtH_score","rFtH_trig","d4","d5","d6","d7"]
 print("mean ms per pair:", {n:round(float(ph[:,i].mean()),3) for i,n in enumerate(names)})
 print("max  ms per pair:", {n:round(float(ph[:,i].max()),3) for i,n in enumerate(names)})
 print("samples mean",st[:,0].mean(),"lo_runs mean",st[:,1].mean(),"degen mean",st[:,5].mean(),"models mean",st[:,4].mean(), "aux", st[:,11].mean(), "hds", st[:,10].mean())
