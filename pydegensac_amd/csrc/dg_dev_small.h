@@ -642,12 +642,28 @@ DG_BIG int dg_eig_sym(double *a, double *w, int n)
  * plane rotations.  Must be called by all 64 lanes of a single wave with identical arguments; the matrix
  * lives in LDS.  n = 9.
  * ---------------------------------------------------------------------------------------------- */
+/* broadcast of a double from lane l (l must be wave-uniform) */
+static __device__ __forceinline__ double dg_rdl_d(double v, int l)
+{
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
 #define DG_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
+#ifdef DG_EIG_TIMING
+__device__ long long dg_eig_ticks[4];
+#define DG_ET(i) do { long long t_ = wall_clock64(); if (lane == 0) dg_eig_ticks[i] += t_ - t_et; t_et = t_; } while (0)
+#else
+#define DG_ET(i)
+#endif
 static __device__ __noinline__ int dg_eig_sym_wave(double *a, double *w, int lane)
 {
     const int n = 9;
+#ifdef DG_EIG_TIMING
+    long long t_et = wall_clock64();
+#endif
     DG_LDS double d[9], e[9], tau[9], work[18];
     int i, j, k, l, m, ii;
 #define A_(r,c) a[(c)*n + (r)]
@@ -688,6 +704,7 @@ static __device__ __noinline__ int dg_eig_sym_wave(double *a, double *w, int lan
         DG_WSYNC();
     }
     if (lane == 0) d[0] = A_(0, 0);
+    DG_ET(0);
     /* ---- dorgtr 'U': shift the reflector vectors one column left, unit last row/column ---- */
     {
         double v0 = 0., v1 = 0.; int e0 = lane, e1 = lane + 64;
@@ -718,108 +735,126 @@ static __device__ __noinline__ int dg_eig_sym_wave(double *a, double *w, int lan
             DG_WSYNC();
         }
     }
-    /* ---- dsteqr 'V': scalar recurrences replicated in every lane (stores by lane 0), rotations by row ---- */
+    DG_ET(1);
+    /* ---- dsteqr 'V' ----
+     * d, e and the saved rotations live in registers, one element per lane (lane i holds d[i], e[i], c_i, s_i);
+     * every lane replays the scalar recurrences on values broadcast with v_readlane (uniform indices).
+     * Lane r < 9 holds row r of Z in nine registers; a sweep's rotations are applied with a statically
+     * unrolled loop over the 8 column pairs, predicated on the (uniform) active range. */
     {
         const double eps = DG_EPS, eps2 = eps*eps, safmin = DG_SAFMIN;
-        int nmaxit = n * 30, jtot = 0, l1 = 0, lsv, lend, lendsv, mm;
+        int nmaxit = n * 30, jtot = 0, l1 = 0, lsv, lend, lendsv;
         double p, g, r, c, s, f, b, rt1, rt2, tst;
-#define DG_ROT(j0, cnt, backward) do { DG_WSYNC(); if (lane < n) { \
-            for (int jj_ = 0; jj_ < (cnt) - 1; jj_++) { int j_ = (backward) ? ((cnt) - 2 - jj_) : jj_; \
-                double ct_ = work[(j0) + j_], st_ = work[n - 1 + (j0) + j_]; \
-                if (ct_ != 1. || st_ != 0.) { double *zj_ = a + (size_t)((j0) + j_) * n, *zj1_ = zj_ + n; \
-                    double temp_ = zj1_[lane]; zj1_[lane] = ct_*temp_ - st_*zj_[lane]; zj_[lane] = st_*temp_ + ct_*zj_[lane]; } } } DG_WSYNC(); } while (0)
         DG_WSYNC();
+        double dreg = lane < n ? d[lane] : 0., ereg = lane < n - 1 ? e[lane] : 0., creg = 1., sreg = 0.;
+        double z[9];
+#pragma unroll
+        for (int cc = 0; cc < 9; cc++) z[cc] = lane < n ? A_(lane, cc) : 0.;
+#define RD(reg, i_) dg_rdl_d(reg, (i_))
+#define WR(reg, i_, v_) do { double v__ = (v_); reg = (lane == (i_)) ? v__ : reg; } while (0)
+        /* rotations j = lo .. hi-1 (pairs (j, j+1)), c/s in creg/sreg at lane j; backward = high j first */
+#define DG_ROTREG(lo, hi, backward) do { \
+            _Pragma("unroll") for (int q_ = 0; q_ < 8; q_++) { const int j_ = (backward) ? 7 - q_ : q_; \
+                if (j_ >= (lo) && j_ < (hi)) { double ct_ = RD(creg, j_), st_ = RD(sreg, j_); \
+                    if (ct_ != 1. || st_ != 0.) { double temp_ = z[j_+1]; z[j_+1] = ct_*temp_ - st_*z[j_]; z[j_] = st_*temp_ + ct_*z[j_]; } } } } while (0)
         while (l1 < n) {
-            if (l1 > 0 && lane == 0) e[l1-1] = 0.;
-            DG_WSYNC();
+            if (l1 > 0) WR(ereg, l1 - 1, 0.);
             for (m = l1; m < n - 1; m++) {
-                tst = fabs(e[m]);
+                tst = fabs(RD(ereg, m));
                 if (tst == 0.) break;
-                if (tst <= (sqrt(fabs(d[m])) * sqrt(fabs(d[m+1]))) * eps) { DG_WSYNC(); if (lane == 0) e[m] = 0.; DG_WSYNC(); break; }
+                if (tst <= (sqrt(fabs(RD(dreg, m))) * sqrt(fabs(RD(dreg, m+1)))) * eps) { WR(ereg, m, 0.); break; }
             }
             l = l1; lsv = l; lend = m; lendsv = lend; l1 = m + 1;
             if (lend == l) continue;
-            if (fabs(d[lend]) < fabs(d[l])) { lend = lsv; l = lendsv; }
+            if (fabs(RD(dreg, lend)) < fabs(RD(dreg, l))) { lend = lsv; l = lendsv; }
             if (lend > l) {
                 for (;;) {
                     if (l != lend) {
-                        for (m = l; m < lend; m++) { tst = fabs(e[m]); tst *= tst; if (tst <= (eps2 * fabs(d[m])) * fabs(d[m+1]) + safmin) break; }
+                        for (m = l; m < lend; m++) { tst = fabs(RD(ereg, m)); tst *= tst; if (tst <= (eps2 * fabs(RD(dreg, m))) * fabs(RD(dreg, m+1)) + safmin) break; }
                     } else m = lend;
-                    if (m < lend) { DG_WSYNC(); if (lane == 0) e[m] = 0.; DG_WSYNC(); }
-                    p = d[l];
+                    if (m < lend) WR(ereg, m, 0.);
+                    p = RD(dreg, l);
                     if (m == l) { l++; if (l <= lend) continue; break; }
                     if (m == l + 1) {
-                        dg_laev2(d[l], e[l], d[l+1], &rt1, &rt2, &c, &s);
-                        DG_WSYNC();
-                        if (lane == 0) { work[l] = c; work[n-1+l] = s; d[l] = rt1; d[l+1] = rt2; e[l] = 0.; }
-                        DG_ROT(l, 2, 1);
+                        dg_laev2(RD(dreg, l), RD(ereg, l), RD(dreg, l+1), &rt1, &rt2, &c, &s);
+                        WR(creg, l, c); WR(sreg, l, s);
+                        DG_ROTREG(l, l + 1, 1);
+                        WR(dreg, l, rt1); WR(dreg, l+1, rt2); WR(ereg, l, 0.);
                         l += 2; if (l <= lend) continue; break;
                     }
                     if (jtot == nmaxit) break;
                     jtot++;
-                    g = (d[l+1] - p) / (2. * e[l]);
-                    r = dg_lapy2(g, 1.);
-                    g = d[m] - p + (e[l] / (g + dg_sign(r, g)));
+                    { double el = RD(ereg, l);
+                      g = (RD(dreg, l+1) - p) / (2. * el);
+                      r = dg_lapy2(g, 1.);
+                      g = RD(dreg, m) - p + (el / (g + dg_sign(r, g))); }
                     s = 1.; c = 1.; p = 0.;
-                    DG_WSYNC();
                     for (i = m - 1; i >= l; i--) {
-                        f = s * e[i]; b = c * e[i];
+                        double ei = RD(ereg, i), di = RD(dreg, i), di1 = RD(dreg, i+1);
+                        f = s * ei; b = c * ei;
                         dg_lartg(g, f, &c, &s, &r);
-                        double di = d[i], di1 = d[i+1];
-                        if (i != m - 1 && lane == 0) e[i+1] = r;
+                        if (i != m - 1) WR(ereg, i+1, r);
                         g = di1 - p;
                         r = (di - g)*s + 2.*c*b;
                         p = s * r;
-                        if (lane == 0) { d[i+1] = g + p; work[i] = c; work[n-1+i] = -s; }
+                        WR(dreg, i+1, g + p);
                         g = c*r - b;
+                        WR(creg, i, c); WR(sreg, i, -s);
                     }
-                    mm = m - l + 1;
-                    DG_WSYNC();
-                    { double dl = d[l]; DG_WSYNC(); if (lane == 0) { d[l] = dl - p; e[l] = g; } }
-                    DG_ROT(l, mm, 1);
+                    DG_ROTREG(l, m, 1);
+                    { double dl = RD(dreg, l); WR(dreg, l, dl - p); WR(ereg, l, g); }
                 }
             } else {
                 for (;;) {
                     if (l != lend) {
-                        for (m = l; m > lend; m--) { tst = fabs(e[m-1]); tst *= tst; if (tst <= (eps2 * fabs(d[m])) * fabs(d[m-1]) + safmin) break; }
+                        for (m = l; m > lend; m--) { tst = fabs(RD(ereg, m-1)); tst *= tst; if (tst <= (eps2 * fabs(RD(dreg, m))) * fabs(RD(dreg, m-1)) + safmin) break; }
                     } else m = lend;
-                    if (m > lend) { DG_WSYNC(); if (lane == 0) e[m-1] = 0.; DG_WSYNC(); }
-                    p = d[l];
+                    if (m > lend) WR(ereg, m-1, 0.);
+                    p = RD(dreg, l);
                     if (m == l) { l--; if (l >= lend) continue; break; }
                     if (m == l - 1) {
-                        dg_laev2(d[l-1], e[l-1], d[l], &rt1, &rt2, &c, &s);
-                        DG_WSYNC();
-                        if (lane == 0) { work[m] = c; work[n-1+m] = s; d[l-1] = rt1; d[l] = rt2; e[l-1] = 0.; }
-                        DG_ROT(l - 1, 2, 0);
+                        dg_laev2(RD(dreg, l-1), RD(ereg, l-1), RD(dreg, l), &rt1, &rt2, &c, &s);
+                        WR(creg, m, c); WR(sreg, m, s);
+                        DG_ROTREG(l - 1, l, 0);
+                        WR(dreg, l-1, rt1); WR(dreg, l, rt2); WR(ereg, l-1, 0.);
                         l -= 2; if (l >= lend) continue; break;
                     }
                     if (jtot == nmaxit) break;
                     jtot++;
-                    g = (d[l-1] - p) / (2. * e[l-1]);
-                    r = dg_lapy2(g, 1.);
-                    g = d[m] - p + (e[l-1] / (g + dg_sign(r, g)));
+                    { double el = RD(ereg, l-1);
+                      g = (RD(dreg, l-1) - p) / (2. * el);
+                      r = dg_lapy2(g, 1.);
+                      g = RD(dreg, m) - p + (el / (g + dg_sign(r, g))); }
                     s = 1.; c = 1.; p = 0.;
-                    DG_WSYNC();
                     for (i = m; i <= l - 1; i++) {
-                        f = s * e[i]; b = c * e[i];
+                        double ei = RD(ereg, i), di = RD(dreg, i), di1 = RD(dreg, i+1);
+                        f = s * ei; b = c * ei;
                         dg_lartg(g, f, &c, &s, &r);
-                        double di = d[i], di1 = d[i+1];
-                        if (i != m && lane == 0) e[i-1] = r;
+                        if (i != m) WR(ereg, i-1, r);
                         g = di - p;
                         r = (di1 - g)*s + 2.*c*b;
                         p = s * r;
-                        if (lane == 0) { d[i] = g + p; work[i] = c; work[n-1+i] = s; }
+                        WR(dreg, i, g + p);
                         g = c*r - b;
+                        WR(creg, i, c); WR(sreg, i, s);
                     }
-                    mm = l - m + 1;
-                    DG_WSYNC();
-                    { double dl = d[l]; DG_WSYNC(); if (lane == 0) { d[l] = dl - p; e[l-1] = g; } }
-                    DG_ROT(m, mm, 0);
+                    DG_ROTREG(m, l, 0);
+                    { double dl = RD(dreg, l); WR(dreg, l, dl - p); WR(ereg, l-1, g); }
                 }
             }
             if (jtot >= nmaxit) break;
         }
+        /* back to LDS for the ordering step */
+        if (lane < n) {
+            d[lane] = dreg;
+#pragma unroll
+            for (int cc = 0; cc < 9; cc++) A_(lane, cc) = z[cc];
+        }
+#undef RD
+#undef WR
+#undef DG_ROTREG
         DG_WSYNC();
+        DG_ET(2);
         /* selection sort, ascending (columns swapped by row lanes) */
         for (ii = 1; ii < n; ii++) {
             i = ii - 1; k = i; p = d[i];
@@ -834,10 +869,88 @@ static __device__ __noinline__ int dg_eig_sym_wave(double *a, double *w, int lan
         }
         if (lane < n) w[lane] = d[lane];
         DG_WSYNC();
+        DG_ET(3);
         return jtot >= nmaxit ? 1 : 0;
     }
-#undef DG_ROT
 #undef A_
+}
+
+/* wave-cooperative form of dg_svd_lastcol_9x8: identical per-element arithmetic; the loops over the other
+ * columns (left reflector) / other rows (right reflector) run in different lanes.  All 64 lanes of one wave. */
+static __device__ __noinline__ void dg_svd_lastcol_9x8_wave(double *a /* LDS 9x8 row-major, destroyed */, double *col /* LDS 9 */, int lane)
+{
+    DG_LDS double w[20];
+    const int m = 9, n = 8;
+    int i, j, mm, nm;
+    for (i = 0, mm = m, nm = n - 1; i < n; ++i, --mm, --nm) {
+        double *p = a + i * (n + 1);
+        DG_WSYNC();
+        if (mm > 1) {
+            double s = 0., h = 0., sv = 0., t = 0.;
+            for (j = 0; j < mm; ++j) { double q = p[j*n]; s += q * q; }           /* every lane, same order */
+            if (s > 0.) {
+                h = sqrt(s); if (*p < 0.) h = -h;
+                double p0 = *p;
+                s += p0 * h; s = 1./s; t = 1./(p0 + h);
+                sv = 1. + fabs(p0/h);
+                DG_WSYNC();
+                if (lane < mm) w[lane] = (lane == 0) ? p0 + h : p[lane*n];
+                DG_WSYNC();
+                { int k = lane + 1; if (k < n - i) { double r = 0.; for (j = 0; j < mm; j++) r += w[j] * p[j*n + k]; r *= s; for (j = 0; j < mm; j++) p[j*n + k] -= r * w[j]; } }
+                DG_WSYNC();
+                if (lane >= 1 && lane < mm) p[lane*n] = t * w[lane];
+            }
+            DG_WSYNC();
+            if (lane == 0) *p = sv;
+        }
+        DG_WSYNC();
+        double *p1 = p + 1;
+        if (nm > 1) {
+            double s = 0., h = 0., sv = 0., t = 0.;
+            for (j = 0; j < nm; ++j) s += p1[j] * p1[j];
+            if (s > 0.) {
+                double q0 = *p1;
+                h = sqrt(s); if (q0 < 0.) h = -h;
+                sv = 1. + fabs(q0/h);
+                s += q0 * h; s = 1./s; t = 1./(q0 + h);
+                DG_WSYNC();
+                if (lane == 0) *p1 = q0 + h;
+                DG_WSYNC();
+                { int rr = lane + 1; if (rr < m - i) { double *pp = p1 + rr*n; double r = 0.; for (j = 0; j < nm; ++j) r += p1[j] * pp[j]; r *= s; for (j = 0; j < nm; ++j) pp[j] -= r * p1[j]; } }
+                DG_WSYNC();
+                if (lane >= 1 && lane < nm) p1[lane] *= t;
+            }
+            DG_WSYNC();
+            if (lane == 0) *p1 = sv;
+        }
+    }
+    DG_WSYNC();
+    /* ldumat restricted to column 8 (sequential recurrence, every lane computes it; lane 0 stores) */
+    {
+        double c[9];
+#pragma unroll
+        for (i = 0; i < 9; i++) c[i] = 0.;
+        c[8] = 1.;
+#pragma unroll
+        for (i = n - 1; i >= 0; --i) {
+            const int mm2 = n - i;             /* rows below row i: 9 - 1 - i */
+            double p0 = a[i*n + i];
+            if (p0 != 0.) {
+                double s = 0.;
+#pragma unroll
+                for (j = 0; j < mm2; j++) s += a[(i + 1 + j)*n + i] * c[i + 1 + j];
+                s *= p0;
+#pragma unroll
+                for (j = 0; j < mm2; j++) c[i + 1 + j] -= s * a[(i + 1 + j)*n + i];
+                c[i] = -s;
+            } else c[i] = 0.;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (i = 0; i < 9; i++) col[i] = c[i];
+        }
+    }
+    DG_WSYNC();
 }
 
 /* ------------------------------------------------------------------------------------------------

@@ -95,7 +95,7 @@ __device__ __forceinline__ dg_pass_res dg_h_pass(CTX &c, const double *Hm /* LDS
 }
 __device__ __forceinline__ dg_pass_cfg dg_cfg0(int n)
 {
-    dg_pass_cfg c; c.n = n; c.src = 0; c.wantJ = 0; c.thJ = 0; c.wantC = 0; c.thC = 0; c.list = 0; c.thL = 0; c.flags = 0; c.thF = 0;
+    dg_pass_cfg c; c.n = n; c.src = 0; c.wantJ = 0; c.thJ = 0; c.wantC = 0; c.thC = 0; c.list = 0; c.thL = 0; c.listStrict = 0; c.flags = 0; c.thF = 0;
     return c;
 }
 
@@ -319,16 +319,10 @@ __device__ __forceinline__ unsigned dg_u2Fit(CTX &c, double *F /* LDS in/out */,
     double dth = (ths - th) / (iters - 1);
     int *inlI = c.L[9];
     for (unsigned iter = 0; iter < iters; ++iter) {
-        /* flags: d < ths (strict); the id list is the same set in index order */
-        dg_pass_cfg cfg = dg_cfg0(n); cfg.flags = inl; cfg.thF = ths;
+        /* flags: d < ths (strict); the id list is the same set in index order (one fused pass) */
+        dg_pass_cfg cfg = dg_cfg0(n); cfg.flags = inl; cfg.thF = ths; cfg.list = inlI; cfg.thL = ths; cfg.listStrict = 1;
         dg_pass_res r = dg_f_pass(c, F, DG_K_FDS, cfg); c.n_aux++;
         if (r.nF < 8) return r.nF;
-        /* list from flags */
-        {
-            dg_pass_cfg c2 = dg_cfg0(n); c2.list = inlI; c2.thL = 0.5;
-            const unsigned char *fl = inl;
-            dg_pass(&c.S->red, c2, [&](int pid, int) { return fl[pid] ? 0.0 : 1.0; }, c.tid);
-        }
         dg_u2f_list(c, inlI, (int)r.nF, 0, 0, F);
         ths -= dth;
     }

@@ -3,18 +3,21 @@
 #define DG_KERNEL_F_MAIN_H
 #include "dg_kernel_f.h"
 
-/* lane 0: hash of an id list in global memory (hash.c:4-47 over the ints' bytes) */
+/* lane 0: hash of an id list in global memory (hash.c:4-47 over the ints' bytes).  The state chain is kept on
+ * the scalar unit (readfirstlane'd operands): 7 dependent SALU ops per element instead of 7 VALU ops. */
 __device__ __forceinline__ unsigned dg_hash_list(const int *list, int count)
 {
-    unsigned hash = (unsigned)(count * 4), tmp;
     if (count <= 0) return 0;
-    for (int k = 0; k < count; k++) {
-        unsigned v = (unsigned)list[k];
-        hash += v & 0xffffu;
-        tmp = ((v >> 16) << 11) ^ hash;
-        hash = (hash << 16) ^ tmp;
-        hash += hash >> 11;
+    unsigned hash = (unsigned)__builtin_amdgcn_readfirstlane(count * 4), tmp;
+#define DG_HSTEP(v_) { unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)(v_)); \
+        hash += v & 0xffffu; tmp = ((v >> 16) << 11) ^ hash; hash = (hash << 16) ^ tmp; hash += hash >> 11; }
+    int k = 0;
+    for (; k + 8 <= count; k += 8) {
+        int v0 = list[k], v1 = list[k+1], v2 = list[k+2], v3 = list[k+3], v4 = list[k+4], v5 = list[k+5], v6 = list[k+6], v7 = list[k+7];
+        DG_HSTEP(v0) DG_HSTEP(v1) DG_HSTEP(v2) DG_HSTEP(v3) DG_HSTEP(v4) DG_HSTEP(v5) DG_HSTEP(v6) DG_HSTEP(v7)
     }
+    for (; k < count; k++) DG_HSTEP(list[k])
+#undef DG_HSTEP
     hash ^= hash << 3;  hash += hash >> 5;
     hash ^= hash << 4;  hash += hash >> 17;
     hash ^= hash << 25; hash += hash >> 6;

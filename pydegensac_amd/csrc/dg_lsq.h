@@ -153,7 +153,18 @@ __device__ __noinline__ void dg_u2f_small_w(dg_lsq_scratch *s, const double *p, 
         }
         DG_WSYNC();
     } else {
-        if (lane == 0) dg_u2f_small(s, p, wts, len, F);
+        /* <= 8 points: lin_fm rows + the stride-9 weight pattern (Ftools.c:427-432), left null vector, rank 2 */
+        if (lane == 0) {
+            for (int i = 0; i < 72; i++) s->Z8[i] = 0.;
+            for (int i = 0; i < len && i < 8; i++) {
+                double a[3] = {p[4*i], p[4*i+1], 1.0}, b[3] = {p[4*i+2], p[4*i+3], 1.0};
+                for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) s->Z8[(k*3+l)*8 + i] = b[k] * a[l];
+            }
+            if (wts) for (int i = 0; i < len && i < 8; i++) for (int k = 0; k < 9; k++) if (i + 9*k < 72) s->Z8[i + 9*k] *= wts[i];
+        }
+        DG_WSYNC();
+        dg_svd_lastcol_9x8_wave(s->Z8, s->U9, lane);
+        if (lane == 0) { for (int i = 0; i < 9; i++) F[i] = s->U9[i]; dg_singulF(F); }
         DG_WSYNC();
     }
 }

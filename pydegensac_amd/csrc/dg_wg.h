@@ -135,7 +135,7 @@ struct dg_pass_cfg {
     /* second counter: #(d <= thC) */
     int         wantC;  double thC;
     /* ordered list of ids with d <= thL  (inlidxs' index list) */
-    int        *list;   double thL;
+    int        *list;   double thL;  int listStrict;   /* listStrict: ids with d < thL instead of d <= thL */
     /* flags[item position] = d < thF (strict, DegUtils.c style) and their count */
     unsigned char *flags; double thF;
 };
@@ -164,7 +164,7 @@ __device__ __forceinline__ dg_pass_res dg_pass(dg_red *r, const dg_pass_cfg &c, 
         if (c.flags) { bool f = act && d < c.thF; cF += f ? 1u : 0u; if (act) c.flags[j] = f ? 1 : 0; }
         if (c.list) {
             /* ordered compaction needs the block's per-wave counts: one barrier per DG_T items */
-            bool in = act && d <= c.thL;
+            bool in = act && (c.listStrict ? d < c.thL : d <= c.thL);
             unsigned long long bL = __ballot(in);
             if (lane == 0) r->u[par][wave][2] = (unsigned)__popcll(bL);
             __syncthreads();
