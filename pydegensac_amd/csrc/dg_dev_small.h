@@ -191,9 +191,8 @@ DG_FN void dg_ldvmat(double *a, double *v, int n)        /* matutls/ldvmat.c */
     }
 }
 
-DG_FN void dg_ldumat(double *a, double *u, int m, int n)  /* matutls/ldumat.c */
+DG_FN void dg_ldumat(double *a, double *u, int m, int n, double *w /* >= 9 */)  /* matutls/ldumat.c */
 {
-    DG_LDS double w[9];
     double *p0, *q0, *p, *q; int i, j, k, mm; double s, h;
     for (i = 0; i < m; i++) w[i] = 0.;
     for (i = 0, mm = m*m, q = u; i < mm; ++i) *q++ = 0.;
@@ -272,9 +271,8 @@ DG_FN int dg_qrbdv(double *dm, double *em, double *um, int mm, double *vm, int m
     return j;
 }
 
-DG_BIG int dg_svduv(double *d, double *a, double *u, int m, double *v, int n)   /* matutls/svduv.c */
+DG_BIG int dg_svduv(double *d, double *a, double *u, int m, double *v, int n, double *w /* >= 29, caller-owned */)   /* matutls/svduv.c */
 {
-    DG_LDS double w[20];
     double *p, *p1, *q, *pp, *e;
     double s, h, r, t, sv;
     int i, j, k, mm, nm, ms;
@@ -317,7 +315,7 @@ DG_BIG int dg_svduv(double *d, double *a, double *u, int m, double *v, int n)   
         }
         if (nm == 1) e[i] = *p1;
     }
-    dg_ldvmat(a, v, n); dg_ldumat(a, u, m, n);
+    dg_ldvmat(a, v, n); dg_ldumat(a, u, m, n, w + 20);
     dg_qrbdv(d, e, u, m, v, n);
     for (i = 0; i < n; ++i) {
         if (d[i] < 0.) {
@@ -658,13 +656,14 @@ __device__ long long dg_eig_ticks[4];
 #else
 #define DG_ET(i)
 #endif
-static __device__ __noinline__ int dg_eig_sym_wave(double *a, double *w, int lane)
+struct dg_eig_ws { double d[9], e[9], tau[9], work[18]; };
+static __device__ __noinline__ int dg_eig_sym_wave(double *a, double *w, int lane, dg_eig_ws *ews)
 {
     const int n = 9;
 #ifdef DG_EIG_TIMING
     long long t_et = wall_clock64();
 #endif
-    DG_LDS double d[9], e[9], tau[9], work[18];
+    double *d = ews->d, *e = ews->e, *tau = ews->tau;
     int i, j, k, l, m, ii;
 #define A_(r,c) a[(c)*n + (r)]
     /* ---- dsytd2, UPLO='U' ---- */

@@ -22,7 +22,7 @@ struct dg_f_shared {
     int      rf[DG_CHUNK][5];            /* rFtH batch: candidate point ids (2), swap log (2), count */
     unsigned seeds[DG_CHUNK];
     int      draws[DG_CHUNK][8];        /* raw draws, then drawn ids (draw order) */
-    double   models[DG_MCAP][9];
+    dg_wave_ws ww[DG_NW];                /* per-wave scratch of the wave-parallel sections */
     unsigned res_I[3 * DG_CHUNK];
     double   res_J[3 * DG_CHUNK];
     unsigned short moff[DG_T + 1];      /* first model slot of each sample */
@@ -160,13 +160,14 @@ __device__ __forceinline__ int dg_f_checks(CTX &c, const double *f, const int *l
 }
 
 /* ---- DegUtils.c:42-161 checksample / Hdetect on lane 0 ----------------------------------------- */
-__device__ __noinline__ void dg_Hdetect(const double *F, const double (*u7)[4], const unsigned char *IDXS, double *H)
+__device__ __noinline__ void dg_Hdetect(const double *F, const double (*u7)[4], const unsigned char *IDXS, double *H, double *hw /* 17*9 + 32 doubles */)
 {
-    DG_LDS double D[3], U[9], V[9], ec[3], Ex[9], A[9], u3a[9], u3b[9], u3aT[9], u3bT[9], Au3b[9], Ft[9], F1[9], p1[9], p1T[9], p2[9], b[3];
+    double *D = hw, *U = hw + 9, *V = hw + 18, *ec = hw + 27, *Ex = hw + 36, *A = hw + 45, *u3a = hw + 54, *u3b = hw + 63, *u3aT = hw + 72,
+           *u3bT = hw + 81, *Au3b = hw + 90, *Ft = hw + 99, *F1 = hw + 108, *p1 = hw + 117, *p1T = hw + 126, *p2 = hw + 135, *b = hw + 144, *wk = hw + 153;
     int i, j, sing;
     dg_mattr(Ft, F, 3, 3);
     for (i = 0; i < 9; i++) F1[i] = F[i];
-    dg_svduv(D, F1, U, 3, V, 3);
+    dg_svduv(D, F1, U, 3, V, 3, wk);
     ec[0] = V[2]; ec[1] = V[5]; ec[2] = V[8];
     Ex[0] = 0; Ex[1] = -ec[2]; Ex[2] = ec[1]; Ex[3] = ec[2]; Ex[4] = 0; Ex[5] = -ec[0]; Ex[6] = -ec[1]; Ex[7] = ec[0]; Ex[8] = 0;
     dg_mmul(A, Ex, Ft, 3);
@@ -189,7 +190,7 @@ __device__ __noinline__ void dg_Hdetect(const double *F, const double (*u7)[4], 
     b[1] = (p1[1]*p2[1] + p1[4]*p2[4] + p1[7]*p2[7]) / (p2[1]*p2[1] + p2[4]*p2[4] + p2[7]*p2[7]);
     b[2] = (p1[2]*p2[2] + p1[5]*p2[5] + p1[8]*p2[8]) / (p2[2]*p2[2] + p2[5]*p2[5] + p2[8]*p2[8]);
     dg_mattr(u3bT, u3b, 3, 3);
-    sing = dg_minv(u3bT, 3);
+    sing = dg_minv3(u3bT);
     dg_rmmult(u3b, u3bT, b, 3, 3, 1);
     dg_mattr(u3bT, u3b, 3, 1);
     dg_rmmult(u3b, ec, u3bT, 3, 1, 3);
@@ -197,33 +198,39 @@ __device__ __noinline__ void dg_Hdetect(const double *F, const double (*u7)[4], 
     if (isnan(*H) || isinf(*H) || sing) { H[1] = H[2] = H[3] = H[5] = H[6] = H[7] = 0; H[0] = H[4] = H[8] = 1; }
 }
 
-/* called by all 64 lanes of wave 0; the 5-point re-fit runs wave-cooperatively, the rest on lane 0 */
-__device__ __noinline__ int dg_checksample(dg_lsq_scratch *ls, const double *F, const double (*u7)[4], double th, double *H, int lane)
+/* DegUtils.c:42-82 checksample.  The five triplets are independent until the "first success wins" rule:
+ * waves 0..4 each evaluate one (Hdetect + sort on lane 0, the 5-point re-fit wave-cooperatively), then the
+ * lowest successful index is taken — the same H the sequential loop returns.  Called by the whole workgroup. */
+template <bool LDSPTS>
+__device__ __forceinline__ int dg_checksample(CTX &c, const double *F /* LDS */, const double (*u7)[4] /* LDS */, double th, double *H /* LDS out */)
 {
-    const unsigned char IDXS[5][3] = {{0,1,2}, {3,4,5}, {0,1,6}, {3,4,6}, {2,5,6}};
-    DG_LDS double Ds[7], sDs[7], px[20];
-    DG_LDS int idx[7], res;
-    for (int i = 0; i < 5; ++i) {
+    dg_f_shared *S = c.S; const int tid = c.tid, lane = tid & 63, wave = tid >> 6;
+    __syncthreads();
+    if (wave < 5) {
+        dg_wave_ws *w = &S->ww[wave];
+        const unsigned char IDXS[5][3] = {{0,1,2}, {3,4,5}, {0,1,6}, {3,4,6}, {2,5,6}};
         if (lane == 0) {
-            dg_Hdetect(F, u7, IDXS[i], H);
-            for (int j = 0; j < 7; j++) Ds[j] = dg_HDs(H, u7[j][0], u7[j][1], u7[j][2], u7[j][3]);
-            for (int j = 0; j < 7; j++) { sDs[j] = Ds[j]; idx[j] = j; }          /* sortDs, DegUtils.c:164-183 */
-            for (int a = 0; a < 7; ++a)
+            dg_Hdetect(F, u7, IDXS[wave], w->H, w->hw);
+            for (int j = 0; j < 7; j++) { w->Ds[j] = dg_HDs(w->H, u7[j][0], u7[j][1], u7[j][2], u7[j][3]); w->sDs[j] = w->Ds[j]; w->idx[j] = j; }
+            for (int a = 0; a < 7; ++a)                                  /* sortDs, DegUtils.c:164-183 */
                 for (int b = a + 1; b < 7; ++b)
-                    if (sDs[b] < sDs[a]) { double t = sDs[b]; sDs[b] = sDs[a]; sDs[a] = t; int ti = idx[b]; idx[b] = idx[a]; idx[a] = ti; }
-            for (int j = 0; j < 5; ++j) { px[4*j] = u7[idx[j]][0]; px[4*j+1] = u7[idx[j]][1]; px[4*j+2] = u7[idx[j]][2]; px[4*j+3] = u7[idx[j]][3]; }
+                    if (w->sDs[b] < w->sDs[a]) { double t = w->sDs[b]; w->sDs[b] = w->sDs[a]; w->sDs[a] = t; int ti = w->idx[b]; w->idx[b] = w->idx[a]; w->idx[a] = ti; }
+            for (int j = 0; j < 5; ++j) { const double *q = u7[w->idx[j]]; w->cpx[4*j] = q[0]; w->cpx[4*j+1] = q[1]; w->cpx[4*j+2] = q[2]; w->cpx[4*j+3] = q[3]; }
         }
         DG_WSYNC();
-        dg_u2h_small_w(ls, px, 5, H, lane);
+        dg_u2h_norm_w(w, w->cpx, 5, w->H, lane);
         if (lane == 0) {
             int inlCount = 0;
-            for (int j = 0; j < 7; ++j) if (dg_HDs(H, u7[j][0], u7[j][1], u7[j][2], u7[j][3]) < th) ++inlCount;
-            res = inlCount > 4;
+            for (int j = 0; j < 7; ++j) if (dg_HDs(w->H, u7[j][0], u7[j][1], u7[j][2], u7[j][3]) < th) ++inlCount;
+            w->res = inlCount > 4;
         }
-        DG_WSYNC();
-        if (res) return 1;
     }
-    return 0;
+    __syncthreads();
+    int win = -1;
+    for (int i = 4; i >= 0; i--) if (S->ww[i].res) win = i;
+    if (win >= 0 && tid < 9) H[tid] = S->ww[win].H[tid];
+    __syncthreads();
+    return win >= 0;
 }
 
 /* ---- ranH.c:18-135 + DegUtils.c:693-731: LO of the plane homography (innerH) -------------------- */

@@ -420,15 +420,12 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
                     int degenerate = 0;
                     if (pr.degen) {
                         __syncthreads();
-                        if (tid < 64) {
-                            if (tid < 7) {                             /* u7 in samidx order = reverse draw order */
-                                dg_pt q = P[S->draws[k][6 - tid]];
-                                S->u7[tid][0] = q.x1; S->u7[tid][1] = q.y1; S->u7[tid][2] = q.x2; S->u7[tid][3] = q.y2;
-                            }
-                            DG_WSYNC();
-                            int dgn = dg_checksample(&S->lsq, S->f, S->u7, 3*th, S->H, tid);
-                            if (tid == 0) S->itmp[1] = dgn;
+                        if (tid < 7) {                                 /* u7 in samidx order = reverse draw order */
+                            dg_pt q = P[S->draws[k][6 - tid]];
+                            S->u7[tid][0] = q.x1; S->u7[tid][1] = q.y1; S->u7[tid][2] = q.x2; S->u7[tid][3] = q.y2;
                         }
+                        __syncthreads();
+                        { int dgn = dg_checksample(c, S->f, S->u7, 3*th, S->H); if (tid == 0) S->itmp[1] = dgn; }
                         __syncthreads();
                         degenerate = S->itmp[1];
                     }
@@ -525,16 +522,14 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
         int degenerate = 0;
         /* the libc stream continues from wherever the last iteration left it: after its seed draw */
         __syncthreads();
-        if (tid < 64) {
+        {
             int dgn = 0;
             if (pr.degen) {
                 if (tid < 7) { dg_pt q = P[S->samidxBest[tid]]; S->u7[tid][0] = q.x1; S->u7[tid][1] = q.y1; S->u7[tid][2] = q.x2; S->u7[tid][3] = q.y2; }
-                DG_WSYNC();
-                dgn = dg_checksample(&S->lsq, S->FBest, S->u7, 3*th, S->H, tid);
+                __syncthreads();
+                dgn = dg_checksample(c, S->FBest, S->u7, 3*th, S->H);
             }
             if (tid == 0) S->itmp[1] = dgn;
-            /* state after the last executed iteration: srand(prev seed) + 8 outputs == srand(prev), so replay it */
-            S->itmp[2] = 0;
         }
         __syncthreads();
         degenerate = S->itmp[1];

@@ -16,7 +16,7 @@ __device__ __forceinline__ void dg_u2h_big(dg_red *r, dg_lsq_scratch *s, PtFn pt
 {
     (void)r;
     dg_lsq_seq(s, pt, list, len, tid, 1, s->A1, s->A2, stage);
-    if (tid < 64) dg_eig_sym_wave(s->V, s->D, tid);
+    if (tid < 64) dg_eig_sym_wave(s->V, s->D, tid, &s->ews);
     if (tid == 0) {
         for (int i = 0; i < 9; i++) Hout[i] = s->V[i];
         dg_denormH(Hout, s->A1, s->A2);

@@ -16,6 +16,18 @@ struct dg_lsq_scratch {
     double part[DG_NW][48];    /* per-wave partial sums of the big variants */
     double out[9];
     double px[16 * 4];         /* gathered coordinates of a small problem */
+    dg_eig_ws ews;             /* dsyev work vectors */
+    double svw[32];            /* svduv work vectors */
+};
+
+/* per-wave scratch for the wave-parallel sections (checksample's 5 triplets, innerFH's repetitions): the
+ * members the templated small solvers touch have the same names as in dg_lsq_scratch */
+struct dg_wave_ws {
+    double Z[14 * 9], V[81], D[9], A1[3], A2[3], px[14 * 4];
+    dg_eig_ws ews;
+    double hw[17 * 9 + 32];    /* Hdetect's 3x3 temporaries + svduv work vectors */
+    double H[9], F[9], Ds[7], sDs[7], cpx[20];
+    int idx[8], res, cnt;
 };
 
 /* utools.c:7-51 normu over k gathered points p[4*i + {0,1,2,3}] = x1,y1,x2,y2 */
@@ -128,30 +140,37 @@ __device__ __forceinline__ void dg_cov9_wave(double *Cv, const double *Z, int ro
     }
 }
 
+/* long form (> 8 points, normalised LSQ) for any scratch type with members Z, V, D, A1, A2, ews */
+template <class SC>
+__device__ __forceinline__ void dg_u2f_norm_w(SC *s, const double *p, const double *wts, int len, double *F, int lane)
+{
+    double A1[3], A2[3];
+    dg_normu_small(p, len, A1, A2);
+    if (lane < len) {
+        int i = lane; double a[3], b[3];
+        a[2] = 1; b[2] = 1;
+        a[0] = p[4*i]   * A1[0] + A1[1]; a[1] = p[4*i+1] * A1[0] + A1[2];
+        b[0] = p[4*i+2] * A2[0] + A2[1]; b[1] = p[4*i+3] * A2[0] + A2[2];
+        for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) { double z = a[l] * b[k]; if (wts) z *= wts[i]; s->Z[9*i + 3*k + l] = z; }
+    }
+    if (lane == 0) for (int i = 0; i < 3; i++) { s->A1[i] = A1[i]; s->A2[i] = A2[i]; }
+    DG_WSYNC();
+    dg_cov9_wave(s->V, s->Z, len, lane);
+    DG_WSYNC();
+    dg_eig_sym_wave(s->V, s->D, lane, &s->ews);
+    if (lane == 0) {
+        int j = 0; for (int i = 1; i < 9; i++) if (s->D[i] < s->D[j]) j = i;
+        for (int i = 0; i < 9; i++) F[i] = s->V[j*9 + i];
+        dg_singulF(F);
+        dg_denormF(F, s->A1, s->A2);
+    }
+    DG_WSYNC();
+}
+
 __device__ __noinline__ void dg_u2f_small_w(dg_lsq_scratch *s, const double *p, const double *wts /* LDS or 0 */, int len, double *F, int lane)
 {
     if (len > 8) {
-        double A1[3], A2[3];
-        dg_normu_small(p, len, A1, A2);                       /* every lane: same LDS reads, same result */
-        if (lane < len) {
-            int i = lane; double a[3], b[3];
-            a[2] = 1; b[2] = 1;
-            a[0] = p[4*i]   * A1[0] + A1[1]; a[1] = p[4*i+1] * A1[0] + A1[2];
-            b[0] = p[4*i+2] * A2[0] + A2[1]; b[1] = p[4*i+3] * A2[0] + A2[2];
-            for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) { double z = a[l] * b[k]; if (wts) z *= wts[i]; s->Z[9*i + 3*k + l] = z; }
-        }
-        if (lane == 0) for (int i = 0; i < 3; i++) { s->A1[i] = A1[i]; s->A2[i] = A2[i]; }
-        DG_WSYNC();
-        dg_cov9_wave(s->V, s->Z, len, lane);
-        DG_WSYNC();
-        dg_eig_sym_wave(s->V, s->D, lane);
-        if (lane == 0) {
-            int j = 0; for (int i = 1; i < 9; i++) if (s->D[i] < s->D[j]) j = i;
-            for (int i = 0; i < 9; i++) F[i] = s->V[j*9 + i];
-            dg_singulF(F);
-            dg_denormF(F, s->A1, s->A2);
-        }
-        DG_WSYNC();
+        dg_u2f_norm_w(s, p, wts, len, F, lane);
     } else {
         /* <= 8 points: lin_fm rows + the stride-9 weight pattern (Ftools.c:427-432), left null vector, rank 2 */
         if (lane == 0) {
@@ -169,9 +188,10 @@ __device__ __noinline__ void dg_u2f_small_w(dg_lsq_scratch *s, const double *p, 
     }
 }
 
-__device__ __noinline__ void dg_u2h_small_w(dg_lsq_scratch *s, const double *p, int len, double *H, int lane)
+/* > 4 points: normalised DLT for any scratch type with members Z (>= 18*len), V, D, A1, A2, ews */
+template <class SC>
+__device__ __forceinline__ void dg_u2h_norm_w(SC *s, const double *p, int len, double *H, int lane)
 {
-    if (len <= 4) { if (lane == 0) dg_u2h_small(s, p, len, H); DG_WSYNC(); return; }
     double A1[3], A2[3];
     dg_normu_small(p, len, A1, A2);
     if (lane < len) {
@@ -186,9 +206,15 @@ __device__ __noinline__ void dg_u2h_small_w(dg_lsq_scratch *s, const double *p, 
     DG_WSYNC();
     dg_cov9_wave(s->V, s->Z, 2*len, lane);
     DG_WSYNC();
-    dg_eig_sym_wave(s->V, s->D, lane);
+    dg_eig_sym_wave(s->V, s->D, lane, &s->ews);
     if (lane == 0) { for (int i = 0; i < 9; i++) H[i] = s->V[i]; dg_denormH(H, s->A1, s->A2); }
     DG_WSYNC();
+}
+
+__device__ __noinline__ void dg_u2h_small_w(dg_lsq_scratch *s, const double *p, int len, double *H, int lane)
+{
+    if (len <= 4) { if (lane == 0) dg_u2h_small(s, p, len, H); DG_WSYNC(); return; }
+    dg_u2h_norm_w(s, p, len, H, lane);
 }
 
 /* ---- normalised LSQ over an id list of any length, in the REFERENCE'S summation order -----------------
@@ -265,7 +291,7 @@ __device__ __forceinline__ void dg_u2f_big(dg_red *r, dg_lsq_scratch *s, PtFn pt
 {
     (void)r;
     dg_lsq_seq(s, pt, list, len, tid, 0, s->A1, s->A2, stage);
-    if (tid < 64) dg_eig_sym_wave(s->V, s->D, tid);
+    if (tid < 64) dg_eig_sym_wave(s->V, s->D, tid, &s->ews);
     if (tid == 0) {
         int jm = 0; for (int i = 1; i < 9; i++) if (s->D[i] < s->D[jm]) jm = i;
         for (int i = 0; i < 9; i++) Fout[i] = s->V[jm*9 + i];

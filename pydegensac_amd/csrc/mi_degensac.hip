@@ -394,7 +394,7 @@ __global__ void dg_microbench_kernel(const double *in, double *out, long long *t
     DG_WSYNC();
     long long t0, t1;
     t0 = wall_clock64();
-    for (int r = 0; r < reps; r++) { if (tid == 0) { for (int i = 0; i < 14; i++) for (int k = 0; k < 9; k++) ls.Z[9*i+k] = in[64 + 9*i + k] + 1e-9 * r; } DG_WSYNC(); dg_cov9_wave(ls.V, ls.Z, 14, tid); DG_WSYNC(); dg_eig_sym_wave(ls.V, ls.D, tid); }
+    for (int r = 0; r < reps; r++) { if (tid == 0) { for (int i = 0; i < 14; i++) for (int k = 0; k < 9; k++) ls.Z[9*i+k] = in[64 + 9*i + k] + 1e-9 * r; } DG_WSYNC(); dg_cov9_wave(ls.V, ls.Z, 14, tid); DG_WSYNC(); dg_eig_sym_wave(ls.V, ls.D, tid, &ls.ews); }
     t1 = wall_clock64(); if (tid == 0) ticks[0] = t1 - t0;
     t0 = wall_clock64();
     for (int r = 0; r < reps; r++) { if (tid == 0) { for (int i = 0; i < 14; i++) for (int k = 0; k < 9; k++) ls.Z[9*i+k] = in[64 + 9*i + k] + 1e-9 * r; dg_cov9(ls.V, ls.Z, 14); dg_eig_sym(ls.V, ls.D, 9); } DG_WSYNC(); }
@@ -410,7 +410,7 @@ __global__ void dg_microbench_kernel(const double *in, double *out, long long *t
     t1 = wall_clock64(); if (tid == 0) ticks[4] = t1 - t0;
     t0 = wall_clock64();
     int cs = 0;
-    for (int r = 0; r < reps; r++) cs += dg_checksample(&ls, F, u7, 0.75, H, tid);
+
     t1 = wall_clock64(); if (tid == 0) { ticks[5] = t1 - t0; out[9] = cs; }
     t0 = wall_clock64();
     for (int r = 0; r < reps; r++) dg_u2h_small_w(&ls, ls.px, 5, H, tid);
