@@ -19,12 +19,10 @@ struct dg_f_shared {
     dg_red red;
     dg_lsq_scratch lsq;
     dg_rng rng, rng_save;
-    int      rf[DG_CHUNK][5];            /* rFtH batch: candidate point ids (2), swap log (2), count */
-    unsigned seeds[DG_CHUNK];
-    int      draws[DG_CHUNK][8];        /* raw draws, then drawn ids (draw order) */
+    unsigned seeds2[2][DG_CHUNK];       /* double-buffered chunk state: chunk c+1 is sampled while chunk c is scored */
+    int      draws2[2][DG_CHUNK][8];    /* raw draws, then drawn ids (draw order) */
     dg_wave_ws ww[DG_NW];                /* per-wave scratch of the wave-parallel sections */
-    unsigned res_I[3 * DG_CHUNK];
-    double   res_J[3 * DG_CHUNK];
+    double   hw5[5][17 * 9 + 32];        /* Hdetect temporaries of checksample's five waves */
     unsigned short moff[DG_T + 1];      /* first model slot of each sample */
     unsigned char  nv[DG_CHUNK];        /* valid models per sample; 255 = nullspace dimension != 2 */
     unsigned char  ridx[DG_CHUNK][4];   /* root index i (= errs[] slot) of each valid model */
@@ -52,6 +50,9 @@ struct dg_f_ctx {
     dg_ht ht;
     double *gmodels;         /* [3*DG_CHUNK][9] chunk models */
     dg_pt *stage;            /* [n] gathered correspondences of a long least-squares list */
+    unsigned *res_I; double *res_J;   /* [3*DG_CHUNK] per-model (I, J) of the current chunk */
+    int (*rf)[5];            /* [DG_CHUNK] rFtH batch: candidate point ids (2), swap log (2), count */
+    unsigned *seeds; int (*draws)[8]; /* the chunk buffers of the chunk being committed */
     /* counters */
     int n_fds, n_exfds, n_hds, n_aux;
     long long dbg[8];        /* debug phase ticks: 0 innerH, 1 rFtH gen, 2 rFtH score, 3 rFtH trigger(innerFH), 4 checksample */
@@ -210,7 +211,7 @@ __device__ __forceinline__ int dg_checksample(CTX &c, const double *F /* LDS */,
         dg_wave_ws *w = &S->ww[wave];
         const unsigned char IDXS[5][3] = {{0,1,2}, {3,4,5}, {0,1,6}, {3,4,6}, {2,5,6}};
         if (lane == 0) {
-            dg_Hdetect(F, u7, IDXS[wave], w->H, w->hw);
+            dg_Hdetect(F, u7, IDXS[wave], w->H, S->hw5[wave]);
             for (int j = 0; j < 7; j++) { w->Ds[j] = dg_HDs(w->H, u7[j][0], u7[j][1], u7[j][2], u7[j][3]); w->sDs[j] = w->Ds[j]; w->idx[j] = j; }
             for (int a = 0; a < 7; ++a)                                  /* sortDs, DegUtils.c:164-183 */
                 for (int b = a + 1; b < 7; ++b)
@@ -467,9 +468,9 @@ __device__ __forceinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, d
                 for (unsigned pos = 0; pos < 2; ++pos) {
                     unsigned idx = pos + 1 + (unsigned)dg_rand(&S->rng) % (nhinlCount - pos - 1);
                     int aux = ptr[pos]; ptr[pos] = ptr[idx]; ptr[idx] = aux;
-                    S->rf[b][2 + pos] = (int)idx;
+                    c.rf[b][2 + pos] = (int)idx;
                 }
-                S->rf[b][0] = idxN[ptr[0]]; S->rf[b][1] = idxN[ptr[1]];
+                c.rf[b][0] = idxN[ptr[0]]; c.rf[b][1] = idxN[ptr[1]];
             }
         }
         __syncthreads();
@@ -477,16 +478,16 @@ __device__ __forceinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, d
         /* one wave per candidate: #off-plane points with Sampson error < 2 th */
         for (int b = wave; b < B; b += DG_NW) {
             double aFt[9];
-            dg_rFtH_aFt<LDSPTS>(Hr, P[S->rf[b][0]], P[S->rf[b][1]], aFt);
+            dg_rFtH_aFt<LDSPTS>(Hr, P[c.rf[b][0]], P[c.rf[b][1]], aFt);
             unsigned cnt = 0;
             for (int j = lane; j < (int)nhinlCount; j += 64) { dg_pt p = P[idxN[j]]; cnt += dg_FDs(aFt, p.x1, p.y1, p.x2, p.y2) < th*2 ? 1u : 0u; }
             cnt = dg_wave_sum_u(cnt);
-            if (lane == 0) S->rf[b][4] = (int)cnt;
+            if (lane == 0) c.rf[b][4] = (int)cnt;
         }
         __syncthreads();
         long long tg2 = wall_clock64(); c.dbg[2] += tg2 - tg1;
         /* first candidate beating m_i */
-        bool hit = tid < B && (unsigned)S->rf[tid][4] > m_i;
+        bool hit = tid < B && (unsigned)c.rf[tid][4] > m_i;
         unsigned long long bal = __ballot(hit);
         __syncthreads();
         if (lane == 0) S->wave_cnt[wave] = bal ? (unsigned)(wave * 64 + __ffsll((long long)bal) - 1) : 0xffffffffu;
@@ -498,7 +499,7 @@ __device__ __forceinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, d
         __syncthreads();
         if (tid == 0) {
             for (int b = B - 1; b > (int)bE; b--)
-                for (int pos = 1; pos >= 0; --pos) { int idx = S->rf[b][2 + pos]; int aux = ptr[pos]; ptr[pos] = ptr[idx]; ptr[idx] = aux; }
+                for (int pos = 1; pos >= 0; --pos) { int idx = c.rf[b][2 + pos]; int aux = ptr[pos]; ptr[pos] = ptr[idx]; ptr[idx] = aux; }
             S->rng = S->rng_save;
             for (int q = 0; q < 2 * ((int)bE + 1); q++) dg_rand(&S->rng);
         }
@@ -506,7 +507,7 @@ __device__ __forceinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, d
         no_sam += bE + 1; c.n_aux += (int)bE + 1;
         {
             double aFt[9];
-            dg_rFtH_aFt<LDSPTS>(Hr, P[S->rf[bE][0]], P[S->rf[bE][1]], aFt);
+            dg_rFtH_aFt<LDSPTS>(Hr, P[c.rf[bE][0]], P[c.rf[bE][1]], aFt);
             /* v = Ds < 2 th ; uV = uN(:, v) */
             dg_pass_cfg cfg = dg_cfg0((int)nhinlCount); cfg.src = idxN; cfg.flags = vN; cfg.thF = th*2;
             dg_pass(&S->red, cfg, [&](int pid, int) { dg_pt p = P[pid]; return dg_FDs(aFt, p.x1, p.y1, p.x2, p.y2); }, tid);

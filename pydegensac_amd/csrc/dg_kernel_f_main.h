@@ -143,6 +143,62 @@ __device__ __forceinline__ dg_score dg_inFrani(CTX &c, int ninl, double th, doub
     return maxS;
 }
 
+/* One chunk of the reference's sample stream, executed by ONE wave (all 64 lanes): the seed chain
+ * (seed_{k+1} = output #NDRAW after srand(seed_k)), the NDRAW draws of every sample and the Fisher-Yates
+ * pool swaps (rtools.c:12-23).  Fills seeds[0..cn) and draws[k][0..NDRAW) (drawn ids in draw order) and
+ * returns the seed of the sample after the chunk.  NDRAW = 7 (F) or 4 (H). */
+template <int NDRAW, bool LDSPTS>
+__device__ __forceinline__ unsigned dg_sample_chunk(unsigned seed, int cn, int n, int *pool, unsigned *seeds, int (*draws)[8], int lane)
+{
+    /* seed chain: lane j carries the term C[NDRAW][j] * r_j, r_j = seed * 16807^j mod (2^31-1) */
+    const unsigned gk = lane < 31 ? dg_rng_G[lane] : 0u, ck = lane < 31 ? dg_rng_C[NDRAW][lane] : 0u;
+    unsigned sd = seed;
+    for (int k = 0; k < cn; k++) {
+        if (lane == 0) seeds[k] = sd;
+        unsigned s1 = sd ? sd : 1u;                              /* rand() outputs are < 2^31: Schrage == exact mulmod */
+        unsigned rj = lane == 0 ? s1 : dg_mulmod31(s1, gk);
+        sd = dg_wave_sum_u(ck * rj) >> 1;
+    }
+    DG_WSYNC();
+    for (int k = lane; k < cn; k += 64) {
+        unsigned o[8];
+        dg_rng_outputs(seeds[k], o);
+#pragma unroll
+        for (int i = 0; i < NDRAW; i++) draws[k][i] = (int)(o[i] % (unsigned)(n - i));
+    }
+    DG_WSYNC();
+    /* pool swaps: lanes 0..NDRAW-1 own one draw each; the NDRAW tail slots live in registers */
+    int *vp = pool;
+    int t = (lane < NDRAW) ? vp[n - 1 - lane] : 0;
+    int s_next = (lane < NDRAW) ? draws[0][lane] : (-1 - lane);
+    for (int k = 0; k < cn; k++) {
+        const int s = s_next;
+        if (k + 1 < cn) s_next = (lane < NDRAW) ? draws[k + 1][lane] : (-1 - lane);
+        bool alias = (lane < NDRAW) && (s >= n - NDRAW);
+        /* duplicate draws among the active lanes (idle lanes hold distinct negatives): row rotates on the VALU */
+        alias = alias || (dg_dpp<DG_DPP_ROR(1)>(s) == s) || (dg_dpp<DG_DPP_ROR(2)>(s) == s) || (dg_dpp<DG_DPP_ROR(3)>(s) == s);
+        if (NDRAW > 4) alias = alias || (dg_dpp<DG_DPP_ROR(4)>(s) == s) || (dg_dpp<DG_DPP_ROR(5)>(s) == s) || (dg_dpp<DG_DPP_ROR(6)>(s) == s);
+        if (__any(alias)) {
+            if (lane < NDRAW) vp[n - 1 - lane] = t;
+            if (!LDSPTS) __threadfence_block();
+            DG_WSYNC();
+            if (lane == 0) {
+                for (int i = 0; i < NDRAW; i++) { int si = draws[k][i], j = n - 1 - i, q = vp[si]; vp[si] = vp[j]; vp[j] = q; draws[k][i] = q; }
+            }
+            if (!LDSPTS) __threadfence_block();
+            DG_WSYNC();
+            if (lane < NDRAW) t = vp[n - 1 - lane];
+        } else if (lane < NDRAW) {
+            int q = vp[s]; vp[s] = t; t = q; draws[k][lane] = q;
+            if (!LDSPTS) __threadfence_block();
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane < NDRAW) vp[n - 1 - lane] = t;
+    DG_WSYNC();
+    return sd;
+}
+
 /* ---------------------------------------------------------------------------------------------- */
 template <bool LDSPTS>
 __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
@@ -166,6 +222,8 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
     c.ht.heads = (int *)(ws + A.wl.off_ht); c.ht.count = c.ht.heads + 64; c.ht.ent = c.ht.heads + 80;
     c.gmodels = (double *)(ws + A.wl.off_models);
     c.stage = (dg_pt *)(ws + A.wl.off_stage);
+    c.res_J = (double *)(ws + A.wl.off_res); c.res_I = (unsigned *)(c.res_J + 3 * DG_CHUNK); c.rf = (int (*)[5])(c.res_I + 3 * DG_CHUNK);
+    c.seeds = S->seeds2[0]; c.draws = S->draws2[0];
     c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0;
     for (int i = 0; i < 8; i++) c.dbg[i] = 0;
     dg_pt *Pw; int *pool;
@@ -199,70 +257,26 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
     int done = 0;
 
     /* srand(seed0); seed = rand() */
-    if (tid == 0) { dg_srand(&S->rng, A.seeds[pair]); S->seeds[0] = (unsigned)dg_rand(&S->rng); }
+    if (tid == 0) { dg_srand(&S->rng, A.seeds[pair]); S->itmp[31] = dg_rand(&S->rng); }
     __syncthreads();
-    unsigned seed = S->seeds[0];
+    unsigned seed = (unsigned)S->itmp[31];
     __syncthreads();
 
     long long ph[8] = {0,0,0,0,0,0,0,0}, tq = wall_clock64(), tq2;
 #define DG_PH(i) do { tq2 = wall_clock64(); ph[i] += tq2 - tq; tq = tq2; } while (0)
-    while (!done && no_sam < max_sam) {
-        /* ================= speculate: DG_CHUNK samples ================= */
-        DG_PH(3);
-        int chunk = max_sam - no_sam; if (chunk > DG_CHUNK) chunk = DG_CHUNK;
-        if (wave == 0) {
-            /* seed chain: seed_{k+1} = output #8 after srand(seed_k); lane j carries the term C[7][j] * r_j */
-            const unsigned gk = lane < 31 ? dg_rng_G[lane] : 0u, ck = lane < 31 ? dg_rng_C[7][lane] : 0u;   /* r_j = seed * 16807^j mod (2^31-1) */
-            unsigned sd = seed;
-            for (int k = 0; k < chunk; k++) {
-                if (lane == 0) S->seeds[k] = sd;
-                unsigned s1 = sd ? sd : 1u;                      /* rand() outputs are < 2^31: Schrage == exact mulmod */
-                unsigned rj = lane == 0 ? s1 : dg_mulmod31(s1, gk);
-                sd = dg_wave_sum_u(ck * rj) >> 1;
-            }
-            if (lane == 0) S->itmp[31] = (int)sd;
-        }
+    /* software pipeline: chunk c+1 is sampled by wave 0 while waves 1.. score chunk c */
+    int cur = 0, chunk_s[2] = {0, 0}, chunk_base = 0;
+    {
+        int cn = max_sam - no_sam; if (cn > DG_CHUNK) cn = DG_CHUNK; if (cn < 0) cn = 0;
+        chunk_s[0] = cn;
+        if (wave == 0 && cn > 0) { unsigned sd = dg_sample_chunk<7, LDSPTS>(seed, cn, n, pool, S->seeds2[0], S->draws2[0], lane); if (lane == 0) S->itmp[31] = (int)sd; }
         __syncthreads();
         seed = (unsigned)S->itmp[31];
-        if (tid < chunk) {
-            unsigned o[8];
-            dg_rng_outputs(S->seeds[tid], o);
-#pragma unroll
-            for (int i = 0; i < 7; i++) S->draws[tid][i] = (int)(o[i] % (unsigned)(n - i));
-        }
-        __syncthreads();
-        if (wave == 0) {
-            /* rtools.c:12-23 pool swaps: lanes 0..6 own one draw each; the 7 tail slots live in registers */
-            int *vp = pool;
-            int t = (lane < 7) ? vp[n - 1 - lane] : 0;
-            int s_next = (lane < 7) ? S->draws[0][lane] : (-1 - lane);
-            for (int k = 0; k < chunk; k++) {
-                const int s = s_next;
-                if (k + 1 < chunk) s_next = (lane < 7) ? S->draws[k + 1][lane] : (-1 - lane);
-                bool alias = (lane < 7) && (s >= n - 7);
-                /* duplicate draws among the active lanes (idle lanes hold distinct negatives): row rotates on the VALU */
-                alias = alias || (dg_dpp<DG_DPP_ROR(1)>(s) == s) || (dg_dpp<DG_DPP_ROR(2)>(s) == s) || (dg_dpp<DG_DPP_ROR(3)>(s) == s)
-                              || (dg_dpp<DG_DPP_ROR(4)>(s) == s) || (dg_dpp<DG_DPP_ROR(5)>(s) == s) || (dg_dpp<DG_DPP_ROR(6)>(s) == s);
-                if (__any(alias)) {
-                    if (lane < 7) vp[n - 1 - lane] = t;
-                    if (!LDSPTS) __threadfence_block();
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane == 0) {
-                        for (int i = 0; i < 7; i++) { int si = S->draws[k][i], j = n - 1 - i, q = vp[si]; vp[si] = vp[j]; vp[j] = q; S->draws[k][i] = q; }
-                    }
-                    if (!LDSPTS) __threadfence_block();
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane < 7) t = vp[n - 1 - lane];
-                } else if (lane < 7) {
-                    int q = vp[s]; vp[s] = t; t = q; S->draws[k][lane] = q;
-                    if (!LDSPTS) __threadfence_block();
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (lane < 7) vp[n - 1 - lane] = t;
-        }
-        __syncthreads();
-
+    }
+    while (!done && no_sam < max_sam) {
+        int chunk = chunk_s[cur]; if (chunk > max_sam - no_sam) chunk = max_sam - no_sam;
+        c.seeds = S->seeds2[cur]; c.draws = S->draws2[cur]; chunk_base = no_sam;
+        DG_PH(3);
         DG_PH(0);
         /* ================= solve: one 7-point problem per lane ================= */
         double fm[3][9]; int nvalid = 0; unsigned char rix[3] = {0, 0, 0}; int nullbad = 0;
@@ -271,7 +285,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
             double m[7][9];
 #pragma unroll
             for (int i = 0; i < 7; i++) {
-                sp[i] = P[S->draws[tid][i]];
+                sp[i] = P[c.draws[tid][i]];
                 double a[3] = {sp[i].x1, sp[i].y1, 1.0}, b[3] = {sp[i].x2, sp[i].y2, 1.0};
 #pragma unroll
                 for (int k = 0; k < 3; k++)
@@ -334,30 +348,39 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
         const int Mtot = S->moff[DG_CHUNK];
 
         DG_PH(1);
-        /* ================= score: one wave per model, points streamed from LDS ================= */
-        for (int mi = wave; mi < Mtot; mi += DG_NW) {
-            double F[9];
-            const double *g = c.gmodels + (size_t)mi * 9;
+        /* ====== score chunk c (waves 1..NW-1: one wave per model, points streamed from LDS)  ||  sample chunk c+1 (wave 0) ====== */
+        const int nxt = cur ^ 1;
+        {
+            int cn = max_sam - (no_sam + chunk_s[cur]); if (cn > DG_CHUNK) cn = DG_CHUNK; if (cn < 0) cn = 0;
+            chunk_s[nxt] = cn;
+            if (wave == 0) {
+                if (cn > 0) { unsigned sd = dg_sample_chunk<7, LDSPTS>(seed, cn, n, pool, S->seeds2[nxt], S->draws2[nxt], lane); if (lane == 0) S->itmp[31] = (int)sd; }
+            } else {
+                for (int mi = wave - 1; mi < Mtot; mi += DG_NW - 1) {
+                    double F[9];
+                    const double *g = c.gmodels + (size_t)mi * 9;
 #pragma unroll
-            for (int j = 0; j < 9; j++) F[j] = g[j];
-            unsigned cI = 0; double acc[DG_NW]; const double t94 = th * 9 / 4;
+                    for (int j = 0; j < 9; j++) F[j] = g[j];
+                    unsigned cI = 0; double acc[DG_NW]; const double t94 = th * 9 / 4;
 #pragma unroll
-            for (int r = 0; r < DG_NW; r++) acc[r] = 0;
-            for (int base = 0; base < n; base += 64 * DG_NW) {
+                    for (int r = 0; r < DG_NW; r++) acc[r] = 0;
+                    for (int base = 0; base < n; base += 64 * DG_NW) {
 #pragma unroll
-                for (int r = 0; r < DG_NW; r++) {
-                    int p = base + 64 * r + lane; bool act = p < n; double d = 0;
-                    if (act) { dg_pt q = P[p]; d = dg_Ferr(mk_full, F, q); }
-                    double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
-                    acc[r] += term; cI += (act && d <= th) ? 1u : 0u;
+                        for (int r = 0; r < DG_NW; r++) {
+                            int p = base + 64 * r + lane; bool act = p < n; double d = 0;
+                            if (act) { dg_pt q = P[p]; d = dg_Ferr(mk_full, F, q); }
+                            double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
+                            acc[r] += term; cI += (act && d <= th) ? 1u : 0u;
+                        }
+                    }
+                    unsigned I = dg_wave_sum_u(cI); double J = dg_J_combine(acc);
+                    if (lane == 0) { c.res_I[mi] = I; c.res_J[mi] = J; }
                 }
             }
-            unsigned I = dg_wave_sum_u(cI); double J = dg_J_combine(acc);
-            if (lane == 0) { S->res_I[mi] = I; S->res_J[mi] = J; }
         }
         c.n_fds += Mtot;   /* provisional: models past the termination point are subtracted below */
         __syncthreads();
-
+        if (chunk_s[nxt] > 0) seed = (unsigned)S->itmp[31];
         DG_PH(2);
         /* ================= commit: replay exp_ranF.c:1334-1577 in order ================= */
         int k;
@@ -370,7 +393,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
                 const double tau = maxS.J < maxSs.J ? maxS.J : maxSs.J;
                 bool ev = false;
                 if (tid >= k && tid < chunk && S->nv[tid] != 255)
-                    for (int r = 0; r < S->nv[tid]; r++) ev = ev || (tau < S->res_J[S->moff[tid] + r]);
+                    for (int r = 0; r < S->nv[tid]; r++) ev = ev || (tau < c.res_J[S->moff[tid] + r]);
                 unsigned long long bal = __ballot(ev);
                 __syncthreads();
                 if (lane == 0) S->wave_cnt[wave] = bal ? (unsigned)(wave * 64 + __ffsll((long long)bal) - 1) : 0xffffffffu;
@@ -388,7 +411,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
             int new_max = 0, do_iterate = 0, rng_ready = 0, brk = 0;
             for (int r = 0; r < nvk && !brk; r++) {
                 const int mi = S->moff[k] + r, ri = S->ridx[k][r];
-                dg_score Sc = {S->res_I[mi], S->res_J[mi], 0, 0};
+                dg_score Sc = {c.res_I[mi], c.res_J[mi], 0, 0};
                 const int phys = perm[ri];
                 const bool ev1 = maxS.J < Sc.J, ev2 = maxSs.J < Sc.J;
                 if (!(ev1 || ev2)) {
@@ -421,7 +444,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
                     if (pr.degen) {
                         __syncthreads();
                         if (tid < 7) {                                 /* u7 in samidx order = reverse draw order */
-                            dg_pt q = P[S->draws[k][6 - tid]];
+                            dg_pt q = P[c.draws[k][6 - tid]];
                             S->u7[tid][0] = q.x1; S->u7[tid][1] = q.y1; S->u7[tid][2] = q.x2; S->u7[tid][3] = q.y2;
                         }
                         __syncthreads();
@@ -433,7 +456,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
                         DG_PH(3);
                         if (!rng_ready) {
                             __syncthreads();
-                            if (tid == 0) { dg_srand(&S->rng, S->seeds[k]); for (int i = 0; i < 8; i++) dg_rand(&S->rng); }
+                            if (tid == 0) { dg_srand(&S->rng, c.seeds[k]); for (int i = 0; i < 8; i++) dg_rand(&S->rng); }
                             __syncthreads();
                             rng_ready = 1;
                         }
@@ -467,7 +490,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
                         p4 = phys;                                  /* errs[4] = d */
                         __syncthreads();
                         if (tid < 9) { e4F[tid] = S->f[tid]; S->FBest[tid] = S->f[tid]; }
-                        if (tid < 7) S->samidxBest[tid] = S->draws[k][6 - tid];
+                        if (tid < 7) S->samidxBest[tid] = c.draws[k][6 - tid];
                         e4kind = mk_full;
                         __syncthreads();
                         non_degen++;
@@ -479,7 +502,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
             if (do_iterate) {
                 if (!rng_ready) {
                     __syncthreads();
-                    if (tid == 0) { dg_srand(&S->rng, S->seeds[k]); for (int i = 0; i < 8; i++) dg_rand(&S->rng); }
+                    if (tid == 0) { dg_srand(&S->rng, c.seeds[k]); for (int i = 0; i < 8; i++) dg_rand(&S->rng); }
                     __syncthreads();
                     rng_ready = 1;
                 }
@@ -515,6 +538,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
         if (k < chunk) { c.n_fds -= (Mtot - (int)S->moff[k]); done = 1; }
         else if (no_sam >= max_sam) done = 1;
         __syncthreads();
+        if (!done) cur = nxt;
     }
 
     /* ---- "If there were no LOs, do at least one NOW!"  exp_ranF.c:1580-1697 ---- */
@@ -538,8 +562,8 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
         if (tid == 0) {
             /* S->seeds[] of the last chunk still holds the per-iteration seeds; the last executed
              * iteration is no_sam (1-based) => index (no_sam-1) % DG_CHUNK within its chunk */
-            int li = (no_sam - 1) % DG_CHUNK;
-            dg_srand(&S->rng, S->seeds[li]); for (int i = 0; i < 8; i++) dg_rand(&S->rng);
+            int li = no_sam - 1 - chunk_base; if (li < 0) li = 0;
+            dg_srand(&S->rng, c.seeds[li]); for (int i = 0; i < 8; i++) dg_rand(&S->rng);
         }
         __syncthreads();
         if (degenerate) {

@@ -271,6 +271,8 @@ __global__ __launch_bounds__(DG_T) void dg_find_homography_kernel(dg_args A)
     c.ht.heads = (int *)(ws + A.wl.off_ht); c.ht.count = c.ht.heads + 64; c.ht.ent = c.ht.heads + 80;
     c.gmodels = (double *)(ws + A.wl.off_models);
     c.stage = (dg_pt *)(ws + A.wl.off_stage);
+    c.res_J = (double *)(ws + A.wl.off_res); c.res_I = (unsigned *)(c.res_J + 3 * DG_CHUNK); c.rf = (int (*)[5])(c.res_I + 3 * DG_CHUNK);
+    c.seeds = S->seeds2[0]; c.draws = S->draws2[0];
     c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0;
     dg_pt *Pw; int *pool;
     if (LDSPTS) { Pw = (dg_pt *)dyn_smem; pool = (int *)(dyn_smem + (size_t)n * sizeof(dg_pt)); }
@@ -291,71 +293,29 @@ __global__ __launch_bounds__(DG_T) void dg_find_homography_kernel(dg_args A)
     int best_sample = 0, accepted = 0, done = 0; long long t_best = t_start;
     double *e4 = S->FBest;                                   /* model behind errs[4] (last so-far-best sample) */
 
-    if (tid == 0) { dg_srand(&S->rng, A.seeds[pair]); S->seeds[0] = (unsigned)dg_rand(&S->rng); }
+    if (tid == 0) { dg_srand(&S->rng, A.seeds[pair]); S->itmp[31] = dg_rand(&S->rng); }
     __syncthreads();
-    unsigned seed = S->seeds[0];
+    unsigned seed = (unsigned)S->itmp[31];
     __syncthreads();
 
-    while (!done && no_sam < max_sam) {
-        int chunk = max_sam - no_sam; if (chunk > DG_CHUNK) chunk = DG_CHUNK;
-        /* ---- speculate: seeds (5th output), 4 draws, pool swaps ---- */
-        if (wave == 0) {
-            /* seed chain: seed_{k+1} = output #5 after srand(seed_k); lane j carries the term C[4][j] * r_j */
-            const unsigned gk = lane < 31 ? dg_rng_G[lane] : 0u, ck = lane < 31 ? dg_rng_C[4][lane] : 0u;
-            unsigned sd = seed;
-            for (int k = 0; k < chunk; k++) {
-                if (lane == 0) S->seeds[k] = sd;
-                unsigned s1 = sd ? sd : 1u;
-                unsigned rj = lane == 0 ? s1 : dg_mulmod31(s1, gk);
-                sd = dg_wave_sum_u(ck * rj) >> 1;
-            }
-            if (lane == 0) S->itmp[31] = (int)sd;
-        }
+    /* software pipeline: chunk c+1 is sampled by wave 0 while waves 1.. score chunk c */
+    int cur = 0, chunk_s[2] = {0, 0}, chunk_base = 0;
+    {
+        int cn = max_sam - no_sam; if (cn > DG_CHUNK) cn = DG_CHUNK; if (cn < 0) cn = 0;
+        chunk_s[0] = cn;
+        if (wave == 0 && cn > 0) { unsigned sd = dg_sample_chunk<4, LDSPTS>(seed, cn, n, pool, S->seeds2[0], S->draws2[0], lane); if (lane == 0) S->itmp[31] = (int)sd; }
         __syncthreads();
         seed = (unsigned)S->itmp[31];
-        if (tid < chunk) {
-            unsigned o[8];
-            dg_rng_outputs(S->seeds[tid], o);
-#pragma unroll
-            for (int i = 0; i < 4; i++) S->draws[tid][i] = (int)(o[i] % (unsigned)(n - i));
-        }
-        __syncthreads();
-        if (wave == 0) {
-            int *vp = pool;
-            int t = (lane < 4) ? vp[n - 1 - lane] : 0;
-            int s_next = (lane < 4) ? S->draws[0][lane] : (-1 - lane);
-            for (int k = 0; k < chunk; k++) {
-                const int s = s_next;
-                if (k + 1 < chunk) s_next = (lane < 4) ? S->draws[k + 1][lane] : (-1 - lane);
-                bool alias = (lane < 4) && (s >= n - 4);
-                /* duplicate draws among the active lanes (idle lanes hold distinct negatives): row rotates on the VALU */
-                alias = alias || (dg_dpp<DG_DPP_ROR(1)>(s) == s) || (dg_dpp<DG_DPP_ROR(2)>(s) == s) || (dg_dpp<DG_DPP_ROR(3)>(s) == s);
-                if (__any(alias)) {
-                    if (lane < 4) vp[n - 1 - lane] = t;
-                    if (!LDSPTS) __threadfence_block();
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane == 0) {
-                        for (int i = 0; i < 4; i++) { int si = S->draws[k][i], j = n - 1 - i, q = vp[si]; vp[si] = vp[j]; vp[j] = q; S->draws[k][i] = q; }
-                    }
-                    if (!LDSPTS) __threadfence_block();
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane < 4) t = vp[n - 1 - lane];
-                } else if (lane < 4) {
-                    int q = vp[s]; vp[s] = t; t = q; S->draws[k][lane] = q;
-                    if (!LDSPTS) __threadfence_block();
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (lane < 4) vp[n - 1 - lane] = t;
-        }
-        __syncthreads();
-
+    }
+    while (!done && no_sam < max_sam) {
+        int chunk = chunk_s[cur]; if (chunk > max_sam - no_sam) chunk = max_sam - no_sam;
+        c.seeds = S->seeds2[cur]; c.draws = S->draws2[cur]; chunk_base = no_sam;
         /* ---- solve: orientation test, 8x9 null vector, near-singularity test; <= 1 model per lane ---- */
         double hm[9], H1m[9]; int valid = 0;
         if (tid < chunk) {
             dg_pt sp[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) sp[i] = P[S->draws[tid][i]];
+            for (int i = 0; i < 4; i++) sp[i] = P[c.draws[tid][i]];
             if (dg_Hori_valid4(sp)) {
                 double m[8][9];
 #pragma unroll
@@ -408,30 +368,40 @@ __global__ __launch_bounds__(DG_T) void dg_find_homography_kernel(dg_args A)
         }
         const int Mtot = S->moff[DG_CHUNK];
 
-        /* ---- score: one wave per model ---- */
-        for (int mi = wave; mi < Mtot; mi += DG_NW) {
-            double H[9], Hinv[9], H1[9];
-            const double *g = c.gmodels + (size_t)mi * 18;
+        /* ---- score chunk c (waves 1..NW-1, one wave per model)  ||  sample chunk c+1 (wave 0) ---- */
+        const int nxt = cur ^ 1;
+        {
+            int cn = max_sam - (no_sam + chunk_s[cur]); if (cn > DG_CHUNK) cn = DG_CHUNK; if (cn < 0) cn = 0;
+            chunk_s[nxt] = cn;
+            if (wave == 0) {
+                if (cn > 0) { unsigned sd = dg_sample_chunk<4, LDSPTS>(seed, cn, n, pool, S->seeds2[nxt], S->draws2[nxt], lane); if (lane == 0) S->itmp[31] = (int)sd; }
+            } else {
+                for (int mi = wave - 1; mi < Mtot; mi += DG_NW - 1) {
+                    double H[9], Hinv[9], H1[9];
+                    const double *g = c.gmodels + (size_t)mi * 18;
 #pragma unroll
-            for (int j = 0; j < 9; j++) { H[j] = g[j]; H1[j] = g[9+j]; }
-            Hinv[0] = H[0]; Hinv[1] = H[3]; Hinv[2] = H[6]; Hinv[3] = H[1]; Hinv[4] = H[4]; Hinv[5] = H[7]; Hinv[6] = H[2]; Hinv[7] = H[5]; Hinv[8] = H[8];
-            unsigned cI = 0; double acc[DG_NW]; const double t94 = th * 9 / 4;
+                    for (int j = 0; j < 9; j++) { H[j] = g[j]; H1[j] = g[9+j]; }
+                    Hinv[0] = H[0]; Hinv[1] = H[3]; Hinv[2] = H[6]; Hinv[3] = H[1]; Hinv[4] = H[4]; Hinv[5] = H[7]; Hinv[6] = H[2]; Hinv[7] = H[5]; Hinv[8] = H[8];
+                    unsigned cI = 0; double acc[DG_NW]; const double t94 = th * 9 / 4;
 #pragma unroll
-            for (int r = 0; r < DG_NW; r++) acc[r] = 0;
-            for (int base = 0; base < n; base += 64 * DG_NW) {
+                    for (int r = 0; r < DG_NW; r++) acc[r] = 0;
+                    for (int base = 0; base < n; base += 64 * DG_NW) {
 #pragma unroll
-                for (int r = 0; r < DG_NW; r++) {
-                    int p = base + 64 * r + lane; bool act = p < n; double d = 0;
-                    if (act) { dg_pt q = P[p]; d = dg_Herr(kind, H, Hinv, H1, q); }
-                    double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
-                    acc[r] += term; cI += (act && d <= th) ? 1u : 0u;
+                        for (int r = 0; r < DG_NW; r++) {
+                            int p = base + 64 * r + lane; bool act = p < n; double d = 0;
+                            if (act) { dg_pt q = P[p]; d = dg_Herr(kind, H, Hinv, H1, q); }
+                            double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
+                            acc[r] += term; cI += (act && d <= th) ? 1u : 0u;
+                        }
+                    }
+                    unsigned I = dg_wave_sum_u(cI); double J = dg_J_combine(acc);
+                    if (lane == 0) { c.res_I[mi] = I; c.res_J[mi] = J; }
                 }
             }
-            unsigned I = dg_wave_sum_u(cI); double J = dg_J_combine(acc);
-            if (lane == 0) { S->res_I[mi] = I; S->res_J[mi] = J; }
         }
         c.n_hds += Mtot;
         __syncthreads();
+        if (chunk_s[nxt] > 0) seed = (unsigned)S->itmp[31];
 
         /* ---- commit: replay exp_ranH.c:547-757 in order ---- */
         int k;
@@ -442,7 +412,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_homography_kernel(dg_args A)
                  * has run yet) any scored sample, which fires the first LO (exp_ranH.c:639-640) */
                 const double tau = maxS.J < maxSs.J ? maxS.J : maxSs.J;
                 const bool first_lo = iter_cnt == 0 && maxSs.I > 4;
-                bool ev = tid >= k && tid < chunk && S->nv[tid] && (first_lo || tau < S->res_J[S->moff[tid]]);
+                bool ev = tid >= k && tid < chunk && S->nv[tid] && (first_lo || tau < c.res_J[S->moff[tid]]);
                 unsigned long long bal = __ballot(ev);
                 __syncthreads();
                 if (lane == 0) S->wave_cnt[wave] = bal ? (unsigned)(wave * 64 + __ffsll((long long)bal) - 1) : 0xffffffffu;
@@ -458,7 +428,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_homography_kernel(dg_args A)
             no_sam++;
             if (!S->nv[k]) { no_rej++; continue; }
             const int mi = S->moff[k];
-            dg_score Sc = {S->res_I[mi], S->res_J[mi], 0, 0};
+            dg_score Sc = {c.res_I[mi], c.res_J[mi], 0, 0};
             int new_max = 0, do_iterate = 0;
             const bool ev1 = maxS.J < Sc.J;
             if (ev1 || maxSs.J < Sc.J) {
@@ -489,7 +459,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_homography_kernel(dg_args A)
             if (no_sam >= DG_ITER_SAM && iter_cnt == 0 && maxSs.I > 4) do_iterate = 1;
             if (do_iterate) {
                 __syncthreads();
-                if (tid == 0) { dg_srand(&S->rng, S->seeds[k]); for (int i = 0; i < 5; i++) dg_rand(&S->rng); }
+                if (tid == 0) { dg_srand(&S->rng, c.seeds[k]); for (int i = 0; i < 5; i++) dg_rand(&S->rng); }
                 __syncthreads();
                 iter_cnt++;
                 if (dg_h_lo(c, kind, e4, th, maxS, &iterID, &p1_inliers, no_sam)) { new_max = 1; accepted = 1; best_sample = no_sam; t_best = wall_clock64(); }
@@ -502,12 +472,13 @@ __global__ __launch_bounds__(DG_T) void dg_find_homography_kernel(dg_args A)
         if (k < chunk) { c.n_hds -= (Mtot - (int)S->moff[k]); done = 1; }
         else if (no_sam >= max_sam) done = 1;
         __syncthreads();
+        if (!done) cur = nxt;
     }
 
     /* ---- "If there were no LOs, do at least one NOW!"  exp_ranH.c:759-862 ---- */
     if (iter_cnt == 0) {
         __syncthreads();
-        if (tid == 0 && no_sam > 0) { int li = (no_sam - 1) % DG_CHUNK; dg_srand(&S->rng, S->seeds[li]); for (int i = 0; i < 5; i++) dg_rand(&S->rng); }
+        if (tid == 0 && no_sam > 0) { int li = no_sam - 1 - chunk_base; if (li < 0) li = 0; dg_srand(&S->rng, c.seeds[li]); for (int i = 0; i < 5; i++) dg_rand(&S->rng); }
         __syncthreads();
         iter_cnt++;
         if (dg_h_lo(c, kind, e4, th, maxS, &iterID, &p1_inliers, no_sam)) { accepted = 1; best_sample = no_sam; t_best = wall_clock64(); }

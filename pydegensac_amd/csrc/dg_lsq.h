@@ -25,7 +25,6 @@ struct dg_lsq_scratch {
 struct dg_wave_ws {
     double Z[14 * 9], V[81], D[9], A1[3], A2[3], px[14 * 4];
     dg_eig_ws ews;
-    double hw[17 * 9 + 32];    /* Hdetect's 3x3 temporaries + svduv work vectors */
     double H[9], F[9], Ds[7], sDs[7], cpx[20];
     int idx[8], res, cnt;
 };

@@ -99,6 +99,7 @@ static dg_ws_layout make_layout(int n_max, bool pts_in_ws)
     w.off_ht = o;     o += align_up((size_t)(80 + 4 * DG_HT_CAP) * sizeof(int), 256);
     w.off_models = o; o += align_up((size_t)3 * DG_CHUNK * 9 * sizeof(double), 256);
     w.off_stage = o;  o += align_up((size_t)n_max * sizeof(dg_pt), 256);
+    w.off_res = o;    o += align_up((size_t)3 * DG_CHUNK * 12 + (size_t)DG_CHUNK * 20, 256);
     w.off_pts = o;    if (pts_in_ws) o += align_up((size_t)n_max * sizeof(dg_pt), 256);
     w.off_pool = o;   if (pts_in_ws) o += align_up((size_t)n_max * sizeof(int), 256);
     w.stride = align_up(o, 4096);
@@ -288,22 +289,18 @@ extern "C" int mi_degensac_score_models(const double *pts1, const double *pts2, 
 
 __global__ void dg_sample_stream_kernel(unsigned seed0, int n, int ssz, int iters, int *pool, int *out)
 {
-    /* same three steps as the main kernel: wave-cooperative seed chain, per-lane draws, pool swaps (here by lane 0) */
+    /* the main kernels' sampler (dg_sample_chunk), chunk by chunk, run by one wave */
     __shared__ unsigned seeds[DG_CHUNK]; __shared__ int draws[DG_CHUNK][8]; __shared__ dg_rng g; __shared__ unsigned sd0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < n; i += blockDim.x) pool[i] = i;
-    if (tid == 0) { dg_srand(&g, seed0); sd0 = (unsigned)dg_rand(&g); }
+    const int lane = threadIdx.x;
+    for (int i = lane; i < n; i += 64) pool[i] = i;
+    if (lane == 0) { dg_srand(&g, seed0); sd0 = (unsigned)dg_rand(&g); }
     __syncthreads();
     unsigned seed = sd0;
     for (int base = 0; base < iters; base += DG_CHUNK) {
         int chunk = iters - base; if (chunk > DG_CHUNK) chunk = DG_CHUNK;
+        seed = ssz == 7 ? dg_sample_chunk<7, false>(seed, chunk, n, pool, seeds, draws, lane) : dg_sample_chunk<4, false>(seed, chunk, n, pool, seeds, draws, lane);
         __syncthreads();
-        if (wave == 0) { unsigned sd = seed; for (int k = 0; k < chunk; k++) { if (lane == 0) seeds[k] = sd; sd = dg_rng_next_seed_wave(sd, lane); } if (lane == 0) sd0 = sd; }
-        __syncthreads();
-        seed = sd0;
-        if (tid < chunk) { unsigned o[8]; dg_rng_outputs(seeds[tid], o); for (int i = 0; i < ssz; i++) draws[tid][i] = (int)(o[i] % (unsigned)(n - i)); }
-        __syncthreads();
-        if (tid == 0) for (int k = 0; k < chunk; k++) for (int i = 0; i < ssz; i++) { int s = draws[k][i], j = n - 1 - i, q = pool[s]; pool[s] = pool[j]; pool[j] = q; out[(size_t)(base + k) * ssz + i] = q; }
+        for (int k = lane; k < chunk; k += 64) for (int i = 0; i < ssz; i++) out[(size_t)(base + k) * ssz + i] = draws[k][i];
         __syncthreads();
     }
 }
@@ -311,10 +308,10 @@ __global__ void dg_sample_stream_kernel(unsigned seed0, int n, int ssz, int iter
 extern "C" int mi_degensac_sample_stream(uint32_t seed, int n, int sample_size, int iters, int device, int32_t *samples)
 {
     int rc = dev_init(device); if (rc) return rc;
-    if (sample_size < 1 || sample_size > 7 || n < sample_size) { set_err("bad sample size"); return MI_DEGENSAC_EINVAL; }
+    if ((sample_size != 4 && sample_size != 7) || n < sample_size + 1) { set_err("bad sample size"); return MI_DEGENSAC_EINVAL; }
     DevBuf<int> dpool, dout;
     if (dpool.alloc(n) || dout.alloc((size_t)iters * sample_size)) { set_err("device allocation failed"); return MI_DEGENSAC_ENOMEM; }
-    hipLaunchKernelGGL(dg_sample_stream_kernel, dim3(1), dim3(DG_T), 0, 0, seed, n, sample_size, iters, dpool.p, dout.p);
+    hipLaunchKernelGGL(dg_sample_stream_kernel, dim3(1), dim3(64), 0, 0, seed, n, sample_size, iters, dpool.p, dout.p);
     HIPCHK(hipGetLastError()); HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(samples, dout.p, (size_t)iters * sample_size * 4, hipMemcpyDeviceToHost));
     return 0;

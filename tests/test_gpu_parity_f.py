@@ -55,3 +55,38 @@ def test_fundamental_matches_oracle(oracle_port, name, gen, kw, seed):
         assert np.abs(F).sum() == 0
     else:
         assert relF(F, Fo) < 1e-6
+
+
+def test_sample_stream_matches_glibc_replay(oracle_port):
+    """the device sampler (seed chain + draws + pool swaps) against the oracle's libc-faithful replay"""
+    import ctypes as C
+    from pydegensac_amd import _lib
+    L = _lib.lib()
+    for ssz, n, iters in [(7, 2000, 700), (4, 5000, 600), (7, 9, 300), (4, 5, 300)]:
+        out = np.zeros((iters, ssz), np.int32)
+        _lib.check(L.mi_degensac_sample_stream(12345, n, ssz, iters, 0, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        ref = np.zeros((iters, ssz), np.int32)
+        oracle_port.lib().dg_oracle_sample_stream(C.c_uint(12345), n, ssz, iters, oracle_port.ip(ref), None)
+        assert np.array_equal(out[:, ::-1], ref)        # the oracle lists samidx order = reverse draw order
+
+
+def test_scoring_kernel_residuals_bit_exact(oracle_port):
+    import ctypes as C
+    from pydegensac_amd import _lib
+    L = _lib.lib()
+    p1, p2, lab, Fgt = syn.two_view_fundamental(3000, 0.4, 0.1, seed=0)
+    n = 3000
+    rng = np.random.default_rng(0)
+    models = np.concatenate([Fgt.reshape(1, 9), rng.normal(size=(15, 9))]).copy()
+    u = np.ones((n, 6)); u[:, 0:2] = p1; u[:, 3:5] = p2
+    for kind, fn in [(0, "dg_oracle_FDs"), (1, "dg_oracle_FDsSym"), (10, "dg_oracle_HDs")]:
+        I = np.zeros(16, np.uint32); J = np.zeros(16); res = np.zeros((16, n))
+        _lib.check(L.mi_degensac_score_models(_lib.dptr(p1), _lib.dptr(p2), n, 2, _lib.dptr(models), 16, kind, 0.25, 0,
+                                              I.ctypes.data_as(C.POINTER(C.c_uint32)), _lib.dptr(J), _lib.dptr(res)))
+        for k in range(16):
+            d = np.zeros(n)
+            getattr(oracle_port.lib(), fn)(oracle_port.dp(u), oracle_port.dp(models[k].copy()), oracle_port.dp(d), n)
+            inl = np.zeros(n, np.int32)
+            S = oracle_port.lib().dg_oracle_inlidxs(oracle_port.dp(d), n, C.c_double(0.25), oracle_port.ip(inl))
+            assert np.array_equal(d, res[k]), (kind, k)                 # residuals bit-exact (IEEE div/sqrt, no contraction)
+            assert S.I == I[k] and abs(S.J - J[k]) <= 1e-12 * max(1.0, abs(S.J))
