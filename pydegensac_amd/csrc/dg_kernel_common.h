@@ -62,6 +62,7 @@ struct dg_args {
  * over Z/2^32, so they collapse into the constant 8 x 31 matrix C (filled by the host at load time
  * by running the generator on unit vectors).  G[j] = 16807^j mod (2^31-1). */
 __constant__ unsigned dg_rng_C[8][32];
+__constant__ unsigned dg_rng_Ct[32][8];     /* transposed copy: one 32-byte scalar load per term j */
 __constant__ unsigned dg_rng_G[32];
 
 __device__ __forceinline__ unsigned dg_mulmod31(unsigned a, unsigned b)
@@ -89,11 +90,12 @@ __device__ __forceinline__ void dg_rng_outputs(unsigned seed, unsigned *o)
     unsigned r1 = dg_lcg_first((int)seed);
     unsigned acc[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) acc[k] = dg_rng_C[k][0] * seed;
+    for (int k = 0; k < 8; k++) acc[k] = dg_rng_Ct[0][k] * seed;
+    (void)r1;
     for (int j = 1; j < 31; j++) {
-        unsigned rj = dg_mulmod31(r1, dg_rng_G[j - 1]);
+        unsigned rj = dg_mulmod31(seed < 0x7fffffffu ? seed : r1, seed < 0x7fffffffu ? dg_rng_G[j] : dg_rng_G[j - 1]);
 #pragma unroll
-        for (int k = 0; k < 8; k++) acc[k] += dg_rng_C[k][j] * rj;
+        for (int k = 0; k < 8; k++) acc[k] += dg_rng_Ct[j][k] * rj;
     }
 #pragma unroll
     for (int k = 0; k < 8; k++) o[k] = acc[k] >> 1;

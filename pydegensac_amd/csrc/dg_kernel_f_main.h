@@ -148,8 +148,10 @@ __device__ __forceinline__ dg_score dg_inFrani(CTX &c, int ninl, double th, doub
  * pool swaps (rtools.c:12-23).  Fills seeds[0..cn) and draws[k][0..NDRAW) (drawn ids in draw order) and
  * returns the seed of the sample after the chunk.  NDRAW = 7 (F) or 4 (H). */
 template <int NDRAW, bool LDSPTS>
-__device__ __forceinline__ unsigned dg_sample_chunk(unsigned seed, int cn, int n, int *pool, unsigned *seeds, int (*draws)[8], int lane)
+__device__ __forceinline__ unsigned dg_sample_chunk(unsigned seed, int cn, int n, int *pool, unsigned *seeds, int (*draws)[8], int lane, long long *dbg = 0)
 {
+    long long ts0 = wall_clock64();
+    __builtin_amdgcn_s_setprio(3);                        /* the serial wave must not queue behind the scoring waves */
     /* seed chain: lane j carries the term C[NDRAW][j] * r_j, r_j = seed * 16807^j mod (2^31-1) */
     const unsigned gk = lane < 31 ? dg_rng_G[lane] : 0u, ck = lane < 31 ? dg_rng_C[NDRAW][lane] : 0u;
     unsigned sd = seed;
@@ -160,26 +162,45 @@ __device__ __forceinline__ unsigned dg_sample_chunk(unsigned seed, int cn, int n
         sd = dg_wave_sum_u(ck * rj) >> 1;
     }
     DG_WSYNC();
-    for (int k = lane; k < cn; k += 64) {
-        unsigned o[8];
-        dg_rng_outputs(seeds[k], o);
+    long long ts1 = wall_clock64();
+    /* draws of every sample (lane = sample) + per-sample alias flag: two draws on the same position, or a draw
+     * inside the tail block, make the swaps of that sample order-dependent -> replayed sequentially below */
+    unsigned long long almask[DG_CHUNK / 64];
 #pragma unroll
-        for (int i = 0; i < NDRAW; i++) draws[k][i] = (int)(o[i] % (unsigned)(n - i));
+    for (int rd = 0; rd < DG_CHUNK / 64; rd++) {
+        const int k = rd * 64 + lane;
+        bool al = false;
+        if (k < cn) {
+            unsigned o[8]; int dr[NDRAW];
+            dg_rng_outputs(seeds[k], o);
+#pragma unroll
+            for (int i = 0; i < NDRAW; i++) { dr[i] = (int)(o[i] % (unsigned)(n - i)); draws[k][i] = dr[i]; al = al || dr[i] >= n - NDRAW; }
+#pragma unroll
+            for (int i = 0; i < NDRAW; i++)
+#pragma unroll
+                for (int j = i + 1; j < NDRAW; j++) al = al || dr[i] == dr[j];
+        }
+        almask[rd] = __ballot(al);
     }
     DG_WSYNC();
-    /* pool swaps: lanes 0..NDRAW-1 own one draw each; the NDRAW tail slots live in registers */
+    long long ts2 = wall_clock64();
+    /* pool swaps (rtools.c:12-23): lanes 0..NDRAW-1 own one draw each, the NDRAW tail slots live in registers.
+     * Software-pipelined: LDS operations of one wave execute in issue order (read_k, write_k, read_{k+1}, ...),
+     * so read_{k+1} is issued before read_k's result is consumed; draw positions are prefetched two ahead. */
     int *vp = pool;
-    int t = (lane < NDRAW) ? vp[n - 1 - lane] : 0;
-    int s_next = (lane < NDRAW) ? draws[0][lane] : (-1 - lane);
+    const bool act = lane < NDRAW;
+    int t = act ? vp[n - 1 - lane] : 0;
+#define DG_AL(k_) ((int)((almask[(k_) >> 6] >> ((k_) & 63)) & 1ull))
+    int s0 = act ? draws[0][lane] : 0, s1 = (act && cn > 1) ? draws[1][lane] : 0;
+    int al0 = DG_AL(0), al1 = cn > 1 ? DG_AL(1) : 1;
+    int r0 = (act && !al0) ? vp[s0] : 0;                  /* read_0 */
     for (int k = 0; k < cn; k++) {
-        const int s = s_next;
-        if (k + 1 < cn) s_next = (lane < NDRAW) ? draws[k + 1][lane] : (-1 - lane);
-        bool alias = (lane < NDRAW) && (s >= n - NDRAW);
-        /* duplicate draws among the active lanes (idle lanes hold distinct negatives): row rotates on the VALU */
-        alias = alias || (dg_dpp<DG_DPP_ROR(1)>(s) == s) || (dg_dpp<DG_DPP_ROR(2)>(s) == s) || (dg_dpp<DG_DPP_ROR(3)>(s) == s);
-        if (NDRAW > 4) alias = alias || (dg_dpp<DG_DPP_ROR(4)>(s) == s) || (dg_dpp<DG_DPP_ROR(5)>(s) == s) || (dg_dpp<DG_DPP_ROR(6)>(s) == s);
-        if (__any(alias)) {
-            if (lane < NDRAW) vp[n - 1 - lane] = t;
+        int s2 = (act && k + 2 < cn) ? draws[k + 2][lane] : 0;
+        int al2 = k + 2 < cn ? DG_AL(k + 2) : 1;
+        int r1 = 0;
+        if (al0) {
+            /* order-dependent sample: replay it sequentially on lane 0 */
+            if (act) vp[n - 1 - lane] = t;
             if (!LDSPTS) __threadfence_block();
             DG_WSYNC();
             if (lane == 0) {
@@ -187,15 +208,21 @@ __device__ __forceinline__ unsigned dg_sample_chunk(unsigned seed, int cn, int n
             }
             if (!LDSPTS) __threadfence_block();
             DG_WSYNC();
-            if (lane < NDRAW) t = vp[n - 1 - lane];
-        } else if (lane < NDRAW) {
-            int q = vp[s]; vp[s] = t; t = q; draws[k][lane] = q;
+            if (act) t = vp[n - 1 - lane];
+            if (act && !al1 && k + 1 < cn) r1 = vp[s1];
+        } else {
+            if (act) vp[s0] = t;                                          /* write_k  (t = result of read_{k-1}) */
             if (!LDSPTS) __threadfence_block();
+            if (act && !al1 && k + 1 < cn) r1 = vp[s1];                   /* read_{k+1} */
+            if (act) { t = r0; draws[k][lane] = r0; }                     /* consume read_k */
         }
-        __builtin_amdgcn_wave_barrier();
+        s0 = s1; s1 = s2; al0 = al1; al1 = al2; r0 = r1;
     }
-    if (lane < NDRAW) vp[n - 1 - lane] = t;
+#undef DG_AL
+    if (act) vp[n - 1 - lane] = t;
     DG_WSYNC();
+    __builtin_amdgcn_s_setprio(0);
+    if (dbg) { long long ts3 = wall_clock64(); dbg[4] += ts1 - ts0; dbg[5] += ts2 - ts1; dbg[6] += ts3 - ts2; }
     return sd;
 }
 
@@ -354,7 +381,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
             int cn = max_sam - (no_sam + chunk_s[cur]); if (cn > DG_CHUNK) cn = DG_CHUNK; if (cn < 0) cn = 0;
             chunk_s[nxt] = cn;
             if (wave == 0) {
-                if (cn > 0) { unsigned sd = dg_sample_chunk<7, LDSPTS>(seed, cn, n, pool, S->seeds2[nxt], S->draws2[nxt], lane); if (lane == 0) S->itmp[31] = (int)sd; }
+                if (cn > 0) { unsigned sd = dg_sample_chunk<7, LDSPTS>(seed, cn, n, pool, S->seeds2[nxt], S->draws2[nxt], lane, c.dbg); if (lane == 0) S->itmp[31] = (int)sd; }
             } else {
                 for (int mi = wave - 1; mi < Mtot; mi += DG_NW - 1) {
                     double F[9];

@@ -75,6 +75,7 @@ static int dev_init(int device)
         unsigned C[8][32], G[32]; rng_tables(C, G);
         HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(dg_rng_C), C, sizeof C));
         HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(dg_rng_G), G, sizeof G));
+        { unsigned Ct[32][8]; for (int j = 0; j < 32; j++) for (int k = 0; k < 8; k++) Ct[j][k] = C[k][j]; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(dg_rng_Ct), Ct, sizeof Ct)); }
         d.max_lds = (int)prop.sharedMemPerBlock;
         hipFuncAttributes fa; HIPCHK(hipFuncGetAttributes(&fa, (const void *)dg_find_fundamental_kernel<true>));
         d.dyn_f = d.max_lds - (int)fa.sharedSizeBytes - 256;          /* what is left of the 160 KiB after the static LDS */
@@ -163,6 +164,7 @@ static int launch_batch(int homography, const double *d_p1, const double *d_p2, 
     if (n_min < min_pts) { set_err(homography ? "need n >= 4 correspondences" : "need n >= 8 correspondences"); return MI_DEGENSAC_EINVAL; }
     size_t dyn = (size_t)n_max * (sizeof(dg_pt) + sizeof(int));
     bool in_lds = dyn <= (size_t)(homography ? g_dev[device].dyn_h : g_dev[device].dyn_f);
+    if (getenv("MI_DEGENSAC_FORCE_GLOBAL")) in_lds = false;     /* development switch: point set in HBM/L2 instead of LDS */
     A.wl = make_layout(n_max, !in_lds);
     char *ws; rc = ensure_ws(device, A.wl.stride * (size_t)n_pairs, &ws); if (rc) return rc;
     A.ws = ws; A.pts1 = d_p1; A.pts2 = d_p2; A.offsets = (const long long *)d_off; A.seeds = d_seeds;

@@ -22,7 +22,7 @@ for it in range(2):
 print("rc",rc,"batch ms",dt*1e3)
 ph=d_ph.cpu().numpy().astype(np.float64)/1e5  # ms
 st=d_st.cpu().numpy()
-names=["sample","solve","score","commit+misc","LO","degen","tail","total","innerH","rFtH_gen","rFtH_score","rFtH_trig","d4","d5","d6","d7"]
+names=["sample","solve","score","commit+misc","LO","degen","tail","total","innerH","rFtH_gen","rFtH_score","rFtH_trig","chain","draws","pool","d7"]
 print("mean ms per pair:", {n:round(float(ph[:,i].mean()),3) for i,n in enumerate(names)})
 print("max  ms per pair:", {n:round(float(ph[:,i].max()),3) for i,n in enumerate(names)})
 print("samples mean",st[:,0].mean(),"lo_runs mean",st[:,1].mean(),"degen mean",st[:,5].mean(),"models mean",st[:,4].mean(), "aux", st[:,11].mean(), "hds", st[:,10].mean())
