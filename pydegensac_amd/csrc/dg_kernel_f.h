@@ -23,9 +23,13 @@ struct dg_f_shared {
     int      draws2[2][DG_CHUNK][8];    /* raw draws, then drawn ids (draw order) */
     dg_wave_ws ww[DG_NW];                /* per-wave scratch of the wave-parallel sections */
     double   hw5[5][17 * 9 + 32];        /* Hdetect temporaries of checksample's five waves */
+    double   fhF[16][9], fhF2[16][9], fhTh[16];   /* innerFH: per-repetition model, its u2Fit refinement, flag threshold */
+    int      fhIds[16][10], fhCnt[16], fhCnt2[16];
+    long long ph[8], dbg[8], tq;          /* phase timers (lane 0), 100 MHz ticks */
     unsigned short moff[DG_T + 1];      /* first model slot of each sample */
     unsigned char  nv[DG_CHUNK];        /* valid models per sample; 255 = nullspace dimension != 2 */
     unsigned char  ridx[DG_CHUNK][4];   /* root index i (= errs[] slot) of each valid model */
+    unsigned short mslot[3 * DG_CHUNK]; /* compact (ordered) model index -> slot in the chunk's model table */
     unsigned wave_cnt[DG_NW];
     double   f[9], F[9], FBest[9], H[9], Hx[9], fLO[9], ftmp[9];
     double   bufF[4][9]; int bufKind[4]; /* model whose residuals each physical errs[] buffer holds */
@@ -53,9 +57,10 @@ struct dg_f_ctx {
     unsigned *res_I; double *res_J;   /* [3*DG_CHUNK] per-model (I, J) of the current chunk */
     int (*rf)[5];            /* [DG_CHUNK] rFtH batch: candidate point ids (2), swap log (2), count */
     unsigned *seeds; int (*draws)[8]; /* the chunk buffers of the chunk being committed */
+    int *wlist; dg_pt *wstage;        /* per-wave buffers [DG_NW][n_max] of the wave-parallel innerFH / u2Fit */
+    int n_max;
     /* counters */
     int n_fds, n_exfds, n_hds, n_aux;
-    long long dbg[8];        /* debug phase ticks: 0 innerH, 1 rFtH gen, 2 rFtH score, 3 rFtH trigger(innerFH), 4 checksample */
 
     __device__ __forceinline__ dg_pt pt(int i) const { return P[i]; }
     /* LAF point sets u_1 (which=1: +a12,+a22) and u_2 (which=2: +a11,+a21): bindings.cpp:337-409 */
@@ -203,7 +208,7 @@ __device__ __noinline__ void dg_Hdetect(const double *F, const double (*u7)[4], 
  * waves 0..4 each evaluate one (Hdetect + sort on lane 0, the 5-point re-fit wave-cooperatively), then the
  * lowest successful index is taken — the same H the sequential loop returns.  Called by the whole workgroup. */
 template <bool LDSPTS>
-__device__ __forceinline__ int dg_checksample(CTX &c, const double *F /* LDS */, const double (*u7)[4] /* LDS */, double th, double *H /* LDS out */)
+__device__ __noinline__ int dg_checksample(CTX &c, const double *F /* LDS */, const double (*u7)[4] /* LDS */, double th, double *H /* LDS out */)
 {
     dg_f_shared *S = c.S; const int tid = c.tid, lane = tid & 63, wave = tid >> 6;
     __syncthreads();
@@ -236,7 +241,7 @@ __device__ __forceinline__ int dg_checksample(CTX &c, const double *F /* LDS */,
 
 /* ---- ranH.c:18-135 + DegUtils.c:693-731: LO of the plane homography (innerH) -------------------- */
 template <bool LDSPTS>
-__device__ __forceinline__ unsigned dg_innerH(CTX &c, double *H /* LDS, in/out */, double th, unsigned inlLimit, unsigned char *inl_flags)
+__device__ __noinline__ unsigned dg_innerH(CTX &c, double *H /* LDS, in/out */, double th, unsigned inlLimit, unsigned char *inl_flags)
 {
     dg_f_shared *S = c.S; const int n = c.n, tid = c.tid;
     int *inliers = c.L[3], *intbuff = c.L[4];
@@ -319,24 +324,76 @@ __device__ __forceinline__ unsigned dg_innerH(CTX &c, double *H /* LDS, in/out *
     }
 }
 
-/* ---- DegUtils.c:635-690 u2Fit ------------------------------------------------------------------- */
-template <bool LDSPTS>
-__device__ __forceinline__ unsigned dg_u2Fit(CTX &c, double *F /* LDS in/out */, unsigned char *inl, double th, double ths, unsigned iters)
+/* ---- wave-level passes (one wave, no workgroup barriers) ------------------------------------------ */
+/* #points with Sampson error < thr (strict, DegUtils.c style) */
+__device__ __forceinline__ unsigned dg_wave_count_lt(const dg_pt *P, int n, const double *F, double thr, int lane)
 {
-    const int n = c.n;
+    unsigned cnt = 0;
+    for (int p = lane; p < n; p += 64) { dg_pt q = P[p]; cnt += dg_FDs(F, q.x1, q.y1, q.x2, q.y2) < thr ? 1u : 0u; }
+    return dg_wave_sum_u(cnt);
+}
+/* ordered id list of the points with error < thr; returns the count */
+__device__ __forceinline__ unsigned dg_wave_list_lt(const dg_pt *P, int n, const double *F, double thr, int *list, int lane)
+{
+    unsigned off = 0;
+    for (int base = 0; base < n; base += 64) {
+        int p = base + lane; bool in = false;
+        if (p < n) { dg_pt q = P[p]; in = dg_FDs(F, q.x1, q.y1, q.x2, q.y2) < thr; }
+        unsigned long long b = __ballot(in);
+        if (in) list[off + (unsigned)__popcll(b & ((1ull << lane) - 1ull))] = p;
+        off += (unsigned)__popcll(b);
+    }
+    return off;
+}
+
+/* ---- DegUtils.c:635-690 u2Fit, run by ONE wave on its own scratch -----------------------------------
+ * F (LDS, 9) in/out.  Returns the count and *thf = the threshold the reference's `inl` flags correspond to
+ * (th after the full schedule, the current ths on the "fewer than 8 inliers" early return). */
+__device__ __noinline__ unsigned dg_u2Fit_wave(dg_wave_ws *w, const dg_pt *P, int n, double *F, double th, double ths, unsigned iters,
+                                              int *list, dg_pt *stage, int lane, double *thf, int *n_aux)
+{
     double dth = (ths - th) / (iters - 1);
-    int *inlI = c.L[9];
     for (unsigned iter = 0; iter < iters; ++iter) {
-        /* flags: d < ths (strict); the id list is the same set in index order (one fused pass) */
-        dg_pass_cfg cfg = dg_cfg0(n); cfg.flags = inl; cfg.thF = ths; cfg.list = inlI; cfg.thL = ths; cfg.listStrict = 1;
-        dg_pass_res r = dg_f_pass(c, F, DG_K_FDS, cfg); c.n_aux++;
-        if (r.nF < 8) return r.nF;
-        dg_u2f_list(c, inlI, (int)r.nF, 0, 0, F);
+        double Fr[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) Fr[i] = F[i];
+        unsigned cnt = dg_wave_list_lt(P, n, Fr, ths, list, lane); (*n_aux)++;
+        if (cnt < 8) { *thf = ths; return cnt; }
+        DG_WSYNC();
+        if (cnt <= 14) {
+            if (lane < (int)cnt) { dg_pt q = P[list[lane]]; w->px[4*lane] = q.x1; w->px[4*lane+1] = q.y1; w->px[4*lane+2] = q.x2; w->px[4*lane+3] = q.y2; }
+            DG_WSYNC();
+            if (cnt > 8) dg_u2f_norm_w(w, w->px, (const double *)0, (int)cnt, F, lane);
+            else {
+                /* exactly 8: the svduv path of u2f (Ftools.c:371-384) */
+                if (lane == 0) { for (int i = 0; i < 72; i++) w->Z[i] = 0.; for (int i = 0; i < 8; i++) { double a[3] = {w->px[4*i], w->px[4*i+1], 1.0}, b[3] = {w->px[4*i+2], w->px[4*i+3], 1.0}; for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) w->Z[(k*3+l)*8 + i] = b[k] * a[l]; } }
+                DG_WSYNC();
+                dg_svd_lastcol_9x8_wave(w->Z, w->V, lane);
+                if (lane == 0) { for (int i = 0; i < 9; i++) F[i] = w->V[i]; dg_singulF(F); }
+                DG_WSYNC();
+            }
+        } else {
+            for (int j = lane; j < (int)cnt; j += 64) stage[j] = P[list[j]];
+            DG_WSYNC();
+            dg_lsq_seq_core(w, stage, (int)cnt, lane, 0, w->A1, w->A2);
+            DG_WSYNC();
+            dg_eig_sym_wave(w->V, w->D, lane, &w->ews);
+            if (lane == 0) {
+                int jm = 0; for (int i = 1; i < 9; i++) if (w->D[i] < w->D[jm]) jm = i;
+                for (int i = 0; i < 9; i++) F[i] = w->V[jm*9 + i];
+                dg_singulF(F);
+                dg_denormF(F, w->A1, w->A2);
+            }
+            DG_WSYNC();
+        }
         ths -= dth;
     }
-    dg_pass_cfg cfg = dg_cfg0(n); cfg.flags = inl; cfg.thF = th;
-    dg_pass_res r = dg_f_pass(c, F, DG_K_FDS, cfg); c.n_aux++;
-    return r.nF;
+    double Fr[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) Fr[i] = F[i];
+    unsigned cnt = dg_wave_count_lt(P, n, Fr, th, lane); (*n_aux)++;
+    *thf = th;
+    return cnt;
 }
 
 /* ---- DegUtils.c:488-632 innerFH + dual_sample ---------------------------------------------------- */
@@ -362,49 +419,78 @@ __device__ __forceinline__ void dg_dual_pick(dg_rng *g, unsigned len, unsigned s
     }
 }
 
+/* The repetitions of innerFH are independent of each other: dual_sample always consumes 6 + 4 draws, u2f / u2Fit
+ * consume none, and whether a repetition is refined by u2Fit depends only on the running maximum of the
+ * pre-refinement counts.  So: lane 0 draws all samples; the waves then fit and score the repetitions in
+ * parallel; the "new record" repetitions are refined in parallel (one wave each); a final scan in repetition
+ * order applies the reference's `max_i < no_i` bookkeeping and one pass materialises the winner's flags. */
 template <bool LDSPTS>
-__device__ __forceinline__ void dg_innerFH(CTX &c, const int *idxH, unsigned lenH, const int *idxO, unsigned lenO,
+__device__ __noinline__ void dg_innerFH(CTX &c, const int *idxH, unsigned lenH, const int *idxO, unsigned lenO,
                                            double th, unsigned repCount, double *F /* LDS out */, unsigned char *inl /* out flags */)
 {
-    dg_f_shared *S = c.S; const int n = c.n, tid = c.tid;
-    unsigned char *v = c.Fl[3];
-    double *aF = S->fLO;
-    unsigned max_i = 0, max_s = 0;
+    dg_f_shared *S = c.S; const int n = c.n, tid = c.tid, lane = tid & 63, wave = tid >> 6;
+    const dg_pt *P = c.P;
     __syncthreads();
-    if (tid < 9) F[tid] = 1;
-    for (int j = tid; j < n; j += DG_T) inl[j] = 0;
-    __syncthreads();
-    for (unsigned rep = 0; rep < repCount; ++rep) {
-        __syncthreads();
-        if (tid == 0) {
+    if (tid == 0) {
+        for (unsigned rep = 0; rep < repCount; ++rep) {
             int pick[16];
             dg_dual_pick(&S->rng, lenH, 6, pick);
             dg_dual_pick(&S->rng, lenO, 4, pick + 6);
-            for (int i = 0; i < 6; i++) S->itmp[i] = idxH[pick[i]];
-            for (int i = 0; i < 4; i++) S->itmp[6+i] = idxO[pick[6+i]];
-            dg_gather(c, S->itmp, 10, S->lsq.px);
+            for (int i = 0; i < 6; i++) S->fhIds[rep][i] = idxH[pick[i]];
+            for (int i = 0; i < 4; i++) S->fhIds[rep][6+i] = idxO[pick[6+i]];
         }
-        if (tid < 64) { DG_WSYNC(); dg_u2f_small_w(&S->lsq, S->lsq.px, 0, 10, aF, tid); }
-        __syncthreads();
-        dg_pass_cfg cfg = dg_cfg0(n); cfg.flags = v; cfg.thF = th;
-        dg_pass_res r = dg_f_pass(c, aF, DG_K_FDS, cfg); c.n_aux++;
-        unsigned no_i = r.nF;
-        if (max_i < no_i) {
-            for (int j = tid; j < n; j += DG_T) inl[j] = v[j];
-            if (tid < 9) F[tid] = aF[tid];
-            __syncthreads();
-            max_i = no_i;
-        }
-        if (no_i > max_s) {
-            max_s = no_i;
-            no_i = dg_u2Fit(c, aF, v, th, th*3, 4);
-            if (max_i < no_i) {
-                for (int j = tid; j < n; j += DG_T) inl[j] = v[j];
-                if (tid < 9) F[tid] = aF[tid];
-                __syncthreads();
-                max_i = no_i;
-            }
-        }
+    }
+    __syncthreads();
+    /* 10-point model + its consensus, one wave per repetition */
+    for (unsigned rep = wave; rep < repCount; rep += DG_NW) {
+        dg_wave_ws *w = &S->ww[wave];
+        if (lane < 10) { dg_pt q = P[S->fhIds[rep][lane]]; w->px[4*lane] = q.x1; w->px[4*lane+1] = q.y1; w->px[4*lane+2] = q.x2; w->px[4*lane+3] = q.y2; }
+        DG_WSYNC();
+        dg_u2f_norm_w(w, w->px, (const double *)0, 10, S->fhF[rep], lane);
+        double Fr[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) Fr[i] = S->fhF[rep][i];
+        unsigned cnt = dg_wave_count_lt(P, n, Fr, th, lane);
+        if (lane == 0) { S->fhCnt[rep] = (int)cnt; S->fhCnt2[rep] = -1; }
+        DG_WSYNC();
+    }
+    c.n_aux += (int)repCount;
+    __syncthreads();
+    /* repetitions that set a new record of the pre-refinement count get u2Fit (DegUtils.c:562-566) */
+    int nfit = 0, fitrep[16];
+    { unsigned max_s = 0; for (unsigned rep = 0; rep < repCount; ++rep) if ((unsigned)S->fhCnt[rep] > max_s) { max_s = (unsigned)S->fhCnt[rep]; fitrep[nfit++] = (int)rep; } }
+    int aux_local = 0;
+    for (int q = wave; q < nfit; q += DG_NW) {
+        const int rep = fitrep[q];
+        if (lane < 9) S->fhF2[rep][lane] = S->fhF[rep][lane];
+        DG_WSYNC();
+        double thf;
+        unsigned cnt = dg_u2Fit_wave(&S->ww[wave], P, n, S->fhF2[rep], th, th*3, 4, c.wlist + (size_t)wave * c.n_max, c.wstage + (size_t)wave * c.n_max, lane, &thf, &aux_local);
+        if (lane == 0) { S->fhCnt2[rep] = (int)cnt; S->fhTh[rep] = thf; S->itmp[8 + wave] = aux_local; }
+        DG_WSYNC();
+    }
+    if (lane == 0 && wave >= nfit) S->itmp[8 + wave] = 0;
+    if (lane == 0 && wave < nfit) S->itmp[8 + wave] = aux_local;
+    __syncthreads();
+    for (int w = 0; w < DG_NW; w++) c.n_aux += S->itmp[8 + w];
+    /* the reference's bookkeeping, in repetition order */
+    unsigned max_i = 0; int best = -1, best_fit = 0;
+    for (unsigned rep = 0; rep < repCount; ++rep) {
+        if (max_i < (unsigned)S->fhCnt[rep]) { max_i = (unsigned)S->fhCnt[rep]; best = (int)rep; best_fit = 0; }
+        if (S->fhCnt2[rep] >= 0 && max_i < (unsigned)S->fhCnt2[rep]) { max_i = (unsigned)S->fhCnt2[rep]; best = (int)rep; best_fit = 1; }
+    }
+    __syncthreads();
+    if (best < 0) {
+        if (tid < 9) F[tid] = 1;
+        for (int j = tid; j < n; j += DG_T) inl[j] = 0;
+    } else {
+        const double *Fb = best_fit ? S->fhF2[best] : S->fhF[best];
+        const double thb = best_fit ? S->fhTh[best] : th;
+        double Fr[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) Fr[i] = Fb[i];
+        if (tid < 9) F[tid] = Fr[tid];
+        for (int j = tid; j < n; j += DG_T) { dg_pt q = P[j]; inl[j] = dg_FDs(Fr, q.x1, q.y1, q.x2, q.y2) < thb ? 1 : 0; }
     }
     __syncthreads();
 }
@@ -432,7 +518,7 @@ __device__ __forceinline__ void dg_rFtH_aFt(const double *Hr, const dg_pt &p0, c
 }
 
 template <bool LDSPTS>
-__device__ __forceinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, double th, const double *H /* LDS */, double *F /* LDS out */)
+__device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, double th, const double *H /* LDS */, double *F /* LDS out */)
 {
     dg_f_shared *S = c.S; const int n = c.n, tid = c.tid, lane = tid & 63, wave = tid >> 6;
     unsigned char *nhinl = c.Fl[1], *vN = c.Fl[2], *inl = c.Fl[4];
@@ -474,7 +560,7 @@ __device__ __forceinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, d
             }
         }
         __syncthreads();
-        long long tg1 = wall_clock64(); c.dbg[1] += tg1 - tg0;
+        long long tg1 = wall_clock64(); if (tid == 0) S->dbg[1] += tg1 - tg0;
         /* one wave per candidate: #off-plane points with Sampson error < 2 th */
         for (int b = wave; b < B; b += DG_NW) {
             double aFt[9];
@@ -485,7 +571,7 @@ __device__ __forceinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, d
             if (lane == 0) c.rf[b][4] = (int)cnt;
         }
         __syncthreads();
-        long long tg2 = wall_clock64(); c.dbg[2] += tg2 - tg1;
+        long long tg2 = wall_clock64(); if (tid == 0) S->dbg[2] += tg2 - tg1;
         /* first candidate beating m_i */
         bool hit = tid < B && (unsigned)c.rf[tid][4] > m_i;
         unsigned long long bal = __ballot(hit);
@@ -531,7 +617,7 @@ __device__ __forceinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, d
                 max_sam = max_sam > ns ? ns : max_sam;
             }
         }
-        c.dbg[3] += wall_clock64() - tg2;
+        if (tid == 0) S->dbg[3] += wall_clock64() - tg2;
     }
     __syncthreads();
     if (LDSPTS) { for (int j = tid; j < n; j += DG_T) c.pool[j] = c.L[8][j]; __syncthreads(); }

@@ -109,7 +109,7 @@ __device__ __forceinline__ dg_score dg_iterF(CTX &c, int *inliers, double th, do
 
 /* exp_ranF.c:745-806 exp_inFranicustom.  inliers = L[0] (in/out), result model -> Fout (LDS). */
 template <bool LDSPTS>
-__device__ __forceinline__ dg_score dg_inFrani(CTX &c, int ninl, double th, double *Fout, int *iterID,
+__device__ __noinline__ dg_score dg_inFrani(CTX &c, int ninl, double th, double *Fout, int *iterID,
                                                int mk_full, int mk_ex, int *kindBest)
 {
     dg_f_shared *S = c.S; const int tid = c.tid;
@@ -143,12 +143,61 @@ __device__ __forceinline__ dg_score dg_inFrani(CTX &c, int ninl, double th, doub
     return maxS;
 }
 
+/* One 7-point problem per lane, registers only (own register allocation: not inlined into the driver).
+ * ids: the 7 drawn ids in draw order.  Writes up to 3 models (9 doubles each) to out[0..27), packs their
+ * root indices (2 bits each) into *rix and returns the number of valid models, or -1 when the null space
+ * of the 7x9 system is not 2-dimensional (exp_ranF.c:1355-1358). */
+__device__ __noinline__ int dg_solve7_lane(const dg_pt *P, const int *ids, double *out, unsigned *rix)
+{
+    dg_pt sp[7];
+    double m[7][9];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        sp[i] = P[ids[i]];
+        double a[3] = {sp[i].x1, sp[i].y1, 1.0}, b[3] = {sp[i].x2, sp[i].y2, 1.0};
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int l = 0; l < 3; l++) m[i][3*k+l] = b[k] * a[l];
+    }
+    double f1[9], f2[9];
+    int ok = dg_gj7(m, f1, f2);
+    if (!ok) {
+        /* general utools.c:97-167 path on a private 9x9 copy (degenerate samples only) */
+        double Ag[81], sol[81]; int nb[18];
+        for (int i = 0; i < 7; i++) {
+            double a[3] = {sp[i].x1, sp[i].y1, 1.0}, b[3] = {sp[i].x2, sp[i].y2, 1.0};
+            for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) Ag[9*i+3*k+l] = b[k] * a[l];
+        }
+        for (int i = 63; i < 81; i++) Ag[i] = 0;
+        for (int i = 0; i < 81; i++) sol[i] = 0;
+        int ns = dg_nullspace(Ag, sol, 9, nb);
+        if (ns == 2) { for (int i = 0; i < 9; i++) { f1[i] = sol[i]; f2[i] = sol[9+i]; } ok = 1; }
+        else return -1;
+    }
+    double poly[4], roots[3];
+    dg_slcm(f1, f2, poly);
+    int nsol = dg_rroots3(poly, roots);
+    int nvalid = 0; unsigned rx = 0;
+    for (int i = 0; i < nsol; i++) {
+        double f[9];
+#pragma unroll
+        for (int j = 0; j < 9; j++) f[j] = f1[j] * roots[i] + f2[j] * (1 - roots[i]);
+        if (!dg_ori_valid7(f, sp)) continue;
+#pragma unroll
+        for (int j = 0; j < 9; j++) out[9*nvalid + j] = f[j];
+        rx |= (unsigned)i << (2*nvalid); nvalid++;
+    }
+    *rix = rx;
+    return nvalid;
+}
+
 /* One chunk of the reference's sample stream, executed by ONE wave (all 64 lanes): the seed chain
  * (seed_{k+1} = output #NDRAW after srand(seed_k)), the NDRAW draws of every sample and the Fisher-Yates
  * pool swaps (rtools.c:12-23).  Fills seeds[0..cn) and draws[k][0..NDRAW) (drawn ids in draw order) and
  * returns the seed of the sample after the chunk.  NDRAW = 7 (F) or 4 (H). */
 template <int NDRAW, bool LDSPTS>
-__device__ __forceinline__ unsigned dg_sample_chunk(unsigned seed, int cn, int n, int *pool, unsigned *seeds, int (*draws)[8], int lane, long long *dbg = 0)
+__device__ __noinline__ unsigned dg_sample_chunk(unsigned seed, int cn, int n, int *pool, unsigned *seeds, int (*draws)[8], int lane, long long *dbg = 0)
 {
     long long ts0 = wall_clock64();
     __builtin_amdgcn_s_setprio(3);                        /* the serial wave must not queue behind the scoring waves */
@@ -222,7 +271,7 @@ __device__ __forceinline__ unsigned dg_sample_chunk(unsigned seed, int cn, int n
     if (act) vp[n - 1 - lane] = t;
     DG_WSYNC();
     __builtin_amdgcn_s_setprio(0);
-    if (dbg) { long long ts3 = wall_clock64(); dbg[4] += ts1 - ts0; dbg[5] += ts2 - ts1; dbg[6] += ts3 - ts2; }
+    if (dbg && lane == 0) { long long ts3 = wall_clock64(); dbg[4] += ts1 - ts0; dbg[5] += ts2 - ts1; dbg[6] += ts3 - ts2; }
     return sd;
 }
 
@@ -251,8 +300,8 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
     c.stage = (dg_pt *)(ws + A.wl.off_stage);
     c.res_J = (double *)(ws + A.wl.off_res); c.res_I = (unsigned *)(c.res_J + 3 * DG_CHUNK); c.rf = (int (*)[5])(c.res_I + 3 * DG_CHUNK);
     c.seeds = S->seeds2[0]; c.draws = S->draws2[0];
+    c.n_max = A.wl.n_max; c.wlist = (int *)(ws + A.wl.off_wave); c.wstage = (dg_pt *)(ws + A.wl.off_wave + (size_t)DG_NW * A.wl.n_max * sizeof(int));
     c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0;
-    for (int i = 0; i < 8; i++) c.dbg[i] = 0;
     dg_pt *Pw; int *pool;
     if (LDSPTS) { Pw = (dg_pt *)dyn_smem; pool = (int *)(dyn_smem + (size_t)n * sizeof(dg_pt)); }
     else        { Pw = (dg_pt *)(ws + A.wl.off_pts); pool = (int *)(ws + A.wl.off_pool); }
@@ -289,8 +338,8 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
     unsigned seed = (unsigned)S->itmp[31];
     __syncthreads();
 
-    long long ph[8] = {0,0,0,0,0,0,0,0}, tq = wall_clock64(), tq2;
-#define DG_PH(i) do { tq2 = wall_clock64(); ph[i] += tq2 - tq; tq = tq2; } while (0)
+    if (tid == 0) { for (int i = 0; i < 8; i++) { S->ph[i] = 0; S->dbg[i] = 0; } S->tq = wall_clock64(); }
+#define DG_PH(i) do { if (tid == 0) { long long tq2_ = wall_clock64(); S->ph[i] += tq2_ - S->tq; S->tq = tq2_; } } while (0)
     /* software pipeline: chunk c+1 is sampled by wave 0 while waves 1.. score chunk c */
     int cur = 0, chunk_s[2] = {0, 0}, chunk_base = 0;
     {
@@ -306,48 +355,10 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
         DG_PH(3);
         DG_PH(0);
         /* ================= solve: one 7-point problem per lane ================= */
-        double fm[3][9]; int nvalid = 0; unsigned char rix[3] = {0, 0, 0}; int nullbad = 0;
+        int nvalid = 0, nullbad = 0; unsigned rixp = 0;
         if (tid < chunk) {
-            dg_pt sp[7];
-            double m[7][9];
-#pragma unroll
-            for (int i = 0; i < 7; i++) {
-                sp[i] = P[c.draws[tid][i]];
-                double a[3] = {sp[i].x1, sp[i].y1, 1.0}, b[3] = {sp[i].x2, sp[i].y2, 1.0};
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-#pragma unroll
-                    for (int l = 0; l < 3; l++) m[i][3*k+l] = b[k] * a[l];
-            }
-            double f1[9], f2[9];
-            int ok = dg_gj7(m, f1, f2);
-            if (!ok) {
-                /* general utools.c:97-167 path on a private 9x9 copy (degenerate samples only) */
-                double Ag[81], sol[81]; int nb[18];
-                for (int i = 0; i < 7; i++) {
-                    double a[3] = {sp[i].x1, sp[i].y1, 1.0}, b[3] = {sp[i].x2, sp[i].y2, 1.0};
-                    for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) Ag[9*i+3*k+l] = b[k] * a[l];
-                }
-                for (int i = 63; i < 81; i++) Ag[i] = 0;
-                for (int i = 0; i < 81; i++) sol[i] = 0;
-                int ns = dg_nullspace(Ag, sol, 9, nb);
-                if (ns == 2) { for (int i = 0; i < 9; i++) { f1[i] = sol[i]; f2[i] = sol[9+i]; } ok = 1; }
-                else nullbad = 1;
-            }
-            if (ok) {
-                double poly[4], roots[3];
-                dg_slcm(f1, f2, poly);
-                int nsol = dg_rroots3(poly, roots);
-                for (int i = 0; i < nsol; i++) {
-                    double f[9];
-#pragma unroll
-                    for (int j = 0; j < 9; j++) f[j] = f1[j] * roots[i] + f2[j] * (1 - roots[i]);
-                    if (!dg_ori_valid7(f, sp)) continue;
-#pragma unroll
-                    for (int j = 0; j < 9; j++) fm[nvalid][j] = f[j];
-                    rix[nvalid] = (unsigned char)i; nvalid++;
-                }
-            }
+            int r_ = dg_solve7_lane(P, c.draws[tid], c.gmodels + (size_t)tid * 27, &rixp);
+            if (r_ < 0) nullbad = 1; else nvalid = r_;
         }
         /* ordered slots: exclusive scan of nvalid over the lanes of the chunk */
         {
@@ -363,10 +374,8 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
                 S->moff[tid] = (unsigned short)excl;
                 S->nv[tid] = nullbad ? 255 : (unsigned char)nvalid;
                 for (int r = 0; r < nvalid; r++) {
-                    S->ridx[tid][r] = rix[r];
-                    double *g = c.gmodels + (size_t)(excl + r) * 9;
-#pragma unroll
-                    for (int j = 0; j < 9; j++) g[j] = fm[r][j];
+                    S->ridx[tid][r] = (unsigned char)((rixp >> (2*r)) & 3u);
+                    S->mslot[excl + r] = (unsigned short)(tid * 3 + r);      /* compact model index -> fixed slot */
                 }
             }
             if (tid == DG_T - 1) S->moff[DG_CHUNK] = (unsigned short)(excl + v);
@@ -381,11 +390,11 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
             int cn = max_sam - (no_sam + chunk_s[cur]); if (cn > DG_CHUNK) cn = DG_CHUNK; if (cn < 0) cn = 0;
             chunk_s[nxt] = cn;
             if (wave == 0) {
-                if (cn > 0) { unsigned sd = dg_sample_chunk<7, LDSPTS>(seed, cn, n, pool, S->seeds2[nxt], S->draws2[nxt], lane, c.dbg); if (lane == 0) S->itmp[31] = (int)sd; }
+                if (cn > 0) { unsigned sd = dg_sample_chunk<7, LDSPTS>(seed, cn, n, pool, S->seeds2[nxt], S->draws2[nxt], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }
             } else {
                 for (int mi = wave - 1; mi < Mtot; mi += DG_NW - 1) {
                     double F[9];
-                    const double *g = c.gmodels + (size_t)mi * 9;
+                    const double *g = c.gmodels + (size_t)S->mslot[mi] * 9;
 #pragma unroll
                     for (int j = 0; j < 9; j++) F[j] = g[j];
                     unsigned cI = 0; double acc[DG_NW]; const double t94 = th * 9 / 4;
@@ -442,11 +451,11 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
                 const int phys = perm[ri];
                 const bool ev1 = maxS.J < Sc.J, ev2 = maxSs.J < Sc.J;
                 if (!(ev1 || ev2)) {
-                    if (track && phys == p4) { __syncthreads(); if (tid < 9) e4F[tid] = c.gmodels[(size_t)mi*9 + tid]; e4kind = mk_full; __syncthreads(); }
+                    if (track && phys == p4) { __syncthreads(); if (tid < 9) e4F[tid] = c.gmodels[(size_t)S->mslot[mi]*9 + tid]; e4kind = mk_full; __syncthreads(); }
                     continue;
                 }
                 __syncthreads();
-                if (tid < 9) S->f[tid] = c.gmodels[(size_t)mi*9 + tid];
+                if (tid < 9) S->f[tid] = c.gmodels[(size_t)S->mslot[mi]*9 + tid];
                 __syncthreads();
                 if (track && phys == p4) { if (tid < 9) e4F[tid] = S->f[tid]; e4kind = mk_full; __syncthreads(); }
                 if (ev1) {
@@ -491,7 +500,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
                         dg_pass_res rh = dg_h_pass(c, S->H, ch); c.n_hds++;
                         unsigned I = rh.nF;
                         if (I < 8) { brk = 1; c.n_fds -= (nvk - 1 - r); break; }   /* exp_ranF.c:1437-1439: later roots are never scored */
-                        { long long ti0 = wall_clock64(); I = dg_innerH(c, S->H, 16*th, 10, c.Fl[0]); c.dbg[0] += wall_clock64() - ti0; }
+                        { long long ti0 = wall_clock64(); I = dg_innerH(c, S->H, 16*th, 10, c.Fl[0]); if (tid == 0) S->dbg[0] += wall_clock64() - ti0; }
                         if ((int)I > Ihmax) Ihmax = (int)I;
                         if (I > 6) {
                             I = dg_rFtH(c, c.Fl[0], th, S->H, S->f);
@@ -675,7 +684,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
         st[14] = 0; st[15] = 0;
     }
     DG_PH(6);
-    if (A.phase_out && tid == 0) { ph[7] = wall_clock64() - t_start; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + i] = ph[i]; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + 8 + i] = c.dbg[i]; }
+    if (A.phase_out && tid == 0) { S->ph[7] = wall_clock64() - t_start; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + i] = S->ph[i]; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + 8 + i] = S->dbg[i]; }
 }
 
 #endif /* DG_KERNEL_F_MAIN_H */

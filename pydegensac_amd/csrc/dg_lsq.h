@@ -223,16 +223,11 @@ __device__ __noinline__ void dg_u2h_small_w(dg_lsq_scratch *s, const double *p, 
  * over the list exactly like normu (utools.c:7-51) and cov_mat (utools.c:170-184) do — but the 4 + 2 + 45
  * independent sums run in different lanes of wave 0 (one lane per output entry).  `rows2`: 0 = fundamental
  * (lin_fmN, Ftools.c:300-328, one row per point), 1 = homography (lin_hgN, Htools.c:60-99, two rows). */
-template <class PtFn>
-__device__ __forceinline__ void dg_lsq_seq(dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, int rows2, double *A1o, double *A2o, dg_pt *stage)
+/* the sequential sums, run by ONE wave on already staged (gathered) correspondences; V, A1o, A2o in LDS */
+template <class SC>
+__device__ __forceinline__ void dg_lsq_seq_core(SC *s, const dg_pt *stage, int len, int lane, int rows2, double *A1o, double *A2o)
 {
-    /* gather the listed correspondences into a contiguous staging array (all lanes), so that the sequential
-     * sums below stream uniform addresses */
-    __syncthreads();
-    for (int j = tid; j < len; j += DG_T) stage[j] = pt(list[j]);
-    __syncthreads();
-    if (tid < 64) {
-        const int lane = tid;
+    {
         /* centroids: lane l in 0..3 sums coordinate l, in list order */
         double acc = 0;
         {
@@ -282,6 +277,17 @@ __device__ __forceinline__ void dg_lsq_seq(dg_lsq_scratch *s, PtFn pt, const int
         if (lane < 45) { s->V[9*ie + je] = val; s->V[ie + 9*je] = val; }
         if (lane == 0) { for (int i = 0; i < 3; i++) { A1o[i] = A1[i]; A2o[i] = A2[i]; } }
     }
+}
+
+template <class PtFn>
+__device__ __forceinline__ void dg_lsq_seq(dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, int rows2, double *A1o, double *A2o, dg_pt *stage)
+{
+    /* gather the listed correspondences into a contiguous staging array (all lanes), so that the sequential
+     * sums stream uniform addresses */
+    __syncthreads();
+    for (int j = tid; j < len; j += DG_T) stage[j] = pt(list[j]);
+    __syncthreads();
+    if (tid < 64) dg_lsq_seq_core(s, stage, len, tid, rows2, A1o, A2o);
     __syncthreads();
 }
 

@@ -100,6 +100,7 @@ static dg_ws_layout make_layout(int n_max, bool pts_in_ws)
     w.off_ht = o;     o += align_up((size_t)(80 + 4 * DG_HT_CAP) * sizeof(int), 256);
     w.off_models = o; o += align_up((size_t)3 * DG_CHUNK * 9 * sizeof(double), 256);
     w.off_stage = o;  o += align_up((size_t)n_max * sizeof(dg_pt), 256);
+    w.off_wave = o;   o += align_up((size_t)DG_NW * n_max * (sizeof(int) + sizeof(dg_pt)), 256);
     w.off_res = o;    o += align_up((size_t)3 * DG_CHUNK * 12 + (size_t)DG_CHUNK * 20, 256);
     w.off_pts = o;    if (pts_in_ws) o += align_up((size_t)n_max * sizeof(dg_pt), 256);
     w.off_pool = o;   if (pts_in_ws) o += align_up((size_t)n_max * sizeof(int), 256);
