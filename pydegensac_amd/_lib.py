@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi_degensac.so")
+LIB_PATH = os.environ.get("MI_DEGENSAC_LIB") or os.path.join(_HERE, "libmi_degensac.so")
 STATS_LEN = 16
 STAT_NAMES = ["samples", "lo_runs", "rejected", "I", "models", "degen", "Ih", "best_sample",
               "full_passes", "ex_passes", "h_passes", "aux_passes", "ticks_best", "ticks_total", "r0", "r1"]

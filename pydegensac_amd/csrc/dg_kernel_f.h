@@ -22,7 +22,8 @@ struct dg_f_shared {
     unsigned seeds2[2][DG_CHUNK];       /* double-buffered chunk state: chunk c+1 is sampled while chunk c is scored */
     int      draws2[2][DG_CHUNK][8];    /* raw draws, then drawn ids (draw order) */
     dg_wave_ws ww[DG_NW];                /* per-wave scratch of the wave-parallel sections */
-    double   hw5[5][17 * 9 + 32];        /* Hdetect temporaries of checksample's five waves */
+    double   hw5[5][17 * 9 + 32];        /* Hdetect temporaries of checksample's five triplets */
+    double   csH[5][9]; int csRes[5];    /* checksample: per-triplet homography and verdict */
     double   fhF[16][9], fhF2[16][9], fhTh[16];   /* innerFH: per-repetition model, its u2Fit refinement, flag threshold */
     int      fhIds[16][10], fhCnt[16], fhCnt2[16];
     long long ph[8], dbg[8], tq;          /* phase timers (lane 0), 100 MHz ticks */
@@ -212,11 +213,11 @@ __device__ __noinline__ int dg_checksample(CTX &c, const double *F /* LDS */, co
 {
     dg_f_shared *S = c.S; const int tid = c.tid, lane = tid & 63, wave = tid >> 6;
     __syncthreads();
-    if (wave < 5) {
+    for (int tr = wave; tr < 5; tr += DG_NW) {
         dg_wave_ws *w = &S->ww[wave];
         const unsigned char IDXS[5][3] = {{0,1,2}, {3,4,5}, {0,1,6}, {3,4,6}, {2,5,6}};
         if (lane == 0) {
-            dg_Hdetect(F, u7, IDXS[wave], w->H, S->hw5[wave]);
+            dg_Hdetect(F, u7, IDXS[tr], w->H, S->hw5[tr]);
             for (int j = 0; j < 7; j++) { w->Ds[j] = dg_HDs(w->H, u7[j][0], u7[j][1], u7[j][2], u7[j][3]); w->sDs[j] = w->Ds[j]; w->idx[j] = j; }
             for (int a = 0; a < 7; ++a)                                  /* sortDs, DegUtils.c:164-183 */
                 for (int b = a + 1; b < 7; ++b)
@@ -228,13 +229,15 @@ __device__ __noinline__ int dg_checksample(CTX &c, const double *F /* LDS */, co
         if (lane == 0) {
             int inlCount = 0;
             for (int j = 0; j < 7; ++j) if (dg_HDs(w->H, u7[j][0], u7[j][1], u7[j][2], u7[j][3]) < th) ++inlCount;
-            w->res = inlCount > 4;
+            S->csRes[tr] = inlCount > 4;
+            for (int j = 0; j < 9; j++) S->csH[tr][j] = w->H[j];
         }
+        DG_WSYNC();
     }
     __syncthreads();
     int win = -1;
-    for (int i = 4; i >= 0; i--) if (S->ww[i].res) win = i;
-    if (win >= 0 && tid < 9) H[tid] = S->ww[win].H[tid];
+    for (int i = 4; i >= 0; i--) if (S->csRes[i]) win = i;
+    if (win >= 0 && tid < 9) H[tid] = S->csH[win][tid];
     __syncthreads();
     return win >= 0;
 }

@@ -3,20 +3,35 @@
 #define DG_KERNEL_F_MAIN_H
 #include "dg_kernel_f.h"
 
-/* lane 0: hash of an id list in global memory (hash.c:4-47 over the ints' bytes).  The state chain is kept on
- * the scalar unit (readfirstlane'd operands): 7 dependent SALU ops per element instead of 7 VALU ops. */
-__device__ __forceinline__ unsigned dg_hash_list(const int *list, int count)
+/* Wave 0 (all 64 lanes): hash of an id list in global memory (hash.c:4-47 over the ints' bytes).  The list is
+ * fetched 64 ids per load (one per lane) and the serial state chain runs on the scalar unit over readlane'd
+ * operands, so the cost is ~13 load latencies + 5-9 SALU ops per id instead of one load latency per 8 ids. */
+__device__ __forceinline__ unsigned dg_hash_list(const int *list, int count, bool small_ids = false)
 {
     if (count <= 0) return 0;
+    const int lane = (int)(threadIdx.x & 63);
     unsigned hash = (unsigned)__builtin_amdgcn_readfirstlane(count * 4), tmp;
-#define DG_HSTEP(v_) { unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)(v_)); \
+#define DG_HSTEP(v_) { unsigned v = (unsigned)(v_); \
         hash += v & 0xffffu; tmp = ((v >> 16) << 11) ^ hash; hash = (hash << 16) ^ tmp; hash += hash >> 11; }
+    /* ids below 65536 (every LDS-resident pair): the high half-word of each int is 0, so tmp == hash */
+#define DG_HSTEP16(v_) { unsigned v = (unsigned)(v_); \
+        hash += v; hash = (hash << 16) ^ hash; hash += hash >> 11; }
     int k = 0;
-    for (; k + 8 <= count; k += 8) {
-        int v0 = list[k], v1 = list[k+1], v2 = list[k+2], v3 = list[k+3], v4 = list[k+4], v5 = list[k+5], v6 = list[k+6], v7 = list[k+7];
-        DG_HSTEP(v0) DG_HSTEP(v1) DG_HSTEP(v2) DG_HSTEP(v3) DG_HSTEP(v4) DG_HSTEP(v5) DG_HSTEP(v6) DG_HSTEP(v7)
+    int cur = (lane < count) ? list[lane] : 0;
+    for (; k + 64 <= count; k += 64) {
+        int nxt = (k + 64 + lane < count) ? list[k + 64 + lane] : 0;
+        if (small_ids) {
+#pragma unroll
+            for (int i = 0; i < 64; i++) DG_HSTEP16(__builtin_amdgcn_readlane(cur, i))
+        } else {
+#pragma unroll
+            for (int i = 0; i < 64; i++) DG_HSTEP(__builtin_amdgcn_readlane(cur, i))
+        }
+        cur = nxt;
     }
-    for (; k < count; k++) DG_HSTEP(list[k])
+    const int rem = count - k;
+    for (int i = 0; i < rem; i++) DG_HSTEP(__builtin_amdgcn_readlane(cur, i))
+#undef DG_HSTEP16
 #undef DG_HSTEP
     hash ^= hash << 3;  hash += hash >> 5;
     hash ^= hash << 4;  hash += hash >> 17;
@@ -60,11 +75,13 @@ __device__ __forceinline__ dg_score dg_iterF(CTX &c, int *inliers, double th, do
         Sc = zero; Sc.I = r1.I; Sc.J = r1.J;
         DG_TRACE(c, 11, Sc.I, Sc.J);
         __syncthreads();
-        if (tid == 0) {
-            unsigned hash = dg_hash_list(inliers, (int)Sc.I);
+        if (tid < 64) {
+            unsigned hash = dg_hash_list(inliers, (int)Sc.I, n < 65536);
+            if (tid == 0) {
             int ret = dg_ht_contains(c.ht, hash, (int)Sc.I, iterID);
             if (ret == -1) dg_ht_insert(c.ht, hash, (int)Sc.I, iterID);
             S->itmp[0] = (ret != -1 && ret != iterID) ? 1 : 0;
+            }
         }
         __syncthreads();
         if (S->itmp[0]) { DG_TRACE(c, 13, 0, 0); return zero; }
@@ -277,7 +294,7 @@ __device__ __noinline__ unsigned dg_sample_chunk(unsigned seed, int cn, int n, i
 
 /* ---------------------------------------------------------------------------------------------- */
 template <bool LDSPTS>
-__global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
+__global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
     __shared__ dg_f_shared Sh;
@@ -381,18 +398,21 @@ __global__ __launch_bounds__(DG_T) void dg_find_fundamental_kernel(dg_args A)
             if (tid == DG_T - 1) S->moff[DG_CHUNK] = (unsigned short)(excl + v);
             __syncthreads();
         }
-        const int Mtot = S->moff[DG_CHUNK];
+        const int Mtot = __builtin_amdgcn_readfirstlane((int)S->moff[DG_CHUNK]);
 
         DG_PH(1);
-        /* ====== score chunk c (waves 1..NW-1: one wave per model, points streamed from LDS)  ||  sample chunk c+1 (wave 0) ====== */
+        /* ====== score chunk c (one wave per model, points streamed from LDS)  ||  sample chunk c+1 (wave 0, which then joins) ====== */
         const int nxt = cur ^ 1;
         {
             int cn = max_sam - (no_sam + chunk_s[cur]); if (cn > DG_CHUNK) cn = DG_CHUNK; if (cn < 0) cn = 0;
             chunk_s[nxt] = cn;
             if (wave == 0) {
                 if (cn > 0) { unsigned sd = dg_sample_chunk<7, LDSPTS>(seed, cn, n, pool, S->seeds2[nxt], S->draws2[nxt], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }
-            } else {
-                for (int mi = wave - 1; mi < Mtot; mi += DG_NW - 1) {
+            }
+            {
+                /* static round-robin over all waves; wave 0 takes its share once the next chunk is sampled */
+                for (int mi = wave; mi < Mtot; mi += DG_NW) {
+
                     double F[9];
                     const double *g = c.gmodels + (size_t)S->mslot[mi] * 9;
 #pragma unroll

@@ -133,11 +133,13 @@ __device__ __forceinline__ dg_score dg_iterHc(CTX &c, int kind, int *inliers, do
         dg_score Ss = zero; Ss.I = r1.I; Ss.J = r1.J;
         DG_TRACE(c, 21, Ss.I, Ss.J);
         __syncthreads();
-        if (tid == 0) {
-            unsigned hash = dg_hash_list(inliers, (int)Ss.I);
-            int ret = dg_ht_contains(c.ht, hash, (int)Ss.I, iterID);
-            if (ret == -1) dg_ht_insert(c.ht, hash, (int)Ss.I, iterID);
-            S->itmp[0] = (ret != -1 && ret != iterID) ? 1 : 0;
+        if (tid < 64) {
+            unsigned hash = dg_hash_list(inliers, (int)Ss.I, n < 65536);
+            if (tid == 0) {
+                int ret = dg_ht_contains(c.ht, hash, (int)Ss.I, iterID);
+                if (ret == -1) dg_ht_insert(c.ht, hash, (int)Ss.I, iterID);
+                S->itmp[0] = (ret != -1 && ret != iterID) ? 1 : 0;
+            }
         }
         __syncthreads();
         if (S->itmp[0]) { DG_TRACE(c, 23, 0, 0); return zero; }
@@ -211,7 +213,7 @@ __device__ __forceinline__ dg_score dg_inHranic(CTX &c, int kind, int ninl, doub
 
 /* one LO run of the driver (exp_ranH.c:678-747 / :795-861).  e4 = model behind errs[4].  Returns 1 if accepted. */
 template <bool LDSPTS>
-__device__ __forceinline__ int dg_h_lo(CTX &c, int kind, const double *e4, double th, dg_score &maxS, int *iterID, int *p1_inliers, int no_sam)
+__device__ __noinline__ int dg_h_lo(CTX &c, int kind, const double *e4, double th, dg_score &maxS, int *iterID, int *p1_inliers, int no_sam)
 {
     dg_f_shared *S = c.S; const int n = c.n, tid = c.tid;
     dg_hbufs B; B.pe[0] = 0; B.pe[1] = 1; B.pe[2] = 2;
@@ -247,9 +249,44 @@ __device__ __forceinline__ int dg_h_lo(CTX &c, int kind, const double *e4, doubl
     return 1;
 }
 
+/* One 4-point problem per lane (own register allocation): orientation test, 8x9 null vector, near-singularity
+ * test and, for the symmetric metrics, H1 = inverse of the transposed H.  Returns 1 when the sample yields a model. */
+__device__ __noinline__ int dg_solve4_lane(const dg_pt *P, const int *ids, int kind, double *hm, double *H1m)
+{
+    dg_pt sp[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) sp[i] = P[ids[i]];
+    if (!dg_Hori_valid4(sp)) return 0;
+    double m[8][9];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        double s0 = sp[i].x1, s1 = sp[i].y1, s3 = sp[i].x2, s4 = sp[i].y2;
+        double z0[9] = {s3, 0, -s0*s3, s4, 0, -s0*s4, 1.0, 0, -s0*1.0};
+        double z1[9] = {0, s3, -s1*s3, 0, s4, -s1*s4, 0, 1.0, -s1*1.0};
+#pragma unroll
+        for (int j = 0; j < 9; j++) { m[2*i][j] = z0[j]; m[2*i+1][j] = z1[j]; }
+    }
+    int ok = dg_gj8(m, hm);
+    if (!ok) {
+        double Ag[81], sol[81]; int nb[18];
+        for (int i = 0; i < 4; i++) {
+            double s0 = sp[i].x1, s1 = sp[i].y1, s3 = sp[i].x2, s4 = sp[i].y2;
+            double z0[9] = {s3, 0, -s0*s3, s4, 0, -s0*s4, 1.0, 0, -s0*1.0};
+            double z1[9] = {0, s3, -s1*s3, 0, s4, -s1*s4, 0, 1.0, -s1*1.0};
+            for (int j = 0; j < 9; j++) { Ag[18*i+j] = z0[j]; Ag[18*i+9+j] = z1[j]; }
+        }
+        for (int i = 72; i < 81; i++) Ag[i] = 0;
+        for (int i = 0; i < 81; i++) sol[i] = 0;
+        if (dg_nullspace(Ag, sol, 9, nb) == 1) { for (int i = 0; i < 9; i++) hm[i] = sol[i]; ok = 1; }
+    }
+    if (!ok || dg_HcloseToSingular(hm)) return 0;
+    if (kind != 0) { double Hi[9]; dg_hsym_prepare(hm, Hi, H1m); }
+    return 1;
+}
+
 /* ---------------------------------------------------------------------------------------------- */
 template <bool LDSPTS>
-__global__ __launch_bounds__(DG_T) void dg_find_homography_kernel(dg_args A)
+__global__ __launch_bounds__(DG_T, 2) void dg_find_homography_kernel(dg_args A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
     __shared__ dg_f_shared Sh;
@@ -313,39 +350,7 @@ __global__ __launch_bounds__(DG_T) void dg_find_homography_kernel(dg_args A)
         c.seeds = S->seeds2[cur]; c.draws = S->draws2[cur]; chunk_base = no_sam;
         /* ---- solve: orientation test, 8x9 null vector, near-singularity test; <= 1 model per lane ---- */
         double hm[9], H1m[9]; int valid = 0;
-        if (tid < chunk) {
-            dg_pt sp[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) sp[i] = P[c.draws[tid][i]];
-            if (dg_Hori_valid4(sp)) {
-                double m[8][9];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    double s0 = sp[i].x1, s1 = sp[i].y1, s3 = sp[i].x2, s4 = sp[i].y2;
-                    double z0[9] = {s3, 0, -s0*s3, s4, 0, -s0*s4, 1.0, 0, -s0*1.0};
-                    double z1[9] = {0, s3, -s1*s3, 0, s4, -s1*s4, 0, 1.0, -s1*1.0};
-#pragma unroll
-                    for (int j = 0; j < 9; j++) { m[2*i][j] = z0[j]; m[2*i+1][j] = z1[j]; }
-                }
-                int ok = dg_gj8(m, hm);
-                if (!ok) {
-                    double Ag[81], sol[81]; int nb[18];
-                    for (int i = 0; i < 4; i++) {
-                        double s0 = sp[i].x1, s1 = sp[i].y1, s3 = sp[i].x2, s4 = sp[i].y2;
-                        double z0[9] = {s3, 0, -s0*s3, s4, 0, -s0*s4, 1.0, 0, -s0*1.0};
-                        double z1[9] = {0, s3, -s1*s3, 0, s4, -s1*s4, 0, 1.0, -s1*1.0};
-                        for (int j = 0; j < 9; j++) { Ag[18*i+j] = z0[j]; Ag[18*i+9+j] = z1[j]; }
-                    }
-                    for (int i = 72; i < 81; i++) Ag[i] = 0;
-                    for (int i = 0; i < 81; i++) sol[i] = 0;
-                    if (dg_nullspace(Ag, sol, 9, nb) == 1) { for (int i = 0; i < 9; i++) hm[i] = sol[i]; ok = 1; }
-                }
-                if (ok && !dg_HcloseToSingular(hm)) {
-                    valid = 1;
-                    if (kind != 0) { double Hi[9]; dg_hsym_prepare(hm, Hi, H1m); }
-                }
-            }
-        }
+        if (tid < chunk) valid = dg_solve4_lane(P, c.draws[tid], kind, hm, H1m);
         {
             unsigned v = (unsigned)valid, incl = v;
 #pragma unroll
@@ -367,17 +372,20 @@ __global__ __launch_bounds__(DG_T) void dg_find_homography_kernel(dg_args A)
             if (tid == DG_T - 1) S->moff[DG_CHUNK] = (unsigned short)(excl + v);
             __syncthreads();
         }
-        const int Mtot = S->moff[DG_CHUNK];
+        const int Mtot = __builtin_amdgcn_readfirstlane((int)S->moff[DG_CHUNK]);
 
-        /* ---- score chunk c (waves 1..NW-1, one wave per model)  ||  sample chunk c+1 (wave 0) ---- */
+        /* ---- score chunk c (one wave per model)  ||  sample chunk c+1 (wave 0, which then joins) ---- */
         const int nxt = cur ^ 1;
         {
             int cn = max_sam - (no_sam + chunk_s[cur]); if (cn > DG_CHUNK) cn = DG_CHUNK; if (cn < 0) cn = 0;
             chunk_s[nxt] = cn;
             if (wave == 0) {
                 if (cn > 0) { unsigned sd = dg_sample_chunk<4, LDSPTS>(seed, cn, n, pool, S->seeds2[nxt], S->draws2[nxt], lane); if (lane == 0) S->itmp[31] = (int)sd; }
-            } else {
-                for (int mi = wave - 1; mi < Mtot; mi += DG_NW - 1) {
+            }
+            {
+                /* static round-robin over all waves; wave 0 takes its share once the next chunk is sampled */
+                for (int mi = wave; mi < Mtot; mi += DG_NW) {
+
                     double H[9], Hinv[9], H1[9];
                     const double *g = c.gmodels + (size_t)mi * 18;
 #pragma unroll
