@@ -34,6 +34,26 @@ __device__ __forceinline__ double dg_exFDsSym(const double *F, double x1, double
     *w = (a*b) / (a + b);
     return r*r / *w;
 }
+enum { DG_K_FDS = 0, DG_K_FSYM = 1, DG_K_EXFSYM = 2 };
+
+/* Conservative, division-free test "could the residual of this point be below t?" used to bound a model's MSAC
+ * gain from above before it is scored exactly (tb = t inflated by 1e-6, FMA allowed: nothing here reaches an
+ * output).  Returns 1 for every point whose exact residual is < t, and for non-finite cases. */
+__device__ __forceinline__ unsigned dg_Fbound(int kind, const double *F, const dg_pt &p, double tb)
+{
+    const double x1 = p.x1, y1 = p.y1, x2 = p.x2, y2 = p.y2;
+    double rxc = __builtin_fma(F[0], x2, __builtin_fma(F[3], y2, F[6]));
+    double ryc = __builtin_fma(F[1], x2, __builtin_fma(F[4], y2, F[7]));
+    double rwc = __builtin_fma(F[2], x2, __builtin_fma(F[5], y2, F[8]));
+    double r   = __builtin_fma(x1, rxc, __builtin_fma(y1, ryc, rwc));
+    double rx  = __builtin_fma(F[0], x1, __builtin_fma(F[1], y1, F[2]));
+    double ry  = __builtin_fma(F[3], x1, __builtin_fma(F[4], y1, F[5]));
+    double a = __builtin_fma(rxc, rxc, ryc*ryc), b = __builtin_fma(rx, rx, ry*ry);
+    double lhs, rhs;
+    if (kind == DG_K_FDS) { lhs = r*r; rhs = tb * (a + b); }
+    else                  { lhs = r*r * (a + b); rhs = tb * (a * b); }
+    return !(lhs >= rhs) ? 1u : 0u;
+}
 /* exFDs weight: 1/sqrt(den) (Ftools.c:137-139); the residual equals FDs bit for bit */
 __device__ __forceinline__ double dg_exFDs_w(const double *F, double x1, double y1, double x2, double y2)
 {
@@ -44,7 +64,6 @@ __device__ __forceinline__ double dg_exFDs_w(const double *F, double x1, double 
 }
 
 /* metric kinds */
-enum { DG_K_FDS = 0, DG_K_FSYM = 1, DG_K_EXFSYM = 2 };
 
 __device__ __forceinline__ double dg_Ferr(int kind, const double *F, const dg_pt &p)
 {

@@ -19,8 +19,11 @@ struct dg_f_shared {
     dg_red red;
     dg_lsq_scratch lsq;
     dg_rng rng, rng_save;
-    unsigned seeds2[2][DG_CHUNK];       /* double-buffered chunk state: chunk c+1 is sampled while chunk c is scored */
-    int      draws2[2][DG_CHUNK][8];    /* raw draws, then drawn ids (draw order) */
+    /* triple-buffered chunk state: while chunk c is scored, wave 0 runs the pool swaps of chunk c+1 and
+     * wave 1 the seed chain + raw draws of chunk c+2 (the sample stream does not depend on outcomes) */
+    unsigned seeds3[3][DG_CHUNK];
+    int      draws3[3][DG_CHUNK][8];    /* raw draws, then drawn ids (draw order) */
+    unsigned long long alm3[3][DG_CHUNK / 64];   /* per-sample alias flags (order-dependent swaps) */
     dg_wave_ws ww[DG_NW];                /* per-wave scratch of the wave-parallel sections */
     double   hw5[5][17 * 9 + 32];        /* Hdetect temporaries of checksample's five triplets */
     double   csH[5][9]; int csRes[5];    /* checksample: per-triplet homography and verdict */

@@ -213,11 +213,14 @@ __device__ __noinline__ int dg_solve7_lane(const dg_pt *P, const int *ids, doubl
  * (seed_{k+1} = output #NDRAW after srand(seed_k)), the NDRAW draws of every sample and the Fisher-Yates
  * pool swaps (rtools.c:12-23).  Fills seeds[0..cn) and draws[k][0..NDRAW) (drawn ids in draw order) and
  * returns the seed of the sample after the chunk.  NDRAW = 7 (F) or 4 (H). */
-template <int NDRAW, bool LDSPTS>
-__device__ __noinline__ unsigned dg_sample_chunk(unsigned seed, int cn, int n, int *pool, unsigned *seeds, int (*draws)[8], int lane, long long *dbg = 0)
+/* Sampler stage 1 (one wave): the seed chain of a chunk and the raw draws of every sample.
+ * Returns the seed that follows the chunk; almask[] (LDS) receives the per-sample alias flags. */
+template <int NDRAW>
+__device__ __noinline__ unsigned dg_sample_draws(unsigned seed, int cn, int n, unsigned *seeds, int (*draws)[8],
+                                                 unsigned long long *almask, int lane, long long *dbg = 0)
 {
     long long ts0 = wall_clock64();
-    __builtin_amdgcn_s_setprio(3);                        /* the serial wave must not queue behind the scoring waves */
+    __builtin_amdgcn_s_setprio(3);                        /* the serial waves must not queue behind the scoring waves */
     /* seed chain: lane j carries the term C[NDRAW][j] * r_j, r_j = seed * 16807^j mod (2^31-1) */
     const unsigned gk = lane < 31 ? dg_rng_G[lane] : 0u, ck = lane < 31 ? dg_rng_C[NDRAW][lane] : 0u;
     unsigned sd = seed;
@@ -230,8 +233,7 @@ __device__ __noinline__ unsigned dg_sample_chunk(unsigned seed, int cn, int n, i
     DG_WSYNC();
     long long ts1 = wall_clock64();
     /* draws of every sample (lane = sample) + per-sample alias flag: two draws on the same position, or a draw
-     * inside the tail block, make the swaps of that sample order-dependent -> replayed sequentially below */
-    unsigned long long almask[DG_CHUNK / 64];
+     * inside the tail block, make the swaps of that sample order-dependent -> replayed sequentially in stage 2 */
 #pragma unroll
     for (int rd = 0; rd < DG_CHUNK / 64; rd++) {
         const int k = rd * 64 + lane;
@@ -246,13 +248,28 @@ __device__ __noinline__ unsigned dg_sample_chunk(unsigned seed, int cn, int n, i
 #pragma unroll
                 for (int j = i + 1; j < NDRAW; j++) al = al || dr[i] == dr[j];
         }
-        almask[rd] = __ballot(al);
+        unsigned long long b = __ballot(al);
+        if (lane == 0) almask[rd] = b;
     }
     DG_WSYNC();
+    __builtin_amdgcn_s_setprio(0);
+    if (dbg && lane == 0) { long long ts2 = wall_clock64(); dbg[4] += ts1 - ts0; dbg[5] += ts2 - ts1; }
+    return sd;
+}
+
+/* Sampler stage 2 (one wave): the pool swaps of a chunk (rtools.c:12-23) turn the raw draws into drawn ids.
+ * Lanes 0..NDRAW-1 own one draw each, the NDRAW tail slots live in registers.  Software-pipelined: LDS
+ * operations of one wave execute in issue order (read_k, write_k, read_{k+1}, ...), so read_{k+1} is issued
+ * before read_k's result is consumed; draw positions are prefetched two ahead. */
+template <int NDRAW, bool LDSPTS>
+__device__ __noinline__ void dg_sample_pool(int cn, int n, int *pool, int (*draws)[8], const unsigned long long *almask_in,
+                                            int lane, long long *dbg = 0)
+{
     long long ts2 = wall_clock64();
-    /* pool swaps (rtools.c:12-23): lanes 0..NDRAW-1 own one draw each, the NDRAW tail slots live in registers.
-     * Software-pipelined: LDS operations of one wave execute in issue order (read_k, write_k, read_{k+1}, ...),
-     * so read_{k+1} is issued before read_k's result is consumed; draw positions are prefetched two ahead. */
+    __builtin_amdgcn_s_setprio(3);
+    unsigned long long almask[DG_CHUNK / 64];
+#pragma unroll
+    for (int rd = 0; rd < DG_CHUNK / 64; rd++) almask[rd] = almask_in[rd];
     int *vp = pool;
     const bool act = lane < NDRAW;
     int t = act ? vp[n - 1 - lane] : 0;
@@ -288,11 +305,20 @@ __device__ __noinline__ unsigned dg_sample_chunk(unsigned seed, int cn, int n, i
     if (act) vp[n - 1 - lane] = t;
     DG_WSYNC();
     __builtin_amdgcn_s_setprio(0);
-    if (dbg && lane == 0) { long long ts3 = wall_clock64(); dbg[4] += ts1 - ts0; dbg[5] += ts2 - ts1; dbg[6] += ts3 - ts2; }
-    return sd;
+    if (dbg && lane == 0) { long long ts3 = wall_clock64(); dbg[6] += ts3 - ts2; }
 }
 
 /* ---------------------------------------------------------------------------------------------- */
+/* both stages back to back on one wave (prologue of the main kernels, unit-test kernel) */
+template <int NDRAW, bool LDSPTS>
+__device__ __forceinline__ unsigned dg_sample_chunk(unsigned seed, int cn, int n, int *pool, unsigned *seeds, int (*draws)[8],
+                                                    unsigned long long *almask, int lane)
+{
+    unsigned sd = dg_sample_draws<NDRAW>(seed, cn, n, seeds, draws, almask, lane);
+    dg_sample_pool<NDRAW, LDSPTS>(cn, n, pool, draws, almask, lane);
+    return sd;
+}
+
 template <bool LDSPTS>
 __global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
 {
@@ -316,7 +342,7 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
     c.gmodels = (double *)(ws + A.wl.off_models);
     c.stage = (dg_pt *)(ws + A.wl.off_stage);
     c.res_J = (double *)(ws + A.wl.off_res); c.res_I = (unsigned *)(c.res_J + 3 * DG_CHUNK); c.rf = (int (*)[5])(c.res_I + 3 * DG_CHUNK);
-    c.seeds = S->seeds2[0]; c.draws = S->draws2[0];
+    c.seeds = S->seeds3[0]; c.draws = S->draws3[0];
     c.n_max = A.wl.n_max; c.wlist = (int *)(ws + A.wl.off_wave); c.wstage = (dg_pt *)(ws + A.wl.off_wave + (size_t)DG_NW * A.wl.n_max * sizeof(int));
     c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0;
     dg_pt *Pw; int *pool;
@@ -357,18 +383,24 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
 
     if (tid == 0) { for (int i = 0; i < 8; i++) { S->ph[i] = 0; S->dbg[i] = 0; } S->tq = wall_clock64(); }
 #define DG_PH(i) do { if (tid == 0) { long long tq2_ = wall_clock64(); S->ph[i] += tq2_ - S->tq; S->tq = tq2_; } } while (0)
-    /* software pipeline: chunk c+1 is sampled by wave 0 while waves 1.. score chunk c */
-    int cur = 0, chunk_s[2] = {0, 0}, chunk_base = 0;
+    /* software pipeline: chunk c is scored while chunk c+1 gets its pool swaps and chunk c+2 its seeds and draws */
+    int cur = 0, chunk_s[3] = {0, 0, 0}, chunk_base = 0;
     {
-        int cn = max_sam - no_sam; if (cn > DG_CHUNK) cn = DG_CHUNK; if (cn < 0) cn = 0;
-        chunk_s[0] = cn;
-        if (wave == 0 && cn > 0) { unsigned sd = dg_sample_chunk<7, LDSPTS>(seed, cn, n, pool, S->seeds2[0], S->draws2[0], lane); if (lane == 0) S->itmp[31] = (int)sd; }
+        int cn0 = max_sam - no_sam; if (cn0 > DG_CHUNK) cn0 = DG_CHUNK; if (cn0 < 0) cn0 = 0;
+        int cn1 = max_sam - no_sam - cn0; if (cn1 > DG_CHUNK) cn1 = DG_CHUNK; if (cn1 < 0) cn1 = 0;
+        chunk_s[0] = cn0; chunk_s[1] = cn1;
+        if (wave == 0) {
+            unsigned sd = seed;
+            if (cn0 > 0) sd = dg_sample_chunk<7, LDSPTS>(sd, cn0, n, pool, S->seeds3[0], S->draws3[0], S->alm3[0], lane);
+            if (cn1 > 0) sd = dg_sample_draws<7>(sd, cn1, n, S->seeds3[1], S->draws3[1], S->alm3[1], lane);
+            if (lane == 0) S->itmp[31] = (int)sd;
+        }
         __syncthreads();
         seed = (unsigned)S->itmp[31];
     }
     while (!done && no_sam < max_sam) {
         int chunk = chunk_s[cur]; if (chunk > max_sam - no_sam) chunk = max_sam - no_sam;
-        c.seeds = S->seeds2[cur]; c.draws = S->draws2[cur]; chunk_base = no_sam;
+        c.seeds = S->seeds3[cur]; c.draws = S->draws3[cur]; chunk_base = no_sam;
         DG_PH(3);
         DG_PH(0);
         /* ================= solve: one 7-point problem per lane ================= */
@@ -401,22 +433,35 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
         const int Mtot = __builtin_amdgcn_readfirstlane((int)S->moff[DG_CHUNK]);
 
         DG_PH(1);
-        /* ====== score chunk c (one wave per model, points streamed from LDS)  ||  sample chunk c+1 (wave 0, which then joins) ====== */
-        const int nxt = cur ^ 1;
+        /* ====== score chunk c (waves 2.., one wave per model, points streamed from LDS)  ||  pool swaps of chunk c+1 (wave 0)  ||  seeds + draws of chunk c+2 (wave 1) ====== */
+        const int nxt = cur == 2 ? 0 : cur + 1, nx2 = nxt == 2 ? 0 : nxt + 1;
+        int cn2;
         {
-            int cn = max_sam - (no_sam + chunk_s[cur]); if (cn > DG_CHUNK) cn = DG_CHUNK; if (cn < 0) cn = 0;
-            chunk_s[nxt] = cn;
+            cn2 = max_sam - (no_sam + chunk_s[cur] + chunk_s[nxt]); if (cn2 > DG_CHUNK) cn2 = DG_CHUNK; if (cn2 < 0) cn2 = 0;
+            chunk_s[nx2] = cn2;
             if (wave == 0) {
-                if (cn > 0) { unsigned sd = dg_sample_chunk<7, LDSPTS>(seed, cn, n, pool, S->seeds2[nxt], S->draws2[nxt], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }
-            }
-            {
-                /* static round-robin over all waves; wave 0 takes its share once the next chunk is sampled */
-                for (int mi = wave; mi < Mtot; mi += DG_NW) {
-
+                if (chunk_s[nxt] > 0) dg_sample_pool<7, LDSPTS>(chunk_s[nxt], n, pool, S->draws3[nxt], S->alm3[nxt], lane, S->dbg);
+            } else if (wave == 1) {
+                if (cn2 > 0) { unsigned sd = dg_sample_draws<7>(seed, cn2, n, S->seeds3[nx2], S->draws3[nx2], S->alm3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }
+            } else {
+                /* Static round-robin over the scoring waves.  A model matters only if its gain beats
+                 * tau = min(maxS.J, maxSs.J) strictly, and J <= #points with residual < 9/4 th: a division-free
+                 * count of a superset of those points rejects most models at a third of the cost; survivors are
+                 * scored exactly.  Rejected models get J = 0 (never an event in the commit). */
+                const double tauJ = maxS.J < maxSs.J ? maxS.J : maxSs.J;
+                const double t94b = (th * 9 / 4) * (1.0 + 1e-6);
+                const bool use_bound = th != 0 && mk_full != DG_K_EXFSYM;
+                for (int mi = wave - 2; mi < Mtot; mi += DG_NW - 2) {
                     double F[9];
                     const double *g = c.gmodels + (size_t)S->mslot[mi] * 9;
 #pragma unroll
                     for (int j = 0; j < 9; j++) F[j] = g[j];
+                    if (use_bound) {
+                        unsigned cb = 0;
+                        for (int p = lane; p < n; p += 64) { dg_pt q = P[p]; cb += dg_Fbound(mk_full, F, q, t94b); }
+                        const unsigned CB = dg_wave_sum_u(cb);
+                        if (!((double)CB > tauJ)) { if (lane == 0) { c.res_I[mi] = 0; c.res_J[mi] = 0; } continue; }
+                    }
                     unsigned cI = 0; double acc[DG_NW]; const double t94 = th * 9 / 4;
 #pragma unroll
                     for (int r = 0; r < DG_NW; r++) acc[r] = 0;
@@ -436,7 +481,7 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
         }
         c.n_fds += Mtot;   /* provisional: models past the termination point are subtracted below */
         __syncthreads();
-        if (chunk_s[nxt] > 0) seed = (unsigned)S->itmp[31];
+        if (cn2 > 0) seed = (unsigned)S->itmp[31];
         DG_PH(2);
         /* ================= commit: replay exp_ranF.c:1334-1577 in order ================= */
         int k;

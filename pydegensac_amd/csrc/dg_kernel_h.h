@@ -309,7 +309,7 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_homography_kernel(dg_args A)
     c.gmodels = (double *)(ws + A.wl.off_models);
     c.stage = (dg_pt *)(ws + A.wl.off_stage);
     c.res_J = (double *)(ws + A.wl.off_res); c.res_I = (unsigned *)(c.res_J + 3 * DG_CHUNK); c.rf = (int (*)[5])(c.res_I + 3 * DG_CHUNK);
-    c.seeds = S->seeds2[0]; c.draws = S->draws2[0];
+    c.seeds = S->seeds3[0]; c.draws = S->draws3[0];
     c.n_max = A.wl.n_max; c.wlist = (int *)(ws + A.wl.off_wave); c.wstage = (dg_pt *)(ws + A.wl.off_wave + (size_t)DG_NW * A.wl.n_max * sizeof(int));
     c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0;
     dg_pt *Pw; int *pool;
@@ -336,18 +336,24 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_homography_kernel(dg_args A)
     unsigned seed = (unsigned)S->itmp[31];
     __syncthreads();
 
-    /* software pipeline: chunk c+1 is sampled by wave 0 while waves 1.. score chunk c */
-    int cur = 0, chunk_s[2] = {0, 0}, chunk_base = 0;
+    /* software pipeline: chunk c is scored while chunk c+1 gets its pool swaps and chunk c+2 its seeds and draws */
+    int cur = 0, chunk_s[3] = {0, 0, 0}, chunk_base = 0;
     {
-        int cn = max_sam - no_sam; if (cn > DG_CHUNK) cn = DG_CHUNK; if (cn < 0) cn = 0;
-        chunk_s[0] = cn;
-        if (wave == 0 && cn > 0) { unsigned sd = dg_sample_chunk<4, LDSPTS>(seed, cn, n, pool, S->seeds2[0], S->draws2[0], lane); if (lane == 0) S->itmp[31] = (int)sd; }
+        int cn0 = max_sam - no_sam; if (cn0 > DG_CHUNK) cn0 = DG_CHUNK; if (cn0 < 0) cn0 = 0;
+        int cn1 = max_sam - no_sam - cn0; if (cn1 > DG_CHUNK) cn1 = DG_CHUNK; if (cn1 < 0) cn1 = 0;
+        chunk_s[0] = cn0; chunk_s[1] = cn1;
+        if (wave == 0) {
+            unsigned sd = seed;
+            if (cn0 > 0) sd = dg_sample_chunk<4, LDSPTS>(sd, cn0, n, pool, S->seeds3[0], S->draws3[0], S->alm3[0], lane);
+            if (cn1 > 0) sd = dg_sample_draws<4>(sd, cn1, n, S->seeds3[1], S->draws3[1], S->alm3[1], lane);
+            if (lane == 0) S->itmp[31] = (int)sd;
+        }
         __syncthreads();
         seed = (unsigned)S->itmp[31];
     }
     while (!done && no_sam < max_sam) {
         int chunk = chunk_s[cur]; if (chunk > max_sam - no_sam) chunk = max_sam - no_sam;
-        c.seeds = S->seeds2[cur]; c.draws = S->draws2[cur]; chunk_base = no_sam;
+        c.seeds = S->seeds3[cur]; c.draws = S->draws3[cur]; chunk_base = no_sam;
         /* ---- solve: orientation test, 8x9 null vector, near-singularity test; <= 1 model per lane ---- */
         double hm[9], H1m[9]; int valid = 0;
         if (tid < chunk) valid = dg_solve4_lane(P, c.draws[tid], kind, hm, H1m);
@@ -374,17 +380,19 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_homography_kernel(dg_args A)
         }
         const int Mtot = __builtin_amdgcn_readfirstlane((int)S->moff[DG_CHUNK]);
 
-        /* ---- score chunk c (one wave per model)  ||  sample chunk c+1 (wave 0, which then joins) ---- */
-        const int nxt = cur ^ 1;
+        /* ---- score chunk c (waves 2.., one wave per model)  ||  pool swaps of chunk c+1 (wave 0)  ||  seeds + draws of chunk c+2 (wave 1) ---- */
+        const int nxt = cur == 2 ? 0 : cur + 1, nx2 = nxt == 2 ? 0 : nxt + 1;
+        int cn2;
         {
-            int cn = max_sam - (no_sam + chunk_s[cur]); if (cn > DG_CHUNK) cn = DG_CHUNK; if (cn < 0) cn = 0;
-            chunk_s[nxt] = cn;
+            cn2 = max_sam - (no_sam + chunk_s[cur] + chunk_s[nxt]); if (cn2 > DG_CHUNK) cn2 = DG_CHUNK; if (cn2 < 0) cn2 = 0;
+            chunk_s[nx2] = cn2;
             if (wave == 0) {
-                if (cn > 0) { unsigned sd = dg_sample_chunk<4, LDSPTS>(seed, cn, n, pool, S->seeds2[nxt], S->draws2[nxt], lane); if (lane == 0) S->itmp[31] = (int)sd; }
-            }
-            {
-                /* static round-robin over all waves; wave 0 takes its share once the next chunk is sampled */
-                for (int mi = wave; mi < Mtot; mi += DG_NW) {
+                if (chunk_s[nxt] > 0) dg_sample_pool<4, LDSPTS>(chunk_s[nxt], n, pool, S->draws3[nxt], S->alm3[nxt], lane, S->dbg);
+            } else if (wave == 1) {
+                if (cn2 > 0) { unsigned sd = dg_sample_draws<4>(seed, cn2, n, S->seeds3[nx2], S->draws3[nx2], S->alm3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }
+            } else {
+                /* static round-robin over the scoring waves */
+                for (int mi = wave - 2; mi < Mtot; mi += DG_NW - 2) {
 
                     double H[9], Hinv[9], H1[9];
                     const double *g = c.gmodels + (size_t)mi * 18;
@@ -410,7 +418,7 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_homography_kernel(dg_args A)
         }
         c.n_hds += Mtot;
         __syncthreads();
-        if (chunk_s[nxt] > 0) seed = (unsigned)S->itmp[31];
+        if (cn2 > 0) seed = (unsigned)S->itmp[31];
 
         /* ---- commit: replay exp_ranH.c:547-757 in order ---- */
         int k;

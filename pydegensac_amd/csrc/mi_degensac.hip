@@ -293,7 +293,7 @@ extern "C" int mi_degensac_score_models(const double *pts1, const double *pts2, 
 __global__ void dg_sample_stream_kernel(unsigned seed0, int n, int ssz, int iters, int *pool, int *out)
 {
     /* the main kernels' sampler (dg_sample_chunk), chunk by chunk, run by one wave */
-    __shared__ unsigned seeds[DG_CHUNK]; __shared__ int draws[DG_CHUNK][8]; __shared__ dg_rng g; __shared__ unsigned sd0;
+    __shared__ unsigned seeds[DG_CHUNK]; __shared__ int draws[DG_CHUNK][8]; __shared__ dg_rng g; __shared__ unsigned sd0; __shared__ unsigned long long alm[DG_CHUNK / 64];
     const int lane = threadIdx.x;
     for (int i = lane; i < n; i += 64) pool[i] = i;
     if (lane == 0) { dg_srand(&g, seed0); sd0 = (unsigned)dg_rand(&g); }
@@ -301,7 +301,7 @@ __global__ void dg_sample_stream_kernel(unsigned seed0, int n, int ssz, int iter
     unsigned seed = sd0;
     for (int base = 0; base < iters; base += DG_CHUNK) {
         int chunk = iters - base; if (chunk > DG_CHUNK) chunk = DG_CHUNK;
-        seed = ssz == 7 ? dg_sample_chunk<7, false>(seed, chunk, n, pool, seeds, draws, lane) : dg_sample_chunk<4, false>(seed, chunk, n, pool, seeds, draws, lane);
+        seed = ssz == 7 ? dg_sample_chunk<7, false>(seed, chunk, n, pool, seeds, draws, alm, lane) : dg_sample_chunk<4, false>(seed, chunk, n, pool, seeds, draws, alm, lane);
         __syncthreads();
         for (int k = lane; k < chunk; k += 64) for (int i = 0; i < ssz; i++) out[(size_t)(base + k) * ssz + i] = draws[k][i];
         __syncthreads();

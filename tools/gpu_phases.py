@@ -27,4 +27,4 @@ print("mean ms per pair:", {n:round(float(ph[:,i].mean()),3) for i,n in enumerat
 print("max  ms per pair:", {n:round(float(ph[:,i].max()),3) for i,n in enumerate(names)})
 print("samples mean",st[:,0].mean(),"lo_runs mean",st[:,1].mean(),"degen mean",st[:,5].mean(),"models mean",st[:,4].mean(), "aux", st[:,11].mean(), "hds", st[:,10].mean())
 worst=np.argsort(-ph[:,7])[:5]
-for w in worst: print("pair",w,"total",ph[w,7],"LO",ph[w,4],"degen",ph[w,5],"stats",st[w,:12])
+for w in worst: print("pair",w,{n:round(float(ph[w,i]),1) for i,n in enumerate(names)},"stats",list(st[w,:12]))
