@@ -74,42 +74,64 @@ __device__ __forceinline__ dg_score dg_iterF(CTX &c, int *inliers, double th, do
         dg_pass_res r1 = dg_f_pass(c, fl, mk_ex, c1); c.n_exfds++;
         Sc = zero; Sc.I = r1.I; Sc.J = r1.J;
         DG_TRACE(c, 11, Sc.I, Sc.J);
+        /* Reference order: hash lookup ("seen" -> return 0), then on improvement rotate the buffers, then the
+         * inlidxs(d, ths*MWM) list, then the weighted 8-point re-fit.  exp_ranF.c:687-696: after a rotation `d`
+         * is the OLD errs[0], so that list is taken on the residuals of the previous best model of this chain
+         * (= the current value of the out-parameter F), not on the new one.  Reproduced.
+         * Here the serial hash (wave 1) runs concurrently with the serial re-fit (wave 0): the list goes to a
+         * second buffer so the hashed list stays intact, and nothing is committed before the lookup is known. */
+        const int improve = maxS.J < Sc.J;
+        int *alt = c.L[9];
+        dg_pass_cfg c2 = dg_cfg0(n); c2.list = alt; c2.thL = ths * DG_MWM;
+        dg_pass_res r2 = improve ? dg_f_pass(c, f, *kind0, c2) : dg_f_pass(c, fl, mk_ex, c2);
+        const int fit = r2.nL >= 8;
+        const int wv = tid >> 6;
         __syncthreads();
-        if (tid < 64) {
+        if (wv == 1) {
             unsigned hash = dg_hash_list(inliers, (int)Sc.I, n < 65536);
-            if (tid == 0) {
-            int ret = dg_ht_contains(c.ht, hash, (int)Sc.I, iterID);
-            if (ret == -1) dg_ht_insert(c.ht, hash, (int)Sc.I, iterID);
-            S->itmp[0] = (ret != -1 && ret != iterID) ? 1 : 0;
+            if ((tid & 63) == 0) {
+                int ret = dg_ht_contains(c.ht, hash, (int)Sc.I, iterID);
+                if (ret == -1) dg_ht_insert(c.ht, hash, (int)Sc.I, iterID);
+                S->itmp[0] = (ret != -1 && ret != iterID) ? 1 : 0;
             }
+        } else if (wv == 0 && fit) {
+            const int cnt = (int)r2.nL; int o = 0, use = cnt;
+            if (tid == 0) {
+                S->rng_save = S->rng;
+                if (8 < cnt) dg_randsubset(&S->rng, alt, cnt, 8);
+            }
+            if (8 < cnt) { use = 8; o = cnt - 8; }
+            DG_WSYNC();
+            /* u2fw: weights are exFDs' w of the current model at the subset points */
+            if (tid == 0) {
+                dg_gather(c, alt + o, use, S->lsq.px);
+                const int wkind = mk_ex == DG_K_FDS ? DG_K_FDS : DG_K_EXFSYM;
+                for (int i = 0; i < use; i++) {
+                    double *q = S->lsq.px + 4*i;
+                    if (wkind == DG_K_FDS) S->lsq.part[0][i] = dg_exFDs_w(fl, q[0], q[1], q[2], q[3]);
+                    else { double w; dg_exFDsSym(fl, q[0], q[1], q[2], q[3], &w); S->lsq.part[0][i] = w; }
+                }
+            }
+            DG_WSYNC();
+            dg_u2f_small_w(&S->lsq, S->lsq.px, S->lsq.part[0], use, S->ftmp, tid);
         }
         __syncthreads();
-        if (S->itmp[0]) { DG_TRACE(c, 13, 0, 0); return zero; }
-        /* exp_ranF.c:687-696: on improvement the buffers rotate and `d` becomes the OLD errs[0], so the
-         * following inlidxs(d, ths*MWM) runs on the residuals of the previous best model of this chain
-         * (= the previous value of the out-parameter F), not on the current one.  Reproduced. */
-        int stale = 0, stale_kind = *kind0;
-        if (maxS.J < Sc.J) {
-            maxS = Sc; stale = 1; *kind0 = mk_ex;
+        if (S->itmp[0]) {
+            if (fit && tid == 0) S->rng = S->rng_save;
             __syncthreads();
-            if (tid < 9) { S->dtmp[16 + tid] = f[tid]; f[tid] = fl[tid]; }
-            __syncthreads();
+            DG_TRACE(c, 13, 0, 0); return zero;
         }
-        dg_pass_cfg c2 = dg_cfg0(n); c2.list = inliers; c2.thL = ths * DG_MWM;
-        dg_pass_res r2 = stale ? dg_f_pass(c, S->dtmp + 16, stale_kind, c2) : dg_f_pass(c, fl, mk_ex, c2);
+        if (improve) {
+            maxS = Sc; *kind0 = mk_ex;
+            if (tid < 9) f[tid] = fl[tid];
+        }
         DG_TRACE(c, 14, r2.nL, 0);
-        if (r2.nL < 8) return maxS;
-        {
-            int cnt = (int)r2.nL, o = 0, use = cnt;
-            __syncthreads();
-            if (8 < cnt) { if (tid == 0) dg_randsubset(&S->rng, inliers, cnt, 8); use = 8; o = cnt - 8; }
-            __syncthreads();
-            /* u2fw: weights are exFDs' w of the current model at the subset points */
-            __syncthreads();
-            if (tid < 9) S->ftmp[tid] = fl[tid];
-            __syncthreads();
-            dg_u2f_list(c, inliers + o, use, S->ftmp, mk_ex == DG_K_FDS ? DG_K_FDS : DG_K_EXFSYM, fl);
-        }
+        /* the reference builds this list (and shuffles it) in `inliers` itself, and callers later read stale
+         * entries of that buffer (exp_ranF.c:776-779 copies maxS.I ids whatever the list length): keep it identical */
+        for (int j = tid; j < (int)r2.nL; j += DG_T) inliers[j] = alt[j];
+        if (tid < 9 && fit) fl[tid] = S->ftmp[tid];
+        __syncthreads();
+        if (!fit) return maxS;
         ths -= dth;
     }
     dg_pass_cfg c3 = dg_cfg0(n); c3.wantJ = 1; c3.thJ = th; c3.list = inliers; c3.thL = th;
