@@ -1170,7 +1170,7 @@ static __device__ __forceinline__ void dg_singulF(double *F)
                 double alpha = 0., beta = 0., gamma = 0.;
 #pragma unroll
                 for (int i = 0; i < 3; i++) { alpha += A[3*i+p]*A[3*i+p]; beta += A[3*i+q]*A[3*i+q]; gamma += A[3*i+p]*A[3*i+q]; }
-                if (!(gamma == 0. || fabs(gamma) <= 1e-17 * sqrt(alpha * beta))) {
+                if (!(gamma == 0. || fabs(gamma) <= 1e-15 * sqrt(alpha * beta))) {
                     rotated = 1;
                     double zeta = (beta - alpha) / (2. * gamma);
                     double t = (zeta >= 0. ? 1. : -1.) / (fabs(zeta) + sqrt(1. + zeta*zeta));

@@ -146,4 +146,40 @@ __device__ __forceinline__ int dg_randsubset(dg_rng *g, int *pool, int max_sz, i
     return max_sz - siz;
 }
 
+
+/* Wave-cooperative randsubset (all 64 lanes of one wave call it; siz <= 32).  The draws depend only on the RNG,
+ * so lane 0 makes them first; the <= 2*siz list positions involved (tail slots T_i = max_sz-1-i in lanes 0..siz-1,
+ * drawn slots s_i in lanes siz..2*siz-1) are then loaded with ONE parallel access, the swaps are replayed on
+ * registers (first lane holding a position is its canonical slot), and the canonical slots are stored back with
+ * one parallel access: two memory round trips instead of 4*siz dependent ones.  Same list contents afterwards.
+ * *id = for lane j < siz, the id at subset position j (list[max_sz - siz + j]).  Returns the subset's offset. */
+__device__ __forceinline__ int dg_randsubset_wave(dg_rng *g, int *pool, int max_sz, int siz, int lane, int *id)
+{
+    int myS = 0;
+    for (int i = 0; i < siz; i++) {
+        int s = 0;
+        if (lane == 0) s = dg_rand(g) % (max_sz - i);
+        s = __builtin_amdgcn_readfirstlane(s);
+        if (lane == i) myS = s;
+    }
+    const bool used = lane < 2 * siz;
+    const int drawn = __shfl(myS, lane >= siz ? lane - siz : 0, 64);
+    const int pos = lane < siz ? max_sz - 1 - lane : (used ? drawn : -1);
+    int val = used ? pool[pos] : 0;
+    for (int i = 0; i < siz; i++) {
+        const int s_i = __builtin_amdgcn_readlane(myS, i), t_i = max_sz - 1 - i;
+        const unsigned long long mA = __ballot(used && pos == s_i), mB = __ballot(used && pos == t_i);
+        const int la = __ffsll((long long)mA) - 1, lb = __ffsll((long long)mB) - 1;
+        const int va = __builtin_amdgcn_readlane(val, la), vb = __builtin_amdgcn_readlane(val, lb);
+        if (lane == la) val = vb;
+        if (lane == lb) val = va;
+    }
+    bool canon = used;
+    for (int j = 0; j < 2 * siz; j++) { const int pj = __builtin_amdgcn_readlane(pos, j); if (j < lane && pj == pos) canon = false; }
+    if (canon) pool[pos] = val;
+    /* subset position j <-> tail slot T_{siz-1-j}; tail lanes are always canonical */
+    *id = __shfl(val, lane < siz ? siz - 1 - lane : 0, 64);
+    return max_sz - siz;
+}
+
 #endif /* DG_KERNEL_COMMON_H */

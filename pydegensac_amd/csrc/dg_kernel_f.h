@@ -29,7 +29,10 @@ struct dg_f_shared {
     double   csH[5][9]; int csRes[5];    /* checksample: per-triplet homography and verdict */
     double   fhF[16][9], fhF2[16][9], fhTh[16];   /* innerFH: per-repetition model, its u2Fit refinement, flag threshold */
     int      fhIds[16][10], fhCnt[16], fhCnt2[16];
-    long long ph[8], dbg[8], tq;          /* phase timers (lane 0), 100 MHz ticks */
+    long long ph[8], dbg[8], tq;
+#ifdef DG_LO_PROF
+    long long lt[16], ltq;
+#endif          /* phase timers (lane 0), 100 MHz ticks */
     unsigned short moff[DG_T + 1];      /* first model slot of each sample */
     unsigned char  nv[DG_CHUNK];        /* valid models per sample; 255 = nullspace dimension != 2 */
     unsigned char  ridx[DG_CHUNK][4];   /* root index i (= errs[] slot) of each valid model */
@@ -116,6 +119,13 @@ __device__ __forceinline__ void dg_gather(CTX &c, const int *ids, int len, doubl
     for (int i = 0; i < len; i++) { dg_pt p = c.P[ids[i]]; px[4*i] = p.x1; px[4*i+1] = p.y1; px[4*i+2] = p.x2; px[4*i+3] = p.y2; }
 }
 
+/* lane j < len writes the coordinates of point `id` (its own) to row j of px */
+template <bool LDSPTS>
+__device__ __forceinline__ void dg_gather_wave(CTX &c, int id, int len, double *px, int lane)
+{
+    if (lane < len) { dg_pt p = c.P[id]; px[4*lane] = p.x1; px[4*lane+1] = p.y1; px[4*lane+2] = p.x2; px[4*lane+3] = p.y2; }
+}
+
 /* u2f on a global id list of any length -> S->f  (exp_ranF.c's u2f(u, inliers, n, f, buffer) calls) */
 template <bool LDSPTS>
 __device__ __forceinline__ void dg_u2f_list(CTX &c, const int *list, int len, const double *wmodel, int wkind, double *Fout)
@@ -124,15 +134,12 @@ __device__ __forceinline__ void dg_u2f_list(CTX &c, const int *list, int len, co
     if (len <= 16) {
         __syncthreads();
         if (c.tid < 64) {
-            if (c.tid == 0) {
-                dg_gather(c, list, len, S->lsq.px);
-                if (wmodel) {
-                    for (int i = 0; i < len; i++) {
-                        double *q = S->lsq.px + 4*i;
-                        if (wkind == DG_K_FDS) S->lsq.part[0][i] = dg_exFDs_w(wmodel, q[0], q[1], q[2], q[3]);
-                        else { double w; dg_exFDsSym(wmodel, q[0], q[1], q[2], q[3], &w); S->lsq.part[0][i] = w; }
-                    }
-                }
+            const int lane = c.tid;
+            dg_gather_wave(c, lane < len ? list[lane] : 0, len, S->lsq.px, lane);
+            if (wmodel && lane < len) {
+                dg_pt q = c.P[list[lane]];
+                if (wkind == DG_K_FDS) S->lsq.part[0][lane] = dg_exFDs_w(wmodel, q.x1, q.y1, q.x2, q.y2);
+                else { double w; dg_exFDsSym(wmodel, q.x1, q.y1, q.x2, q.y2, &w); S->lsq.part[0][lane] = w; }
             }
             DG_WSYNC();
             dg_u2f_small_w(&S->lsq, S->lsq.px, wmodel ? S->lsq.part[0] : 0, len, Fout, c.tid);
@@ -262,7 +269,7 @@ __device__ __noinline__ unsigned dg_innerH(CTX &c, double *H /* LDS, in/out */, 
         for (int rep = 0; rep < DG_RAN_REP; ++rep) {
             __syncthreads();
             if (tid < 64) {
-                if (tid == 0) { int o = dg_randsubset(&S->rng, inliers, ninl, ssiz); dg_gather(c, inliers + o, ssiz, S->lsq.px); }
+                { int id; dg_randsubset_wave(&S->rng, inliers, ninl, ssiz, tid, &id); dg_gather_wave(c, id, ssiz, S->lsq.px, tid); }
                 DG_WSYNC();
                 dg_u2h_small_w(&S->lsq, S->lsq.px, ssiz, h, tid);
             }
@@ -280,7 +287,7 @@ __device__ __noinline__ unsigned dg_innerH(CTX &c, double *H /* LDS, in/out */, 
                     __syncthreads();
                     if (tid < 64) {
                         int cnt = (int)mI > (int)inlLimit ? (int)inlLimit : (int)mI;
-                        if (tid == 0) { int o = 0; if (mI > inlLimit) o = dg_randsubset(&S->rng, intbuff, (int)mI, (int)inlLimit); dg_gather(c, intbuff + o, cnt, S->lsq.px); }
+                        { int id; if (mI > inlLimit) dg_randsubset_wave(&S->rng, intbuff, (int)mI, (int)inlLimit, tid, &id); else id = tid < cnt ? intbuff[tid] : 0; dg_gather_wave(c, id, cnt, S->lsq.px, tid); }
                         DG_WSYNC();
                         dg_u2h_small_w(&S->lsq, S->lsq.px, cnt, hl, tid);
                     }
@@ -294,7 +301,7 @@ __device__ __noinline__ unsigned dg_innerH(CTX &c, double *H /* LDS, in/out */, 
                         __syncthreads();
                         if (tid < 64) {
                             int cnt = r2.nL > inlLimit ? (int)inlLimit : (int)r2.nL;
-                            if (tid == 0) { int o = 0; if (r2.nL > inlLimit) o = dg_randsubset(&S->rng, intbuff, (int)r2.nL, (int)inlLimit); dg_gather(c, intbuff + o, cnt, S->lsq.px); }
+                            { int id; if (r2.nL > inlLimit) dg_randsubset_wave(&S->rng, intbuff, (int)r2.nL, (int)inlLimit, tid, &id); else id = tid < cnt ? intbuff[tid] : 0; dg_gather_wave(c, id, cnt, S->lsq.px, tid); }
                             DG_WSYNC();
                             dg_u2h_small_w(&S->lsq, S->lsq.px, cnt, hl, tid);
                         }

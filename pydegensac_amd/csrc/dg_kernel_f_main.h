@@ -39,6 +39,12 @@ __device__ __forceinline__ unsigned dg_hash_list(const int *list, int count, boo
     return hash;
 }
 
+#ifdef DG_LO_PROF
+#define DG_LT(i) do { __syncthreads(); if (c.tid == 0) { long long t_ = wall_clock64(); c.S->lt[i] += t_ - c.S->ltq; c.S->ltq = t_; } } while (0)
+#else
+#define DG_LT(i) do {} while (0)
+#endif
+
 /* exp_ranF.c:621-743 exp_iterFcustom.  f (LDS) is the in/out model parameter `F`; on return *kind0 is the
  * metric variant (FDS1 / EXFDS1) whose residuals the reference would hold in errs[0] for that model. */
 template <bool LDSPTS>
@@ -51,7 +57,9 @@ __device__ __forceinline__ dg_score dg_iterF(CTX &c, int *inliers, double th, do
     double dth = (ths - th) / DG_ILSQ_ITERS;
     /* errs[4] = errs[0] = FDS1(f): one pass gives inlidxs(.., th) and the list at th*MWM */
     dg_pass_cfg c0 = dg_cfg0(n); c0.wantJ = 1; c0.thJ = th; c0.list = inliers; c0.thL = th * DG_MWM;
+    DG_LT(0);
     dg_pass_res r0 = dg_f_pass(c, f, mk_full, c0); c.n_fds++;
+    DG_LT(1);
     maxS.I = r0.I; maxS.J = r0.J;
     *kind0 = mk_full;
     DG_TRACE(c, 10, maxS.I, maxS.J);
@@ -65,13 +73,15 @@ __device__ __forceinline__ dg_score dg_iterF(CTX &c, int *inliers, double th, do
         DG_TRACE(c, 15, cnt, 0);
         int o = 0, use = cnt;
         __syncthreads();
-        if (8 < cnt) { if (tid == 0) o = dg_randsubset(&S->rng, inliers, cnt, 8); use = 8; o = cnt - 8; }
+        if (8 < cnt) { if (tid < 64) { int id; dg_randsubset_wave(&S->rng, inliers, cnt, 8, tid, &id); } use = 8; o = cnt - 8; }
         __syncthreads();
         dg_u2f_list(c, inliers + o, use, 0, 0, fl);
     }
+    DG_LT(2);
     for (int it = 0; it < DG_ILSQ_ITERS; it++) {
         dg_pass_cfg c1 = dg_cfg0(n); c1.wantJ = 1; c1.thJ = th; c1.list = inliers; c1.thL = th;
         dg_pass_res r1 = dg_f_pass(c, fl, mk_ex, c1); c.n_exfds++;
+        DG_LT(3);
         Sc = zero; Sc.I = r1.I; Sc.J = r1.J;
         DG_TRACE(c, 11, Sc.I, Sc.J);
         /* Reference order: hash lookup ("seen" -> return 0), then on improvement rotate the buffers, then the
@@ -87,6 +97,7 @@ __device__ __forceinline__ dg_score dg_iterF(CTX &c, int *inliers, double th, do
         const int fit = r2.nL >= 8;
         const int wv = tid >> 6;
         __syncthreads();
+        DG_LT(4);
         if (wv == 1) {
             unsigned hash = dg_hash_list(inliers, (int)Sc.I, n < 65536);
             if ((tid & 63) == 0) {
@@ -95,27 +106,23 @@ __device__ __forceinline__ dg_score dg_iterF(CTX &c, int *inliers, double th, do
                 S->itmp[0] = (ret != -1 && ret != iterID) ? 1 : 0;
             }
         } else if (wv == 0 && fit) {
-            const int cnt = (int)r2.nL; int o = 0, use = cnt;
-            if (tid == 0) {
-                S->rng_save = S->rng;
-                if (8 < cnt) dg_randsubset(&S->rng, alt, cnt, 8);
-            }
-            if (8 < cnt) { use = 8; o = cnt - 8; }
+            const int cnt = (int)r2.nL; int use = cnt, id;
+            if (tid == 0) S->rng_save = S->rng;
             DG_WSYNC();
+            if (8 < cnt) { dg_randsubset_wave(&S->rng, alt, cnt, 8, tid, &id); use = 8; }
+            else id = tid < cnt ? alt[tid] : 0;
             /* u2fw: weights are exFDs' w of the current model at the subset points */
-            if (tid == 0) {
-                dg_gather(c, alt + o, use, S->lsq.px);
-                const int wkind = mk_ex == DG_K_FDS ? DG_K_FDS : DG_K_EXFSYM;
-                for (int i = 0; i < use; i++) {
-                    double *q = S->lsq.px + 4*i;
-                    if (wkind == DG_K_FDS) S->lsq.part[0][i] = dg_exFDs_w(fl, q[0], q[1], q[2], q[3]);
-                    else { double w; dg_exFDsSym(fl, q[0], q[1], q[2], q[3], &w); S->lsq.part[0][i] = w; }
-                }
+            if (tid < use) {
+                dg_pt q = c.P[id];
+                double *px = S->lsq.px + 4*tid; px[0] = q.x1; px[1] = q.y1; px[2] = q.x2; px[3] = q.y2;
+                if (mk_ex == DG_K_FDS) S->lsq.part[0][tid] = dg_exFDs_w(fl, q.x1, q.y1, q.x2, q.y2);
+                else { double w; dg_exFDsSym(fl, q.x1, q.y1, q.x2, q.y2, &w); S->lsq.part[0][tid] = w; }
             }
             DG_WSYNC();
             dg_u2f_small_w(&S->lsq, S->lsq.px, S->lsq.part[0], use, S->ftmp, tid);
         }
         __syncthreads();
+        DG_LT(5);
         if (S->itmp[0]) {
             if (fit && tid == 0) S->rng = S->rng_save;
             __syncthreads();
@@ -131,11 +138,14 @@ __device__ __forceinline__ dg_score dg_iterF(CTX &c, int *inliers, double th, do
         for (int j = tid; j < (int)r2.nL; j += DG_T) inliers[j] = alt[j];
         if (tid < 9 && fit) fl[tid] = S->ftmp[tid];
         __syncthreads();
+        DG_LT(6);
         if (!fit) return maxS;
         ths -= dth;
     }
     dg_pass_cfg c3 = dg_cfg0(n); c3.wantJ = 1; c3.thJ = th; c3.list = inliers; c3.thL = th;
+    DG_LT(0);
     dg_pass_res r3 = dg_f_pass(c, fl, mk_full, c3); c.n_fds++;
+    DG_LT(7);
     DG_TRACE(c, 12, r3.I, r3.J);
     if (maxS.J < r3.J) {
         maxS = zero; maxS.I = r3.I; maxS.J = r3.J; *kind0 = mk_full;
@@ -158,12 +168,14 @@ __device__ __noinline__ dg_score dg_inFrani(CTX &c, int ninl, double th, double 
     if (ninl < 16) return maxS;
     int ssiz = ninl / 2; if (ssiz > 14) ssiz = 14;
     for (int i = 0; i < DG_RAN_REP; i++) {
+        DG_LT(0);
         __syncthreads();
         if (tid < 64) {
-            if (tid == 0) { int o = dg_randsubset(&S->rng, inliers, ninl, ssiz); dg_gather(c, inliers + o, ssiz, S->lsq.px); }
+            { int id; dg_randsubset_wave(&S->rng, inliers, ninl, ssiz, tid, &id); dg_gather_wave(c, id, ssiz, S->lsq.px, tid); }
             DG_WSYNC();
             dg_u2f_small_w(&S->lsq, S->lsq.px, 0, ssiz, S->f, tid);
         }
+        DG_LT(8);
         __syncthreads();
         int k0;
         ++*iterID;
@@ -404,6 +416,9 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
     __syncthreads();
 
     if (tid == 0) { for (int i = 0; i < 8; i++) { S->ph[i] = 0; S->dbg[i] = 0; } S->tq = wall_clock64(); }
+#ifdef DG_LO_PROF
+    if (tid == 0) { for (int i = 0; i < 16; i++) S->lt[i] = 0; S->ltq = wall_clock64(); }
+#endif
 #define DG_PH(i) do { if (tid == 0) { long long tq2_ = wall_clock64(); S->ph[i] += tq2_ - S->tq; S->tq = tq2_; } } while (0)
     /* software pipeline: chunk c is scored while chunk c+1 gets its pool swaps and chunk c+2 its seeds and draws */
     int cur = 0, chunk_s[3] = {0, 0, 0}, chunk_base = 0;
@@ -771,6 +786,10 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
         st[14] = 0; st[15] = 0;
     }
     DG_PH(6);
+#ifdef DG_LO_PROF
+    if (A.phase_out && tid == 0) { for (int i = 0; i < 16; i++) A.phase_out[(size_t)pair * 16 + i] = S->lt[i]; }
+    if (0)
+#endif
     if (A.phase_out && tid == 0) { S->ph[7] = wall_clock64() - t_start; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + i] = S->ph[i]; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + 8 + i] = S->dbg[i]; }
 }
 

@@ -172,13 +172,17 @@ __device__ __noinline__ void dg_u2f_small_w(dg_lsq_scratch *s, const double *p, 
         dg_u2f_norm_w(s, p, wts, len, F, lane);
     } else {
         /* <= 8 points: lin_fm rows + the stride-9 weight pattern (Ftools.c:427-432), left null vector, rank 2 */
-        if (lane == 0) {
-            for (int i = 0; i < 72; i++) s->Z8[i] = 0.;
-            for (int i = 0; i < len && i < 8; i++) {
-                double a[3] = {p[4*i], p[4*i+1], 1.0}, b[3] = {p[4*i+2], p[4*i+3], 1.0};
-                for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) s->Z8[(k*3+l)*8 + i] = b[k] * a[l];
+        /* entry e = 8*row + point; the weight pattern of Ftools.c:427-432 hits entry e with wts[e % 9] */
+        for (int e = lane; e < 72; e += 64) {
+            const int r = e >> 3, i = e & 7, k = r / 3, l = r - 3*k;
+            double z = 0.;
+            if (i < len) {
+                const double a = l == 2 ? 1.0 : p[4*i + l], b = k == 2 ? 1.0 : p[4*i + 2 + k];
+                z = b * a;
             }
-            if (wts) for (int i = 0; i < len && i < 8; i++) for (int k = 0; k < 9; k++) if (i + 9*k < 72) s->Z8[i + 9*k] *= wts[i];
+            const int wi = e % 9;
+            if (wts && wi < len && wi < 8) z *= wts[wi];
+            s->Z8[e] = z;
         }
         DG_WSYNC();
         dg_svd_lastcol_9x8_wave(s->Z8, s->U9, lane);
