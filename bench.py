@@ -4,9 +4,11 @@
 A "step" is one pass of the hot path (the persistent LO-RANSAC/DEGENSAC kernel, one workgroup
 per image pair) over one batch of synthetic image pairs.  Workload at every N: each GPU owns
 PAIRS_PER_GPU independent pairs of BASELINE config C2 (2000 correspondences, 40 % inliers,
-sigma 0.1 px, px_th 0.5, conf 0.9999, max_iters 100000, degeneracy check on, symmetric check on)
-= its share of config C4 (4096 pairs over 8 GPUs -> 512 per GPU): weak scaling.  Inputs are
-resident in HBM before the timed region; the per-pair results are gathered over RCCL inside it.
+sigma 0.1 px, px_th 0.5, conf 0.9999, max_iters 100000, degeneracy check on, symmetric check on);
+PAIRS_PER_GPU = 4096 is config C4's batch size, held per GPU: weak scaling.  (One workgroup owns
+one pair and ~9 % of C2 pairs run all 100 000 samples, so a batch needs many pairs per CU for the
+256 CUs to stay busy; --pairs-per-gpu 512 gives C4's 8-GPU share and is tail-latency bound.)  Inputs
+are resident in HBM before the timed region; the per-pair results are gathered over RCCL inside it.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -27,11 +29,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
 N_CORR = 2000
-PAIRS_PER_GPU = 512
+PAIRS_PER_GPU = 4096
 PRM = dict(px_th=0.5, conf=0.9999, max_iters=100000, error_type=0, sym=True, laf=0.0, degen=True)
 
 
-def cpu_baseline(budget_s=20.0, max_pairs=64):
+def cpu_baseline(budget_s=20.0, max_pairs=1024):
     """The reference CPU path timed on this box's host cores (1 thread): oracle/_ref (the unmodified
     reference build, kind 'reference') when it loads, else the restatement (kind 'port')."""
     from pydegensac_amd import synthetic, parallel
@@ -64,6 +66,24 @@ def cpu_baseline(budget_s=20.0, max_pairs=64):
     return {"value": models / t_total, "unit": "models/s", "cores": 1, "kind": kind,
             "sample": f"{n_done} C2 pairs (pair ids 1..{n_done}, same generator/seeds as the GPU batch), "
                       f"{t_total:.1f} s, {samples / t_total:.0f} samples/s, {t_total / n_done * 1e3:.1f} ms/pair"}
+
+
+def pmc_traffic(pairs_per_gpu):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/README.md):
+    2 x FETCH_SIZE + WRITE_SIZE KiB (MI355X_MICROARCH.md: FETCH_SIZE under-reports coalesced reads 2x on gfx950).
+    Counters cannot be read from inside the process, so this is null unless the committed pass matches the batch."""
+    import csv
+    vals = {}
+    for name in ("fetch", "write"):
+        path = os.path.join(ROOT, "profiles", f"r1_bench_pmc_{name}_size.csv")
+        if not os.path.exists(path):
+            return None
+        rows = list(csv.DictReader(open(path)))
+        rows = [r for r in rows if "dg_find_fundamental_kernel" in r["Kernel_Name"]]
+        if not rows or int(rows[0]["Grid_Size"]) != pairs_per_gpu * int(rows[0]["Workgroup_Size"]):
+            return None
+        vals[name] = float(rows[0]["Counter_Value"])
+    return (2.0 * vals["fetch"] + vals["write"]) * 1024.0
 
 
 def main():
@@ -159,7 +179,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"C2 x {P} pairs per GPU (= per-GPU share of C4: 4096 pairs / 8 GPUs): findFundamentalMatrix, "
+            "config": {"workload": f"C2 x {P} pairs per GPU (C4 is a batch of 4096 such pairs): findFundamentalMatrix, "
                                    f"{N_CORR} correspondences, 40% inliers, sigma 0.1 px, px_th 0.5, conf 0.9999, max_iters 100000, "
                                    "sampson error, symmetric check on, degeneracy check on",
                        "pairs_total": total_pairs, "pairs_per_gpu": P, "n_corr": N_CORR,
@@ -171,11 +191,12 @@ def main():
             "time_to_best_ms": {"mean": float(tbest.mean() * 1e3), "p50": float(np.median(tbest) * 1e3), "max": float(tbest.max() * 1e3)},
             "pair_latency_ms": {"mean": float(ticks.mean() * 1e3), "p50": float(np.median(ticks) * 1e3), "max": float(ticks.max() * 1e3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(P),
                          "kernel": L.mi_degensac_kernel_name(0).decode(), "kernel_ms": kms,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "algorithmic bytes = models scored x 32 B x N (SURVEY 8d); the point set is LDS-resident, "
-                                 "real HBM traffic is the one-off 64 kB/pair load (see profiles/)"},
+                         "note": "achieved = algorithmic bytes (models scored x 32 B x N, SURVEY 8d) / kernel time; the point set is "
+                                 "LDS-resident, so `traffic` (HBM bytes per launch from the committed PMC passes, profiles/) is far "
+                                 "below it: inputs once, then model tables, lists and scratch"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

@@ -414,6 +414,39 @@ DG_FN void dg_lartg(double f, double g, double *c, double *s, double *r)   /* LA
     else { d = sqrt(f*f + g*g); *c = f1 / d; *r = dg_sign(d, f); *s = g / *r; }
 }
 
+/* dlartg for the wave eigen-solver's rotation chain (the latency-critical scalar recurrence of dsteqr).
+ * Same values as dg_lartg bit for bit: the compiler's IEEE fp64 sqrt / divide are v_rsq_f64 / v_rcp_f64 + Newton
+ * steps + a Markstein correction wrapped in scaling and fix-up code for denormal or overflowing operands; with
+ * 1e-140 < |f|,|g| < 1e140 none of that can trigger, and the two quotients share one refined reciprocal of d.
+ * Outside that range (never seen in practice) the plain path runs. */
+__device__ __forceinline__ void dg_lartg_fast(double f, double g, double *c, double *s, double *r)
+{
+    const double f1 = fabs(f), g1 = fabs(g);
+    if (g == 0.) { *c = 1.; *s = 0.; *r = f; return; }
+    if (f == 0.) { *c = 0.; *s = dg_sign(1., g); *r = g1; return; }
+    const bool ok = f1 > 1e-140 && f1 < 1e140 && g1 > 1e-140 && g1 < 1e140;
+    if (!ok) { dg_lartg(f, g, c, s, r); return; }
+    const double x = f*f + g*g;
+    /* sqrt(x) */
+    double y = __builtin_amdgcn_rsq(x);
+    double sg = x * y, sh = y * 0.5;
+    double sr = __builtin_fma(-sh, sg, 0.5);
+    sg = __builtin_fma(sg, sr, sg); sh = __builtin_fma(sh, sr, sh);
+    double sd = __builtin_fma(-sg, sg, x); sg = __builtin_fma(sd, sh, sg);
+    sd = __builtin_fma(-sg, sg, x);        sg = __builtin_fma(sd, sh, sg);
+    const double d = sg;
+    /* 1/d refined, then f1/d and g/d */
+    double ry = __builtin_amdgcn_rcp(d);
+    double re = __builtin_fma(-d, ry, 1.0); ry = __builtin_fma(ry, re, ry);
+    re = __builtin_fma(-d, ry, 1.0);        ry = __builtin_fma(ry, re, ry);
+    double q0 = f1 * ry, rr = __builtin_fma(-d, q0, f1);
+    *c = __builtin_fma(rr, ry, q0);
+    q0 = g * ry; rr = __builtin_fma(-d, q0, g);
+    const double sq = __builtin_fma(rr, ry, q0);
+    *r = dg_sign(d, f);
+    *s = f < 0. ? -sq : sq;
+}
+
 DG_FN void dg_laev2(double a, double b, double c, double *rt1, double *rt2, double *cs1, double *sn1)
 {
     double sm = a + c, df = a - c, adf = fabs(df), tb = b + b, ab = fabs(tb);
@@ -758,10 +791,12 @@ static __device__ __noinline__ int dg_eig_sym_wave(double *a, double *w, int lan
                     if (ct_ != 1. || st_ != 0.) { double temp_ = z[j_+1]; z[j_+1] = ct_*temp_ - st_*z[j_]; z[j_] = st_*temp_ + ct_*z[j_]; } } } } while (0)
         while (l1 < n) {
             if (l1 > 0) WR(ereg, l1 - 1, 0.);
-            for (m = l1; m < n - 1; m++) {
-                tst = fabs(RD(ereg, m));
-                if (tst == 0.) break;
-                if (tst <= (sqrt(fabs(RD(dreg, m))) * sqrt(fabs(RD(dreg, m+1)))) * eps) { WR(ereg, m, 0.); break; }
+            {   /* first negligible subdiagonal at or after l1: every lane tests its own (e_i, d_i, d_{i+1}) */
+                const double dn = __shfl_down(dreg, 1, 64), ae = fabs(ereg);
+                const bool cnd = lane >= l1 && lane < n - 1 && (ae == 0. || ae <= (sqrt(fabs(dreg)) * sqrt(fabs(dn))) * eps);
+                const unsigned long long bm = __ballot(cnd);
+                m = bm ? __ffsll((long long)bm) - 1 : n - 1;
+                if (bm) WR(ereg, m, 0.);
             }
             l = l1; lsv = l; lend = m; lendsv = lend; l1 = m + 1;
             if (lend == l) continue;
@@ -769,7 +804,10 @@ static __device__ __noinline__ int dg_eig_sym_wave(double *a, double *w, int lan
             if (lend > l) {
                 for (;;) {
                     if (l != lend) {
-                        for (m = l; m < lend; m++) { tst = fabs(RD(ereg, m)); tst *= tst; if (tst <= (eps2 * fabs(RD(dreg, m))) * fabs(RD(dreg, m+1)) + safmin) break; }
+                        const double dn = __shfl_down(dreg, 1, 64); double t2 = fabs(ereg); t2 *= t2;
+                        const bool cnd = lane >= l && lane < lend && t2 <= (eps2 * fabs(dreg)) * fabs(dn) + safmin;
+                        const unsigned long long bm = __ballot(cnd);
+                        m = bm ? __ffsll((long long)bm) - 1 : lend;
                     } else m = lend;
                     if (m < lend) WR(ereg, m, 0.);
                     p = RD(dreg, l);
@@ -791,7 +829,7 @@ static __device__ __noinline__ int dg_eig_sym_wave(double *a, double *w, int lan
                     for (i = m - 1; i >= l; i--) {
                         double ei = RD(ereg, i), di = RD(dreg, i), di1 = RD(dreg, i+1);
                         f = s * ei; b = c * ei;
-                        dg_lartg(g, f, &c, &s, &r);
+                        dg_lartg_fast(g, f, &c, &s, &r);
                         if (i != m - 1) WR(ereg, i+1, r);
                         g = di1 - p;
                         r = (di - g)*s + 2.*c*b;
@@ -806,7 +844,11 @@ static __device__ __noinline__ int dg_eig_sym_wave(double *a, double *w, int lan
             } else {
                 for (;;) {
                     if (l != lend) {
-                        for (m = l; m > lend; m--) { tst = fabs(RD(ereg, m-1)); tst *= tst; if (tst <= (eps2 * fabs(RD(dreg, m))) * fabs(RD(dreg, m-1)) + safmin) break; }
+                        /* lane i stands for m = i+1: e[m-1] = e_i, d[m] = d_{i+1}, d[m-1] = d_i; the highest hit wins */
+                        const double dn = __shfl_down(dreg, 1, 64); double t2 = fabs(ereg); t2 *= t2;
+                        const bool cnd = lane >= lend && lane < l && t2 <= (eps2 * fabs(dn)) * fabs(dreg) + safmin;
+                        const unsigned long long bm = __ballot(cnd);
+                        m = bm ? 64 - __clzll((long long)bm) : lend;
                     } else m = lend;
                     if (m > lend) WR(ereg, m-1, 0.);
                     p = RD(dreg, l);
@@ -828,7 +870,7 @@ static __device__ __noinline__ int dg_eig_sym_wave(double *a, double *w, int lan
                     for (i = m; i <= l - 1; i++) {
                         double ei = RD(ereg, i), di = RD(dreg, i), di1 = RD(dreg, i+1);
                         f = s * ei; b = c * ei;
-                        dg_lartg(g, f, &c, &s, &r);
+                        dg_lartg_fast(g, f, &c, &s, &r);
                         if (i != m) WR(ereg, i-1, r);
                         g = di - p;
                         r = (di1 - g)*s + 2.*c*b;

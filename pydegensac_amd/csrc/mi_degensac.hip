@@ -396,6 +396,9 @@ __global__ void dg_microbench_kernel(const double *in, double *out, long long *t
     t0 = wall_clock64();
     for (int r = 0; r < reps; r++) { if (tid == 0) { for (int i = 0; i < 14; i++) for (int k = 0; k < 9; k++) ls.Z[9*i+k] = in[64 + 9*i + k] + 1e-9 * r; } DG_WSYNC(); dg_cov9_wave(ls.V, ls.Z, 14, tid); DG_WSYNC(); dg_eig_sym_wave(ls.V, ls.D, tid, &ls.ews); }
     t1 = wall_clock64(); if (tid == 0) ticks[0] = t1 - t0;
+#ifdef DG_EIG_TIMING
+    long long et_[4]; for (int i = 0; i < 4; i++) et_[i] = dg_eig_ticks[i];
+#endif
     t0 = wall_clock64();
     for (int r = 0; r < reps; r++) { if (tid == 0) { for (int i = 0; i < 14; i++) for (int k = 0; k < 9; k++) ls.Z[9*i+k] = in[64 + 9*i + k] + 1e-9 * r; dg_cov9(ls.V, ls.Z, 14); dg_eig_sym(ls.V, ls.D, 9); } DG_WSYNC(); }
     t1 = wall_clock64(); if (tid == 0) ticks[1] = t1 - t0;
@@ -409,9 +412,22 @@ __global__ void dg_microbench_kernel(const double *in, double *out, long long *t
     for (int r = 0; r < reps; r++) { if (tid == 0) { for (int i = 0; i < 9; i++) F[i] = in[200 + i] + 1e-9 * r; dg_singulF(F); } DG_WSYNC(); }
     t1 = wall_clock64(); if (tid == 0) ticks[4] = t1 - t0;
     t0 = wall_clock64();
-    int cs = 0;
-
-    t1 = wall_clock64(); if (tid == 0) { ticks[5] = t1 - t0; out[9] = cs; }
+    /* slot 5: number of (f, g) pairs (out of 64 * 20000, exponents spread over +-2^60) on which dg_lartg_fast differs
+     * from dg_lartg in any bit */
+    {
+        unsigned long long st = 0x9E3779B97F4A7C15ull * (unsigned long long)(tid + 1); unsigned bad = 0;
+        for (int it = 0; it < 20000; it++) {
+            st = st * 6364136223846793005ull + 1442695040888963407ull; const unsigned long long a = st;
+            st = st * 6364136223846793005ull + 1442695040888963407ull; const unsigned long long b = st;
+            double f = (double)(long long)(a >> 11) * (1.0 / 9007199254740992.0) - 0.5, g = (double)(long long)(b >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+            f = ldexp(f, (int)(a & 127) - 64); g = ldexp(g, (int)(b & 127) - 64);
+            double c1, s1, r1, c2, s2, r2;
+            dg_lartg(f, g, &c1, &s1, &r1); dg_lartg_fast(f, g, &c2, &s2, &r2);
+            bad += (__double_as_longlong(c1) != __double_as_longlong(c2) || __double_as_longlong(s1) != __double_as_longlong(s2) || __double_as_longlong(r1) != __double_as_longlong(r2)) ? 1u : 0u;
+        }
+        bad = dg_wave_sum_u(bad);
+        if (tid == 0) ticks[5] = (long long)bad;
+    }
     t0 = wall_clock64();
     for (int r = 0; r < reps; r++) dg_u2h_small_w(&ls, ls.px, 5, H, tid);
     t1 = wall_clock64(); if (tid == 0) ticks[6] = t1 - t0;
@@ -419,7 +435,46 @@ __global__ void dg_microbench_kernel(const double *in, double *out, long long *t
     if (tid < 64) { unsigned hsum = 0; for (int r = 0; r < reps; r++) hsum += dg_hash_list(list, 800 - (r & 1), true); if (tid == 0) out[10] = hsum; }
     t1 = wall_clock64(); if (tid == 0) ticks[7] = t1 - t0;
     if (tid == 0) for (int i = 0; i < 9; i++) out[i] = F[i];
+#ifdef DG_EIG_TIMING
+    if (tid == 0) for (int i = 0; i < 4; i++) ticks[4 + i] = et_[i];
+#endif
 }
+
+/* dev probe: dependent-issue latency of the fp64 building blocks, one wave.  out[k] = wall_clock64 ticks (10 ns) per 1000 ops */
+__global__ void dg_latency_kernel(double *io, long long *out)
+{
+    const int lane = threadIdx.x;
+    double x = io[0] + lane * 1e-9, y = io[1], z;
+    long long t0, t1; const int N = 4000;
+    t0 = wall_clock64(); for (int i = 0; i < N; i++) x = __builtin_fma(x, y, 1e-3); t1 = wall_clock64(); out[0] = (t1 - t0);
+    t0 = wall_clock64(); for (int i = 0; i < N; i++) x = x * y; t1 = wall_clock64(); out[1] = (t1 - t0);
+    t0 = wall_clock64(); for (int i = 0; i < N; i++) x = x + y; t1 = wall_clock64(); out[2] = (t1 - t0);
+    x = io[0] + 3.0;
+    t0 = wall_clock64(); for (int i = 0; i < N; i++) x = 1.7 / x + 1.0; t1 = wall_clock64(); out[3] = (t1 - t0);
+    t0 = wall_clock64(); for (int i = 0; i < N; i++) x = sqrt(x) + 2.0; t1 = wall_clock64(); out[4] = (t1 - t0);
+    z = x;
+    t0 = wall_clock64(); for (int i = 0; i < N; i++) { double c, s, r; dg_lartg_fast(z, y, &c, &s, &r); z = r * 0.7 + s; } t1 = wall_clock64(); out[5] = (t1 - t0);
+    t0 = wall_clock64(); for (int i = 0; i < N; i++) { double c, s, r; dg_lartg(z, y, &c, &s, &r); z = r * 0.7 + s; } t1 = wall_clock64(); out[6] = (t1 - t0);
+    int k = lane & 7; double w = x;
+    t0 = wall_clock64(); for (int i = 0; i < N; i++) { w = dg_rdl_d(w, (i + (int)io[2]) & 7) + 1.0; } t1 = wall_clock64(); out[7] = (t1 - t0);
+    unsigned u = (unsigned)lane;
+    t0 = wall_clock64(); for (int i = 0; i < N; i++) { u = u * 1664525u + 1013904223u; } t1 = wall_clock64(); out[8] = (t1 - t0);
+    long long c0 = clock64(); for (int i = 0; i < N; i++) x = __builtin_fma(x, y, 1e-3); long long c1 = clock64(); out[9] = (c1 - c0);
+    io[8 + lane] = x + z + w + (double)u + k;
+}
+extern "C" int mi_degensac_latency_probe(long long *out_host)
+{
+    int rc = dev_init(0); if (rc) return rc;
+    DevBuf<double> io; DevBuf<long long> o;
+    if (io.alloc(128) || o.alloc(16)) return MI_DEGENSAC_ENOMEM;
+    double h[8] = {1.0000001, 0.9999999, 0.0, 0, 0, 0, 0, 0};
+    HIPCHK(hipMemcpy(io.p, h, sizeof h, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(dg_latency_kernel, dim3(1), dim3(64), 0, 0, io.p, o.p);
+    HIPCHK(hipGetLastError()); HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out_host, o.p, 16 * sizeof(long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int mi_degensac_microbench(const double *in_host, int reps, long long *ticks_host)
 {
     int rc = dev_init(0); if (rc) return rc;

@@ -9,4 +9,8 @@ rng=np.random.default_rng(0); inp[64:64+14*9]=rng.normal(size=14*9); inp[200:209
 t=np.zeros(8,np.int64); reps=50
 rc=L.mi_degensac_microbench(inp.ctypes.data_as(C.POINTER(C.c_double)),reps,t.ctypes.data_as(C.POINTER(C.c_longlong)))
 names=["cov9+eig9 WAVE","cov9+eig9 lane0","u2f_small(14)","u2f_small(8)","singulF","checksample","u2h_small(5)","hash(800)"]
-for n,v in zip(names,t): print(f"{n:16s} {v/reps/100:.1f} us")
+for n,v in zip(names,t):
+    if n=="checksample": print(f"lartg_fast mismatches (of 1.28M): {v}")
+    else: print(f"{n:16s} {v/reps/100:.1f} us")
+
+if os.environ.get("MI_DEGENSAC_LIB","").endswith("exp_et.so"): print("eig stages (us per call): tridiag %.1f  orgtr %.1f  steqr %.1f  sort %.1f" % tuple(t[4:8]/reps/100))
