@@ -25,12 +25,38 @@ class MiDegensacError(RuntimeError):
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1 (same SONAMEs as /opt/rocm's).
+    Whichever copy is mapped first serves the whole process; if /opt/rocm's comes first, a later `import torch` finds
+    "No HIP GPUs".  So when torch is installed, map ITS runtime before libmi_degensac.so (without importing torch:
+    that costs seconds); the library then runs on that runtime, exactly as when the caller imported torch first."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("MI_DEGENSAC_NO_TORCH_RUNTIME"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise MiDegensacError(f"{LIB_PATH} is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                                   "there is no CPU fallback")
+        _preload_torch_hip_runtime()
         l = C.CDLL(LIB_PATH)
         dp = C.POINTER(C.c_double); ip = C.POINTER(C.c_int32); up = C.POINTER(C.c_uint32); bp = C.POINTER(C.c_uint8)
         lp = C.POINTER(C.c_int64); pp = C.POINTER(Params)

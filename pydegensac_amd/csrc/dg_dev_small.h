@@ -896,8 +896,9 @@ static __device__ __noinline__ int dg_eig_sym_wave(double *a, double *w, int lan
 #undef DG_ROTREG
         DG_WSYNC();
         DG_ET(2);
-        /* selection sort, ascending (columns swapped by row lanes) */
-        for (ii = 1; ii < n; ii++) {
+        /* dsteqr ends with an ascending selection sort; every caller only consumes the smallest pair (column 0,
+         * or the first minimum of w[]), which the sort's first pass already puts in place: run that pass only */
+        for (ii = 1; ii < 2; ii++) {
             i = ii - 1; k = i; p = d[i];
             for (j = ii; j < n; j++) if (d[j] < p) { k = j; p = d[j]; }
             DG_WSYNC();

@@ -12,7 +12,9 @@
 
 static thread_local char g_err[512] = "";
 static void set_err(const char *fmt, const char *a = "", const char *b = "") { snprintf(g_err, sizeof g_err, fmt, a, b); }
-#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err("%s failed: %s", #x, hipGetErrorString(e_)); return MI_DEGENSAC_EHIP; } } while (0)
+/* a failed call must not leave HIP's per-thread "last error" set: other users of the runtime in this process
+ * (e.g. torch's lazy device initialisation) treat a stale error as their own */
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err("%s failed: %s", #x, hipGetErrorString(e_)); (void)hipGetLastError(); return MI_DEGENSAC_EHIP; } } while (0)
 
 extern "C" const char *mi_degensac_last_error(void) { return g_err; }
 /* debug trace (device buffer owned by the caller of mi_degensac_debug_trace); not part of the public header */

@@ -120,3 +120,14 @@ def test_gather_invariant_to_world_size(tmp_path):
     for k in ["F", "st", "mk"]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
     assert outs[0]["st"][:, 0].min() > 0
+
+
+def test_tensor_api_rejects_host_and_wrong_dtype_inputs():
+    """tensor_api validates before touching the library: CPU tensors / float32 / shape mismatches are ValueErrors."""
+    import torch
+    from pydegensac_amd import tensor_api
+    a = torch.zeros((16, 2), dtype=torch.float64)
+    with pytest.raises(ValueError):
+        tensor_api.find_fundamental_batch_tensors(a, a, [16])                     # not on a GPU
+    with pytest.raises(ValueError):
+        tensor_api.find_fundamental_batch_tensors(a.numpy(), a.numpy(), [16])     # not tensors
