@@ -684,7 +684,7 @@ static __device__ __forceinline__ double dg_rdl_d(double v, int l)
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 #ifdef DG_EIG_TIMING
-__device__ long long dg_eig_ticks[4];
+static __device__ long long dg_eig_ticks[4];
 #define DG_ET(i) do { long long t_ = wall_clock64(); if (lane == 0) dg_eig_ticks[i] += t_ - t_et; t_et = t_; } while (0)
 #else
 #define DG_ET(i)

@@ -62,9 +62,9 @@ struct dg_args {
  * r_j = 16807 * r_{j-1} mod (2^31-1): the 310 discarded steps of r[i] = r[i-31] + r[i-3] are linear
  * over Z/2^32, so they collapse into the constant 8 x 31 matrix C (filled by the host at load time
  * by running the generator on unit vectors).  G[j] = 16807^j mod (2^31-1). */
-__constant__ unsigned dg_rng_C[8][32];
-__constant__ unsigned dg_rng_Ct[32][8];     /* transposed copy: one 32-byte scalar load per term j */
-__constant__ unsigned dg_rng_G[32];
+static __constant__ unsigned dg_rng_C[8][32];
+static __constant__ unsigned dg_rng_Ct[32][8];     /* transposed copy: one 32-byte scalar load per term j */
+static __constant__ unsigned dg_rng_G[32];
 
 __device__ __forceinline__ unsigned dg_mulmod31(unsigned a, unsigned b)
 {

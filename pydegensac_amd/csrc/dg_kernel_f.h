@@ -47,7 +47,7 @@ struct dg_f_shared {
 };
 
 /* ------------------------------------------------------------------------------------------------ */
-template <bool LDSPTS>
+template <int LDSPTS>
 struct dg_f_ctx {
     dg_f_shared *S;
     const dg_pt *P;          /* correspondences (LDS or global) */
@@ -88,7 +88,7 @@ struct dg_f_ctx {
     t_[3+4*k_] = (int)(jb_ & 0xffffffffll); t_[4+4*k_] = (int)(jb_ >> 32); t_[0] = k_ + 1; } } } while (0)
 
 /* a full scoring pass of model F (kind) with optional list/flags; counts as FDS1/EXFDS1/aux */
-template <bool LDSPTS>
+template <int LDSPTS>
 __device__ __forceinline__ dg_pass_res dg_f_pass(CTX &c, const double *Fm /* LDS */, int kind, dg_pass_cfg cfg)
 {
     double F[9];
@@ -97,7 +97,7 @@ __device__ __forceinline__ dg_pass_res dg_f_pass(CTX &c, const double *Fm /* LDS
     const dg_pt *P = c.P;
     return dg_pass(&c.S->red, cfg, [&](int pid, int) { return dg_Ferr(kind, F, P[pid]); }, c.tid);
 }
-template <bool LDSPTS>
+template <int LDSPTS>
 __device__ __forceinline__ dg_pass_res dg_h_pass(CTX &c, const double *Hm /* LDS */, dg_pass_cfg cfg)
 {
     double H[9];
@@ -113,21 +113,21 @@ __device__ __forceinline__ dg_pass_cfg dg_cfg0(int n)
 }
 
 /* gather `len` points of a global id list into the lane-0 scratch (coordinates x1,y1,x2,y2) */
-template <bool LDSPTS>
+template <int LDSPTS>
 __device__ __forceinline__ void dg_gather(CTX &c, const int *ids, int len, double *px)
 {
     for (int i = 0; i < len; i++) { dg_pt p = c.P[ids[i]]; px[4*i] = p.x1; px[4*i+1] = p.y1; px[4*i+2] = p.x2; px[4*i+3] = p.y2; }
 }
 
 /* lane j < len writes the coordinates of point `id` (its own) to row j of px */
-template <bool LDSPTS>
+template <int LDSPTS>
 __device__ __forceinline__ void dg_gather_wave(CTX &c, int id, int len, double *px, int lane)
 {
     if (lane < len) { dg_pt p = c.P[id]; px[4*lane] = p.x1; px[4*lane+1] = p.y1; px[4*lane+2] = p.x2; px[4*lane+3] = p.y2; }
 }
 
 /* u2f on a global id list of any length -> S->f  (exp_ranF.c's u2f(u, inliers, n, f, buffer) calls) */
-template <bool LDSPTS>
+template <int LDSPTS>
 __device__ __forceinline__ void dg_u2f_list(CTX &c, const int *list, int len, const double *wmodel, int wkind, double *Fout)
 {
     dg_f_shared *S = c.S;
@@ -153,7 +153,7 @@ __device__ __forceinline__ void dg_u2f_list(CTX &c, const int *list, int len, co
 
 /* symmetric + LAF consistency of candidate f over the ids list[0..cnt) (exp_ranF.c:1383-1411,
  * :1526-1556, :1654-1682).  Returns 0 when the candidate must be rejected. */
-template <bool LDSPTS>
+template <int LDSPTS>
 __device__ __forceinline__ int dg_f_checks(CTX &c, const double *f, const int *list, int cnt, dg_score &S, const dg_score &maxS, int mkind)
 {
     const dg_params &pr = c.A->prm;
@@ -218,7 +218,7 @@ __device__ __noinline__ void dg_Hdetect(const double *F, const double (*u7)[4], 
 /* DegUtils.c:42-82 checksample.  The five triplets are independent until the "first success wins" rule:
  * waves 0..4 each evaluate one (Hdetect + sort on lane 0, the 5-point re-fit wave-cooperatively), then the
  * lowest successful index is taken — the same H the sequential loop returns.  Called by the whole workgroup. */
-template <bool LDSPTS>
+template <int LDSPTS>
 __device__ __noinline__ int dg_checksample(CTX &c, const double *F /* LDS */, const double (*u7)[4] /* LDS */, double th, double *H /* LDS out */)
 {
     dg_f_shared *S = c.S; const int tid = c.tid, lane = tid & 63, wave = tid >> 6;
@@ -253,7 +253,7 @@ __device__ __noinline__ int dg_checksample(CTX &c, const double *F /* LDS */, co
 }
 
 /* ---- ranH.c:18-135 + DegUtils.c:693-731: LO of the plane homography (innerH) -------------------- */
-template <bool LDSPTS>
+template <int LDSPTS>
 __device__ __noinline__ unsigned dg_innerH(CTX &c, double *H /* LDS, in/out */, double th, unsigned inlLimit, unsigned char *inl_flags)
 {
     dg_f_shared *S = c.S; const int n = c.n, tid = c.tid;
@@ -437,7 +437,7 @@ __device__ __forceinline__ void dg_dual_pick(dg_rng *g, unsigned len, unsigned s
  * pre-refinement counts.  So: lane 0 draws all samples; the waves then fit and score the repetitions in
  * parallel; the "new record" repetitions are refined in parallel (one wave each); a final scan in repetition
  * order applies the reference's `max_i < no_i` bookkeeping and one pass materialises the winner's flags. */
-template <bool LDSPTS>
+template <int LDSPTS>
 __device__ __noinline__ void dg_innerFH(CTX &c, const int *idxH, unsigned lenH, const int *idxO, unsigned lenO,
                                            double th, unsigned repCount, double *F /* LDS out */, unsigned char *inl /* out flags */)
 {
@@ -513,7 +513,7 @@ __device__ __noinline__ void dg_innerFH(CTX &c, const int *idxH, unsigned lenH, 
  * ptr[] swaps for the whole batch, one wave scores each candidate on the off-plane points, and the first
  * candidate that beats m_i (the only kind that has side effects) is then processed exactly as the
  * sequential loop would: RNG and ptr[] are rolled back to their state right after that iteration. */
-template <bool LDSPTS>
+template <int LDSPTS>
 __device__ __forceinline__ void dg_rFtH_aFt(const double *Hr, const dg_pt &p0, const dg_pt &p1, double *aFt)
 {
     double a0[3] = {p0.x1, p0.y1, 1.0}, a1[3] = {p1.x1, p1.y1, 1.0}, b0[3], b1[3], c1[3], c2[3], ec[3];
@@ -530,7 +530,7 @@ __device__ __forceinline__ void dg_rFtH_aFt(const double *Hr, const dg_pt &p0, c
     dg_mattr(aFt, aFtH, 3, 3);
 }
 
-template <bool LDSPTS>
+template <int LDSPTS>
 __device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, double th, const double *H /* LDS */, double *F /* LDS out */)
 {
     dg_f_shared *S = c.S; const int n = c.n, tid = c.tid, lane = tid & 63, wave = tid >> 6;
@@ -551,8 +551,8 @@ __device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, doub
     }
     if (nhinlCount < 4 || hinlCount < 6) return 0;
     /* ptr[] lives in the sampler pool's LDS for the duration (the pool is parked in global memory) */
-    int *ptr = LDSPTS ? c.pool : c.L[8];
-    if (LDSPTS) { for (int j = tid; j < n; j += DG_T) c.L[8][j] = c.pool[j]; __syncthreads(); }
+    int *ptr = LDSPTS != 0 ? c.pool : c.L[8];
+    if (LDSPTS != 0) { for (int j = tid; j < n; j += DG_T) c.L[8][j] = c.pool[j]; __syncthreads(); }
     for (int j = tid; j < (int)nhinlCount; j += DG_T) ptr[j] = j;
     __syncthreads();
     unsigned max_i = 3, m_i = 4, max_sam = MAX_SAM;
@@ -633,7 +633,7 @@ __device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, doub
         if (tid == 0) S->dbg[3] += wall_clock64() - tg2;
     }
     __syncthreads();
-    if (LDSPTS) { for (int j = tid; j < n; j += DG_T) c.pool[j] = c.L[8][j]; __syncthreads(); }
+    if (LDSPTS != 0) { for (int j = tid; j < n; j += DG_T) c.pool[j] = c.L[8][j]; __syncthreads(); }
     return max_i;
 }
 

@@ -47,7 +47,7 @@ __device__ __forceinline__ unsigned dg_hash_list(const int *list, int count, boo
 
 /* exp_ranF.c:621-743 exp_iterFcustom.  f (LDS) is the in/out model parameter `F`; on return *kind0 is the
  * metric variant (FDS1 / EXFDS1) whose residuals the reference would hold in errs[0] for that model. */
-template <bool LDSPTS>
+template <int LDSPTS>
 __device__ __forceinline__ dg_score dg_iterF(CTX &c, int *inliers, double th, double ths, double *f, int iterID,
                                              int mk_full, int mk_ex, int *kind0)
 {
@@ -157,7 +157,7 @@ __device__ __forceinline__ dg_score dg_iterF(CTX &c, int *inliers, double th, do
 }
 
 /* exp_ranF.c:745-806 exp_inFranicustom.  inliers = L[0] (in/out), result model -> Fout (LDS). */
-template <bool LDSPTS>
+template <int LDSPTS>
 __device__ __noinline__ dg_score dg_inFrani(CTX &c, int ninl, double th, double *Fout, int *iterID,
                                                int mk_full, int mk_ex, int *kindBest)
 {
@@ -295,7 +295,7 @@ __device__ __noinline__ unsigned dg_sample_draws(unsigned seed, int cn, int n, u
  * Lanes 0..NDRAW-1 own one draw each, the NDRAW tail slots live in registers.  Software-pipelined: LDS
  * operations of one wave execute in issue order (read_k, write_k, read_{k+1}, ...), so read_{k+1} is issued
  * before read_k's result is consumed; draw positions are prefetched two ahead. */
-template <int NDRAW, bool LDSPTS>
+template <int NDRAW, int LDSPTS>
 __device__ __noinline__ void dg_sample_pool(int cn, int n, int *pool, int (*draws)[8], const unsigned long long *almask_in,
                                             int lane, long long *dbg = 0)
 {
@@ -318,18 +318,18 @@ __device__ __noinline__ void dg_sample_pool(int cn, int n, int *pool, int (*draw
         if (al0) {
             /* order-dependent sample: replay it sequentially on lane 0 */
             if (act) vp[n - 1 - lane] = t;
-            if (!LDSPTS) __threadfence_block();
+            if (LDSPTS == 0) __threadfence_block();
             DG_WSYNC();
             if (lane == 0) {
                 for (int i = 0; i < NDRAW; i++) { int si = draws[k][i], j = n - 1 - i, q = vp[si]; vp[si] = vp[j]; vp[j] = q; draws[k][i] = q; }
             }
-            if (!LDSPTS) __threadfence_block();
+            if (LDSPTS == 0) __threadfence_block();
             DG_WSYNC();
             if (act) t = vp[n - 1 - lane];
             if (act && !al1 && k + 1 < cn) r1 = vp[s1];
         } else {
             if (act) vp[s0] = t;                                          /* write_k  (t = result of read_{k-1}) */
-            if (!LDSPTS) __threadfence_block();
+            if (LDSPTS == 0) __threadfence_block();
             if (act && !al1 && k + 1 < cn) r1 = vp[s1];                   /* read_{k+1} */
             if (act) { t = r0; draws[k][lane] = r0; }                     /* consume read_k */
         }
@@ -343,8 +343,81 @@ __device__ __noinline__ void dg_sample_pool(int cn, int n, int *pool, int (*draw
 }
 
 /* ---------------------------------------------------------------------------------------------- */
+/* Scoring phase of one wave: its groups of four consecutive models of the chunk (dg_group_owner), own register
+ * allocation.  A model matters only if its MSAC gain beats tau = min(maxS.J, maxSs.J) strictly, and
+ * J <= #points with residual < 9/4 th.  So models are first screened FOUR AT A TIME with a division-free count of a
+ * superset of those points (one load of a correspondence serves four models: a quarter of the LDS / L2 traffic and of
+ * the load latency per model); only survivors are scored exactly, the others get J = 0 (never an event in the commit,
+ * so decisions are unchanged).  With tau < 4 nearly every model survives and the screen is skipped. */
+/* which wave scores group g (4 consecutive models).  With >= 6 waves the scoring waves 2.. share the groups round-robin
+ * and the two sampler waves do not score (their stages are the critical path).  With 4 waves the two scoring waves alone
+ * would be the critical path, so the sampler waves take a small share after their stage: per 8 groups, 3 + 3 for waves
+ * 2 and 3, one each for waves 1 (seeds + draws, ~44 us per chunk) and 0 (pool swaps, ~60 us). */
+__device__ __forceinline__ int dg_group_owner(int g)
+{
+#if DG_NW >= 6
+    return 2 + g % (DG_NW - 2);
+#else
+    return (0x01323232 >> (4 * (g & 7))) & 15;            /* g & 7 = 0..7 -> 2,3,2,3,2,3,1,0 */
+#endif
+}
+
+template <int LDSPTS>
+__device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const double *gmodels, const unsigned short *mslot,
+                                             int Mtot, int wave, int kind, double th, double tauJ,
+                                             unsigned *res_I, double *res_J, int lane)
+{
+    const double t94 = th * 9 / 4, t94b = t94 * (1.0 + 1e-6);
+    const bool use_bound = th != 0 && kind != DG_K_EXFSYM && tauJ >= 4.0;
+    for (int grp = 0; 4 * grp < Mtot; grp++) {
+        if (dg_group_owner(grp) != wave) continue;
+        const int m0 = 4 * grp;
+        int mi[4], ng = 0; double F[4][9];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int idx = m0 + g;
+            mi[g] = idx < Mtot ? idx : m0;                       /* pad the last group with its first model */
+            if (idx < Mtot) ng = g + 1;
+            const double *gp = gmodels + (size_t)mslot[mi[g]] * 9;
+#pragma unroll
+            for (int j = 0; j < 9; j++) F[g][j] = gp[j];
+        }
+        unsigned surv = (1u << ng) - 1u;
+        if (use_bound) {
+            unsigned cb0 = 0, cb1 = 0, cb2 = 0, cb3 = 0;
+            for (int p = lane; p < n; p += 64) {
+                const dg_pt q = P[p];
+                cb0 += dg_Fbound(kind, F[0], q, t94b); cb1 += dg_Fbound(kind, F[1], q, t94b);
+                cb2 += dg_Fbound(kind, F[2], q, t94b); cb3 += dg_Fbound(kind, F[3], q, t94b);
+            }
+            const unsigned CB[4] = {dg_wave_sum_u(cb0), dg_wave_sum_u(cb1), dg_wave_sum_u(cb2), dg_wave_sum_u(cb3)};
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                if (g < ng && !((double)CB[g] > tauJ)) { surv &= ~(1u << g); if (lane == 0) { res_I[mi[g]] = 0; res_J[mi[g]] = 0; } }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            if (!((surv >> g) & 1u)) continue;
+            unsigned cI = 0; double acc[DG_NW];
+#pragma unroll
+            for (int r = 0; r < DG_NW; r++) acc[r] = 0;
+            for (int base = 0; base < n; base += 64 * DG_NW) {
+#pragma unroll
+                for (int r = 0; r < DG_NW; r++) {
+                    int p = base + 64 * r + lane; bool act = p < n; double d = 0;
+                    if (act) { dg_pt q = P[p]; d = dg_Ferr(kind, F[g], q); }
+                    double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
+                    acc[r] += term; cI += (act && d <= th) ? 1u : 0u;
+                }
+            }
+            unsigned I = dg_wave_sum_u(cI); double J = dg_J_combine(acc);
+            if (lane == 0) { res_I[mi[g]] = I; res_J[mi[g]] = J; }
+        }
+    }
+}
+
 /* both stages back to back on one wave (prologue of the main kernels, unit-test kernel) */
-template <int NDRAW, bool LDSPTS>
+template <int NDRAW, int LDSPTS>
 __device__ __forceinline__ unsigned dg_sample_chunk(unsigned seed, int cn, int n, int *pool, unsigned *seeds, int (*draws)[8],
                                                     unsigned long long *almask, int lane)
 {
@@ -353,7 +426,7 @@ __device__ __forceinline__ unsigned dg_sample_chunk(unsigned seed, int cn, int n
     return sd;
 }
 
-template <bool LDSPTS>
+template <int T, int LDSPTS>
 __global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
@@ -380,8 +453,9 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
     c.n_max = A.wl.n_max; c.wlist = (int *)(ws + A.wl.off_wave); c.wstage = (dg_pt *)(ws + A.wl.off_wave + (size_t)DG_NW * A.wl.n_max * sizeof(int));
     c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0;
     dg_pt *Pw; int *pool;
-    if (LDSPTS) { Pw = (dg_pt *)dyn_smem; pool = (int *)(dyn_smem + (size_t)n * sizeof(dg_pt)); }
-    else        { Pw = (dg_pt *)(ws + A.wl.off_pts); pool = (int *)(ws + A.wl.off_pool); }
+    /* LDSPTS: 1 = point set and sampler pool in LDS, 2 = pool in LDS / points in the HBM workspace (L2), 0 = both in HBM */
+    if (LDSPTS == 1) { Pw = (dg_pt *)dyn_smem; pool = (int *)(dyn_smem + (size_t)n * sizeof(dg_pt)); }
+    else             { Pw = (dg_pt *)(ws + A.wl.off_pts); pool = LDSPTS == 2 ? (int *)dyn_smem : (int *)(ws + A.wl.off_pool); }
     c.P = Pw; c.pool = pool;
     const dg_pt *P = Pw;
 
@@ -480,41 +554,10 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
                 if (chunk_s[nxt] > 0) dg_sample_pool<7, LDSPTS>(chunk_s[nxt], n, pool, S->draws3[nxt], S->alm3[nxt], lane, S->dbg);
             } else if (wave == 1) {
                 if (cn2 > 0) { unsigned sd = dg_sample_draws<7>(seed, cn2, n, S->seeds3[nx2], S->draws3[nx2], S->alm3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }
-            } else {
-                /* Static round-robin over the scoring waves.  A model matters only if its gain beats
-                 * tau = min(maxS.J, maxSs.J) strictly, and J <= #points with residual < 9/4 th: a division-free
-                 * count of a superset of those points rejects most models at a third of the cost; survivors are
-                 * scored exactly.  Rejected models get J = 0 (never an event in the commit). */
-                const double tauJ = maxS.J < maxSs.J ? maxS.J : maxSs.J;
-                const double t94b = (th * 9 / 4) * (1.0 + 1e-6);
-                const bool use_bound = th != 0 && mk_full != DG_K_EXFSYM;
-                for (int mi = wave - 2; mi < Mtot; mi += DG_NW - 2) {
-                    double F[9];
-                    const double *g = c.gmodels + (size_t)S->mslot[mi] * 9;
-#pragma unroll
-                    for (int j = 0; j < 9; j++) F[j] = g[j];
-                    if (use_bound) {
-                        unsigned cb = 0;
-                        for (int p = lane; p < n; p += 64) { dg_pt q = P[p]; cb += dg_Fbound(mk_full, F, q, t94b); }
-                        const unsigned CB = dg_wave_sum_u(cb);
-                        if (!((double)CB > tauJ)) { if (lane == 0) { c.res_I[mi] = 0; c.res_J[mi] = 0; } continue; }
-                    }
-                    unsigned cI = 0; double acc[DG_NW]; const double t94 = th * 9 / 4;
-#pragma unroll
-                    for (int r = 0; r < DG_NW; r++) acc[r] = 0;
-                    for (int base = 0; base < n; base += 64 * DG_NW) {
-#pragma unroll
-                        for (int r = 0; r < DG_NW; r++) {
-                            int p = base + 64 * r + lane; bool act = p < n; double d = 0;
-                            if (act) { dg_pt q = P[p]; d = dg_Ferr(mk_full, F, q); }
-                            double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
-                            acc[r] += term; cI += (act && d <= th) ? 1u : 0u;
-                        }
-                    }
-                    unsigned I = dg_wave_sum_u(cI); double J = dg_J_combine(acc);
-                    if (lane == 0) { c.res_I[mi] = I; c.res_J[mi] = J; }
-                }
             }
+            if (wave >= 2 || DG_NW < 6)
+                dg_score_chunk_F<LDSPTS>(P, n, c.gmodels, S->mslot, Mtot, wave, mk_full, th,
+                                         maxS.J < maxSs.J ? maxS.J : maxSs.J, c.res_I, c.res_J, lane);
         }
         c.n_fds += Mtot;   /* provisional: models past the termination point are subtracted below */
         __syncthreads();

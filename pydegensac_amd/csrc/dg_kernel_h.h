@@ -25,7 +25,7 @@ __device__ __forceinline__ void dg_u2h_big(dg_red *r, dg_lsq_scratch *s, PtFn pt
 }
 
 /* u2h over a global id list of any length (lane 0 for <= 12 points, cooperative otherwise) */
-template <bool LDSPTS>
+template <int LDSPTS>
 __device__ __forceinline__ void dg_u2h_list(CTX &c, const int *list, int len, double *Hout)
 {
     dg_f_shared *S = c.S;
@@ -40,7 +40,7 @@ __device__ __forceinline__ void dg_u2h_list(CTX &c, const int *list, int len, do
 }
 
 /* a full pass of the selected H metric; counts as one HDS1 call when `count` */
-template <bool LDSPTS>
+template <int LDSPTS>
 __device__ __forceinline__ dg_pass_res dg_hm_pass(CTX &c, int kind, const double *Hm /* LDS */, dg_pass_cfg cfg)
 {
     dg_f_shared *S = c.S;
@@ -59,7 +59,7 @@ __device__ __forceinline__ dg_pass_res dg_hm_pass(CTX &c, int kind, const double
 /* symmetric (HDsSymMaxidx, eps variant) and LAF (HDSi1 on u_1, u_2) consistency of model h over the ids
  * list[0..cnt): exp_ranH.c:587-618, :706-735, :828-853.  p1_inliers is the driver's never-reset counter
  * (exp_ranH.c:501).  early_p1: the main loop bails out after the first LAF set when p1 < maxS.Ilafs. */
-template <bool LDSPTS>
+template <int LDSPTS>
 __device__ __forceinline__ int dg_h_checks(CTX &c, int kind, const double *h /* LDS */, const int *list, int cnt, dg_score &S,
                                            const dg_score &maxS, int *p1_inliers, int early_p1)
 {
@@ -100,7 +100,7 @@ struct dg_hbufs { int pe[3]; };
 #define DG_BUFSET(S, b, src) do { __syncthreads(); if (tid < 9) (S)->bufF[(b)][tid] = (src)[tid]; __syncthreads(); } while (0)
 
 /* exp_ranH.c:291-412 exp_iterHcustom; h (LDS) = in/out parameter H */
-template <bool LDSPTS>
+template <int LDSPTS>
 __device__ __forceinline__ dg_score dg_iterHc(CTX &c, int kind, int *inliers, double th, double ths, double *h, int iterID, unsigned inlLimit, dg_hbufs &B)
 {
     dg_f_shared *S = c.S; const int n = c.n, tid = c.tid;
@@ -179,7 +179,7 @@ __device__ __forceinline__ dg_score dg_iterHc(CTX &c, int kind, int *inliers, do
 }
 
 /* exp_ranH.c:415-467 exp_inHranicustom; inliers = L[0]; result model -> Hout (LDS) */
-template <bool LDSPTS>
+template <int LDSPTS>
 __device__ __forceinline__ dg_score dg_inHranic(CTX &c, int kind, int ninl, double th, double *Hout, int *iterID, unsigned inlLimit, dg_hbufs &B)
 {
     dg_f_shared *S = c.S; const int tid = c.tid;
@@ -212,7 +212,7 @@ __device__ __forceinline__ dg_score dg_inHranic(CTX &c, int kind, int ninl, doub
 }
 
 /* one LO run of the driver (exp_ranH.c:678-747 / :795-861).  e4 = model behind errs[4].  Returns 1 if accepted. */
-template <bool LDSPTS>
+template <int LDSPTS>
 __device__ __noinline__ int dg_h_lo(CTX &c, int kind, const double *e4, double th, dg_score &maxS, int *iterID, int *p1_inliers, int no_sam)
 {
     dg_f_shared *S = c.S; const int n = c.n, tid = c.tid;
@@ -285,7 +285,7 @@ __device__ __noinline__ int dg_solve4_lane(const dg_pt *P, const int *ids, int k
 }
 
 /* ---------------------------------------------------------------------------------------------- */
-template <bool LDSPTS>
+template <int T, int LDSPTS>
 __global__ __launch_bounds__(DG_T, 2) void dg_find_homography_kernel(dg_args A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
@@ -313,8 +313,9 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_homography_kernel(dg_args A)
     c.n_max = A.wl.n_max; c.wlist = (int *)(ws + A.wl.off_wave); c.wstage = (dg_pt *)(ws + A.wl.off_wave + (size_t)DG_NW * A.wl.n_max * sizeof(int));
     c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0;
     dg_pt *Pw; int *pool;
-    if (LDSPTS) { Pw = (dg_pt *)dyn_smem; pool = (int *)(dyn_smem + (size_t)n * sizeof(dg_pt)); }
-    else        { Pw = (dg_pt *)(ws + A.wl.off_pts); pool = (int *)(ws + A.wl.off_pool); }
+    /* LDSPTS: 1 = point set and sampler pool in LDS, 2 = pool in LDS / points in the HBM workspace (L2), 0 = both in HBM */
+    if (LDSPTS == 1) { Pw = (dg_pt *)dyn_smem; pool = (int *)(dyn_smem + (size_t)n * sizeof(dg_pt)); }
+    else             { Pw = (dg_pt *)(ws + A.wl.off_pts); pool = LDSPTS == 2 ? (int *)dyn_smem : (int *)(ws + A.wl.off_pool); }
     c.P = Pw; c.pool = pool;
     const dg_pt *P = Pw;
     for (int i = tid; i < n; i += DG_T) {

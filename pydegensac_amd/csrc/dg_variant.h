@@ -1,0 +1,19 @@
+/* Host-visible interface of one compiled kernel variant (workgroup size is a compile-time constant of the device
+ * code, so each variant is its own translation unit: mi_degensac.hip = 512 threads, mi_degensac_t256.hip = 256). */
+#ifndef DG_VARIANT_H
+#define DG_VARIANT_H
+#include <hip/hip_runtime.h>
+#include "dg_kernel_common.h"
+
+/* placement of the per-pair arrays: DG_MODE_HBM = point set and sampler pool in the HBM workspace (L2),
+ * DG_MODE_LDS = both in LDS, DG_MODE_POOL_LDS = pool in LDS, points in the workspace */
+enum { DG_MODE_HBM = 0, DG_MODE_LDS = 1, DG_MODE_POOL_LDS = 2 };
+
+/* init: uploads the RNG tables of the variant's translation unit, raises the dynamic-LDS limit of its kernels and
+ * reports the static LDS bytes of the F / H kernels.  launch: enqueues one workgroup per pair. */
+#define DG_VARIANT_DECL(T_) \
+    hipError_t dg_variant_##T_##_init(const unsigned C[8][32], const unsigned Ct[32][8], const unsigned G[32], int max_lds, int static_lds[2]); \
+    hipError_t dg_variant_##T_##_launch(int homography, int mode, int n_pairs, size_t dyn, hipStream_t stream, const dg_args &A);
+DG_VARIANT_DECL(512)
+DG_VARIANT_DECL(256)
+#endif /* DG_VARIANT_H */

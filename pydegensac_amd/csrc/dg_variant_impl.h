@@ -1,0 +1,38 @@
+/* Included once per translation unit after the device headers, with DG_T defined (512 or 256). */
+#define DG_VCAT2(a, b, c) a##b##c
+#define DG_VCAT(a, b, c) DG_VCAT2(a, b, c)
+#include "dg_variant.h"
+
+hipError_t DG_VCAT(dg_variant_, DG_T, _init)(const unsigned C[8][32], const unsigned Ct[32][8], const unsigned G[32], int max_lds, int static_lds[2])
+{
+    hipError_t e;
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(dg_rng_C), C, sizeof(unsigned) * 8 * 32)) != hipSuccess) return e;
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(dg_rng_Ct), Ct, sizeof(unsigned) * 32 * 8)) != hipSuccess) return e;
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(dg_rng_G), G, sizeof(unsigned) * 32)) != hipSuccess) return e;
+    hipFuncAttributes fa;
+    const void *kf[2] = {(const void *)dg_find_fundamental_kernel<DG_T, DG_MODE_LDS>, (const void *)dg_find_fundamental_kernel<DG_T, DG_MODE_POOL_LDS>};
+    const void *kh[2] = {(const void *)dg_find_homography_kernel<DG_T, DG_MODE_LDS>, (const void *)dg_find_homography_kernel<DG_T, DG_MODE_POOL_LDS>};
+    for (int h = 0; h < 2; h++) {
+        const void **k = h ? kh : kf;
+        if ((e = hipFuncGetAttributes(&fa, k[0])) != hipSuccess) return e;
+        static_lds[h] = (int)fa.sharedSizeBytes;
+        for (int m = 0; m < 2; m++)
+            if ((e = hipFuncSetAttribute(k[m], hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - static_lds[h] - 256)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t DG_VCAT(dg_variant_, DG_T, _launch)(int homography, int mode, int n_pairs, size_t dyn, hipStream_t stream, const dg_args &A)
+{
+    const dim3 g(n_pairs), b(DG_T);
+    if (!homography) {
+        if (mode == DG_MODE_LDS)           hipLaunchKernelGGL((dg_find_fundamental_kernel<DG_T, DG_MODE_LDS>), g, b, dyn, stream, A);
+        else if (mode == DG_MODE_POOL_LDS) hipLaunchKernelGGL((dg_find_fundamental_kernel<DG_T, DG_MODE_POOL_LDS>), g, b, dyn, stream, A);
+        else                               hipLaunchKernelGGL((dg_find_fundamental_kernel<DG_T, DG_MODE_HBM>), g, b, 0, stream, A);
+    } else {
+        if (mode == DG_MODE_LDS)           hipLaunchKernelGGL((dg_find_homography_kernel<DG_T, DG_MODE_LDS>), g, b, dyn, stream, A);
+        else if (mode == DG_MODE_POOL_LDS) hipLaunchKernelGGL((dg_find_homography_kernel<DG_T, DG_MODE_POOL_LDS>), g, b, dyn, stream, A);
+        else                               hipLaunchKernelGGL((dg_find_homography_kernel<DG_T, DG_MODE_HBM>), g, b, 0, stream, A);
+    }
+    return hipGetLastError();
+}

@@ -7,8 +7,10 @@
 #include <mutex>
 #include <vector>
 #include "../../include/mi_degensac.h"
+#define DG_T 512
 #include "dg_kernel_f_main.h"
 #include "dg_kernel_h.h"
+#include "dg_variant_impl.h"
 
 static thread_local char g_err[512] = "";
 static void set_err(const char *fmt, const char *a = "", const char *b = "") { snprintf(g_err, sizeof g_err, fmt, a, b); }
@@ -40,8 +42,13 @@ extern "C" const char *mi_degensac_kernel_name(int homography) { return homograp
 extern "C" int mi_degensac_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
 /* ---- per-device state: RNG tables uploaded, cached workspace ---------------------------------- */
-struct DevState { bool init = false; char *ws = nullptr; size_t ws_bytes = 0; int max_lds = 0; int dyn_f = 0; int dyn_h = 0; };
+struct DevState { bool init = false; char *ws = nullptr; size_t ws_bytes = 0; int max_lds = 0, cus = 0;
+                  int static_lds[2][2] = {{0, 0}, {0, 0}};   /* [variant: 0 = 512 threads, 1 = 256][F, H] */ };
+static const int g_variant_threads[2] = {512, 256};
 static DevState g_dev[64];
+static int g_last_variant = 0, g_last_mode = 0;
+/* which kernel variant (threads per workgroup) and placement mode the last launch of this process used */
+extern "C" void mi_degensac_debug_last_launch(int *threads, int *mode) { *threads = g_last_variant; *mode = g_last_mode; }
 static std::mutex g_mu;
 
 static void rng_tables(unsigned C[8][32], unsigned G[32])
@@ -74,17 +81,11 @@ static int dev_init(int device)
     if (!d.init) {
         hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device));
         if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { set_err("device is %s, this build targets gfx950 only", prop.gcnArchName); return MI_DEGENSAC_ENODEV; }
-        unsigned C[8][32], G[32]; rng_tables(C, G);
-        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(dg_rng_C), C, sizeof C));
-        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(dg_rng_G), G, sizeof G));
-        { unsigned Ct[32][8]; for (int j = 0; j < 32; j++) for (int k = 0; k < 8; k++) Ct[j][k] = C[k][j]; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(dg_rng_Ct), Ct, sizeof Ct)); }
-        d.max_lds = (int)prop.sharedMemPerBlock;
-        hipFuncAttributes fa; HIPCHK(hipFuncGetAttributes(&fa, (const void *)dg_find_fundamental_kernel<true>));
-        d.dyn_f = d.max_lds - (int)fa.sharedSizeBytes - 256;          /* what is left of the 160 KiB after the static LDS */
-        HIPCHK(hipFuncSetAttribute((const void *)dg_find_fundamental_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, d.dyn_f));
-        HIPCHK(hipFuncGetAttributes(&fa, (const void *)dg_find_homography_kernel<true>));
-        d.dyn_h = d.max_lds - (int)fa.sharedSizeBytes - 256;
-        HIPCHK(hipFuncSetAttribute((const void *)dg_find_homography_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, d.dyn_h));
+        unsigned C[8][32], G[32], Ct[32][8]; rng_tables(C, G);
+        for (int j = 0; j < 32; j++) for (int k = 0; k < 8; k++) Ct[j][k] = C[k][j];
+        d.max_lds = (int)prop.sharedMemPerBlock; d.cus = prop.multiProcessorCount;
+        HIPCHK(dg_variant_512_init(C, Ct, G, d.max_lds, d.static_lds[0]));
+        HIPCHK(dg_variant_256_init(C, Ct, G, d.max_lds, d.static_lds[1]));
         d.init = true;
     }
     return 0;
@@ -165,22 +166,33 @@ static int launch_batch(int homography, const double *d_p1, const double *d_p2, 
     for (int p = 0; p < n_pairs; p++) { long long n = h_off[p+1] - h_off[p]; if (n > n_max) n_max = (int)n; if (n < n_min) n_min = (int)n; }
     const int min_pts = homography ? 4 : 8;                      /* bindings.cpp:35,270 */
     if (n_min < min_pts) { set_err(homography ? "need n >= 4 correspondences" : "need n >= 8 correspondences"); return MI_DEGENSAC_EINVAL; }
-    size_t dyn = (size_t)n_max * (sizeof(dg_pt) + sizeof(int));
-    bool in_lds = dyn <= (size_t)(homography ? g_dev[device].dyn_h : g_dev[device].dyn_f);
-    if (getenv("MI_DEGENSAC_FORCE_GLOBAL")) in_lds = false;     /* development switch: point set in HBM/L2 instead of LDS */
-    A.wl = make_layout(n_max, !in_lds);
+    /* Variant and placement.  Latency: 512-thread workgroups, one pair per CU, point set + sampler pool in LDS when
+     * they fit (36 B per correspondence next to the static LDS).  Throughput: once the batch holds several pairs per CU,
+     * 256-thread workgroups with only the pool in LDS leave room for two resident pairs per CU, which hides the serial
+     * small-solver chains of one pair behind the other.  MI_DEGENSAC_VARIANT / MI_DEGENSAC_MODE override. */
+    const DevState &ds = g_dev[device];
+    const size_t dyn_all = (size_t)n_max * (sizeof(dg_pt) + sizeof(int)), dyn_pool = (size_t)n_max * sizeof(int);
+    int variant = 0, mode;
+    if (!homography && n_pairs >= 4 * ds.cus && ds.static_lds[1][0] + dyn_pool + 512 <= (size_t)ds.max_lds / 2) variant = 1;
+    if (const char *e = getenv("MI_DEGENSAC_VARIANT")) variant = atoi(e) == 256 ? 1 : 0;
+    const size_t room = (size_t)(ds.max_lds - ds.static_lds[variant][homography] - 256);
+    if (variant == 1)           mode = dyn_pool <= room ? DG_MODE_POOL_LDS : DG_MODE_HBM;
+    else if (dyn_all <= room)   mode = DG_MODE_LDS;
+    else                        mode = dyn_pool <= room ? DG_MODE_POOL_LDS : DG_MODE_HBM;
+    if (const char *e = getenv("MI_DEGENSAC_MODE")) {
+        const int m = atoi(e);
+        if (m == DG_MODE_HBM || (m == DG_MODE_POOL_LDS && dyn_pool <= room) || (m == DG_MODE_LDS && dyn_all <= room)) mode = m;
+    }
+    if (getenv("MI_DEGENSAC_FORCE_GLOBAL")) mode = DG_MODE_HBM;
+    const size_t dyn = mode == DG_MODE_LDS ? dyn_all : (mode == DG_MODE_POOL_LDS ? dyn_pool : 0);
+    A.wl = make_layout(n_max, mode != DG_MODE_LDS);
     char *ws; rc = ensure_ws(device, A.wl.stride * (size_t)n_pairs, &ws); if (rc) return rc;
     A.ws = ws; A.pts1 = d_p1; A.pts2 = d_p2; A.offsets = (const long long *)d_off; A.seeds = d_seeds;
     A.trace = g_trace_dev; A.trace_cap = g_trace_cap; A.phase_out = g_phase_dev;
-    A.model_out = d_model; A.mask_out = d_mask; A.stats_out = d_stats; A.dim = dim; A.n_pairs = n_pairs; A.pts_in_lds = in_lds;
-    if (!homography) {
-        if (in_lds) hipLaunchKernelGGL(dg_find_fundamental_kernel<true>, dim3(n_pairs), dim3(DG_T), dyn, stream, A);
-        else        hipLaunchKernelGGL(dg_find_fundamental_kernel<false>, dim3(n_pairs), dim3(DG_T), 0, stream, A);
-    } else {
-        if (in_lds) hipLaunchKernelGGL(dg_find_homography_kernel<true>, dim3(n_pairs), dim3(DG_T), dyn, stream, A);
-        else        hipLaunchKernelGGL(dg_find_homography_kernel<false>, dim3(n_pairs), dim3(DG_T), 0, stream, A);
-    }
-    HIPCHK(hipGetLastError());
+    A.model_out = d_model; A.mask_out = d_mask; A.stats_out = d_stats; A.dim = dim; A.n_pairs = n_pairs; A.pts_in_lds = mode == DG_MODE_LDS;
+    if (variant == 1) HIPCHK(dg_variant_256_launch(homography, mode, n_pairs, dyn, stream, A));
+    else              HIPCHK(dg_variant_512_launch(homography, mode, n_pairs, dyn, stream, A));
+    g_last_variant = g_variant_threads[variant]; g_last_mode = mode;
     return 0;
 }
 
@@ -303,7 +315,7 @@ __global__ void dg_sample_stream_kernel(unsigned seed0, int n, int ssz, int iter
     unsigned seed = sd0;
     for (int base = 0; base < iters; base += DG_CHUNK) {
         int chunk = iters - base; if (chunk > DG_CHUNK) chunk = DG_CHUNK;
-        seed = ssz == 7 ? dg_sample_chunk<7, false>(seed, chunk, n, pool, seeds, draws, alm, lane) : dg_sample_chunk<4, false>(seed, chunk, n, pool, seeds, draws, alm, lane);
+        seed = ssz == 7 ? dg_sample_chunk<7, 0>(seed, chunk, n, pool, seeds, draws, alm, lane) : dg_sample_chunk<4, 0>(seed, chunk, n, pool, seeds, draws, alm, lane);
         __syncthreads();
         for (int k = lane; k < chunk; k += 64) for (int i = 0; i < ssz; i++) out[(size_t)(base + k) * ssz + i] = draws[k][i];
         __syncthreads();

@@ -21,4 +21,5 @@ for it in range(3):
     rc=L.mi_degensac_find_fundamental_batch_dev(d_a.data_ptr(),d_b.data_ptr(),d_off.data_ptr(),offs.ctypes.data_as(C.POINTER(C.c_int64)),P,2,C.byref(prm),d_seeds.data_ptr(),0,None,d_F.data_ptr(),d_mask.data_ptr(),d_st.data_ptr())
     torch.cuda.synchronize(); dt=time.perf_counter()-t; best=min(best,dt)
 st=d_st.cpu().numpy()
-print(f"lib={os.environ.get('MI_DEGENSAC_LIB','default')} global={os.environ.get('MI_DEGENSAC_FORCE_GLOBAL','0')} P={P} rc={rc} batch_ms={best*1e3:.1f} models/s={st[:,4].sum()/best/1e6:.2f}M pairs/s={P/best:.0f} sumI={st[:,3].sum()} ticks_total mean ms={st[:,13].mean()/1e5:.2f} max={st[:,13].max()/1e5:.1f}")
+th=C.c_int(0); md=C.c_int(0); L.mi_degensac_debug_last_launch(C.byref(th),C.byref(md))
+print(f"variant={th.value} mode={md.value} P={P} rc={rc} batch_ms={best*1e3:.1f} models/s={st[:,4].sum()/best/1e6:.2f}M pairs/s={P/best:.0f} sumI={st[:,3].sum()} ticks_total mean ms={st[:,13].mean()/1e5:.2f} max={st[:,13].max()/1e5:.1f}")
