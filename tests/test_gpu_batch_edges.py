@@ -1,0 +1,62 @@
+"""GPU: batch-level edge cases of the C-ABI — ragged batches that straddle the LDS limit, the size-independent
+properties of a full-size batch, error codes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import pydegensac_amd as pd
+from pydegensac_amd import _lib, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ragged_batch_across_the_lds_limit_equals_single_calls():
+    """n = 64 .. 6000 in one launch: n_max decides the placement (pool in LDS, points in the workspace) for every pair."""
+    sizes = [64, 2500, 6000, 8, 1000]
+    A, B = [], []
+    for i, n in enumerate(sizes):
+        p1, p2, _, _ = syn.two_view_fundamental(n, 0.5, 0.1, seed=40 + i); A.append(p1); B.append(p2)
+    seeds = [9, 8, 7, 6, 5]
+    Fb, mb = pd.findFundamentalMatrixBatch(A, B, max_iters=5000, seeds=seeds)
+    for p in range(len(sizes)):
+        F1, m1 = pd.findFundamentalMatrix(A[p], B[p], max_iters=5000, seed=seeds[p])
+        assert np.array_equal(np.asarray(Fb[p]), np.asarray(F1))
+        assert np.array_equal(np.asarray(mb[p], dtype=bool), np.asarray(m1, dtype=bool))
+
+
+def test_full_size_batch_properties():
+    """1100 C2 pairs (enough for the throughput variant): results do not depend on the batch a pair sits in or on its
+    position; every mask is consistent with its model; the stats block is sane."""
+    P, N = 1100, 2000
+    base = [syn.two_view_fundamental(N, 0.4, 0.1, seed=i)[:2] for i in range(20)]
+    A = [base[i % 20][0] for i in range(P)]; B = [base[i % 20][1] for i in range(P)]
+    seeds = [1 + (i % 20) for i in range(P)]                     # pair i == pair i + 20: identical problems
+    F, m = pd.findFundamentalMatrixBatch(A, B, seeds=seeds)
+    th, md = C.c_int(0), C.c_int(0); _lib.lib().mi_degensac_debug_last_launch(C.byref(th), C.byref(md))
+    assert th.value == 256, "a batch of > 4 pairs per CU must take the throughput variant"
+    F = np.asarray(F)
+    for i in range(20, P):
+        assert np.array_equal(F[i], F[i % 20]) and np.array_equal(np.asarray(m[i]), np.asarray(m[i % 20]))
+    F20, m20 = pd.findFundamentalMatrixBatch(A[:20], B[:20], seeds=seeds[:20])          # latency variant
+    assert np.array_equal(np.asarray(F20), F[:20])
+    for i in range(20):
+        assert np.array_equal(np.asarray(m20[i]), np.asarray(m[i]))
+        # mask == Sampson error <= th^2 under the returned model, recomputed in numpy (allowing knife-edge points)
+        p1, p2 = A[i], B[i]; Fi = F[i]
+        x1 = np.c_[p1, np.ones(N)]; x2 = np.c_[p2, np.ones(N)]
+        Fx1 = x1 @ Fi.T; Ftx2 = x2 @ Fi
+        d = (np.sum(x2 * Fx1, 1) ** 2) / (Fx1[:, 0] ** 2 + Fx1[:, 1] ** 2 + Ftx2[:, 0] ** 2 + Ftx2[:, 1] ** 2)
+        mi = np.asarray(m[i], dtype=bool)
+        assert (d[mi] <= 0.25 * (1 + 1e-9)).all() and mi.sum() >= 700
+
+
+def test_error_codes():
+    L = _lib.lib()
+    p1, p2, _, _ = syn.two_view_fundamental(100, 0.5, 0.1, seed=1)
+    with pytest.raises(ValueError):
+        pd.findFundamentalMatrixBatch([p1[:7]], [p2[:7]], seeds=[1])           # n < 8 (bindings.cpp:270)
+    with pytest.raises(ValueError):
+        pd.findHomographyBatch([p1[:3]], [p2[:3]], seeds=[1])                  # n < 4 (bindings.cpp:35)
+    with pytest.raises(_lib.MiDegensacError):
+        pd.findFundamentalMatrix(p1, p2, seed=1, device=63)                    # no such device: no CPU fallback
