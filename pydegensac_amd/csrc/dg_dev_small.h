@@ -699,43 +699,60 @@ static __device__ __noinline__ int dg_eig_sym_wave(double *a, double *w, int lan
     double *d = ews->d, *e = ews->e, *tau = ews->tau;
     int i, j, k, l, m, ii;
 #define A_(r,c) a[(c)*n + (r)]
-    /* ---- dsytd2, UPLO='U' ---- */
-    for (i = n - 2; i >= 0; i--) {
-        double alpha = A_(i, i+1), xnorm = 0., taui, beta, sc = 0.;
-        for (k = 0; k < i; k++) xnorm += A_(k, i+1) * A_(k, i+1);
-        xnorm = sqrt(xnorm);
-        if (xnorm == 0.) taui = 0.;
-        else { beta = -dg_sign(dg_lapy2(alpha, xnorm), alpha); taui = (beta - alpha) / beta; sc = 1. / (alpha - beta); alpha = beta; }
-        DG_WSYNC();
-        if (xnorm != 0. && lane < i) A_(lane, i+1) *= sc;
-        if (lane == 0) e[i] = alpha;
-        if (taui != 0.) {
-            if (lane == 0) A_(i, i+1) = 1.;
-            DG_WSYNC();
-            if (lane <= i) {
-                double sum = 0.;
-                for (j = 0; j <= i; j++) sum += (j >= lane ? A_(lane, j) : A_(j, lane)) * A_(j, i+1);
-                tau[lane] = taui * sum;
+    /* ---- dsytd2, UPLO='U' ----
+     * Lane r (< 9) keeps row r of the symmetric matrix in nine registers (both triangles, kept in step), every index
+     * below is a compile-time constant after unrolling, and values cross lanes through v_readlane: no LDS round trips
+     * inside the eight Householder steps.  Sums run in the reference's element order; the rank-2 update evaluates
+     * A(kr,jc) - v_kr*tau_jc - tau_kr*v_jc with (kr, jc) = (min, max) of (row, column) for both triangles. */
+    {
+        double R[9];
+#pragma unroll
+        for (int cc = 0; cc < 9; cc++) R[cc] = lane < n ? A_(lane, cc) : 0.;
+#pragma unroll
+        for (int ih = n - 2; ih >= 0; ih--) {
+            const int c1 = ih + 1;                                     /* column holding the reflector */
+            double alpha = dg_rdl_d(R[c1], ih), xnorm = 0., taui, beta, sc = 0.;
+            { const double sq = R[c1] * R[c1];
+#pragma unroll
+              for (int kk = 0; kk < ih; kk++) xnorm += dg_rdl_d(sq, kk); }
+            xnorm = sqrt(xnorm);
+            if (xnorm == 0.) taui = 0.;
+            else { beta = -dg_sign(dg_lapy2(alpha, xnorm), alpha); taui = (beta - alpha) / beta; sc = 1. / (alpha - beta); alpha = beta; }
+            if (xnorm != 0. && lane < ih) R[c1] *= sc;
+            if (lane == 0) e[ih] = alpha;
+            if (taui != 0.) {
+                if (lane == ih) R[c1] = 1.;
+                double tl = 0.;                                        /* tau_lane */
+                { double sum = 0.;
+#pragma unroll
+                  for (int jj = 0; jj <= ih; jj++) sum += R[jj] * dg_rdl_d(R[c1], jj);
+                  if (lane <= ih) tl = taui * sum; }
+                double dot = 0.;
+                { const double pr = tl * R[c1];
+#pragma unroll
+                  for (int kk = 0; kk <= ih; kk++) dot += dg_rdl_d(pr, kk); }
+                const double al = -.5 * taui * dot;
+                if (lane <= ih) tl += al * R[c1];
+                const double vl = R[c1];
+#pragma unroll
+                for (int cc = 0; cc <= ih; cc++) {
+                    const double vc = dg_rdl_d(vl, cc), tc = dg_rdl_d(tl, cc);
+                    const double up = R[cc] - vl * tc - tl * vc;       /* row <= column: kr = lane, jc = cc */
+                    const double lo = R[cc] - vc * tl - tc * vl;       /* row >  column: kr = cc,   jc = lane */
+                    if (lane <= ih) R[cc] = lane <= cc ? up : lo;
+                }
+                if (lane == ih) R[c1] = alpha;
             }
-            DG_WSYNC();
-            double dot = 0.; for (k = 0; k <= i; k++) dot += tau[k] * A_(k, i+1);
-            double al = -.5 * taui * dot;
-            DG_WSYNC();
-            if (lane <= i) tau[lane] += al * A_(lane, i+1);
-            DG_WSYNC();
-            if (lane < (i+1)*(i+2)/2) {
-                int jc = 0; while ((jc+1)*(jc+2)/2 <= lane) jc++;
-                int kr = lane - jc*(jc+1)/2;
-                A_(kr, jc) = A_(kr, jc) - A_(kr, i+1) * tau[jc] - tau[kr] * A_(jc, i+1);
-            }
-            DG_WSYNC();
-            if (lane == 0) A_(i, i+1) = alpha;
+            if (lane == c1) d[c1] = R[c1];
+            if (lane == 0) tau[ih] = taui;
+        }
+        if (lane == 0) d[0] = R[0];
+        if (lane < n) {
+#pragma unroll
+            for (int cc = 0; cc < 9; cc++) A_(lane, cc) = R[cc];
         }
         DG_WSYNC();
-        if (lane == 0) { d[i+1] = A_(i+1, i+1); tau[i] = taui; }
-        DG_WSYNC();
     }
-    if (lane == 0) d[0] = A_(0, 0);
     DG_ET(0);
     /* ---- dorgtr 'U': shift the reflector vectors one column left, unit last row/column ---- */
     {
