@@ -754,35 +754,52 @@ static __device__ __noinline__ int dg_eig_sym_wave(double *a, double *w, int lan
         DG_WSYNC();
     }
     DG_ET(0);
-    /* ---- dorgtr 'U': shift the reflector vectors one column left, unit last row/column ---- */
+    /* ---- dorgtr 'U' + dorg2l(n-1, n-1, n-1) ----
+     * Lane c (< 9) takes column c of the shifted matrix into nine registers (reflector vectors one column left, unit
+     * last row/column), applies H(0..7) with the reflector column broadcast by v_readlane from lane ii, and writes the
+     * finished Q back once. */
     {
-        double v0 = 0., v1 = 0.; int e0 = lane, e1 = lane + 64;
-        { int r = e0 % n, c = e0 / n; v0 = (c < n-1 && r < c) ? A_(r, c+1) : A_(r, c); }
-        if (e1 < n*n) { int r = e1 % n, c = e1 / n; v1 = (c < n-1 && r < c) ? A_(r, c+1) : A_(r, c); }
-        DG_WSYNC();
-        { int r = e0 % n, c = e0 / n; if (r == n-1 || c == n-1) v0 = (r == n-1 && c == n-1) ? 1. : 0.; a[e0] = v0; }
-        if (e1 < n*n) { int r = e1 % n, c = e1 / n; if (r == n-1 || c == n-1) v1 = (r == n-1 && c == n-1) ? 1. : 0.; a[e1] = v1; }
-        DG_WSYNC();
-    }
-    /* ---- dorg2l(n-1, n-1, n-1) ---- */
-    {
-        const int mq = n - 1;
-        for (i = 0; i < mq; i++) {
-            ii = i;
-            if (lane == 0) A_(ii, ii) = 1.;
-            DG_WSYNC();
-            if (lane < ii) {
-                double sum = 0.;
-                for (k = 0; k <= ii; k++) sum += A_(k, lane) * A_(k, ii);
-                sum *= tau[i];
-                for (k = 0; k <= ii; k++) A_(k, lane) -= sum * A_(k, ii);
+        double Cq[9];
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+            double v = 0.;
+            if (lane < n) {
+                if (r == n - 1 || lane == n - 1) v = (r == n - 1 && lane == n - 1) ? 1. : 0.;
+                else v = r < lane ? A_(r, lane + 1) : A_(r, lane);
             }
-            DG_WSYNC();
-            if (lane < ii) A_(lane, ii) *= -tau[i];
-            if (lane == 0) A_(ii, ii) = 1. - tau[i];
-            if (lane > ii && lane < mq) A_(lane, ii) = 0.;
-            DG_WSYNC();
+            Cq[r] = v;
         }
+        double tq[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) tq[q] = tau[q];
+        DG_WSYNC();
+#pragma unroll
+        for (int iq = 0; iq < n - 1; iq++) {
+            if (lane == iq) Cq[iq] = 1.;
+            double wv[9];
+#pragma unroll
+            for (int kk = 0; kk <= iq; kk++) wv[kk] = dg_rdl_d(Cq[kk], iq);
+            if (lane < iq) {
+                double sum = 0.;
+#pragma unroll
+                for (int kk = 0; kk <= iq; kk++) sum += Cq[kk] * wv[kk];
+                sum *= tq[iq];
+#pragma unroll
+                for (int kk = 0; kk <= iq; kk++) Cq[kk] -= sum * wv[kk];
+            }
+            if (lane == iq) {
+#pragma unroll
+                for (int kk = 0; kk < iq; kk++) Cq[kk] *= -tq[iq];
+                Cq[iq] = 1. - tq[iq];
+#pragma unroll
+                for (int kk = iq + 1; kk < n - 1; kk++) Cq[kk] = 0.;
+            }
+        }
+        if (lane < n) {
+#pragma unroll
+            for (int r = 0; r < 9; r++) A_(r, lane) = Cq[r];
+        }
+        DG_WSYNC();
     }
     DG_ET(1);
     /* ---- dsteqr 'V' ----
