@@ -951,79 +951,129 @@ static __device__ __noinline__ int dg_eig_sym_wave(double *a, double *w, int lan
 #undef A_
 }
 
-/* wave-cooperative form of dg_svd_lastcol_9x8: identical per-element arithmetic; the loops over the other
- * columns (left reflector) / other rows (right reflector) run in different lanes.  All 64 lanes of one wave. */
-static __device__ __noinline__ void dg_svd_lastcol_9x8_wave(double *a /* LDS 9x8 row-major, destroyed */, double *col /* LDS 9 */, int lane)
+/* wave-cooperative form of dg_svd_lastcol_9x8: identical per-element arithmetic, no LDS inside the sweep.
+ * The 9x8 matrix is held twice in registers — lane r (< 9) owns row r (Rw[0..7]), lane c (< 8) owns column c
+ * (Cl[0..8]) — so the column reflector finds its column locally in lane i and the row reflector its row locally
+ * in lane i; scalars and reflector entries travel by v_readlane with compile-time lane numbers, and every update is
+ * applied to both copies with the same operands (bitwise equal).  All 64 lanes of one wave. */
+static __device__ __noinline__ void dg_svd_lastcol_9x8_wave(double *a /* LDS 9x8 row-major */, double *col /* LDS 9 */, int lane)
 {
-    DG_LDS double w[20];
     const int m = 9, n = 8;
-    int i, j, mm, nm;
-    for (i = 0, mm = m, nm = n - 1; i < n; ++i, --mm, --nm) {
-        double *p = a + i * (n + 1);
-        DG_WSYNC();
-        if (mm > 1) {
-            double s = 0., h = 0., sv = 0., t = 0.;
-            for (j = 0; j < mm; ++j) { double q = p[j*n]; s += q * q; }           /* every lane, same order */
+    double Rw[8], Cl[9];
+#pragma unroll
+    for (int c = 0; c < 8; c++) Rw[c] = lane < m ? a[lane * n + c] : 0.;
+#pragma unroll
+    for (int r = 0; r < 9; r++) Cl[r] = lane < n ? a[r * n + lane] : 0.;
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+        const int mm = m - i, nm = n - 1 - i;
+        /* ---- column reflector on a[i..8][i] ---- */
+        {
+            double sl = 0.;
+#pragma unroll
+            for (int j = 0; j < mm; j++) sl += Cl[i + j] * Cl[i + j];
+            double s = dg_rdl_d(sl, i), sv = 0.;
             if (s > 0.) {
-                h = sqrt(s); if (*p < 0.) h = -h;
-                double p0 = *p;
-                s += p0 * h; s = 1./s; t = 1./(p0 + h);
-                sv = 1. + fabs(p0/h);
-                DG_WSYNC();
-                if (lane < mm) w[lane] = (lane == 0) ? p0 + h : p[lane*n];
-                DG_WSYNC();
-                { int k = lane + 1; if (k < n - i) { double r = 0.; for (j = 0; j < mm; j++) r += w[j] * p[j*n + k]; r *= s; for (j = 0; j < mm; j++) p[j*n + k] -= r * w[j]; } }
-                DG_WSYNC();
-                if (lane >= 1 && lane < mm) p[lane*n] = t * w[lane];
+                const double p0 = dg_rdl_d(Cl[i], i);
+                double h = sqrt(s); if (p0 < 0.) h = -h;
+                s += p0 * h; s = 1. / s; const double t = 1. / (p0 + h);
+                sv = 1. + fabs(p0 / h);
+                double wv[9];
+                wv[0] = p0 + h;
+#pragma unroll
+                for (int j = 1; j < mm; j++) wv[j] = dg_rdl_d(Cl[i + j], i);
+                /* column copy: lanes k > i */
+                double rl = 0.;
+#pragma unroll
+                for (int j = 0; j < mm; j++) rl += wv[j] * Cl[i + j];
+                rl *= s;
+                if (lane > i && lane < n) {
+#pragma unroll
+                    for (int j = 0; j < mm; j++) Cl[i + j] -= rl * wv[j];
+                }
+                /* row copy: lanes i..8, columns k > i, with r_k from column lane k */
+                const double wl = lane == i ? p0 + h : Rw[i];
+#pragma unroll
+                for (int k = i + 1; k < n; k++) {
+                    const double rk = dg_rdl_d(rl, k);
+                    if (lane >= i && lane < m) Rw[k] -= rk * wl;
+                }
+                /* scaled reflector below the diagonal */
+                if (lane == i) {
+#pragma unroll
+                    for (int j = 1; j < mm; j++) Cl[i + j] = t * wv[j];
+                }
+                if (lane > i && lane < m) Rw[i] = t * wl;
             }
-            DG_WSYNC();
-            if (lane == 0) *p = sv;
+            if (lane == i) { Cl[i] = sv; Rw[i] = sv; }
         }
-        DG_WSYNC();
-        double *p1 = p + 1;
+        /* ---- row reflector on a[i][i+1..7] ---- */
         if (nm > 1) {
-            double s = 0., h = 0., sv = 0., t = 0.;
-            for (j = 0; j < nm; ++j) s += p1[j] * p1[j];
+            double sl = 0.;
+#pragma unroll
+            for (int j = 0; j < nm; j++) sl += Rw[i + 1 + j] * Rw[i + 1 + j];
+            double s = dg_rdl_d(sl, i), sv = 0.;
             if (s > 0.) {
-                double q0 = *p1;
-                h = sqrt(s); if (q0 < 0.) h = -h;
-                sv = 1. + fabs(q0/h);
-                s += q0 * h; s = 1./s; t = 1./(q0 + h);
-                DG_WSYNC();
-                if (lane == 0) *p1 = q0 + h;
-                DG_WSYNC();
-                { int rr = lane + 1; if (rr < m - i) { double *pp = p1 + rr*n; double r = 0.; for (j = 0; j < nm; ++j) r += p1[j] * pp[j]; r *= s; for (j = 0; j < nm; ++j) pp[j] -= r * p1[j]; } }
-                DG_WSYNC();
-                if (lane >= 1 && lane < nm) p1[lane] *= t;
+                const double q0 = dg_rdl_d(Rw[i + 1], i);
+                double h = sqrt(s); if (q0 < 0.) h = -h;
+                sv = 1. + fabs(q0 / h);
+                s += q0 * h; s = 1. / s; const double t = 1. / (q0 + h);
+                double pv[8];
+                pv[0] = q0 + h;
+#pragma unroll
+                for (int j = 1; j < nm; j++) pv[j] = dg_rdl_d(Rw[i + 1 + j], i);
+                /* row copy: lanes R > i */
+                double rl = 0.;
+#pragma unroll
+                for (int j = 0; j < nm; j++) rl += pv[j] * Rw[i + 1 + j];
+                rl *= s;
+                if (lane > i && lane < m) {
+#pragma unroll
+                    for (int j = 0; j < nm; j++) Rw[i + 1 + j] -= rl * pv[j];
+                }
+                /* column copy: lanes i+1..7, rows R > i, with r_R from row lane R */
+                const double pl = lane == i + 1 ? q0 + h : Cl[i];
+#pragma unroll
+                for (int R = i + 1; R < m; R++) {
+                    const double rR = dg_rdl_d(rl, R);
+                    if (lane > i && lane < n) Cl[R] -= rR * pl;
+                }
+                if (lane == i) {
+#pragma unroll
+                    for (int j = 1; j < nm; j++) Rw[i + 1 + j] *= t;
+                }
+                if (lane > i + 1 && lane < n) Cl[i] *= t;
             }
-            DG_WSYNC();
-            if (lane == 0) *p1 = sv;
+            if (lane == i) Rw[i + 1] = sv;
+            if (lane == i + 1) Cl[i] = sv;
         }
     }
-    DG_WSYNC();
     /* ldumat restricted to column 8 (sequential recurrence, every lane computes it; lane 0 stores) */
     {
         double c[9];
 #pragma unroll
-        for (i = 0; i < 9; i++) c[i] = 0.;
+        for (int i = 0; i < 9; i++) c[i] = 0.;
         c[8] = 1.;
 #pragma unroll
-        for (i = n - 1; i >= 0; --i) {
+        for (int i = n - 1; i >= 0; --i) {
             const int mm2 = n - i;             /* rows below row i: 9 - 1 - i */
-            double p0 = a[i*n + i];
+            const double p0 = dg_rdl_d(Cl[i], i);
             if (p0 != 0.) {
+                double av[9];
+#pragma unroll
+                for (int j = 0; j < mm2; j++) av[j] = dg_rdl_d(Cl[i + 1 + j], i);
                 double s = 0.;
 #pragma unroll
-                for (j = 0; j < mm2; j++) s += a[(i + 1 + j)*n + i] * c[i + 1 + j];
+                for (int j = 0; j < mm2; j++) s += av[j] * c[i + 1 + j];
                 s *= p0;
 #pragma unroll
-                for (j = 0; j < mm2; j++) c[i + 1 + j] -= s * a[(i + 1 + j)*n + i];
+                for (int j = 0; j < mm2; j++) c[i + 1 + j] -= s * av[j];
                 c[i] = -s;
             } else c[i] = 0.;
         }
         if (lane == 0) {
 #pragma unroll
-            for (i = 0; i < 9; i++) col[i] = c[i];
+            for (int i = 0; i < 9; i++) col[i] = c[i];
         }
     }
     DG_WSYNC();
