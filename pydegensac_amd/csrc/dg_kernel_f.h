@@ -41,6 +41,7 @@ struct dg_f_shared {
     double   f[9], F[9], FBest[9], H[9], Hx[9], fLO[9], ftmp[9];
     double   bufF[4][9]; int bufKind[4]; /* model whose residuals each physical errs[] buffer holds */
     double   u7[7][4];
+    double   ext[4], extw[DG_NW][4];     /* max |x1|, |y1|, |x2|, |y2| over the pair (screening bound), per-wave partials */
     int      samidxBest[7];
     int      itmp[32];
     double   dtmp[32];

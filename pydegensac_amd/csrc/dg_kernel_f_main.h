@@ -364,7 +364,7 @@ __device__ __forceinline__ int dg_group_owner(int g)
 
 template <int LDSPTS>
 __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const double *gmodels, const unsigned short *mslot,
-                                             int Mtot, int wave, int kind, double th, double tauJ,
+                                             int Mtot, int wave, int kind, double th, double tauJ, const double *ext /* LDS[4] */,
                                              unsigned *res_I, double *res_J, int lane)
 {
     const double t94 = th * 9 / 4, t94b = t94 * (1.0 + 1e-6);
@@ -383,7 +383,38 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
             for (int j = 0; j < 9; j++) F[g][j] = gp[j];
         }
         unsigned surv = (1u << ng) - 1u;
-        if (use_bound) {
+        if (use_bound && tauJ >= 64.0) {
+            /* level 1: only the epipolar residual r.  The Sampson denominator is at most Dmax = sum of the squared
+             * bounds |F00| X + |F10| Y + |F20| ... over the pair's coordinate extents, so {d < t} is inside
+             * {r^2 < t Dmax}; for the symmetric metric d = r^2 (a + b) / (a b) >= r^2 / min(a, b).  Random models have a
+             * few percent of the points even inside this looser band, far below tau. */
+            const double X1 = ext[0], Y1 = ext[1], X2 = ext[2], Y2 = ext[3];
+            double lim[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const double *f = F[g];
+                const double u1 = fabs(f[0]) * X2 + fabs(f[3]) * Y2 + fabs(f[6]), u2 = fabs(f[1]) * X2 + fabs(f[4]) * Y2 + fabs(f[7]);
+                const double u3 = fabs(f[0]) * X1 + fabs(f[1]) * Y1 + fabs(f[2]), u4 = fabs(f[3]) * X1 + fabs(f[4]) * Y1 + fabs(f[5]);
+                const double am = u1*u1 + u2*u2, bm = u3*u3 + u4*u4;
+                lim[g] = t94b * (1.0 + 1e-9) * (kind == DG_K_FDS ? am + bm : fmin(am, bm));
+            }
+            unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            for (int p = lane; p < n; p += 64) {
+                const dg_pt q = P[p];
+#define DG_R2(f_) ({ const double rxc_ = __builtin_fma((f_)[0], q.x2, __builtin_fma((f_)[3], q.y2, (f_)[6])), \
+                                  ryc_ = __builtin_fma((f_)[1], q.x2, __builtin_fma((f_)[4], q.y2, (f_)[7])), \
+                                  rwc_ = __builtin_fma((f_)[2], q.x2, __builtin_fma((f_)[5], q.y2, (f_)[8])); \
+                     const double r_ = __builtin_fma(q.x1, rxc_, __builtin_fma(q.y1, ryc_, rwc_)); r_ * r_; })
+                c0 += !(DG_R2(F[0]) >= lim[0]) ? 1u : 0u; c1 += !(DG_R2(F[1]) >= lim[1]) ? 1u : 0u;
+                c2 += !(DG_R2(F[2]) >= lim[2]) ? 1u : 0u; c3 += !(DG_R2(F[3]) >= lim[3]) ? 1u : 0u;
+#undef DG_R2
+            }
+            const unsigned C1[4] = {dg_wave_sum_u(c0), dg_wave_sum_u(c1), dg_wave_sum_u(c2), dg_wave_sum_u(c3)};
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                if (g < ng && !((double)C1[g] > tauJ)) { surv &= ~(1u << g); if (lane == 0) { res_I[mi[g]] = 0; res_J[mi[g]] = 0; } }
+        }
+        if (use_bound && surv) {
             unsigned cb0 = 0, cb1 = 0, cb2 = 0, cb3 = 0;
             for (int p = lane; p < n; p += 64) {
                 const dg_pt q = P[p];
@@ -393,7 +424,7 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
             const unsigned CB[4] = {dg_wave_sum_u(cb0), dg_wave_sum_u(cb1), dg_wave_sum_u(cb2), dg_wave_sum_u(cb3)};
 #pragma unroll
             for (int g = 0; g < 4; g++)
-                if (g < ng && !((double)CB[g] > tauJ)) { surv &= ~(1u << g); if (lane == 0) { res_I[mi[g]] = 0; res_J[mi[g]] = 0; } }
+                if (((surv >> g) & 1u) && !((double)CB[g] > tauJ)) { surv &= ~(1u << g); if (lane == 0) { res_I[mi[g]] = 0; res_J[mi[g]] = 0; } }
         }
 #pragma unroll
         for (int g = 0; g < 4; g++) {
@@ -460,13 +491,24 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
     const dg_pt *P = Pw;
 
     /* ---- stage the correspondences (bindings.cpp:337-409: only x,y of each row are geometry) ---- */
+    double ex0 = 0., ex1 = 0., ex2 = 0., ex3 = 0.;
     for (int i = tid; i < n; i += DG_T) {
         const double *a = A.pts1 + (size_t)(off + i) * A.dim, *b = A.pts2 + (size_t)(off + i) * A.dim;
         dg_pt p; p.x1 = a[0]; p.y1 = a[1]; p.x2 = b[0]; p.y2 = b[1];
         Pw[i] = p; pool[i] = i;
+        ex0 = fmax(ex0, fabs(p.x1)); ex1 = fmax(ex1, fabs(p.y1)); ex2 = fmax(ex2, fabs(p.x2)); ex3 = fmax(ex3, fabs(p.y2));
     }
+    /* coordinate extents of the pair (used only by the conservative screening bound of the scoring phase) */
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        ex0 = fmax(ex0, __shfl_xor(ex0, o, 64)); ex1 = fmax(ex1, __shfl_xor(ex1, o, 64));
+        ex2 = fmax(ex2, __shfl_xor(ex2, o, 64)); ex3 = fmax(ex3, __shfl_xor(ex3, o, 64));
+    }
+    if (lane == 0) { S->extw[wave][0] = ex0; S->extw[wave][1] = ex1; S->extw[wave][2] = ex2; S->extw[wave][3] = ex3; }
     dg_ht_init(c.ht, tid);
     if (tid < 9) { S->F[tid] = 0; S->FBest[tid] = 0; }
+    __syncthreads();
+    if (tid < 4) { double e = 0.; for (int w = 0; w < DG_NW; w++) e = fmax(e, S->extw[w][tid]); S->ext[tid] = e; }
     __syncthreads();
 
     const int mk_full = pr.error_type == 1 ? DG_K_FSYM : DG_K_FDS;
@@ -557,7 +599,7 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
             }
             if (wave >= 2 || DG_NW < 6)
                 dg_score_chunk_F<LDSPTS>(P, n, c.gmodels, S->mslot, Mtot, wave, mk_full, th,
-                                         maxS.J < maxSs.J ? maxS.J : maxSs.J, c.res_I, c.res_J, lane);
+                                         maxS.J < maxSs.J ? maxS.J : maxSs.J, S->ext, c.res_I, c.res_J, lane);
         }
         c.n_fds += Mtot;   /* provisional: models past the termination point are subtracted below */
         __syncthreads();
