@@ -247,7 +247,14 @@ __device__ __forceinline__ void dg_lsq_seq_core(SC *s, const dg_pt *stage, int l
         {
             const double *sp = (const double *)stage + ((lane & 1) ? 2 : 0);
             const double mx = (lane & 1) ? m2x : m1x, my = (lane & 1) ? m2y : m1y;
-            for (int j = 0; j < len; j++) { double a = sp[4*j] - mx, b = sp[4*j+1] - my; dsum += sqrt(a*a + b*b); }
+            /* four points per step so that their loads are in flight together (the stage can be HBM/L2); same order */
+            int j = 0;
+            for (; j + 4 <= len; j += 4) {
+                double a0 = sp[4*j], b0 = sp[4*j+1], a1 = sp[4*j+4], b1 = sp[4*j+5], a2 = sp[4*j+8], b2 = sp[4*j+9], a3 = sp[4*j+12], b3 = sp[4*j+13];
+                a0 -= mx; b0 -= my; a1 -= mx; b1 -= my; a2 -= mx; b2 -= my; a3 -= mx; b3 -= my;
+                dsum += sqrt(a0*a0 + b0*b0); dsum += sqrt(a1*a1 + b1*b1); dsum += sqrt(a2*a2 + b2*b2); dsum += sqrt(a3*a3 + b3*b3);
+            }
+            for (; j < len; j++) { double a = sp[4*j] - mx, b = sp[4*j+1] - my; dsum += sqrt(a*a + b*b); }
         }
         double A1[3], A2[3];
         A1[0] = __shfl(dsum, 0, 64); A2[0] = __shfl(dsum, 1, 64);
@@ -261,23 +268,30 @@ __device__ __forceinline__ void dg_lsq_seq_core(SC *s, const dg_pt *stage, int l
         { int e = 0; for (int i = 0; i < 9; i++) for (int q = 0; q <= i; q++) { if (e == lane) { ie = i; je = q; } e++; } }
         const int ki = ie / 3, li = ie % 3, kj = je / 3, lj = je % 3;
         double val = 0;
-        if (lane < 45) for (int j = 0; j < len; j++) {
-            dg_pt p = stage[j];
-            double a0 = p.x1 * A1[0] + A1[1], a1 = p.y1 * A1[0] + A1[2];
-            double b0 = p.x2 * A2[0] + A2[1], b1 = p.y2 * A2[0] + A2[2];
-            if (!rows2) {
-                double ai = li == 0 ? a0 : li == 1 ? a1 : 1.0, bi = ki == 0 ? b0 : ki == 1 ? b1 : 1.0;
-                double aj = lj == 0 ? a0 : lj == 1 ? a1 : 1.0, bj = kj == 0 ? b0 : kj == 1 ? b1 : 1.0;
-                val += (ai * bi) * (aj * bj);
-            } else {
-                /* row 0: z[3q] = b[q], z[3q+1] = 0, z[3q+2] = -a0*b[q];  row 1: z[3q] = 0, z[3q+1] = b[q], z[3q+2] = -a1*b[q] */
-                double bqi = ki == 0 ? b0 : ki == 1 ? b1 : 1.0, bqj = kj == 0 ? b0 : kj == 1 ? b1 : 1.0;
-                double z0i = li == 0 ? bqi : li == 1 ? 0.0 : -a0 * bqi, z0j = lj == 0 ? bqj : lj == 1 ? 0.0 : -a0 * bqj;
-                double z1i = li == 0 ? 0.0 : li == 1 ? bqi : -a1 * bqi, z1j = lj == 0 ? 0.0 : lj == 1 ? bqj : -a1 * bqj;
-                val += z0i * z0j;
-                val += z1i * z1j;
+#define DG_NM_TERM(p) do { \
+            double a0 = (p).x1 * A1[0] + A1[1], a1 = (p).y1 * A1[0] + A1[2]; \
+            double b0 = (p).x2 * A2[0] + A2[1], b1 = (p).y2 * A2[0] + A2[2]; \
+            if (!rows2) { \
+                double ai = li == 0 ? a0 : li == 1 ? a1 : 1.0, bi = ki == 0 ? b0 : ki == 1 ? b1 : 1.0; \
+                double aj = lj == 0 ? a0 : lj == 1 ? a1 : 1.0, bj = kj == 0 ? b0 : kj == 1 ? b1 : 1.0; \
+                val += (ai * bi) * (aj * bj); \
+            } else { \
+                /* row 0: z[3q] = b[q], z[3q+1] = 0, z[3q+2] = -a0*b[q];  row 1: z[3q] = 0, z[3q+1] = b[q], z[3q+2] = -a1*b[q] */ \
+                double bqi = ki == 0 ? b0 : ki == 1 ? b1 : 1.0, bqj = kj == 0 ? b0 : kj == 1 ? b1 : 1.0; \
+                double z0i = li == 0 ? bqi : li == 1 ? 0.0 : -a0 * bqi, z0j = lj == 0 ? bqj : lj == 1 ? 0.0 : -a0 * bqj; \
+                double z1i = li == 0 ? 0.0 : li == 1 ? bqi : -a1 * bqi, z1j = lj == 0 ? 0.0 : lj == 1 ? bqj : -a1 * bqj; \
+                val += z0i * z0j; \
+                val += z1i * z1j; \
+            } } while (0)
+        if (lane < 45) {
+            int j = 0;
+            for (; j + 4 <= len; j += 4) {                   /* four loads in flight, terms added in list order */
+                const dg_pt p0 = stage[j], p1 = stage[j+1], p2 = stage[j+2], p3 = stage[j+3];
+                DG_NM_TERM(p0); DG_NM_TERM(p1); DG_NM_TERM(p2); DG_NM_TERM(p3);
             }
+            for (; j < len; j++) { const dg_pt p = stage[j]; DG_NM_TERM(p); }
         }
+#undef DG_NM_TERM
         if (lane < 45) { s->V[9*ie + je] = val; s->V[ie + 9*je] = val; }
         if (lane == 0) { for (int i = 0; i < 3; i++) { A1o[i] = A1[i]; A2o[i] = A2[i]; } }
     }
