@@ -285,7 +285,13 @@ __device__ __forceinline__ void dg_lsq_seq_core(SC *s, const dg_pt *stage, int l
             } } while (0)
         if (lane < 45) {
             int j = 0;
-            for (; j + 4 <= len; j += 4) {                   /* four loads in flight, terms added in list order */
+            for (; j + 8 <= len; j += 8) {                   /* eight loads in flight, terms added in list order */
+                const dg_pt p0 = stage[j], p1 = stage[j+1], p2 = stage[j+2], p3 = stage[j+3];
+                const dg_pt p4 = stage[j+4], p5 = stage[j+5], p6 = stage[j+6], p7 = stage[j+7];
+                DG_NM_TERM(p0); DG_NM_TERM(p1); DG_NM_TERM(p2); DG_NM_TERM(p3);
+                DG_NM_TERM(p4); DG_NM_TERM(p5); DG_NM_TERM(p6); DG_NM_TERM(p7);
+            }
+            for (; j + 4 <= len; j += 4) {
                 const dg_pt p0 = stage[j], p1 = stage[j+1], p2 = stage[j+2], p3 = stage[j+3];
                 DG_NM_TERM(p0); DG_NM_TERM(p1); DG_NM_TERM(p2); DG_NM_TERM(p3);
             }
