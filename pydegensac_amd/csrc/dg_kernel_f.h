@@ -148,7 +148,7 @@ __device__ __forceinline__ void dg_u2f_list(CTX &c, const int *list, int len, co
         __syncthreads();
     } else {
         const dg_pt *P = c.P;
-        dg_u2f_big(&S->red, &S->lsq, [&](int i) { return P[i]; }, list, len, c.tid, Fout, c.stage);
+        dg_u2f_big(&S->red, &S->lsq, [&](int i) { return P[i]; }, list, len, c.tid, Fout, c.stage, c.n_max);
     }
 }
 
@@ -364,7 +364,7 @@ __device__ __forceinline__ unsigned dg_wave_list_lt(const dg_pt *P, int n, const
  * F (LDS, 9) in/out.  Returns the count and *thf = the threshold the reference's `inl` flags correspond to
  * (th after the full schedule, the current ths on the "fewer than 8 inliers" early return). */
 __device__ __noinline__ unsigned dg_u2Fit_wave(dg_wave_ws *w, const dg_pt *P, int n, double *F, double th, double ths, unsigned iters,
-                                              int *list, dg_pt *stage, int lane, double *thf, int *n_aux)
+                                              int *list, dg_pt *stage, int stage_cap, int lane, double *thf, int *n_aux)
 {
     double dth = (ths - th) / (iters - 1);
     for (unsigned iter = 0; iter < iters; ++iter) {
@@ -389,7 +389,8 @@ __device__ __noinline__ unsigned dg_u2Fit_wave(dg_wave_ws *w, const dg_pt *P, in
         } else {
             for (int j = lane; j < (int)cnt; j += 64) stage[j] = P[list[j]];
             DG_WSYNC();
-            dg_lsq_seq_core(w, stage, (int)cnt, lane, 0, w->A1, w->A2);
+            if (2 * stage_cap >= 3 * (int)cnt) dg_lsq_seq_par(w, stage, (int)cnt, lane, 64, 0, w->A1, w->A2, [] { DG_WSYNC(); });
+            else dg_lsq_seq_core(w, stage, (int)cnt, lane, 0, w->A1, w->A2);
             DG_WSYNC();
             dg_eig_sym_wave(w->V, w->D, lane, &w->ews);
             if (lane == 0) {
@@ -479,7 +480,7 @@ __device__ __noinline__ void dg_innerFH(CTX &c, const int *idxH, unsigned lenH, 
         if (lane < 9) S->fhF2[rep][lane] = S->fhF[rep][lane];
         DG_WSYNC();
         double thf;
-        unsigned cnt = dg_u2Fit_wave(&S->ww[wave], P, n, S->fhF2[rep], th, th*3, 4, c.wlist + (size_t)wave * c.n_max, c.wstage + (size_t)wave * c.n_max, lane, &thf, &aux_local);
+        unsigned cnt = dg_u2Fit_wave(&S->ww[wave], P, n, S->fhF2[rep], th, th*3, 4, c.wlist + (size_t)wave * c.n_max, c.wstage + (size_t)wave * c.n_max, c.n_max, lane, &thf, &aux_local);
         if (lane == 0) { S->fhCnt2[rep] = (int)cnt; S->fhTh[rep] = thf; S->itmp[8 + wave] = aux_local; }
         DG_WSYNC();
     }

@@ -12,10 +12,10 @@
 
 /* u2h (Htools.c:115-131) over a list of ids, reference summation order (see dg_lsq_seq) */
 template <class PtFn>
-__device__ __forceinline__ void dg_u2h_big(dg_red *r, dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, double *Hout /* LDS */, dg_pt *stage)
+__device__ __forceinline__ void dg_u2h_big(dg_red *r, dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, double *Hout /* LDS */, dg_pt *stage, int stage_cap)
 {
     (void)r;
-    dg_lsq_seq(s, pt, list, len, tid, 1, s->A1, s->A2, stage);
+    dg_lsq_seq(s, pt, list, len, tid, 1, s->A1, s->A2, stage, stage_cap);
     if (tid < 64) dg_eig_sym_wave(s->V, s->D, tid, &s->ews);
     if (tid == 0) {
         for (int i = 0; i < 9; i++) Hout[i] = s->V[i];
@@ -35,7 +35,7 @@ __device__ __forceinline__ void dg_u2h_list(CTX &c, const int *list, int len, do
         __syncthreads();
     } else {
         const dg_pt *P = c.P;
-        dg_u2h_big(&S->red, &S->lsq, [&](int i) { return P[i]; }, list, len, c.tid, Hout, c.stage);
+        dg_u2h_big(&S->red, &S->lsq, [&](int i) { return P[i]; }, list, len, c.tid, Hout, c.stage, c.n_max);
     }
 }
 

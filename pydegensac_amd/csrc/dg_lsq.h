@@ -303,23 +303,111 @@ __device__ __forceinline__ void dg_lsq_seq_core(SC *s, const dg_pt *stage, int l
     }
 }
 
+/* The same sums with the per-point work taken out of the serial loops.  `nthr` threads (a whole workgroup, or one
+ * wave) compute in parallel, per listed point, the two centroid distances and then the Hartley-normalised
+ * coordinates (identical operations to the serial form, so identical bits); the sequential, reference-order
+ * accumulations that remain are plain adds (distances) or two to four multiplies and an add (normal matrix) per
+ * term.  Needs 16 B of scratch per point behind the staged points: stage must hold 3/2 * len entries.
+ * `sync` separates the phases (__syncthreads for a workgroup, a wave barrier for one wave); tid < 64 is the wave that
+ * runs the serial parts. */
+template <class SC, class Sync>
+__device__ __forceinline__ void dg_lsq_seq_par(SC *s, dg_pt *stage, int len, int tid, int nthr, int rows2, double *A1o, double *A2o, Sync sync)
+{
+    double *aux = (double *)(stage + len);
+    const int lane = tid & 63; const bool w0 = tid < 64;
+    if (w0) {                                                     /* centroids: lane l in 0..3 sums coordinate l, in list order */
+        double acc = 0;
+        const double *sp = (const double *)stage + (lane & 3);
+        int j = 0;
+        for (; j + 4 <= len; j += 4) { double v0 = sp[4*j], v1 = sp[4*j+4], v2 = sp[4*j+8], v3 = sp[4*j+12]; acc += v0; acc += v1; acc += v2; acc += v3; }
+        for (; j < len; j++) acc += sp[4*j];
+        if (len > 0) acc /= len;
+        if (lane < 4) s->D[lane] = acc;
+    }
+    sync();
+    const double m1x = s->D[0], m1y = s->D[1], m2x = s->D[2], m2y = s->D[3];
+    for (int j = tid; j < len; j += nthr) {                       /* distances to the centroids, one point per thread */
+        const dg_pt p = stage[j];
+        double a = p.x1 - m1x, b = p.y1 - m1y; aux[2*j] = sqrt(a*a + b*b);
+        a = p.x2 - m2x; b = p.y2 - m2y; aux[2*j+1] = sqrt(a*a + b*b);
+    }
+    sync();
+    if (w0) {                                                     /* mean distances: lane 0 image 1, lane 1 image 2 */
+        double dsum = 0;
+        const double *sp = aux + (lane & 1);
+        int j = 0;
+        for (; j + 8 <= len; j += 8) {
+            double v0 = sp[2*j], v1 = sp[2*j+2], v2 = sp[2*j+4], v3 = sp[2*j+6], v4 = sp[2*j+8], v5 = sp[2*j+10], v6 = sp[2*j+12], v7 = sp[2*j+14];
+            dsum += v0; dsum += v1; dsum += v2; dsum += v3; dsum += v4; dsum += v5; dsum += v6; dsum += v7;
+        }
+        for (; j < len; j++) dsum += sp[2*j];
+        double A1[3], A2[3];
+        A1[0] = __shfl(dsum, 0, 64); A2[0] = __shfl(dsum, 1, 64);
+        if (A1[0] != 0) A1[0] = len * sqrt(2.0) / A1[0];
+        if (A2[0] != 0) A2[0] = len * sqrt(2.0) / A2[0];
+        A1[1] = m1x * -A1[0]; A1[2] = m1y * -A1[0];
+        A2[1] = m2x * -A2[0]; A2[2] = m2y * -A2[0];
+        if (lane == 0) { for (int i = 0; i < 3; i++) { A1o[i] = A1[i]; A2o[i] = A2[i]; } }
+    }
+    sync();
+    {
+        const double s1 = A1o[0], t1x = A1o[1], t1y = A1o[2], s2 = A2o[0], t2x = A2o[1], t2y = A2o[2];
+        for (int j = tid; j < len; j += nthr) {                   /* normalised coordinates in place */
+            const dg_pt p = stage[j]; dg_pt q;
+            q.x1 = p.x1 * s1 + t1x; q.y1 = p.y1 * s1 + t1y; q.x2 = p.x2 * s2 + t2x; q.y2 = p.y2 * s2 + t2y;
+            stage[j] = q;
+        }
+    }
+    sync();
+    if (w0 && lane < 45) {                                        /* normal matrix: lane e owns entry (ie, je), je <= ie */
+        int ie = 0, je = 0;
+        { int e = 0; for (int i = 0; i < 9; i++) for (int q = 0; q <= i; q++) { if (e == lane) { ie = i; je = q; } e++; } }
+        const int ki = ie / 3, li = ie % 3, kj = je / 3, lj = je % 3;
+        double val = 0;
+#define DG_NM_TERM(p) do { \
+            const double a0 = (p).x1, a1 = (p).y1, b0 = (p).x2, b1 = (p).y2; \
+            if (!rows2) { \
+                double ai = li == 0 ? a0 : li == 1 ? a1 : 1.0, bi = ki == 0 ? b0 : ki == 1 ? b1 : 1.0; \
+                double aj = lj == 0 ? a0 : lj == 1 ? a1 : 1.0, bj = kj == 0 ? b0 : kj == 1 ? b1 : 1.0; \
+                val += (ai * bi) * (aj * bj); \
+            } else { \
+                double bqi = ki == 0 ? b0 : ki == 1 ? b1 : 1.0, bqj = kj == 0 ? b0 : kj == 1 ? b1 : 1.0; \
+                double z0i = li == 0 ? bqi : li == 1 ? 0.0 : -a0 * bqi, z0j = lj == 0 ? bqj : lj == 1 ? 0.0 : -a0 * bqj; \
+                double z1i = li == 0 ? 0.0 : li == 1 ? bqi : -a1 * bqi, z1j = lj == 0 ? 0.0 : lj == 1 ? bqj : -a1 * bqj; \
+                val += z0i * z0j; \
+                val += z1i * z1j; \
+            } } while (0)
+        int j = 0;
+        for (; j + 8 <= len; j += 8) {
+            const dg_pt p0 = stage[j], p1 = stage[j+1], p2 = stage[j+2], p3 = stage[j+3];
+            const dg_pt p4 = stage[j+4], p5 = stage[j+5], p6 = stage[j+6], p7 = stage[j+7];
+            DG_NM_TERM(p0); DG_NM_TERM(p1); DG_NM_TERM(p2); DG_NM_TERM(p3);
+            DG_NM_TERM(p4); DG_NM_TERM(p5); DG_NM_TERM(p6); DG_NM_TERM(p7);
+        }
+        for (; j < len; j++) { const dg_pt p = stage[j]; DG_NM_TERM(p); }
+#undef DG_NM_TERM
+        s->V[9*ie + je] = val; s->V[ie + 9*je] = val;
+    }
+}
+
 template <class PtFn>
-__device__ __forceinline__ void dg_lsq_seq(dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, int rows2, double *A1o, double *A2o, dg_pt *stage)
+__device__ __forceinline__ void dg_lsq_seq(dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, int rows2, double *A1o, double *A2o, dg_pt *stage, int stage_cap)
 {
     /* gather the listed correspondences into a contiguous staging array (all lanes), so that the sequential
      * sums stream uniform addresses */
     __syncthreads();
     for (int j = tid; j < len; j += DG_T) stage[j] = pt(list[j]);
     __syncthreads();
-    if (tid < 64) dg_lsq_seq_core(s, stage, len, tid, rows2, A1o, A2o);
+    if (2 * stage_cap >= 3 * len) dg_lsq_seq_par(s, stage, len, tid, DG_T, rows2, A1o, A2o, [] { __syncthreads(); });
+    else if (tid < 64) dg_lsq_seq_core(s, stage, len, tid, rows2, A1o, A2o);
     __syncthreads();
 }
 
 template <class PtFn>
-__device__ __forceinline__ void dg_u2f_big(dg_red *r, dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, double *Fout /* LDS */, dg_pt *stage)
+__device__ __forceinline__ void dg_u2f_big(dg_red *r, dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, double *Fout /* LDS */, dg_pt *stage, int stage_cap)
 {
     (void)r;
-    dg_lsq_seq(s, pt, list, len, tid, 0, s->A1, s->A2, stage);
+    dg_lsq_seq(s, pt, list, len, tid, 0, s->A1, s->A2, stage, stage_cap);
     if (tid < 64) dg_eig_sym_wave(s->V, s->D, tid, &s->ews);
     if (tid == 0) {
         int jm = 0; for (int i = 1; i < 9; i++) if (s->D[i] < s->D[jm]) jm = i;
