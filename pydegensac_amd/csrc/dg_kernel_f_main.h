@@ -429,12 +429,12 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             if (!((surv >> g) & 1u)) continue;
-            unsigned cI = 0; double acc[DG_NW];
+            unsigned cI = 0; double acc[DG_JC];
 #pragma unroll
-            for (int r = 0; r < DG_NW; r++) acc[r] = 0;
-            for (int base = 0; base < n; base += 64 * DG_NW) {
+            for (int r = 0; r < DG_JC; r++) acc[r] = 0;
+            for (int base = 0; base < n; base += 64 * DG_JC) {
 #pragma unroll
-                for (int r = 0; r < DG_NW; r++) {
+                for (int r = 0; r < DG_JC; r++) {
                     int p = base + 64 * r + lane; bool act = p < n; double d = 0;
                     if (act) { dg_pt q = P[p]; d = dg_Ferr(kind, F[g], q); }
                     double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);

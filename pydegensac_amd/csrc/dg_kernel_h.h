@@ -400,12 +400,12 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_homography_kernel(dg_args A)
 #pragma unroll
                     for (int j = 0; j < 9; j++) { H[j] = g[j]; H1[j] = g[9+j]; }
                     Hinv[0] = H[0]; Hinv[1] = H[3]; Hinv[2] = H[6]; Hinv[3] = H[1]; Hinv[4] = H[4]; Hinv[5] = H[7]; Hinv[6] = H[2]; Hinv[7] = H[5]; Hinv[8] = H[8];
-                    unsigned cI = 0; double acc[DG_NW]; const double t94 = th * 9 / 4;
+                    unsigned cI = 0; double acc[DG_JC]; const double t94 = th * 9 / 4;
 #pragma unroll
-                    for (int r = 0; r < DG_NW; r++) acc[r] = 0;
-                    for (int base = 0; base < n; base += 64 * DG_NW) {
+                    for (int r = 0; r < DG_JC; r++) acc[r] = 0;
+                    for (int base = 0; base < n; base += 64 * DG_JC) {
 #pragma unroll
-                        for (int r = 0; r < DG_NW; r++) {
+                        for (int r = 0; r < DG_JC; r++) {
                             int p = base + 64 * r + lane; bool act = p < n; double d = 0;
                             if (act) { dg_pt q = P[p]; d = dg_Herr(kind, H, Hinv, H1, q); }
                             double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);

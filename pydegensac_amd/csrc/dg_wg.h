@@ -60,15 +60,18 @@ __device__ __forceinline__ unsigned dg_wave_sum_u(unsigned v)
 }
 __device__ __forceinline__ double dg_wave_sum_d(double v) { return dg_tile_sum(v); }
 
-/* Canonical MSAC gain J of one model over n points (DG_NW is part of the definition):
- *   S_r[l] = sum over tiles t = r (mod DG_NW), in tile order, of term(64 t + l)      r = 0..DG_NW-1, l = lane
- *   J      = dg_tile_sum( (((S_0[l] + S_1[l]) + S_2[l]) + ...) + S_{NW-1}[l] )
- * A single wave keeps DG_NW accumulators per lane; in a workgroup pass wave r owns residue class r. */
+/* Canonical MSAC gain J of one model over n points — the same value in every kernel variant and on every path:
+ *   S_r[l] = sum over tiles t = r (mod DG_JC), in tile order, of term(64 t + l)      r = 0..DG_JC-1, l = lane
+ *   J      = dg_tile_sum( (((S_0[l] + S_1[l]) + S_2[l]) + ...) + S_{JC-1}[l] )            DG_JC = 8 residue classes
+ * A single wave keeps DG_JC accumulators per lane; in a workgroup pass of DG_NW waves, wave w meets the classes
+ * w, w + DG_NW, ... in turn (one per DG_T items) and keeps DG_JC / DG_NW accumulators. */
+#define DG_JC 8
+static_assert(DG_JC % DG_NW == 0, "the workgroup's waves must tile the canonical residue classes");
 __device__ __forceinline__ double dg_J_combine(const double *s)
 {
     double t = s[0];
 #pragma unroll
-    for (int r = 1; r < DG_NW; r++) t += s[r];
+    for (int r = 1; r < DG_JC; r++) t += s[r];
     return dg_tile_sum(t);
 }
 
@@ -76,7 +79,7 @@ __device__ __forceinline__ double dg_J_combine(const double *s)
 struct dg_red {
     double   d[2][DG_NW][4];
     unsigned u[2][DG_NW][4];
-    double   jp[DG_NW][64];   /* per-lane MSAC partial sums of the four residue classes */
+    double   jp[DG_JC][64];   /* per-lane MSAC partial sums of the residue classes */
     double   bc[96];          /* broadcast slots */
     int      bi[16];
 };
@@ -147,9 +150,11 @@ __device__ __forceinline__ dg_pass_res dg_pass(dg_red *r, const dg_pass_cfg &c, 
     const int lane = tid & 63, wave = tid >> 6;
     dg_pass_res out; out.I = 0; out.J = 0; out.C = 0; out.nL = 0; out.nF = 0;
     const double t94 = c.thJ * 9 / 4;
-    double accJ = 0; unsigned cI = 0, cC = 0, cF = 0;
-    int par = 0;
-    for (int base = 0; base < c.n; base += DG_T) {
+    double accJ[DG_JC / DG_NW]; unsigned cI = 0, cC = 0, cF = 0;
+#pragma unroll
+    for (int q = 0; q < DG_JC / DG_NW; q++) accJ[q] = 0;
+    int par = 0, it = 0;
+    for (int base = 0; base < c.n; base += DG_T, it++) {
         int j = base + tid;
         bool act = j < c.n;
         int pid = act ? (c.src ? c.src[j] : j) : 0;
@@ -157,7 +162,9 @@ __device__ __forceinline__ dg_pass_res dg_pass(dg_red *r, const dg_pass_cfg &c, 
         if (c.wantJ) {
             double term = 0.0;
             if (act && c.thJ != 0 && !(d >= t94)) term = 1 - (d / t94);
-            accJ += term;
+            /* tile of this item = it * DG_NW + wave: residue class wave + DG_NW * (it mod (DG_JC / DG_NW)) */
+#pragma unroll
+            for (int q = 0; q < DG_JC / DG_NW; q++) if ((it % (DG_JC / DG_NW)) == q) accJ[q] += term;
             cI += (act && d <= c.thJ) ? 1u : 0u;
         }
         if (c.wantC) cC += (act && d <= c.thC) ? 1u : 0u;
@@ -178,14 +185,15 @@ __device__ __forceinline__ dg_pass_res dg_pass(dg_red *r, const dg_pass_cfg &c, 
     /* final reductions: counts exact, J in the canonical association */
     cI = dg_wave_sum_u(cI); cC = dg_wave_sum_u(cC); cF = dg_wave_sum_u(cF);
     __syncthreads();
-    r->jp[wave][lane] = accJ;
+#pragma unroll
+    for (int q = 0; q < DG_JC / DG_NW; q++) r->jp[wave + DG_NW * q][lane] = accJ[q];
     if (lane == 0) { r->u[0][wave][0] = cI; r->u[0][wave][1] = cC; r->u[0][wave][3] = cF; }
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < DG_NW; w++) { out.I += r->u[0][w][0]; out.C += r->u[0][w][1]; out.nF += r->u[0][w][3]; }
-    if (c.wantJ) { double sp[DG_NW];
+    if (c.wantJ) { double sp[DG_JC];
 #pragma unroll
-        for (int w = 0; w < DG_NW; w++) sp[w] = r->jp[w][lane];
+        for (int w = 0; w < DG_JC; w++) sp[w] = r->jp[w][lane];
         out.J = dg_J_combine(sp); }
     __syncthreads();
     return out;

@@ -264,12 +264,12 @@ __global__ void dg_score_models_kernel(const double *p1, const double *p2, int n
     double M[9], Hinv[9], H1[9];
     for (int j = 0; j < 9; j++) { M[j] = models[(size_t)mi * 9 + j]; Hinv[j] = 0; H1[j] = 0; }
     if (kind > 10) dg_hsym_prepare(M, Hinv, H1);
-    unsigned cI = 0; double acc[DG_NW]; const double t94 = th * 9 / 4;
+    unsigned cI = 0; double acc[DG_JC]; const double t94 = th * 9 / 4;
 #pragma unroll
-    for (int r = 0; r < DG_NW; r++) acc[r] = 0;
-    for (int base = 0; base < n; base += 64 * DG_NW) {
+    for (int r = 0; r < DG_JC; r++) acc[r] = 0;
+    for (int base = 0; base < n; base += 64 * DG_JC) {
 #pragma unroll
-        for (int r = 0; r < DG_NW; r++) {
+        for (int r = 0; r < DG_JC; r++) {
             int p = base + 64 * r + lane; bool act = p < n; double d = 0;
             if (act) {
                 dg_pt q; q.x1 = p1[(size_t)p * dim]; q.y1 = p1[(size_t)p * dim + 1]; q.x2 = p2[(size_t)p * dim]; q.y2 = p2[(size_t)p * dim + 1];
