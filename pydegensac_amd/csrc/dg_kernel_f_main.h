@@ -350,15 +350,15 @@ __device__ __noinline__ void dg_sample_pool(int cn, int n, int *pool, int (*draw
  * the load latency per model); only survivors are scored exactly, the others get J = 0 (never an event in the commit,
  * so decisions are unchanged).  With tau < 4 nearly every model survives and the screen is skipped. */
 /* which wave scores group g (4 consecutive models).  With >= 6 waves the scoring waves 2.. share the groups round-robin
- * and the two sampler waves do not score (their stages are the critical path).  With 4 waves the two scoring waves alone
- * would be the critical path, so the sampler waves take a small share after their stage: per 8 groups, 3 + 3 for waves
- * 2 and 3, one each for waves 1 (seeds + draws, ~44 us per chunk) and 0 (pool swaps, ~60 us). */
+ * and the two sampler waves do not score (their stages are the critical path).  With 4 waves the pool-swap wave 0
+ * (~57 us per chunk) still does not score; wave 1 (seeds + draws, ~44 us) takes 2 of every 16 groups (~7 us each),
+ * waves 2 and 3 seven each. */
 __device__ __forceinline__ int dg_group_owner(int g)
 {
 #if DG_NW >= 6
     return 2 + g % (DG_NW - 2);
 #else
-    return (0x01323232 >> (4 * (g & 7))) & 15;            /* g & 7 = 0..7 -> 2,3,2,3,2,3,1,0 */
+    return (int)((0x1132323232323232ull >> (4 * (g & 15))) & 15ull);   /* g & 15 = 0..15 -> 2,3,2,3,...,2,3,1,1 */
 #endif
 }
 
@@ -388,26 +388,38 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
              * bounds |F00| X + |F10| Y + |F20| ... over the pair's coordinate extents, so {d < t} is inside
              * {r^2 < t Dmax}; for the symmetric metric d = r^2 (a + b) / (a b) >= r^2 / min(a, b).  Random models have a
              * few percent of the points even inside this looser band, far below tau. */
+            /* The residual is evaluated in SINGLE precision (half the issue cost of fp64 on this part) against a
+             * threshold widened by a rigorous rounding bound: with u = 2^-24, inputs rounded to fp32 and 4 nested FMAs,
+             * |r32 - r| <= 8 u M,  M = X1 u1 + Y1 u2 + (|F02| X2 + |F12| Y2 + |F22|) >= sum of |terms|;  32 u M is used.
+             * So every point with r^2 < t Dmax has |r32| < sqrt(t Dmax) + 32 u M.  Models whose bound is not a normal
+             * fp32 number skip this level. */
             const double X1 = ext[0], Y1 = ext[1], X2 = ext[2], Y2 = ext[3];
-            double lim[4];
+            float thr[4], Ff[4][9];
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const double *f = F[g];
                 const double u1 = fabs(f[0]) * X2 + fabs(f[3]) * Y2 + fabs(f[6]), u2 = fabs(f[1]) * X2 + fabs(f[4]) * Y2 + fabs(f[7]);
                 const double u3 = fabs(f[0]) * X1 + fabs(f[1]) * Y1 + fabs(f[2]), u4 = fabs(f[3]) * X1 + fabs(f[4]) * Y1 + fabs(f[5]);
+                const double uw = fabs(f[2]) * X2 + fabs(f[5]) * Y2 + fabs(f[8]);
                 const double am = u1*u1 + u2*u2, bm = u3*u3 + u4*u4;
-                lim[g] = t94b * (1.0 + 1e-9) * (kind == DG_K_FDS ? am + bm : fmin(am, bm));
+                const double lim = t94b * (1.0 + 1e-9) * (kind == DG_K_FDS ? am + bm : fmin(am, bm));
+                const double M = X1 * u1 + Y1 * u2 + uw;
+                const double tg = sqrt(lim) + M * (32.0 / 16777216.0);
+                /* unusable bound (overflow / underflow / NaN): make the level pass everything for this model */
+                thr[g] = (tg > 1e-30 && tg < 1e30 && M < 1e30) ? (float)tg * (1.0f + 1.1920929e-7f) : __builtin_inff();
+#pragma unroll
+                for (int j = 0; j < 9; j++) Ff[g][j] = (float)f[j];
             }
             unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
             for (int p = lane; p < n; p += 64) {
                 const dg_pt q = P[p];
-#define DG_R2(f_) ({ const double rxc_ = __builtin_fma((f_)[0], q.x2, __builtin_fma((f_)[3], q.y2, (f_)[6])), \
-                                  ryc_ = __builtin_fma((f_)[1], q.x2, __builtin_fma((f_)[4], q.y2, (f_)[7])), \
-                                  rwc_ = __builtin_fma((f_)[2], q.x2, __builtin_fma((f_)[5], q.y2, (f_)[8])); \
-                     const double r_ = __builtin_fma(q.x1, rxc_, __builtin_fma(q.y1, ryc_, rwc_)); r_ * r_; })
-                c0 += !(DG_R2(F[0]) >= lim[0]) ? 1u : 0u; c1 += !(DG_R2(F[1]) >= lim[1]) ? 1u : 0u;
-                c2 += !(DG_R2(F[2]) >= lim[2]) ? 1u : 0u; c3 += !(DG_R2(F[3]) >= lim[3]) ? 1u : 0u;
-#undef DG_R2
+                const float x1 = (float)q.x1, y1 = (float)q.y1, x2 = (float)q.x2, y2 = (float)q.y2;
+#define DG_R32(f_) fabsf(__builtin_fmaf(x1, __builtin_fmaf((f_)[0], x2, __builtin_fmaf((f_)[3], y2, (f_)[6])), \
+                         __builtin_fmaf(y1, __builtin_fmaf((f_)[1], x2, __builtin_fmaf((f_)[4], y2, (f_)[7])), \
+                                        __builtin_fmaf((f_)[2], x2, __builtin_fmaf((f_)[5], y2, (f_)[8])))))
+                c0 += !(DG_R32(Ff[0]) >= thr[0]) ? 1u : 0u; c1 += !(DG_R32(Ff[1]) >= thr[1]) ? 1u : 0u;
+                c2 += !(DG_R32(Ff[2]) >= thr[2]) ? 1u : 0u; c3 += !(DG_R32(Ff[3]) >= thr[3]) ? 1u : 0u;
+#undef DG_R32
             }
             const unsigned C1[4] = {dg_wave_sum_u(c0), dg_wave_sum_u(c1), dg_wave_sum_u(c2), dg_wave_sum_u(c3)};
 #pragma unroll
@@ -597,7 +609,7 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
             } else if (wave == 1) {
                 if (cn2 > 0) { unsigned sd = dg_sample_draws<7>(seed, cn2, n, S->seeds3[nx2], S->draws3[nx2], S->alm3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }
             }
-            if (wave >= 2 || DG_NW < 6)
+            if (wave >= 2 || (DG_NW < 6 && wave == 1))
                 dg_score_chunk_F<LDSPTS>(P, n, c.gmodels, S->mslot, Mtot, wave, mk_full, th,
                                          maxS.J < maxSs.J ? maxS.J : maxSs.J, S->ext, c.res_I, c.res_J, lane);
         }
