@@ -365,7 +365,7 @@ __device__ __forceinline__ int dg_group_owner(int g)
 template <int LDSPTS>
 __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const double *gmodels, const unsigned short *mslot,
                                              int Mtot, int wave, int kind, double th, double tauJ, const double *ext /* LDS[4] */,
-                                             unsigned *res_I, double *res_J, int lane)
+                                             double *jbuf /* this wave's scratch, >= n doubles */, unsigned *res_I, double *res_J, int lane)
 {
     const double t94 = th * 9 / 4, t94b = t94 * (1.0 + 1e-6);
     const bool use_bound = th != 0 && kind != DG_K_EXFSYM && tauJ >= 4.0;
@@ -441,19 +441,24 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             if (!((surv >> g) & 1u)) continue;
-            unsigned cI = 0; double acc[DG_JC];
-#pragma unroll
-            for (int r = 0; r < DG_JC; r++) acc[r] = 0;
-            for (int base = 0; base < n; base += 64 * DG_JC) {
-#pragma unroll
-                for (int r = 0; r < DG_JC; r++) {
-                    int p = base + 64 * r + lane; bool act = p < n; double d = 0;
-                    if (act) { dg_pt q = P[p]; d = dg_Ferr(kind, F[g], q); }
-                    double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
-                    acc[r] += term; cI += (act && d <= th) ? 1u : 0u;
-                }
+            /* exact score: I, and J as the reference's sequential sum (dg_seq_sum): the wave stores the nonzero terms in
+             * point order, lane 0 adds them one after the other */
+            unsigned cI = 0, cnt = 0;
+            for (int base = 0; base < n; base += 64) {
+                const int p = base + lane; const bool act = p < n; double d = 0;
+                if (act) { dg_pt q = P[p]; d = dg_Ferr(kind, F[g], q); }
+                double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
+                cI += (act && d <= th) ? 1u : 0u;
+                const bool nz = !(term == 0.0);
+                const unsigned long long bJ = __ballot(nz);
+                if (nz) jbuf[cnt + (unsigned)__popcll(bJ & ((1ull << lane) - 1ull))] = term;
+                cnt += (unsigned)__popcll(bJ);
             }
-            unsigned I = dg_wave_sum_u(cI); double J = dg_J_combine(acc);
+            DG_WSYNC();
+            double J = 0.0; if (lane == 0) J = dg_seq_sum(jbuf, (int)cnt);
+            J = __shfl(J, 0, 64);
+            unsigned I = dg_wave_sum_u(cI);
+            DG_WSYNC();
             if (lane == 0) { res_I[mi[g]] = I; res_J[mi[g]] = J; }
         }
     }
@@ -611,7 +616,7 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
             }
             if (wave >= 2 || (DG_NW < 6 && wave == 1))
                 dg_score_chunk_F<LDSPTS>(P, n, c.gmodels, S->mslot, Mtot, wave, mk_full, th,
-                                         maxS.J < maxSs.J ? maxS.J : maxSs.J, S->ext, c.res_I, c.res_J, lane);
+                                         maxS.J < maxSs.J ? maxS.J : maxSs.J, S->ext, (double *)(c.wstage + (size_t)wave * c.n_max), c.res_I, c.res_J, lane);
         }
         c.n_fds += Mtot;   /* provisional: models past the termination point are subtracted below */
         __syncthreads();

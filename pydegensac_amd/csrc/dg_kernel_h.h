@@ -53,6 +53,7 @@ __device__ __forceinline__ dg_pass_res dg_hm_pass(CTX &c, int kind, const double
 #pragma unroll
     for (int i = 0; i < 9; i++) { H[i] = Hm[i]; Hinv[i] = kind ? S->lsq.Z8[i] : 0; H1[i] = kind ? S->lsq.Z8[9+i] : 0; }
     const dg_pt *P = c.P;
+    cfg.jbuf = (double *)c.stage;
     return dg_pass(&S->red, cfg, [&](int pid, int) { return dg_Herr(kind, H, Hinv, H1, P[pid]); }, c.tid);
 }
 
@@ -400,19 +401,24 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_homography_kernel(dg_args A)
 #pragma unroll
                     for (int j = 0; j < 9; j++) { H[j] = g[j]; H1[j] = g[9+j]; }
                     Hinv[0] = H[0]; Hinv[1] = H[3]; Hinv[2] = H[6]; Hinv[3] = H[1]; Hinv[4] = H[4]; Hinv[5] = H[7]; Hinv[6] = H[2]; Hinv[7] = H[5]; Hinv[8] = H[8];
-                    unsigned cI = 0; double acc[DG_JC]; const double t94 = th * 9 / 4;
-#pragma unroll
-                    for (int r = 0; r < DG_JC; r++) acc[r] = 0;
-                    for (int base = 0; base < n; base += 64 * DG_JC) {
-#pragma unroll
-                        for (int r = 0; r < DG_JC; r++) {
-                            int p = base + 64 * r + lane; bool act = p < n; double d = 0;
-                            if (act) { dg_pt q = P[p]; d = dg_Herr(kind, H, Hinv, H1, q); }
-                            double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
-                            acc[r] += term; cI += (act && d <= th) ? 1u : 0u;
-                        }
+                    /* I, and J as the reference's sequential sum (dg_seq_sum) over the nonzero terms in point order */
+                    unsigned cI = 0, cnt = 0; const double t94 = th * 9 / 4;
+                    double *jbuf = (double *)(c.wstage + (size_t)wave * c.n_max);
+                    for (int base = 0; base < n; base += 64) {
+                        const int p = base + lane; const bool act = p < n; double d = 0;
+                        if (act) { dg_pt q = P[p]; d = dg_Herr(kind, H, Hinv, H1, q); }
+                        double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
+                        cI += (act && d <= th) ? 1u : 0u;
+                        const bool nz = !(term == 0.0);
+                        const unsigned long long bJ = __ballot(nz);
+                        if (nz) jbuf[cnt + (unsigned)__popcll(bJ & ((1ull << lane) - 1ull))] = term;
+                        cnt += (unsigned)__popcll(bJ);
                     }
-                    unsigned I = dg_wave_sum_u(cI); double J = dg_J_combine(acc);
+                    DG_WSYNC();
+                    double J = 0.0; if (lane == 0) J = dg_seq_sum(jbuf, (int)cnt);
+                    J = __shfl(J, 0, 64);
+                    unsigned I = dg_wave_sum_u(cI);
+                    DG_WSYNC();
                     if (lane == 0) { c.res_I[mi] = I; c.res_J[mi] = J; }
                 }
             }

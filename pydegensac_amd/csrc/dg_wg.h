@@ -4,9 +4,8 @@
  * workgroup-uniform: every thread executes the same branches on the same (LDS-broadcast or reduced)
  * values; scalar "reference-order" arithmetic is done by lane 0 between barriers.
  *
- * Canonical MSAC sum: see dg_J_combine below.  Every scoring path (wave-per-model in the main loop,
- * all-waves-per-model in LO) uses this same association, so J of a model does not depend on which
- * path scored it.
+ * MSAC sum: see dg_seq_sum below — every scoring path reproduces the reference's sequential sum, so J of a
+ * model does not depend on which path or kernel variant scored it.
  */
 #ifndef DG_WG_H
 #define DG_WG_H
@@ -60,26 +59,25 @@ __device__ __forceinline__ unsigned dg_wave_sum_u(unsigned v)
 }
 __device__ __forceinline__ double dg_wave_sum_d(double v) { return dg_tile_sum(v); }
 
-/* Canonical MSAC gain J of one model over n points — the same value in every kernel variant and on every path:
- *   S_r[l] = sum over tiles t = r (mod DG_JC), in tile order, of term(64 t + l)      r = 0..DG_JC-1, l = lane
- *   J      = dg_tile_sum( (((S_0[l] + S_1[l]) + S_2[l]) + ...) + S_{JC-1}[l] )            DG_JC = 8 residue classes
- * A single wave keeps DG_JC accumulators per lane; in a workgroup pass of DG_NW waves, wave w meets the classes
- * w, w + DG_NW, ... in turn (one per DG_T items) and keeps DG_JC / DG_NW accumulators. */
-#define DG_JC 8
-static_assert(DG_JC % DG_NW == 0, "the workgroup's waves must tile the canonical residue classes");
-__device__ __forceinline__ double dg_J_combine(const double *s)
+/* MSAC gain J of one model = the reference's sequential fp64 sum of truncQuad terms in point order (rtools.c:160-171,
+ * 228-236).  Terms that are exactly zero do not change a running sum, so every scoring path stores the nonzero terms in
+ * point order and one thread adds them one after the other: bit-identical to the reference for identical residuals,
+ * whatever the kernel variant or path.  Eight independent loads are kept in flight; the adds stay strictly ordered. */
+__device__ __forceinline__ double dg_seq_sum(const double *t, int cnt)
 {
-    double t = s[0];
-#pragma unroll
-    for (int r = 1; r < DG_JC; r++) t += s[r];
-    return dg_tile_sum(t);
+    double J = 0.0; int k = 0;
+    for (; k + 8 <= cnt; k += 8) {
+        const double v0 = t[k], v1 = t[k+1], v2 = t[k+2], v3 = t[k+3], v4 = t[k+4], v5 = t[k+5], v6 = t[k+6], v7 = t[k+7];
+        J += v0; J += v1; J += v2; J += v3; J += v4; J += v5; J += v6; J += v7;
+    }
+    for (; k < cnt; k++) J += t[k];
+    return J;
 }
 
 /* LDS block used by the reductions below (declared once per kernel) */
 struct dg_red {
     double   d[2][DG_NW][4];
     unsigned u[2][DG_NW][4];
-    double   jp[DG_JC][64];   /* per-lane MSAC partial sums of the residue classes */
     double   bc[96];          /* broadcast slots */
     int      bi[16];
 };
@@ -134,7 +132,7 @@ struct dg_pass_cfg {
     int         n;
     const int  *src;        /* optional indirection */
     /* (I, J): I = #(d <= thJ), J = sum truncQuad(d, thJ)  (rtools.c:160-171, 228-236) */
-    int         wantJ;  double thJ;
+    int         wantJ;  double thJ;  double *jbuf;   /* jbuf: >= n doubles of scratch (HBM) for the ordered nonzero MSAC terms */
     /* second counter: #(d <= thC) */
     int         wantC;  double thC;
     /* ordered list of ids with d <= thL  (inlidxs' index list) */
@@ -150,51 +148,49 @@ __device__ __forceinline__ dg_pass_res dg_pass(dg_red *r, const dg_pass_cfg &c, 
     const int lane = tid & 63, wave = tid >> 6;
     dg_pass_res out; out.I = 0; out.J = 0; out.C = 0; out.nL = 0; out.nF = 0;
     const double t94 = c.thJ * 9 / 4;
-    double accJ[DG_JC / DG_NW]; unsigned cI = 0, cC = 0, cF = 0;
-#pragma unroll
-    for (int q = 0; q < DG_JC / DG_NW; q++) accJ[q] = 0;
-    int par = 0, it = 0;
-    for (int base = 0; base < c.n; base += DG_T, it++) {
+    unsigned cI = 0, cC = 0, cF = 0, nJ = 0;
+    int par = 0;
+    for (int base = 0; base < c.n; base += DG_T) {
         int j = base + tid;
         bool act = j < c.n;
         int pid = act ? (c.src ? c.src[j] : j) : 0;
         double d = act ? err(pid, j) : 0.0;
+        double term = 0.0; bool nz = false;
         if (c.wantJ) {
-            double term = 0.0;
             if (act && c.thJ != 0 && !(d >= t94)) term = 1 - (d / t94);
-            /* tile of this item = it * DG_NW + wave: residue class wave + DG_NW * (it mod (DG_JC / DG_NW)) */
-#pragma unroll
-            for (int q = 0; q < DG_JC / DG_NW; q++) if ((it % (DG_JC / DG_NW)) == q) accJ[q] += term;
+            nz = !(term == 0.0);                                   /* also true for NaN */
             cI += (act && d <= c.thJ) ? 1u : 0u;
         }
         if (c.wantC) cC += (act && d <= c.thC) ? 1u : 0u;
         if (c.flags) { bool f = act && d < c.thF; cF += f ? 1u : 0u; if (act) c.flags[j] = f ? 1 : 0; }
-        if (c.list) {
-            /* ordered compaction needs the block's per-wave counts: one barrier per DG_T items */
-            bool in = act && (c.listStrict ? d < c.thL : d <= c.thL);
-            unsigned long long bL = __ballot(in);
-            if (lane == 0) r->u[par][wave][2] = (unsigned)__popcll(bL);
+        if (c.list || c.wantJ) {
+            /* ordered compaction (inlier ids, nonzero MSAC terms) needs the block's per-wave counts: one barrier per DG_T items */
+            bool in = c.list && act && (c.listStrict ? d < c.thL : d <= c.thL);
+            unsigned long long bL = __ballot(in), bJ = __ballot(nz);
+            if (lane == 0) { r->u[par][wave][2] = (unsigned)__popcll(bL); r->u[par][wave][3] = (unsigned)__popcll(bJ); }
             __syncthreads();
-            unsigned lbase = out.nL;
+            unsigned lbase = out.nL, jbase = nJ;
 #pragma unroll
-            for (int w = 0; w < DG_NW; w++) { if (w < wave) lbase += r->u[par][w][2]; out.nL += r->u[par][w][2]; }
+            for (int w = 0; w < DG_NW; w++) {
+                if (w < wave) { lbase += r->u[par][w][2]; jbase += r->u[par][w][3]; }
+                out.nL += r->u[par][w][2]; nJ += r->u[par][w][3];
+            }
             if (in) c.list[lbase + (unsigned)__popcll(bL & ((1ull << lane) - 1ull))] = pid;
+            if (nz) c.jbuf[jbase + (unsigned)__popcll(bJ & ((1ull << lane) - 1ull))] = term;
             par ^= 1;
         }
     }
-    /* final reductions: counts exact, J in the canonical association */
+    /* final reductions: counts, and J = the reference's own sequential sum (rtools.c:160-171 adds truncQuad(d_i) in point
+     * order): the terms that are exactly 0 leave the running sum unchanged, so thread 0 adds the nonzero terms, which
+     * the loop above stored in point order, one after the other — the same roundings as the reference. */
     cI = dg_wave_sum_u(cI); cC = dg_wave_sum_u(cC); cF = dg_wave_sum_u(cF);
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < DG_JC / DG_NW; q++) r->jp[wave + DG_NW * q][lane] = accJ[q];
     if (lane == 0) { r->u[0][wave][0] = cI; r->u[0][wave][1] = cC; r->u[0][wave][3] = cF; }
+    if (tid == 0 && c.wantJ) r->bc[0] = dg_seq_sum(c.jbuf, (int)nJ);
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < DG_NW; w++) { out.I += r->u[0][w][0]; out.C += r->u[0][w][1]; out.nF += r->u[0][w][3]; }
-    if (c.wantJ) { double sp[DG_JC];
-#pragma unroll
-        for (int w = 0; w < DG_JC; w++) sp[w] = r->jp[w][lane];
-        out.J = dg_J_combine(sp); }
+    if (c.wantJ) out.J = r->bc[0];
     __syncthreads();
     return out;
 }

@@ -257,31 +257,30 @@ extern "C" int mi_degensac_find_homography(const double *pts1, const double *pts
 __global__ void dg_score_models_kernel(const double *p1, const double *p2, int n, int dim, const double *models, int n_models,
                                        int kind, double th, unsigned *Iout, double *Jout, double *resid)
 {
-    /* one wave per model, canonical tile order — the same loop body as the main kernel's scoring phase */
+    /* one wave per model, the same residual code as the main kernels' scoring phase */
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int mi = blockIdx.x * (blockDim.x >> 6) + wave;
     if (mi >= n_models) return;
     double M[9], Hinv[9], H1[9];
     for (int j = 0; j < 9; j++) { M[j] = models[(size_t)mi * 9 + j]; Hinv[j] = 0; H1[j] = 0; }
     if (kind > 10) dg_hsym_prepare(M, Hinv, H1);
-    unsigned cI = 0; double acc[DG_JC]; const double t94 = th * 9 / 4;
-#pragma unroll
-    for (int r = 0; r < DG_JC; r++) acc[r] = 0;
-    for (int base = 0; base < n; base += 64 * DG_JC) {
-#pragma unroll
-        for (int r = 0; r < DG_JC; r++) {
-            int p = base + 64 * r + lane; bool act = p < n; double d = 0;
-            if (act) {
-                dg_pt q; q.x1 = p1[(size_t)p * dim]; q.y1 = p1[(size_t)p * dim + 1]; q.x2 = p2[(size_t)p * dim]; q.y2 = p2[(size_t)p * dim + 1];
-                if (kind < 10) d = dg_Ferr(kind, M, q); else d = dg_Herr(kind - 10, M, Hinv, H1, q);
-                if (resid) resid[(size_t)mi * n + p] = d;
-            }
-            double term = 0.0;
-            if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
-            acc[r] += term; cI += (act && d <= th) ? 1u : 0u;
+    /* J = the reference's sequential sum: the wave walks the points in order; the nonzero terms of each tile are added
+     * lane after lane (no scratch buffer in this unit kernel) */
+    unsigned cI = 0; const double t94 = th * 9 / 4; double J = 0.0;
+    for (int base = 0; base < n; base += 64) {
+        int p = base + lane; bool act = p < n; double d = 0;
+        if (act) {
+            dg_pt q; q.x1 = p1[(size_t)p * dim]; q.y1 = p1[(size_t)p * dim + 1]; q.x2 = p2[(size_t)p * dim]; q.y2 = p2[(size_t)p * dim + 1];
+            if (kind < 10) d = dg_Ferr(kind, M, q); else d = dg_Herr(kind - 10, M, Hinv, H1, q);
+            if (resid) resid[(size_t)mi * n + p] = d;
         }
+        double term = 0.0;
+        if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
+        cI += (act && d <= th) ? 1u : 0u;
+        unsigned long long m = __ballot(!(term == 0.0));
+        while (m) { const int l = __ffsll((long long)m) - 1; J += dg_rdl_d(term, l); m &= m - 1; }
     }
-    unsigned I = dg_wave_sum_u(cI); double J = dg_J_combine(acc);
+    unsigned I = dg_wave_sum_u(cI);
     if (lane == 0) { Iout[mi] = I; Jout[mi] = J; }
 }
 

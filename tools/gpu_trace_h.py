@@ -1,0 +1,27 @@
+"""First divergence between the GPU's and the oracle's H-driver checkpoint traces for one fuzz case."""
+import sys, os, numpy as np, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pydegensac_amd as pd
+from pydegensac_amd import synthetic as syn, _lib
+from oracle import port
+case, n, ir, sg, laf, et, sym, th, mi, seed = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3]), float(sys.argv[4]), sys.argv[5] == "1", int(sys.argv[6]), sys.argv[7] == "1", float(sys.argv[8]), int(sys.argv[9]), int(sys.argv[10])
+L = _lib.lib(); P = port.lib()
+p1, p2, _, _ = syn.homography_pairs(n, ir, sg, seed=case, laf=laf); lc = 3.0 if laf else 0.0
+tr_o = []
+CB = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_double); cb = CB(lambda t, i, j: tr_o.append((t, i, j)))
+P.dg_oracle_set_trace2(cb)
+Mo, mo, so = port.find_homography(p1, p2, th, 0.999, mi, et, sym, lc, seed=seed)
+P.dg_oracle_set_trace2(CB(0))
+cap = 20000; L.mi_degensac_debug_trace(cap, None)
+Mg, mg = pd.findHomography_(p1, p2, th, 0.999, mi, et, sym, lc, seed=seed); sg_ = pd.last_stats()
+buf = np.zeros(1 + 4 * cap, np.int32); L.mi_degensac_debug_trace(0, buf.ctypes.data_as(C.POINTER(C.c_int)))
+k = buf[0]; rec = buf[1:1 + 4 * k].reshape(k, 4)
+tr_g = [(int(r[0]), int(r[1]), float(np.array([(int(r[2]) & 0xffffffff) | (int(r[3]) << 32)], dtype=np.int64).view(np.float64)[0])) for r in rec]
+print("lo_runs gpu", sg_["lo_runs"], "oracle", so["lo_runs"], "trace lengths", len(tr_o), len(tr_g))
+for i, (a, b) in enumerate(zip(tr_o, tr_g)):
+    if a[0] in (13, 23) and b[0] == a[0]: continue
+    if a[0] != b[0] or a[1] != b[1] or abs(a[2] - b[2]) > 1e-9 * max(1, abs(a[2])):
+        print("first diff at", i)
+        for j in range(max(0, i - 8), min(len(tr_o), len(tr_g), i + 6)): print(j, tr_o[j], tr_g[j])
+        break
+else: print("traces equal over common prefix")
