@@ -11,6 +11,7 @@
  */
 #ifndef DG_KERNEL_F_H
 #define DG_KERNEL_F_H
+#include <stddef.h>
 #include "dg_lsq.h"
 
 struct dg_score { unsigned I; double J; unsigned Is; unsigned Ilafs; };
@@ -81,6 +82,11 @@ struct dg_f_ctx {
     }
 };
 
+/* ww[] and hw5[] are adjacent double arrays that only the single-wave solver sections use: during a workgroup pass
+ * they hold the ordered MSAC terms */
+#define DG_JBUF_LDS_BYTES (offsetof(dg_f_shared, hw5) + sizeof(((dg_f_shared *)0)->hw5) - offsetof(dg_f_shared, ww))
+static_assert(offsetof(dg_f_shared, hw5) == offsetof(dg_f_shared, ww) + sizeof(((dg_f_shared *)0)->ww), "ww and hw5 must be contiguous");
+
 #define CTX dg_f_ctx<LDSPTS>
 
 /* debug checkpoints (tag, I, J), mirrored by the oracle's TRACE2 hook; active only when A.trace != 0 */
@@ -96,7 +102,8 @@ __device__ __forceinline__ dg_pass_res dg_f_pass(CTX &c, const double *Fm /* LDS
 #pragma unroll
     for (int i = 0; i < 9; i++) F[i] = Fm[i];
     const dg_pt *P = c.P;
-    cfg.jbuf = (double *)c.stage;
+    /* ordered MSAC terms: the per-wave solver scratch is idle during a workgroup pass (LDS); HBM staging area otherwise */
+    cfg.jbuf = (size_t)cfg.n * sizeof(double) <= DG_JBUF_LDS_BYTES ? (double *)c.S->ww : (double *)c.stage;
     return dg_pass(&c.S->red, cfg, [&](int pid, int) { return dg_Ferr(kind, F, P[pid]); }, c.tid);
 }
 template <int LDSPTS>
@@ -106,7 +113,8 @@ __device__ __forceinline__ dg_pass_res dg_h_pass(CTX &c, const double *Hm /* LDS
 #pragma unroll
     for (int i = 0; i < 9; i++) H[i] = Hm[i];
     const dg_pt *P = c.P;
-    cfg.jbuf = (double *)c.stage;
+    /* ordered MSAC terms: the per-wave solver scratch is idle during a workgroup pass (LDS); HBM staging area otherwise */
+    cfg.jbuf = (size_t)cfg.n * sizeof(double) <= DG_JBUF_LDS_BYTES ? (double *)c.S->ww : (double *)c.stage;
     return dg_pass(&c.S->red, cfg, [&](int pid, int) { dg_pt p = P[pid]; return dg_HDs(H, p.x1, p.y1, p.x2, p.y2); }, c.tid);
 }
 __device__ __forceinline__ dg_pass_cfg dg_cfg0(int n)
