@@ -29,7 +29,7 @@ struct dg_f_shared {
     double   hw5[5][17 * 9 + 32];        /* Hdetect temporaries of checksample's five triplets */
     double   csH[5][9]; int csRes[5];    /* checksample: per-triplet homography and verdict */
     double   fhF[16][9], fhF2[16][9], fhTh[16];   /* innerFH: per-repetition model, its u2Fit refinement, flag threshold */
-    int      fhIds[16][10], fhCnt[16], fhCnt2[16];
+    int      fhIds[16][10], fhCnt[16], fhCnt2[16], fhRaw[160];
     long long ph[8], dbg[8], tq;
 #ifdef DG_LO_PROF
     long long lt[16], ltq;
@@ -424,11 +424,11 @@ __device__ __noinline__ unsigned dg_u2Fit_wave(dg_wave_ws *w, const dg_pt *P, in
 /* ---- DegUtils.c:488-632 innerFH + dual_sample ---------------------------------------------------- */
 /* dual_sample draws on freshly initialised identity permutations; only the first sA (sB) entries are
  * read afterwards, so the permutation is tracked sparsely on lane 0. */
-__device__ __forceinline__ void dg_dual_pick(dg_rng *g, unsigned len, unsigned s, int *out /* s entries */)
+__device__ __forceinline__ void dg_dual_pick(const int *raw /* s rand() outputs, in draw order */, unsigned len, unsigned s, int *out /* s entries */)
 {
     int pos_key[16], pos_val[16], np = 0;
     for (unsigned pos = 0; pos < s; ++pos) {
-        unsigned idx = (unsigned)dg_rand(g) % len;
+        unsigned idx = (unsigned)raw[pos] % len;
         /* swap ptr[pos] <-> ptr[idx] on a sparse identity map */
         int vp = (int)pos, vi = (int)idx, ip = -1, ii = -1;
         for (int k = 0; k < np; k++) { if (pos_key[k] == (int)pos) { vp = pos_val[k]; ip = k; } if (pos_key[k] == (int)idx) { vi = pos_val[k]; ii = k; } }
@@ -456,14 +456,17 @@ __device__ __noinline__ void dg_innerFH(CTX &c, const int *idxH, unsigned lenH, 
     dg_f_shared *S = c.S; const int n = c.n, tid = c.tid, lane = tid & 63, wave = tid >> 6;
     const dg_pt *P = c.P;
     __syncthreads();
-    if (tid == 0) {
-        for (unsigned rep = 0; rep < repCount; ++rep) {
-            int pick[16];
-            dg_dual_pick(&S->rng, lenH, 6, pick);
-            dg_dual_pick(&S->rng, lenO, 4, pick + 6);
-            for (int i = 0; i < 6; i++) S->fhIds[rep][i] = idxH[pick[i]];
-            for (int i = 0; i < 4; i++) S->fhIds[rep][6+i] = idxO[pick[6+i]];
-        }
+    /* dual_sample consumes exactly 6 + 4 rand() outputs per repetition, whatever they are: lane 0 draws them all,
+     * then one lane per repetition replays its two sparse permutations */
+    if (tid == 0) for (unsigned q = 0; q < repCount * 10; ++q) S->fhRaw[q] = dg_rand(&S->rng);
+    __syncthreads();
+    if (tid < (int)repCount) {
+        const unsigned rep = (unsigned)tid;
+        int pick[16];
+        dg_dual_pick(S->fhRaw + rep * 10, lenH, 6, pick);
+        dg_dual_pick(S->fhRaw + rep * 10 + 6, lenO, 4, pick + 6);
+        for (int i = 0; i < 6; i++) S->fhIds[rep][i] = idxH[pick[i]];
+        for (int i = 0; i < 4; i++) S->fhIds[rep][6+i] = idxO[pick[6+i]];
     }
     __syncthreads();
     /* 10-point model + its consensus, one wave per repetition */
