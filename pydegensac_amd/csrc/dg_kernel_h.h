@@ -347,7 +347,7 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_homography_kernel(dg_args A)
         chunk_s[0] = cn0; chunk_s[1] = cn1;
         if (wave == 0) {
             unsigned sd = seed;
-            if (cn0 > 0) sd = dg_sample_chunk<4, LDSPTS>(sd, cn0, n, pool, S->seeds3[0], S->draws3[0], S->alm3[0], lane);
+            if (cn0 > 0) sd = dg_sample_chunk<4, LDSPTS>(sd, cn0, n, pool, S->seeds3[0], S->draws3[0], S->alm3[0], (int *)S->ww, lane);
             if (cn1 > 0) sd = dg_sample_draws<4>(sd, cn1, n, S->seeds3[1], S->draws3[1], S->alm3[1], lane);
             if (lane == 0) S->itmp[31] = (int)sd;
         }
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_homography_kernel(dg_args A)
             cn2 = max_sam - (no_sam + chunk_s[cur] + chunk_s[nxt]); if (cn2 > DG_CHUNK) cn2 = DG_CHUNK; if (cn2 < 0) cn2 = 0;
             chunk_s[nx2] = cn2;
             if (wave == 0) {
-                if (chunk_s[nxt] > 0) dg_sample_pool<4, LDSPTS>(chunk_s[nxt], n, pool, S->draws3[nxt], S->alm3[nxt], lane, S->dbg);
+                if (chunk_s[nxt] > 0) dg_sample_pool<4, LDSPTS>(chunk_s[nxt], n, pool, S->draws3[nxt], S->alm3[nxt], (int *)S->ww, lane, S->dbg);
             } else if (wave == 1) {
                 if (cn2 > 0) { unsigned sd = dg_sample_draws<4>(seed, cn2, n, S->seeds3[nx2], S->draws3[nx2], S->alm3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }
             } else {

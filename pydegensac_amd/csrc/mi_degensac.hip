@@ -303,18 +303,23 @@ extern "C" int mi_degensac_score_models(const double *pts1, const double *pts2, 
     return 0;
 }
 
-__global__ void dg_sample_stream_kernel(unsigned seed0, int n, int ssz, int iters, int *pool, int *out)
+__global__ void dg_sample_stream_kernel(unsigned seed0, int n, int ssz, int iters, int *pool_g, int *out)
 {
-    /* the main kernels' sampler (dg_sample_chunk), chunk by chunk, run by one wave */
+    /* the main kernels' sampler (dg_sample_chunk), chunk by chunk, run by one wave: with the pool in LDS (n <= 4096:
+     * the parallel pool stage) or in global memory (the sequential one) */
     __shared__ unsigned seeds[DG_CHUNK]; __shared__ int draws[DG_CHUNK][8]; __shared__ dg_rng g; __shared__ unsigned sd0; __shared__ unsigned long long alm[DG_CHUNK / 64];
+    __shared__ int pool_l[4096]; __shared__ int scratch[2 * DG_CHUNK * 7];
     const int lane = threadIdx.x;
+    const bool lds = n <= 4096;
+    int *pool = lds ? pool_l : pool_g;
     for (int i = lane; i < n; i += 64) pool[i] = i;
     if (lane == 0) { dg_srand(&g, seed0); sd0 = (unsigned)dg_rand(&g); }
     __syncthreads();
     unsigned seed = sd0;
     for (int base = 0; base < iters; base += DG_CHUNK) {
         int chunk = iters - base; if (chunk > DG_CHUNK) chunk = DG_CHUNK;
-        seed = ssz == 7 ? dg_sample_chunk<7, 0>(seed, chunk, n, pool, seeds, draws, alm, lane) : dg_sample_chunk<4, 0>(seed, chunk, n, pool, seeds, draws, alm, lane);
+        if (lds) seed = ssz == 7 ? dg_sample_chunk<7, 2>(seed, chunk, n, pool, seeds, draws, alm, scratch, lane) : dg_sample_chunk<4, 2>(seed, chunk, n, pool, seeds, draws, alm, scratch, lane);
+        else     seed = ssz == 7 ? dg_sample_chunk<7, 0>(seed, chunk, n, pool, seeds, draws, alm, 0, lane) : dg_sample_chunk<4, 0>(seed, chunk, n, pool, seeds, draws, alm, 0, lane);
         __syncthreads();
         for (int k = lane; k < chunk; k += 64) for (int i = 0; i < ssz; i++) out[(size_t)(base + k) * ssz + i] = draws[k][i];
         __syncthreads();
@@ -485,6 +490,39 @@ extern "C" int mi_degensac_latency_probe(long long *out_host)
     hipLaunchKernelGGL(dg_latency_kernel, dim3(1), dim3(64), 0, 0, io.p, o.p);
     HIPCHK(hipGetLastError()); HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out_host, o.p, 16 * sizeof(long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+
+/* dev probe: when several lanes of ONE ds_wrxchg_rtn instruction hit the same LDS address, are they serialised in
+ * ascending lane order?  out[0] = violations over all repetitions and patterns, out[1] = exchanges checked */
+__global__ void dg_atomic_order_kernel(long long *out)
+{
+    __shared__ int tab[64];
+    const int lane = threadIdx.x; long long bad = 0, tot = 0;
+    for (int rep = 0; rep < 2000; rep++) {
+        for (int K = 1; K <= 64; K = (K < 8 ? K + 1 : K * 2)) {
+            tab[lane] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int addr = (lane * 7 + rep) % K;                         /* many lanes per address, scattered */
+            const int old = atomicExch(&tab[addr], lane + 1);
+            /* expected predecessor: the largest lane l' < lane with the same address, else 0 */
+            int exp = 0;
+            for (int l2 = 0; l2 < lane; l2++) if ((l2 * 7 + rep) % K == addr) exp = l2 + 1;
+            bad += (old != exp); tot++;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    for (int o = 32; o >= 1; o >>= 1) { bad += __shfl_xor(bad, o, 64); tot += __shfl_xor(tot, o, 64); }
+    if (lane == 0) { out[0] = bad; out[1] = tot; }
+}
+extern "C" int mi_degensac_atomic_order_probe(long long *out_host)
+{
+    int rc = dev_init(0); if (rc) return rc;
+    DevBuf<long long> o; if (o.alloc(2)) return MI_DEGENSAC_ENOMEM;
+    hipLaunchKernelGGL(dg_atomic_order_kernel, dim3(1), dim3(64), 0, 0, o.p);
+    HIPCHK(hipGetLastError()); HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out_host, o.p, 16, hipMemcpyDeviceToHost));
     return 0;
 }
 

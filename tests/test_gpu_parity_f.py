@@ -62,7 +62,8 @@ def test_sample_stream_matches_glibc_replay(oracle_port):
     import ctypes as C
     from pydegensac_amd import _lib
     L = _lib.lib()
-    for ssz, n, iters in [(7, 2000, 700), (4, 5000, 600), (7, 9, 300), (4, 5, 300)]:
+    # n <= 4096 runs the parallel pool stage (pool in LDS), larger n the sequential one; tiny n = every draw aliases
+    for ssz, n, iters in [(7, 2000, 700), (4, 5000, 600), (7, 9, 300), (4, 5, 300), (4, 3000, 900), (7, 64, 600), (7, 4096, 1000), (7, 8, 256)]:
         out = np.zeros((iters, ssz), np.int32)
         _lib.check(L.mi_degensac_sample_stream(12345, n, ssz, iters, 0, out.ctypes.data_as(C.POINTER(C.c_int32))))
         ref = np.zeros((iters, ssz), np.int32)
