@@ -506,7 +506,8 @@ __device__ __noinline__ void dg_sample_pool_par(int cn, int n, int *vp_generic, 
         }
     }
     DG_WSYNC();
-    /* B: pointer jumping until every touch holds a value (negative = -1 - id) */
+    /* B: pointer jumping until every touch holds a value (negative = -1 - id); two hops per round, 8 touches per lane in
+     * flight */
     for (;;) {
         bool any = false;
         for (int u0 = lane; u0 < M2; u0 += 64 * 8) {
@@ -516,6 +517,8 @@ __device__ __noinline__ void dg_sample_pool_par(int cn, int n, int *vp_generic, 
 #pragma unroll
             for (int q = 0; q < 8; q++) qv[q] = pv[q] >= 0 ? ptr[pv[q]] : -1;
 #pragma unroll
+            for (int q = 0; q < 8; q++) if (pv[q] >= 0 && qv[q] >= 0) qv[q] = ptr[qv[q]];
+#pragma unroll
             for (int q = 0; q < 8; q++) { const int u = u0 + 64 * q; if (pv[q] >= 0) { ptr[u] = qv[q]; any = any || qv[q] >= 0; } }
         }
         DG_WSYNC();
@@ -523,28 +526,41 @@ __device__ __noinline__ void dg_sample_pool_par(int cn, int n, int *vp_generic, 
     }
     /* D1: which touches are the last on their position (reads the markers; writes come after a wave barrier) */
     unsigned long long lastm = 0;
-    {
-        int slot = 0;
-        for (int u = lane; u < M2; u += 64, slot++) {
-            const int tau = u >> 1, k = tau / NDRAW, i = tau - k * NDRAW;
-            const int pos = (u & 1) ? n - 1 - i : draws[k][i];
-            if ((int)((unsigned)vp[pos] >> 16) == u + 1) lastm |= 1ull << slot;
+    for (int u0 = lane, s0 = 0; u0 < M2; u0 += 64 * 8, s0 += 8) {
+        int pos[8], mk[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int u = u0 + 64 * q; const int tau = u >> 1, k = tau / NDRAW, i = tau - k * NDRAW;
+            pos[q] = u < M2 ? ((u & 1) ? n - 1 - i : draws[k][i]) : 0;
         }
+#pragma unroll
+        for (int q = 0; q < 8; q++) mk[q] = vp[pos[q]];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const int u = u0 + 64 * q; if (u < M2 && (int)((unsigned)mk[q] >> 16) == u + 1) lastm |= 1ull << (s0 + q); }
     }
     DG_WSYNC();
     /* D2: they store what their swap left there = the value the other side held before it */
-    {
-        int slot = 0;
-        for (int u = lane; u < M2; u += 64, slot++) {
-            if (!((lastm >> slot) & 1ull)) continue;
-            const int tau = u >> 1, k = tau / NDRAW, i = tau - k * NDRAW;
-            const int pos = (u & 1) ? n - 1 - i : draws[k][i];
-            vp[pos] = -1 - ptr[u ^ 1];
+    for (int u0 = lane, s0 = 0; u0 < M2; u0 += 64 * 8, s0 += 8) {
+        int pos[8], val[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int u = u0 + 64 * q; const int tau = u >> 1, k = tau / NDRAW, i = tau - k * NDRAW;
+            const bool on = u < M2 && ((lastm >> (s0 + q)) & 1ull);
+            pos[q] = on ? ((u & 1) ? n - 1 - i : draws[k][i]) : -1;
+            val[q] = on ? ptr[u ^ 1] : 0;
         }
+#pragma unroll
+        for (int q = 0; q < 8; q++) if (pos[q] >= 0) vp[pos[q]] = -1 - val[q];
     }
     DG_WSYNC();
     /* C: the drawn ids replace the raw draws */
-    for (int tau = lane; tau < cn * NDRAW; tau += 64) { const int k = tau / NDRAW, i = tau - k * NDRAW; draws[k][i] = -1 - ptr[2 * tau]; }
+    for (int t0 = lane; t0 < cn * NDRAW; t0 += 64 * 8) {
+        int val[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const int tau = t0 + 64 * q; val[q] = tau < cn * NDRAW ? ptr[2 * tau] : 0; }
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const int tau = t0 + 64 * q; if (tau < cn * NDRAW) { const int k = tau / NDRAW, i = tau - k * NDRAW; draws[k][i] = -1 - val[q]; } }
+    }
     DG_WSYNC();
     __builtin_amdgcn_s_setprio(0);
     if (dbg && lane == 0) { long long ts3 = wall_clock64(); dbg[6] += ts3 - ts2; }
