@@ -111,3 +111,15 @@ def test_port_matches_reference_live(oracle_port, oracle_ref, dseed, plane):
         assert (st["samples"], st["lo_runs"], st["full_passes"], st["ex_passes"]) == \
                (st2["samples"], st2["lo_runs"], st2["full_passes"], st2["ex_passes"])
         assert np.array_equal(m, m2) and gu.rel(F, F2) < 1e-9
+
+
+def test_port_matches_reference_random_sweep(oracle_port, oracle_ref):
+    """Randomised F / H problems (every metric, LAF on/off, plane-dominated scenes, n = 8..3000): the restatement and the
+    unmodified reference build agree on masks and sample / LO counters (tools/cpu_port_vs_ref.py runs longer sweeps and
+    documents the three known exceptions through the reference's uninitialised-memory paths; this seed has none)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import cpu_port_vs_ref
+    bad, loose, worst, _ = cpu_port_vs_ref.run(150, 5, verbose=True)
+    assert bad == 0
+    assert worst < 1e-5          # ill-conditioned (plane-dominated) final fits may differ beyond rounding, never grossly
