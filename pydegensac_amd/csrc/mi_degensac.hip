@@ -173,7 +173,7 @@ static int launch_batch(int homography, const double *d_p1, const double *d_p2, 
     const DevState &ds = g_dev[device];
     const size_t dyn_all = (size_t)n_max * (sizeof(dg_pt) + sizeof(int)), dyn_pool = (size_t)n_max * sizeof(int);
     int variant = 0, mode;
-    if (!homography && n_pairs >= 4 * ds.cus && ds.static_lds[1][0] + dyn_pool + 512 <= (size_t)ds.max_lds / 2) variant = 1;
+    if (!homography && n_pairs >= 3 * ds.cus && ds.static_lds[1][0] + dyn_pool + 512 <= (size_t)ds.max_lds / 2) variant = 1;
     if (const char *e = getenv("MI_DEGENSAC_VARIANT")) variant = atoi(e) == 256 ? 1 : 0;
     const size_t room = (size_t)(ds.max_lds - ds.static_lds[variant][homography] - 256);
     if (variant == 1)           mode = dyn_pool <= room ? DG_MODE_POOL_LDS : DG_MODE_HBM;
