@@ -13,7 +13,8 @@ are resident in HBM before the timed region; the per-pair results are gathered o
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract of the driver) with `roofline` and `cpu_baseline`.
+Prints ONE JSON line on rank 0 (contract of the driver) with `roofline` and `cpu_baseline` (the reference on one host
+core, the north-star denominator) plus `cpu_baseline_all_cores` (one reference process per host core).
 """
 import argparse
 import ctypes as C
@@ -66,6 +67,48 @@ def cpu_baseline(budget_s=20.0, max_pairs=1024):
     return {"value": models / t_total, "unit": "models/s", "cores": 1, "kind": kind,
             "sample": f"{n_done} C2 pairs (pair ids 1..{n_done}, same generator/seeds as the GPU batch), "
                       f"{t_total:.1f} s, {samples / t_total:.0f} samples/s, {t_total / n_done * 1e3:.1f} ms/pair"}
+
+
+def _cpu_worker(args):
+    """One host core: the reference CPU path on its share of pair ids for `budget` seconds (spawned process, no torch)."""
+    ids, budget = args
+    import time as _t
+    sys.path.insert(0, ROOT)
+    from pydegensac_amd import synthetic, parallel
+    from oracle import ref
+    ref.lib()
+    models = 0; t_used = 0.0; n = 0
+    for p in ids:
+        p1, p2, _, _ = synthetic.two_view_fundamental(N_CORR, 0.4, 0.1, seed=p)
+        t = _t.perf_counter()
+        _, _, st = ref.find_fundamental(p1, p2, PRM["px_th"], PRM["conf"], PRM["max_iters"], 0, True, 0.0, True,
+                                        seed=parallel.pair_seed(p), count_models=True)
+        t_used += _t.perf_counter() - t; models += st["models"]; n += 1
+        if t_used > budget:
+            break
+    return models, t_used, n
+
+
+def cpu_baseline_all_cores(budget_s=8.0):
+    """Embarrassingly parallel reference run, one process per host core, pairs disjoint from each other.
+    Returns None when the reference build is not loadable or the pool cannot be started."""
+    try:
+        import multiprocessing as mp
+        from oracle import ref
+        if not ref.available():
+            return None
+        cores = min(os.cpu_count() or 1, 64)
+        ctx = mp.get_context("spawn")
+        shares = [(list(range(1 + c, 4096, cores)), budget_s) for c in range(cores)]
+        t = time.perf_counter()
+        with ctx.Pool(cores) as pool:
+            res = pool.map_async(_cpu_worker, shares).get(timeout=budget_s * 4 + 60)
+        wall = time.perf_counter() - t
+        models = sum(r[0] for r in res); busy = max(r[1] for r in res); pairs = sum(r[2] for r in res)
+        return {"value": models / busy, "unit": "models/s", "cores": cores, "kind": "reference",
+                "sample": f"{pairs} C2 pairs over {cores} processes, {busy:.1f} s of solver time per process ({wall:.1f} s wall incl. start-up)"}
+    except Exception as e:                                     # never let the side measurement break the bench line
+        return {"value": None, "error": str(e)[:200]}
 
 
 def pmc_traffic(pairs_per_gpu):
@@ -201,6 +244,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            allc = cpu_baseline_all_cores()
+            if allc is not None:
+                out["cpu_baseline_all_cores"] = allc
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
