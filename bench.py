@@ -29,9 +29,40 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
-N_CORR = 2000
-PAIRS_PER_GPU = 4096
-PRM = dict(px_th=0.5, conf=0.9999, max_iters=100000, error_type=0, sym=True, laf=0.0, degen=True)
+# --config c2 (default, the configuration BASELINE.json's metric is quoted on): findFundamentalMatrix, 2000 correspondences
+# --config c3: findHomography, 5000 correspondences with LAFs, LAF + symmetric checks, LO on (BASELINE configs[2])
+CONFIGS = {
+    "c2": dict(which="F", n_corr=2000, dim=2, pairs=4096,
+               prm=dict(px_th=0.5, conf=0.9999, max_iters=100000, error_type=0, sym=True, laf=0.0, degen=True)),
+    "c3": dict(which="H", n_corr=5000, dim=6, pairs=1024,
+               prm=dict(px_th=2.0, conf=0.999, max_iters=50000, error_type=0, sym=True, laf=3.0, degen=True)),
+}
+CFG = CONFIGS["c2"]
+N_CORR = CFG["n_corr"]
+PAIRS_PER_GPU = CFG["pairs"]
+PRM = CFG["prm"]
+
+
+def set_config(name):
+    global CFG, N_CORR, PAIRS_PER_GPU, PRM
+    CFG = CONFIGS[name]; N_CORR = CFG["n_corr"]; PAIRS_PER_GPU = CFG["pairs"]; PRM = CFG["prm"]
+
+
+def make_pair(pid):
+    """synthetic correspondences of global pair id `pid` (SURVEY 8d generators)"""
+    from pydegensac_amd import synthetic
+    if CFG["which"] == "F":
+        return synthetic.two_view_fundamental(N_CORR, 0.4, 0.1, seed=pid)[:2]
+    return synthetic.homography_pairs(N_CORR, 0.4, 0.5, seed=pid, laf=True)[:2]
+
+
+def cpu_call(mod, p1, p2, seed, **kw):
+    """one pair through oracle/_ref (mod = oracle.ref) or the restatement (oracle.port) with the bench parameters"""
+    if CFG["which"] == "F":
+        return mod.find_fundamental(p1, p2, PRM["px_th"], PRM["conf"], PRM["max_iters"], PRM["error_type"], PRM["sym"], PRM["laf"],
+                                    PRM["degen"], seed=seed, **kw)
+    return mod.find_homography(p1, p2, PRM["px_th"], PRM["conf"], PRM["max_iters"], PRM["error_type"], PRM["sym"], PRM["laf"],
+                               seed=seed, **kw)
 
 
 def cpu_baseline(budget_s=20.0, max_pairs=1024):
@@ -50,14 +81,13 @@ def cpu_baseline(budget_s=20.0, max_pairs=1024):
         port.lib()
     models = 0; samples = 0; t_total = 0.0; n_done = 0
     for p in range(max_pairs):
-        p1, p2, _, _ = synthetic.two_view_fundamental(N_CORR, 0.4, 0.1, seed=p)
+        p1, p2 = make_pair(p)
         seed = parallel.pair_seed(p)
         t = time.perf_counter()
         if kind == "reference":
-            _, _, st = ref.find_fundamental(p1, p2, PRM["px_th"], PRM["conf"], PRM["max_iters"], 0, True, 0.0, True,
-                                            seed=seed, count_models=True)
+            _, _, st = cpu_call(ref, p1, p2, seed, count_models=True)
         else:
-            _, _, st = port.find_fundamental(p1, p2, PRM["px_th"], PRM["conf"], PRM["max_iters"], 0, True, 0.0, True, seed=seed)
+            _, _, st = cpu_call(port, p1, p2, seed)
         dt = time.perf_counter() - t
         if p == 0:
             continue                                   # first call warms LAPACK / page cache
@@ -65,31 +95,31 @@ def cpu_baseline(budget_s=20.0, max_pairs=1024):
         if t_total > budget_s:
             break
     return {"value": models / t_total, "unit": "models/s", "cores": 1, "kind": kind,
-            "sample": f"{n_done} C2 pairs (pair ids 1..{n_done}, same generator/seeds as the GPU batch), "
+            "sample": f"{n_done} pairs of the workload (pair ids 1..{n_done}, same generator/seeds as the GPU batch), "
                       f"{t_total:.1f} s, {samples / t_total:.0f} samples/s, {t_total / n_done * 1e3:.1f} ms/pair"}
 
 
 def _cpu_worker(args):
     """One host core: the reference CPU path on its share of pair ids for `budget` seconds (spawned process, no torch)."""
-    ids, budget = args
+    ids, budget, cfg_name = args
     import time as _t
     sys.path.insert(0, ROOT)
-    from pydegensac_amd import synthetic, parallel
+    set_config(cfg_name)
+    from pydegensac_amd import parallel
     from oracle import ref
     ref.lib()
     models = 0; t_used = 0.0; n = 0
     for p in ids:
-        p1, p2, _, _ = synthetic.two_view_fundamental(N_CORR, 0.4, 0.1, seed=p)
+        p1, p2 = make_pair(p)
         t = _t.perf_counter()
-        _, _, st = ref.find_fundamental(p1, p2, PRM["px_th"], PRM["conf"], PRM["max_iters"], 0, True, 0.0, True,
-                                        seed=parallel.pair_seed(p), count_models=True)
+        _, _, st = cpu_call(ref, p1, p2, parallel.pair_seed(p), count_models=True)
         t_used += _t.perf_counter() - t; models += st["models"]; n += 1
         if t_used > budget:
             break
     return models, t_used, n
 
 
-def cpu_baseline_all_cores(budget_s=8.0):
+def cpu_baseline_all_cores(cfg_name, budget_s=8.0):
     """Embarrassingly parallel reference run, one process per host core, pairs disjoint from each other.
     Returns None when the reference build is not loadable or the pool cannot be started."""
     try:
@@ -99,34 +129,85 @@ def cpu_baseline_all_cores(budget_s=8.0):
             return None
         cores = min(os.cpu_count() or 1, 64)
         ctx = mp.get_context("spawn")
-        shares = [(list(range(1 + c, 4096, cores)), budget_s) for c in range(cores)]
+        shares = [(list(range(1 + c, 4096, cores)), budget_s, cfg_name) for c in range(cores)]
         t = time.perf_counter()
         with ctx.Pool(cores) as pool:
             res = pool.map_async(_cpu_worker, shares).get(timeout=budget_s * 4 + 60)
         wall = time.perf_counter() - t
         models = sum(r[0] for r in res); busy = max(r[1] for r in res); pairs = sum(r[2] for r in res)
         return {"value": models / busy, "unit": "models/s", "cores": cores, "kind": "reference",
-                "sample": f"{pairs} C2 pairs over {cores} processes, {busy:.1f} s of solver time per process ({wall:.1f} s wall incl. start-up)"}
+                "sample": f"{pairs} pairs over {cores} processes, {busy:.1f} s of solver time per process ({wall:.1f} s wall incl. start-up)"}
     except Exception as e:                                     # never let the side measurement break the bench line
         return {"value": None, "error": str(e)[:200]}
 
 
-def pmc_traffic(pairs_per_gpu):
+def source_id():
+    """hash of the kernel sources: ties a committed PMC pass to the build it was measured on"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "pydegensac_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "pydegensac_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "pydegensac_amd", "csrc", "*.inc"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(cfg_name, pairs_per_gpu):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/README.md):
     2 x FETCH_SIZE + WRITE_SIZE KiB (MI355X_MICROARCH.md: FETCH_SIZE under-reports coalesced reads 2x on gfx950).
-    Counters cannot be read from inside the process, so this is null unless the committed pass matches the batch."""
-    import csv
-    vals = {}
-    for name in ("fetch", "write"):
-        path = os.path.join(ROOT, "profiles", f"r1_bench_pmc_{name}_size.csv")
-        if not os.path.exists(path):
+    Counters cannot be read from inside the process, so the figure comes from profiles/r2_pmc_<config>.json, which
+    tools/pmc_summary.py writes next to the rocprofv3 CSVs together with the hash of the kernel sources it was measured
+    on and the batch size; any mismatch with this build / this batch gives null instead of a stale number."""
+    path = os.path.join(ROOT, "profiles", f"r2_pmc_{cfg_name}.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        m = json.load(open(path))
+        if m.get("source_id") != source_id() or int(m.get("pairs_per_gpu", -1)) != pairs_per_gpu:
             return None
-        rows = list(csv.DictReader(open(path)))
-        rows = [r for r in rows if "dg_find_fundamental_kernel" in r["Kernel_Name"]]
-        if not rows or int(rows[0]["Grid_Size"]) != pairs_per_gpu * int(rows[0]["Workgroup_Size"]):
-            return None
-        vals[name] = float(rows[0]["Counter_Value"])
-    return (2.0 * vals["fetch"] + vals["write"]) * 1024.0
+        return (2.0 * float(m["FETCH_SIZE_KiB"]) + float(m["WRITE_SIZE_KiB"])) * 1024.0
+    except Exception:
+        return None
+
+
+def parity_check(which, cfg_pairs, n_check, lo, models, masks, stats):
+    """After the timed region: `n_check` pairs of the timed batch (spread over it) against the CPU oracle — masks and
+    counters bit-exact, model within 1e-6 relative Frobenius.  Raises on any mismatch; returns the number checked."""
+    from oracle import port
+    from pydegensac_amd import parallel
+    port.lib()
+    P = models.shape[0]
+    pick = sorted(set(int(x) for x in np.linspace(0, P - 1, n_check)))
+    for p in pick:
+        p1, p2 = make_pair(lo + p)
+        Mo, mo, so = cpu_call(port, p1, p2, parallel.pair_seed(lo + p))
+        st = stats[p]
+        if (int(st[0]), int(st[1])) != (so["samples"], so["lo_runs"]):
+            raise SystemExit(f"parity check failed: pair {lo + p} counters {int(st[0])},{int(st[1])} vs oracle {so['samples']},{so['lo_runs']}")
+        if not np.array_equal(masks[p].astype(bool), mo):
+            raise SystemExit(f"parity check failed: pair {lo + p} mask differs in {(masks[p].astype(bool) != mo).sum()} bits")
+        a = models[p].ravel(); b = np.asarray(Mo).ravel()
+        na, nb = np.linalg.norm(a), np.linalg.norm(b)
+        if (na == 0) != (nb == 0) or (nb and np.linalg.norm(a / na - b / nb) > 1e-6):
+            raise SystemExit(f"parity check failed: pair {lo + p} model differs")
+    return len(pick)
+
+
+def single_call_ms(reps=7):
+    """wall time of ONE call through the host-pointer API (pageable numpy arrays in, numpy out: staging over PCIe, one
+    pair on one CU, sync): the reference's own use case.  Median over `reps` seeds after one warm-up call."""
+    import pydegensac_amd as pd
+    p1, p2 = make_pair(0)
+    ts = []
+    for r in range(reps + 1):
+        t = time.perf_counter()
+        if CFG["which"] == "F":
+            pd.findFundamentalMatrix_(p1, p2, PRM["px_th"], PRM["conf"], PRM["max_iters"], PRM["error_type"], PRM["sym"], PRM["laf"], PRM["degen"], seed=r + 1)
+        else:
+            pd.findHomography_(p1, p2, PRM["px_th"], PRM["conf"], PRM["max_iters"], PRM["error_type"], PRM["sym"], PRM["laf"], seed=r + 1)
+        ts.append((time.perf_counter() - t) * 1e3)
+    return {"median": float(np.median(ts[1:])), "min": float(min(ts[1:])), "max": float(max(ts[1:])),
+            "note": "host-pointer API, PCIe staging included, 1 pair = 1 workgroup; never used as `value`"}
 
 
 def main():
@@ -134,9 +215,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs-per-gpu", type=int, default=PAIRS_PER_GPU)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--pairs-per-gpu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-pairs", type=int, default=16, help="pairs of the timed batch checked against the oracle afterwards")
     args = ap.parse_args()
+    set_config(args.config)
+    if args.pairs_per_gpu <= 0:
+        args.pairs_per_gpu = PAIRS_PER_GPU
 
     import torch
     import torch.distributed as dist
@@ -156,9 +242,10 @@ def main():
     total_pairs = P * world
     lo, hi = parallel.shard_range(total_pairs, rank, world)
     # synthetic inputs of this rank's pairs (data seed = global pair id), staged to HBM once
-    a = np.empty((P * N_CORR, 2)); b = np.empty((P * N_CORR, 2))
+    DIM = CFG["dim"]; homography = CFG["which"] == "H"
+    a = np.empty((P * N_CORR, DIM)); b = np.empty((P * N_CORR, DIM))
     for i, pid in enumerate(range(lo, hi)):
-        p1, p2, _, _ = synthetic.two_view_fundamental(N_CORR, 0.4, 0.1, seed=pid)
+        p1, p2 = make_pair(pid)
         a[i * N_CORR:(i + 1) * N_CORR] = p1; b[i * N_CORR:(i + 1) * N_CORR] = p2
     offs = np.arange(P + 1, dtype=np.int64) * N_CORR
     d_a = torch.from_numpy(a).to(dev); d_b = torch.from_numpy(b).to(dev)
@@ -170,15 +257,15 @@ def main():
     prm = _lib.make_params(PRM["px_th"], PRM["conf"], PRM["max_iters"], PRM["error_type"], PRM["sym"], PRM["laf"], PRM["degen"])
     L = _lib.lib()
     stream = torch.cuda.current_stream(dev)
-    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    entry = L.mi_degensac_find_homography_batch_dev if homography else L.mi_degensac_find_fundamental_batch_dev
 
     def step(timed_events=None):
         if timed_events:
             timed_events[0].record(stream)
-        rc = L.mi_degensac_find_fundamental_batch_dev(d_a.data_ptr(), d_b.data_ptr(), d_off.data_ptr(),
-                                                      offs.ctypes.data_as(C.POINTER(C.c_int64)), P, 2, C.byref(prm),
-                                                      d_seeds.data_ptr(), local_rank, C.c_void_p(stream.cuda_stream),
-                                                      d_F.data_ptr(), d_mask.data_ptr(), d_st.data_ptr())
+        rc = entry(d_a.data_ptr(), d_b.data_ptr(), d_off.data_ptr(),
+                   offs.ctypes.data_as(C.POINTER(C.c_int64)), P, DIM, C.byref(prm),
+                   d_seeds.data_ptr(), local_rank, C.c_void_p(stream.cuda_stream),
+                   d_F.data_ptr(), d_mask.data_ptr(), d_st.data_ptr())
         _lib.check(rc)
         if timed_events:
             timed_events[1].record(stream)
@@ -206,25 +293,34 @@ def main():
     st = gs.cpu().numpy()
     models_step = int(st[:, 4].sum()); samples_step = int(st[:, 0].sum())
     kms = float(np.mean([a_.elapsed_time(b_) for a_, b_ in kernel_ms]))       # this rank's kernel, HIP events on its stream
-    local_models = int(d_st.cpu().numpy()[:, 4].sum())
+    local_st = d_st.cpu().numpy()
+    local_models = int(local_st[:, 4].sum())
     alg_bytes = local_models * 32.0 * N_CORR                                   # 32*N bytes per model scored
     achieved = alg_bytes / (kms * 1e-3) / 1e9
+    # spot check of THIS rank's timed batch against the CPU oracle (outside the timed region)
+    n_checked = 0
+    if args.parity_pairs > 0:
+        n_checked = parity_check(CFG["which"], P, args.parity_pairs, lo, d_F.cpu().numpy().reshape(P, 9),
+                                 d_mask.cpu().numpy().reshape(P, N_CORR), local_st)
 
     if rank == 0:
         inl = gmask.sum(dim=1).cpu().numpy()
         ticks = st[:, 13].astype(np.float64) / 100e6                           # 100 MHz device wall clock
         tbest = st[:, 12].astype(np.float64) / 100e6
         out = {
-            "metric": "models/sec, findFundamentalMatrix @2000 corrs (LO-RANSAC + DEGENSAC, batched pairs)",
+            "metric": ("models/sec, findFundamentalMatrix @2000 corrs (LO-RANSAC + DEGENSAC, batched pairs)" if not homography else
+                       "models/sec, findHomography @5000 corrs with LAFs (LO-RANSAC, LAF + symmetric checks, batched pairs)"),
             "value": models_step * args.steps / dt,
             "unit": "models/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"C2 x {P} pairs per GPU (C4 is a batch of 4096 such pairs): findFundamentalMatrix, "
-                                   f"{N_CORR} correspondences, 40% inliers, sigma 0.1 px, px_th 0.5, conf 0.9999, max_iters 100000, "
-                                   "sampson error, symmetric check on, degeneracy check on",
+            "config": {"workload": (f"C2 x {P} pairs per GPU (C4 is a batch of 4096 such pairs): findFundamentalMatrix, "
+                                    f"{N_CORR} correspondences, 40% inliers, sigma 0.1 px, px_th 0.5, conf 0.9999, max_iters 100000, "
+                                    "sampson error, symmetric check on, degeneracy check on") if not homography else
+                                   (f"C3 x {P} pairs per GPU: findHomography, {N_CORR} correspondences with LAFs, 40% inliers, sigma 0.5 px, "
+                                    "px_th 2, conf 0.999, max_iters 50000, sampson error, laf_consistensy_coef 3, symmetric check on, LO on"),
                        "pairs_total": total_pairs, "pairs_per_gpu": P, "n_corr": N_CORR,
                        "parallelism": f"pair-sharded x{world}, RCCL all-gather of per-pair results"},
             "samples_per_s": samples_step * args.steps / dt,
@@ -234,17 +330,21 @@ def main():
             "time_to_best_ms": {"mean": float(tbest.mean() * 1e3), "p50": float(np.median(tbest) * 1e3), "max": float(tbest.max() * 1e3)},
             "pair_latency_ms": {"mean": float(ticks.mean() * 1e3), "p50": float(np.median(ticks) * 1e3), "max": float(ticks.max() * 1e3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(P),
-                         "kernel": L.mi_degensac_kernel_name(0).decode(), "kernel_ms": kms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.config, P),
+                         "kernel": L.mi_degensac_kernel_name(int(homography)).decode(), "kernel_ms": kms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "achieved = algorithmic bytes (models scored x 32 B x N, SURVEY 8d) / kernel time; the point set is "
-                                 "LDS-resident, so `traffic` (HBM bytes per launch from the committed PMC passes, profiles/) is far "
+                                 "LDS/L2-resident, so `traffic` (HBM bytes per launch from the committed PMC passes, profiles/) is far "
                                  "below it: inputs once, then model tables, lists and scratch"},
+            "parity_checked": n_checked,
+            "kernel_variant": {"threads": int(local_st[0, 14]), "placement": int(local_st[0, 15])},
         }
+        if world == 1:
+            out["single_call_ms"] = single_call_ms()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-            allc = cpu_baseline_all_cores()
+            allc = cpu_baseline_all_cores(args.config)
             if allc is not None:
                 out["cpu_baseline_all_cores"] = allc
         print(json.dumps(out))

@@ -11,8 +11,19 @@
  * negative MI_DEGENSAC_E* code.  Host-pointer entry points stage through device memory themselves;
  * the *_dev entry points take device pointers (HBM-resident inputs/outputs) and a hipStream_t.
  * The whole estimation (sampling, minimal solver, scoring, DEGENSAC test, local optimisation,
- * adaptive termination, final mask) runs in one persistent HIP kernel, one workgroup per image pair.
+ * adaptive termination, final mask) runs in one persistent HIP kernel; workgroups pull image pairs
+ * from a device-wide ticket.
  * There is NO CPU fallback: without a usable gfx950 device every call fails with MI_DEGENSAC_ENODEV.
+ *
+ * Threading (SURVEY 8b "thread-safe handle/context"; the reference is not re-entrant: global
+ * HASH_TABLE hash.h:32 + libc RNG).  Every entry point may be called from any number of host
+ * threads at once:
+ *   - a `mi_degensac_ctx` owns one HIP stream, pinned host staging and its device buffers; calls on
+ *     ONE context are serialised by the caller, different contexts are independent;
+ *   - the entry points without a context argument use a context private to the calling thread;
+ *   - the *_dev entry points are asynchronous on the caller's stream; the per-launch scratch is
+ *     private to (device, stream), so launches on different streams never share memory, and the
+ *     thread's current HIP device is left as it was found.
  */
 #ifndef MI_DEGENSAC_H
 #define MI_DEGENSAC_H
@@ -41,6 +52,17 @@ extern "C" {
 #define MI_DEGENSAC_FLAG_FINAL_LAF_FILTER 1u  /* apply the F driver's final LAF filter, which the reference
                                                  guards with an uninitialised variable (exp_ranF.c:1254,1725) */
 
+/* tuning word (0 = let the library decide; results never depend on it, only speed does):
+ *   bits 0-1  kernel variant    1 = latency (512-thread workgroups)   2 = throughput (256-thread)
+ *   bits 2-3  placement         1 = points + sampler pool in HBM      2 = both in LDS      3 = pool in LDS
+ *             (a placement that does not fit the device's LDS is ignored)
+ *   bit  4    sampler           1 = always use the sequential pool-swap stage
+ *   bits 8-15 helper workgroups per pair of the cooperative large-n mode (0 = automatic) */
+#define MI_DEGENSAC_TUNE_VARIANT(v)   ((uint32_t)(v) & 3u)
+#define MI_DEGENSAC_TUNE_PLACEMENT(p) (((uint32_t)(p) & 3u) << 2)
+#define MI_DEGENSAC_TUNE_SEQ_POOL     (1u << 4)
+#define MI_DEGENSAC_TUNE_HELPERS(h)   (((uint32_t)(h) & 255u) << 8)
+
 typedef struct mi_degensac_params {
     double   px_th;                    /* pixel threshold (utils.py:76,113)                         */
     double   conf;                     /* confidence for adaptive termination                       */
@@ -50,7 +72,7 @@ typedef struct mi_degensac_params {
     int32_t  enable_degeneracy_check;  /* bool, fundamental only (utils.py:119)                     */
     double   laf_consistensy_coef;     /* <=0: off; needs dim == 6                                  */
     uint32_t flags;
-    uint32_t reserved;
+    uint32_t tuning;                   /* MI_DEGENSAC_TUNE_*; 0 = automatic                          */
 } mi_degensac_params;
 
 /* per-pair int32 statistics block (the reference computes most of these and drops them:
@@ -66,10 +88,18 @@ enum {
     MI_ST_IH = 6,           /* F: largest H-inlier count seen (exp_ranF.c *Ih)                      */
     MI_ST_BEST_SAMPLE = 7,  /* sample number at which the returned model was committed              */
     MI_ST_FULL_PASSES = 8, MI_ST_EX_PASSES = 9, MI_ST_H_PASSES = 10, MI_ST_AUX_PASSES = 11,
-    MI_ST_TICKS_BEST = 12,  /* 100 MHz device wall-clock ticks from kernel entry to that commit     */
-    MI_ST_TICKS_TOTAL = 13, /* ... to kernel exit                                                   */
-    MI_ST_RESERVED0 = 14, MI_ST_RESERVED1 = 15
+    MI_ST_TICKS_BEST = 12,  /* 100 MHz device wall-clock ticks from the pair's start to that commit */
+    MI_ST_TICKS_TOTAL = 13, /* ... to the pair's end                                                */
+    MI_ST_THREADS = 14,     /* workgroup size of the kernel variant that ran (512 / 256)            */
+    MI_ST_PLACEMENT = 15    /* 0 = points + pool in HBM, 1 = both in LDS, 2 = pool in LDS           */
 };
+
+/* ---- contexts ---------------------------------------------------------------------------------- */
+typedef struct mi_degensac_ctx mi_degensac_ctx;
+int  mi_degensac_ctx_create(int device, mi_degensac_ctx **out);
+void mi_degensac_ctx_destroy(mi_degensac_ctx *ctx);
+/* the context's stream (hipStream_t), e.g. to order other work after a call */
+void *mi_degensac_ctx_stream(mi_degensac_ctx *ctx);
 
 /* ---- host-pointer entry points (mirror the pybind signatures) -------------------------------- */
 /* pts1, pts2: [n, dim] row-major float64, dim in {2, 6}; F/H: 9 doubles row-major as the reference's C
@@ -92,9 +122,19 @@ int mi_degensac_find_homography_batch(const double *pts1, const double *pts2, co
                                       int n_pairs, int dim, const mi_degensac_params *prm,
                                       const uint32_t *seeds, int device,
                                       double *H, uint8_t *mask, int32_t *stats);
+/* the same on an explicit context (its device, its stream, its staging buffers); blocking */
+int mi_degensac_ctx_find_fundamental_batch(mi_degensac_ctx *ctx, const double *pts1, const double *pts2,
+                                           const int64_t *offsets, int n_pairs, int dim,
+                                           const mi_degensac_params *prm, const uint32_t *seeds,
+                                           double *F, uint8_t *mask, int32_t *stats);
+int mi_degensac_ctx_find_homography_batch(mi_degensac_ctx *ctx, const double *pts1, const double *pts2,
+                                          const int64_t *offsets, int n_pairs, int dim,
+                                          const mi_degensac_params *prm, const uint32_t *seeds,
+                                          double *H, uint8_t *mask, int32_t *stats);
 
 /* ---- device-pointer entry points: everything except `offsets_host` and `prm` lives in HBM ----- */
-/* `stream` is a hipStream_t (NULL = default stream).  Asynchronous: returns after enqueueing. */
+/* `stream` is a hipStream_t (NULL = default stream).  Asynchronous: returns after enqueueing; never
+ * synchronises the device. */
 int mi_degensac_find_fundamental_batch_dev(const double *d_pts1, const double *d_pts2,
                                            const int64_t *d_offsets, const int64_t *offsets_host,
                                            int n_pairs, int dim, const mi_degensac_params *prm,
@@ -105,6 +145,9 @@ int mi_degensac_find_homography_batch_dev(const double *d_pts1, const double *d_
                                           int n_pairs, int dim, const mi_degensac_params *prm,
                                           const uint32_t *d_seeds, int device, void *stream,
                                           double *d_H, uint8_t *d_mask, int32_t *d_stats);
+/* release the scratch cached for (device, stream) pairs whose work has completed (all of them when
+ * `stream_or_null` is NULL, else only that stream's); call before destroying a stream */
+int mi_degensac_release_scratch(int device, void *stream_or_null);
 
 /* ---- unit-level device entry points (parity tests of the kernels' building blocks) ------------ */
 /* score n_models fundamental (kind 0: Sampson, 1: symmetric epipolar) or homography (kind 10..14:
@@ -113,11 +156,15 @@ int mi_degensac_find_homography_batch_dev(const double *d_pts1, const double *d_
 int mi_degensac_score_models(const double *pts1, const double *pts2, int n, int dim,
                              const double *models, int n_models, int kind, double th, int device,
                              uint32_t *I, double *J, double *resid /*nullable*/);
-/* the main-loop sample stream: for `iters` iterations the 7 (or 4) drawn ids in draw order. */
+/* the main-loop sample stream: for `iters` iterations the 7 (or 4) drawn ids in draw order.
+ * seq_pool != 0 forces the sequential pool-swap stage. */
 int mi_degensac_sample_stream(uint32_t seed, int n, int sample_size, int iters, int device,
                               int32_t *samples /*[iters*sample_size]*/);
+int mi_degensac_sample_stream_ex(uint32_t seed, int n, int sample_size, int iters, int device,
+                                 int seq_pool, int32_t *samples);
 /* the 7-point solver + oriented-epipolar test on given samples: for each of n_samples 7-tuples of
- * ids (draw order) nsol[i] in 0..3 valid models and up to 3 models (27 doubles per sample). */
+ * ids (draw order) nsol[i] in 0..3 valid models (-1: null space not 2-dimensional) and up to 3 models
+ * (27 doubles per sample) with the index of the cubic's root each came from. */
 int mi_degensac_solve7(const double *pts1, const double *pts2, int n, int dim,
                        const int32_t *samples, int n_samples, int device,
                        int32_t *nsol, int32_t *root_idx /*[3*n_samples]*/, double *models /*[27*n_samples]*/);
@@ -126,9 +173,11 @@ int mi_degensac_solve7(const double *pts1, const double *pts2, int n, int dim,
 int         mi_degensac_device_count(void);
 const char *mi_degensac_last_error(void);
 const char *mi_degensac_version(void);
-/* name of the dominant kernel for profiling and the algorithmic bytes it processed in the last
- * batch call on this thread (32*N per model scored) */
+/* name of the dominant kernel (for profiling) */
 const char *mi_degensac_kernel_name(int homography);
+/* result of the one-time LDS exchange-order self-check of `device` (1 = the parallel pool-swap stage is in use,
+ * 0 = the check failed and the sequential stage is used, <0 = error) */
+int         mi_degensac_pool_stage_parallel(int device);
 
 #ifdef __cplusplus
 }

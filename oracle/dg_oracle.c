@@ -1092,6 +1092,8 @@ static void HDS_full(int kind, const double *u, const double *H, double *p, int 
     if (kind == 0) { HDs(u, H, p, len); return; }
     { hsym_t t; hsym_prepare(H, &t); for (i = 0; i < len; i++) p[i] = hsym_one(&t, u + 6*i, kind, kind >= 3); }
 }
+/* unit-level wrapper: kind 0 Sampson, 1 SymMaxSq, 2 SymMax, 3 SymSumSq, 4 SymSum (bindings.cpp:64-107 order) */
+void dg_oracle_HDS_full(int kind, const double *u, const double *H, double *p, int len) { HDS_full(kind, u, H, p, len); }
 /* HDSi1 / HDSidx1 value for point id on point set ul (original points uo) */
 static double HDS_sub(int kind, const hsym_t *t, const double *uo, const double *ul, const double *H)
 {

@@ -44,6 +44,7 @@ void dg_oracle_FDs(const double *u, const double *F, double *p, int len);
 void dg_oracle_exFDs(const double *u, const double *F, double *p, double *w, int len);
 void dg_oracle_FDsSym(const double *u, const double *F, double *p, int len);
 void dg_oracle_HDs(const double *u, const double *H, double *p, int len);
+void dg_oracle_HDS_full(int kind, const double *u, const double *H, double *p, int len);
 void dg_oracle_u2f(const double *u, const int *inl, int len, double *F);
 void dg_oracle_u2fw(const double *u, const int *inl, const double *w, int len, double *F);
 void dg_oracle_u2h(const double *u, const int *inl, int len, double *H);

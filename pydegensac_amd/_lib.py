@@ -8,14 +8,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI_DEGENSAC_LIB") or os.path.join(_HERE, "libmi_degensac.so")
 STATS_LEN = 16
 STAT_NAMES = ["samples", "lo_runs", "rejected", "I", "models", "degen", "Ih", "best_sample",
-              "full_passes", "ex_passes", "h_passes", "aux_passes", "ticks_best", "ticks_total", "r0", "r1"]
+              "full_passes", "ex_passes", "h_passes", "aux_passes", "ticks_best", "ticks_total", "threads", "placement"]
 FLAG_FINAL_LAF_FILTER = 1
+# params.tuning (include/mi_degensac.h MI_DEGENSAC_TUNE_*): speed knobs only, results never depend on them
+TUNE_LATENCY, TUNE_THROUGHPUT = 1, 2                       # kernel variant: 512- / 256-thread workgroups
+TUNE_PLACE_HBM, TUNE_PLACE_LDS, TUNE_PLACE_POOL_LDS = 1 << 2, 2 << 2, 3 << 2
+TUNE_SEQ_POOL = 1 << 4
 
 
 class Params(C.Structure):
     _fields_ = [("px_th", C.c_double), ("conf", C.c_double), ("max_iters", C.c_int32), ("error_type", C.c_int32),
                 ("symmetric_error_check", C.c_int32), ("enable_degeneracy_check", C.c_int32),
-                ("laf_consistensy_coef", C.c_double), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+                ("laf_consistensy_coef", C.c_double), ("flags", C.c_uint32), ("tuning", C.c_uint32)]
 
 
 class MiDegensacError(RuntimeError):
@@ -70,6 +74,21 @@ def lib():
             f = getattr(l, name); f.restype = C.c_int
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, lp, C.c_int, C.c_int, pp, C.c_void_p, C.c_int, C.c_void_p,
                           C.c_void_p, C.c_void_p, C.c_void_p]
+        for name in ("mi_degensac_ctx_find_fundamental_batch", "mi_degensac_ctx_find_homography_batch"):
+            f = getattr(l, name); f.restype = C.c_int
+            f.argtypes = [C.c_void_p, dp, dp, lp, C.c_int, C.c_int, pp, up, dp, bp, ip]
+        l.mi_degensac_ctx_create.restype = C.c_int
+        l.mi_degensac_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        l.mi_degensac_ctx_destroy.restype = None
+        l.mi_degensac_ctx_destroy.argtypes = [C.c_void_p]
+        l.mi_degensac_ctx_stream.restype = C.c_void_p
+        l.mi_degensac_ctx_stream.argtypes = [C.c_void_p]
+        l.mi_degensac_release_scratch.restype = C.c_int
+        l.mi_degensac_release_scratch.argtypes = [C.c_int, C.c_void_p]
+        l.mi_degensac_pool_stage_parallel.restype = C.c_int
+        l.mi_degensac_pool_stage_parallel.argtypes = [C.c_int]
+        l.mi_degensac_sample_stream_ex.restype = C.c_int
+        l.mi_degensac_sample_stream_ex.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip]
         l.mi_degensac_score_models.restype = C.c_int
         l.mi_degensac_score_models.argtypes = [dp, dp, C.c_int, C.c_int, dp, C.c_int, C.c_int, C.c_double, C.c_int, up, dp, dp]
         l.mi_degensac_sample_stream.restype = C.c_int
@@ -96,9 +115,9 @@ def dptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def make_params(px_th, conf, max_iters, error_type, sym_check, laf_coef, degen=True, flags=0):
+def make_params(px_th, conf, max_iters, error_type, sym_check, laf_coef, degen=True, flags=0, tuning=0):
     return Params(float(px_th), float(conf), int(max_iters), int(error_type), int(bool(sym_check)), int(bool(degen)),
-                  float(laf_coef), int(flags), 0)
+                  float(laf_coef), int(flags), int(tuning))
 
 
 def stats_dict(st):

@@ -26,12 +26,14 @@ except Exception:  # pragma: no cover
 error_type_dict_homography = {"sampson": 0, "symm_sq_max": 1, "symm_max": 2, "symm_sq_sum": 3, "symm_sum": 4}
 error_type_dict_fundamental = {"sampson": 0, "symm_epipolar": 1}
 
-_last_stats = None
+import threading
+
+_tls = threading.local()
 
 
 def last_stats():
-    """Statistics of the most recent call in this process (dict, or list of dicts for a batch)."""
-    return _last_stats
+    """Statistics of the calling thread's most recent call (dict, or list of dicts for a batch)."""
+    return getattr(_tls, "stats", None)
 
 
 def convert_cv2_kpts_to_xyA(kps):
@@ -88,8 +90,7 @@ def _time_seed():
 
 
 def _call_single(which, x1y1, x2y2, px_th, conf, max_iters, error_type, sym_check_enable, laf_coef, degen, seed, device,
-                 flags=0):
-    global _last_stats
+                 flags=0, tuning=0):
     a = np.ascontiguousarray(x1y1, dtype=np.float64)
     b = np.ascontiguousarray(x2y2, dtype=np.float64)
     if a.ndim != 2 or b.ndim != 2:
@@ -99,7 +100,9 @@ def _call_single(which, x1y1, x2y2, px_th, conf, max_iters, error_type, sym_chec
         raise ValueError("x1y1 and x2y2 should be the same size")          # bindings.cpp:45-47, :280-282
     if b.shape[1] != dim:
         raise ValueError("x1y1 and x2y2 should have the same number of columns")
-    prm = _lib.make_params(px_th, conf, max_iters, error_type, sym_check_enable, laf_coef, degen, flags)
+    if dim not in (2, 6):
+        raise ValueError("x1y1 should be an array with dims [n,2] or [n,6]")   # bindings.cpp:32-41, :267-276
+    prm = _lib.make_params(px_th, conf, max_iters, error_type, sym_check_enable, laf_coef, degen, flags, tuning)
     model = np.zeros(9, np.float64)
     mask = np.zeros(n, np.uint8)
     st = np.zeros(_lib.STATS_LEN, np.int32)
@@ -107,22 +110,23 @@ def _call_single(which, x1y1, x2y2, px_th, conf, max_iters, error_type, sym_chec
     rc = fn(_lib.dptr(a), _lib.dptr(b), n, dim, C.byref(prm), int(seed) & 0xFFFFFFFF, int(device), _lib.dptr(model),
             mask.ctypes.data_as(C.POINTER(C.c_uint8)), st.ctypes.data_as(C.POINTER(C.c_int32)))
     _lib.check(rc)
-    _last_stats = _lib.stats_dict(st)
+    _tls.stats = _lib.stats_dict(st)
     return model.reshape(3, 3), mask.astype(bool)
 
 
 def findHomography_(x1y1, x2y2, px_th=1.0, conf=0.999, max_iters=10000, error_type=0, sym_check_enable=True,
-                    laf_coef=0.0, seed=None, device=0):
-    """bindings.cpp:19-251 / :484-492.  Returns the driver's raw H (column-wise, image2->image1) and the mask."""
+                    laf_coef=0.0, seed=None, device=0, tuning=0):
+    """bindings.cpp:19-251; defaults of the pybind definition, bindings.cpp:484-492.
+    Returns the driver's raw H (column-wise, image2->image1) and the mask."""
     return _call_single("H", x1y1, x2y2, px_th, conf, max_iters, error_type, sym_check_enable, laf_coef, True,
-                        _time_seed() if seed is None else seed, device)
+                        _time_seed() if seed is None else seed, device, 0, tuning)
 
 
-def findFundamentalMatrix_(x1y1, x2y2, px_th=1.0, conf=0.999, max_iters=200000, error_type=0, sym_check_enable=True,
-                           laf_coef=0.0, enable_degeneracy_check=True, seed=None, device=0, flags=0):
-    """bindings.cpp:253-467 / :494-503."""
+def findFundamentalMatrix_(x1y1, x2y2, px_th=0.5, conf=0.9999, max_iters=200000, error_type=0, sym_check_enable=True,
+                           laf_coef=0.0, enable_degeneracy_check=True, seed=None, device=0, flags=0, tuning=0):
+    """bindings.cpp:253-467; defaults of the pybind definition, bindings.cpp:494-503."""
     return _call_single("F", x1y1, x2y2, px_th, conf, max_iters, error_type, sym_check_enable, laf_coef,
-                        enable_degeneracy_check, _time_seed() if seed is None else seed, device, flags)
+                        enable_degeneracy_check, _time_seed() if seed is None else seed, device, flags, tuning)
 
 
 def findHomography(pts1_, pts2_, px_th=1.0, conf=0.999, max_iters=50000, laf_consistensy_coef=-1.0,
@@ -178,16 +182,34 @@ def findFundamentalMatrix(pts1_, pts2_, px_th=0.5, conf=0.9999, max_iters=100000
     return F, mask
 
 
-def _batch(which, pts1_list, pts2_list, px_th, conf, max_iters, error_type_int, sym, laf, degen, seeds, device):
-    global _last_stats
+def _error_type(table, error_type):
+    try:
+        return table[error_type.lower()]
+    except Exception:
+        raise ValueError("Error type should be on of {}. Got {} instead".format(list(table.keys()), error_type))
+
+
+def _batch(which, pts1_list, pts2_list, px_th, conf, max_iters, error_type_int, sym, laf, degen, seeds, device, tuning=0):
     n_pairs = len(pts1_list)
+    if n_pairs == 0 or len(pts2_list) != n_pairs:
+        raise ValueError("pts1_list and pts2_list must hold the same, non-zero number of pairs")
     a = [np.ascontiguousarray(p, dtype=np.float64) for p in pts1_list]
     b = [np.ascontiguousarray(p, dtype=np.float64) for p in pts2_list]
+    if a[0].ndim != 2 or a[0].shape[1] not in (2, 6):
+        raise ValueError("x1y1 should be an array with dims [n,2] or [n,6]")
     dim = a[0].shape[1]
+    for i in range(n_pairs):
+        # same checks as the single-pair path (bindings.cpp:32-47): per pair, both sides [n_i, dim]
+        if a[i].ndim != 2 or a[i].shape[1] != dim:
+            raise ValueError(f"pair {i}: x1y1 should be an array with dims [n,{dim}] like pair 0")
+        if b[i].shape != a[i].shape:
+            raise ValueError(f"pair {i}: x1y1 and x2y2 should be the same size")
+    if len(seeds) != n_pairs:
+        raise ValueError("one seed per pair")
     offs = np.zeros(n_pairs + 1, np.int64)
     offs[1:] = np.cumsum([x.shape[0] for x in a])
     A = np.ascontiguousarray(np.concatenate(a, 0)); B = np.ascontiguousarray(np.concatenate(b, 0))
-    prm = _lib.make_params(px_th, conf, max_iters, error_type_int, sym, laf, degen)
+    prm = _lib.make_params(px_th, conf, max_iters, error_type_int, sym, laf, degen, 0, tuning)
     model = np.zeros((n_pairs, 9)); mask = np.zeros(int(offs[-1]), np.uint8); st = np.zeros((n_pairs, 16), np.int32)
     sd = np.ascontiguousarray(seeds, dtype=np.uint32)
     fn = _lib.lib().mi_degensac_find_fundamental_batch if which == "F" else _lib.lib().mi_degensac_find_homography_batch
@@ -195,30 +217,31 @@ def _batch(which, pts1_list, pts2_list, px_th, conf, max_iters, error_type_int, 
             sd.ctypes.data_as(C.POINTER(C.c_uint32)), int(device), _lib.dptr(model),
             mask.ctypes.data_as(C.POINTER(C.c_uint8)), st.ctypes.data_as(C.POINTER(C.c_int32)))
     _lib.check(rc)
-    _last_stats = [_lib.stats_dict(s) for s in st]
+    _tls.stats = [_lib.stats_dict(s) for s in st]
     masks = [mask[offs[i]:offs[i + 1]].astype(bool) for i in range(n_pairs)]
     return model.reshape(n_pairs, 3, 3), masks
 
 
 def findFundamentalMatrixBatch(pts1_list, pts2_list, px_th=0.5, conf=0.9999, max_iters=100000,
                                laf_consistensy_coef=-1.0, error_type="sampson", symmetric_error_check=True,
-                               enable_degeneracy_check=True, seeds=None, device=0):
-    """Independent image pairs in one launch (one workgroup per pair).  Returns (F [P,3,3], [mask_p])."""
-    et = error_type_dict_fundamental[error_type.lower()]
+                               enable_degeneracy_check=True, seeds=None, device=0, tuning=0):
+    """Independent image pairs in one launch (persistent workgroups, one pair at a time each).
+    Returns (F [P,3,3], [mask_p])."""
+    et = _error_type(error_type_dict_fundamental, error_type)
     if seeds is None:
         seeds = (_time_seed() + np.arange(len(pts1_list))) & 0xFFFFFFFF
     return _batch("F", pts1_list, pts2_list, px_th, conf, max_iters, et, symmetric_error_check,
-                  max(0, laf_consistensy_coef), enable_degeneracy_check, seeds, device)
+                  max(0, laf_consistensy_coef), enable_degeneracy_check, seeds, device, tuning)
 
 
 def findHomographyBatch(pts1_list, pts2_list, px_th=1.0, conf=0.999, max_iters=50000, laf_consistensy_coef=-1.0,
-                        error_type="sampson", symmetric_error_check=True, seeds=None, device=0):
+                        error_type="sampson", symmetric_error_check=True, seeds=None, device=0, tuning=0):
     """Batch homographies; returns the user-facing H_out = inv(H.T) per pair (zeros when none found)."""
-    et = error_type_dict_homography[error_type.lower()]
+    et = _error_type(error_type_dict_homography, error_type)
     if seeds is None:
         seeds = (_time_seed() + np.arange(len(pts1_list))) & 0xFFFFFFFF
     H, masks = _batch("H", pts1_list, pts2_list, px_th, conf, max_iters, et, symmetric_error_check,
-                      max(0, laf_consistensy_coef), True, seeds, device)
+                      max(0, laf_consistensy_coef), True, seeds, device, tuning)
     out = np.zeros_like(H)
     for i in range(len(H)):
         if np.abs(H[i]).sum() != 0:

@@ -48,10 +48,14 @@ struct dg_args {
     double *model_out;               /* [n_pairs, 9] */
     unsigned char *mask_out;         /* [total] */
     int *stats_out;                  /* [n_pairs, 16] or null */
-    char *ws;
+    char *ws;                        /* per-SLOT scratch (slot = resident workgroup), wl.stride bytes each */
     dg_ws_layout wl;
     dg_params prm;
     int dim, n_pairs, pts_in_lds;
+    int *ticket;                     /* device counter, zeroed per launch: persistent workgroups pull the next pair from it */
+    const int *order;                /* optional processing order (ticket t -> pair order[t]); null = identity              */
+    int pool_seq;                    /* 1 = always use the sequential pool-swap stage (LDS exchange-order self-check failed, or forced) */
+    int variant_threads, mode;       /* reported in the stats block */
     int *trace;                      /* debug: [0] = count, then (tag, I, J lo, J hi) records; null = off */
     int trace_cap;
     long long *phase_out;            /* debug: [n_pairs][8] 100 MHz ticks per phase (sample, solve, score, commit+events, LO, degen, tail, total) */

@@ -585,21 +585,18 @@ __device__ __forceinline__ unsigned dg_sample_chunk(unsigned seed, int cn, int n
     return sd;
 }
 
+/* the whole driver for ONE pair, run by one workgroup on scratch slot `slot` */
 template <int T, int LDSPTS>
-__global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
+__device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsigned char *dyn_smem, const int pair, const int slot)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
-    __shared__ dg_f_shared Sh;
-    dg_f_shared *S = &Sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pair = blockIdx.x;
     const long long off = A.offsets[pair];
     const int n = (int)(A.offsets[pair + 1] - off);
     const dg_params &pr = A.prm;
     const double th = pr.th;
     long long t_start = wall_clock64();
 
-    char *ws = A.ws + (size_t)pair * A.wl.stride;
+    char *ws = A.ws + (size_t)slot * A.wl.stride;
     CTX c;
     c.S = S; c.n = n; c.tid = tid; c.A = &A; c.off = off;
     for (int i = 0; i < 10; i++) c.L[i] = (int *)(ws + A.wl.off_lists) + (size_t)i * A.wl.n_max;
@@ -617,6 +614,7 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
     else             { Pw = (dg_pt *)(ws + A.wl.off_pts); pool = LDSPTS == 2 ? (int *)dyn_smem : (int *)(ws + A.wl.off_pool); }
     c.P = Pw; c.pool = pool;
     const dg_pt *P = Pw;
+    int *const pscr = A.pool_seq ? (int *)0 : (int *)S->ww;     /* LDS scratch of the parallel pool stage; null selects the sequential one */
 
     /* ---- stage the correspondences (bindings.cpp:337-409: only x,y of each row are geometry) ---- */
     double ex0 = 0., ex1 = 0., ex2 = 0., ex3 = 0.;
@@ -672,7 +670,7 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
         chunk_s[0] = cn0; chunk_s[1] = cn1;
         if (wave == 0) {
             unsigned sd = seed;
-            if (cn0 > 0) sd = dg_sample_chunk<7, LDSPTS>(sd, cn0, n, pool, S->seeds3[0], S->draws3[0], S->alm3[0], (int *)S->ww, lane);
+            if (cn0 > 0) sd = dg_sample_chunk<7, LDSPTS>(sd, cn0, n, pool, S->seeds3[0], S->draws3[0], S->alm3[0], pscr, lane);
             if (cn1 > 0) sd = dg_sample_draws<7>(sd, cn1, n, S->seeds3[1], S->draws3[1], S->alm3[1], lane);
             if (lane == 0) S->itmp[31] = (int)sd;
         }
@@ -721,7 +719,7 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
             cn2 = max_sam - (no_sam + chunk_s[cur] + chunk_s[nxt]); if (cn2 > DG_CHUNK) cn2 = DG_CHUNK; if (cn2 < 0) cn2 = 0;
             chunk_s[nx2] = cn2;
             if (wave == 0) {
-                if (chunk_s[nxt] > 0) dg_sample_pool<7, LDSPTS>(chunk_s[nxt], n, pool, S->draws3[nxt], S->alm3[nxt], (int *)S->ww, lane, S->dbg);
+                if (chunk_s[nxt] > 0) dg_sample_pool<7, LDSPTS>(chunk_s[nxt], n, pool, S->draws3[nxt], S->alm3[nxt], pscr, lane, S->dbg);
             } else if (wave == 1) {
                 if (cn2 > 0) { unsigned sd = dg_sample_draws<7>(seed, cn2, n, S->seeds3[nx2], S->draws3[nx2], S->alm3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }
             }
@@ -996,7 +994,7 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
         st[0] = no_sam; st[1] = iter_cnt; st[2] = 0; st[3] = (int)maxS.I; st[4] = c.n_fds + c.n_exfds;
         st[5] = degen_cnt; st[6] = Ihmax; st[7] = best_sample; st[8] = c.n_fds; st[9] = c.n_exfds;
         st[10] = c.n_hds; st[11] = c.n_aux; st[12] = (int)(t_best - t_start); st[13] = (int)(t_end - t_start);
-        st[14] = 0; st[15] = 0;
+        st[14] = A.variant_threads; st[15] = A.mode;
     }
     DG_PH(6);
 #ifdef DG_LO_PROF
@@ -1004,6 +1002,33 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
     if (0)
 #endif
     if (A.phase_out && tid == 0) { S->ph[7] = wall_clock64() - t_start; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + i] = S->ph[i]; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + 8 + i] = S->dbg[i]; }
+#undef DG_PH
+}
+
+/* Persistent workgroups: the grid is at most the number of workgroups the device keeps resident, every workgroup owns
+ * one scratch slot and pulls pairs from a device-wide ticket counter until the batch is exhausted (optionally in a
+ * caller-given order, e.g. expected-cost descending). */
+__device__ __forceinline__ int dg_next_pair(const dg_args &A, int *bc /* LDS */)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) *bc = atomicAdd(A.ticket, 1);
+    __syncthreads();
+    const int t = *bc;
+    if (t >= A.n_pairs) return -1;
+    return A.order ? A.order[t] : t;
+}
+
+template <int T, int LDSPTS>
+__global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+    __shared__ dg_f_shared Sh;
+    __shared__ int next_pair;
+    for (;;) {
+        const int pair = dg_next_pair(A, &next_pair);
+        if (pair < 0) break;
+        dg_f_pair<T, LDSPTS>(A, &Sh, dyn_smem, pair, (int)blockIdx.x);
+    }
 }
 
 #endif /* DG_KERNEL_F_MAIN_H */

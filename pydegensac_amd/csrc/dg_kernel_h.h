@@ -288,13 +288,9 @@ __device__ __noinline__ int dg_solve4_lane(const dg_pt *P, const int *ids, int k
 
 /* ---------------------------------------------------------------------------------------------- */
 template <int T, int LDSPTS>
-__global__ __launch_bounds__(DG_T, 2) void dg_find_homography_kernel(dg_args A)
+__device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsigned char *dyn_smem, const int pair, const int slot)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
-    __shared__ dg_f_shared Sh;
-    dg_f_shared *S = &Sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pair = blockIdx.x;
     const long long off = A.offsets[pair];
     const int n = (int)(A.offsets[pair + 1] - off);
     const dg_params &pr = A.prm;
@@ -302,7 +298,7 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_homography_kernel(dg_args A)
     const int kind = pr.error_type;
     long long t_start = wall_clock64();
 
-    char *ws = A.ws + (size_t)pair * A.wl.stride;
+    char *ws = A.ws + (size_t)slot * A.wl.stride;
     CTX c;
     c.S = S; c.n = n; c.tid = tid; c.A = &A; c.off = off;
     for (int i = 0; i < 10; i++) c.L[i] = (int *)(ws + A.wl.off_lists) + (size_t)i * A.wl.n_max;
@@ -320,6 +316,7 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_homography_kernel(dg_args A)
     else             { Pw = (dg_pt *)(ws + A.wl.off_pts); pool = LDSPTS == 2 ? (int *)dyn_smem : (int *)(ws + A.wl.off_pool); }
     c.P = Pw; c.pool = pool;
     const dg_pt *P = Pw;
+    int *const pscr = A.pool_seq ? (int *)0 : (int *)S->ww;     /* LDS scratch of the parallel pool stage; null selects the sequential one */
     for (int i = tid; i < n; i += DG_T) {
         const double *a = A.pts1 + (size_t)(off + i) * A.dim, *b = A.pts2 + (size_t)(off + i) * A.dim;
         dg_pt p; p.x1 = a[0]; p.y1 = a[1]; p.x2 = b[0]; p.y2 = b[1];
@@ -347,7 +344,7 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_homography_kernel(dg_args A)
         chunk_s[0] = cn0; chunk_s[1] = cn1;
         if (wave == 0) {
             unsigned sd = seed;
-            if (cn0 > 0) sd = dg_sample_chunk<4, LDSPTS>(sd, cn0, n, pool, S->seeds3[0], S->draws3[0], S->alm3[0], (int *)S->ww, lane);
+            if (cn0 > 0) sd = dg_sample_chunk<4, LDSPTS>(sd, cn0, n, pool, S->seeds3[0], S->draws3[0], S->alm3[0], pscr, lane);
             if (cn1 > 0) sd = dg_sample_draws<4>(sd, cn1, n, S->seeds3[1], S->draws3[1], S->alm3[1], lane);
             if (lane == 0) S->itmp[31] = (int)sd;
         }
@@ -390,7 +387,7 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_homography_kernel(dg_args A)
             cn2 = max_sam - (no_sam + chunk_s[cur] + chunk_s[nxt]); if (cn2 > DG_CHUNK) cn2 = DG_CHUNK; if (cn2 < 0) cn2 = 0;
             chunk_s[nx2] = cn2;
             if (wave == 0) {
-                if (chunk_s[nxt] > 0) dg_sample_pool<4, LDSPTS>(chunk_s[nxt], n, pool, S->draws3[nxt], S->alm3[nxt], (int *)S->ww, lane, S->dbg);
+                if (chunk_s[nxt] > 0) dg_sample_pool<4, LDSPTS>(chunk_s[nxt], n, pool, S->draws3[nxt], S->alm3[nxt], pscr, lane, S->dbg);
             } else if (wave == 1) {
                 if (cn2 > 0) { unsigned sd = dg_sample_draws<4>(seed, cn2, n, S->seeds3[nx2], S->draws3[nx2], S->alm3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }
             } else {
@@ -540,7 +537,20 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_homography_kernel(dg_args A)
         long long t_end = wall_clock64();
         st[0] = no_sam; st[1] = iter_cnt; st[2] = no_rej; st[3] = (int)maxS.I; st[4] = c.n_hds;
         st[5] = 0; st[6] = 0; st[7] = best_sample; st[8] = c.n_hds; st[9] = 0; st[10] = 0; st[11] = 0;
-        st[12] = (int)(t_best - t_start); st[13] = (int)(t_end - t_start); st[14] = 0; st[15] = 0;
+        st[12] = (int)(t_best - t_start); st[13] = (int)(t_end - t_start); st[14] = A.variant_threads; st[15] = A.mode;
+    }
+}
+
+template <int T, int LDSPTS>
+__global__ __launch_bounds__(DG_T, 2) void dg_find_homography_kernel(dg_args A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+    __shared__ dg_f_shared Sh;
+    __shared__ int next_pair;
+    for (;;) {
+        const int pair = dg_next_pair(A, &next_pair);
+        if (pair < 0) break;
+        dg_h_pair<T, LDSPTS>(A, &Sh, dyn_smem, pair, (int)blockIdx.x);
     }
 }
 

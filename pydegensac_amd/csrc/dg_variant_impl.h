@@ -22,9 +22,26 @@ hipError_t DG_VCAT(dg_variant_, DG_T, _init)(const unsigned C[8][32], const unsi
     return hipSuccess;
 }
 
-hipError_t DG_VCAT(dg_variant_, DG_T, _launch)(int homography, int mode, int n_pairs, size_t dyn, hipStream_t stream, const dg_args &A)
+static const void *DG_VCAT(dg_variant_, DG_T, _fn)(int homography, int mode)
 {
-    const dim3 g(n_pairs), b(DG_T);
+    if (!homography) {
+        if (mode == DG_MODE_LDS)      return (const void *)dg_find_fundamental_kernel<DG_T, DG_MODE_LDS>;
+        if (mode == DG_MODE_POOL_LDS) return (const void *)dg_find_fundamental_kernel<DG_T, DG_MODE_POOL_LDS>;
+        return (const void *)dg_find_fundamental_kernel<DG_T, DG_MODE_HBM>;
+    }
+    if (mode == DG_MODE_LDS)      return (const void *)dg_find_homography_kernel<DG_T, DG_MODE_LDS>;
+    if (mode == DG_MODE_POOL_LDS) return (const void *)dg_find_homography_kernel<DG_T, DG_MODE_POOL_LDS>;
+    return (const void *)dg_find_homography_kernel<DG_T, DG_MODE_HBM>;
+}
+
+hipError_t DG_VCAT(dg_variant_, DG_T, _resident)(int homography, int mode, size_t dyn, int *blocks_per_cu)
+{
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, DG_VCAT(dg_variant_, DG_T, _fn)(homography, mode), DG_T, dyn);
+}
+
+hipError_t DG_VCAT(dg_variant_, DG_T, _launch)(int homography, int mode, int grid, size_t dyn, hipStream_t stream, const dg_args &A)
+{
+    const dim3 g(grid), b(DG_T);
     if (!homography) {
         if (mode == DG_MODE_LDS)           hipLaunchKernelGGL((dg_find_fundamental_kernel<DG_T, DG_MODE_LDS>), g, b, dyn, stream, A);
         else if (mode == DG_MODE_POOL_LDS) hipLaunchKernelGGL((dg_find_fundamental_kernel<DG_T, DG_MODE_POOL_LDS>), g, b, dyn, stream, A);

@@ -29,30 +29,42 @@ def pair_seeds(lo, hi, base_seed=1):
 def gather_results(models, stats, masks, n_per_pair, n_pairs_total, group=None):
     """All-gather the per-pair results of every rank (torch tensors on the rank's device).
 
-    models [P_r, 9] float64, stats [P_r, 16] int32, masks [P_r * n_per_pair] uint8 for equally sized
-    pairs.  Ranks may own different numbers of pairs (padded to the maximum for the collective).
-    Returns (models [P,9], stats [P,16], masks [P, n_per_pair]) in global pair order.
+    models [P_r, 9] float64, stats [P_r, 16] int32, masks [sum of the rank's pair sizes] uint8.
+    `n_per_pair`: an int (every pair has that many correspondences) or the sequence of ALL n_pairs_total pair sizes
+    (ragged batch, the C-ABI's offsets form).  Ranks may own different numbers of pairs / bytes (padded to the
+    maximum for the collective).  Returns (models [P,9], stats [P,16], masks) in global pair order, where masks is
+    [P, n] for equal sizes and a flat [sum of all sizes] uint8 tensor for a ragged batch (pair p at
+    offsets[p]:offsets[p+1] with offsets = cumsum of the sizes).
     """
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    ragged = not isinstance(n_per_pair, (int, np.integer))
+    counts = np.asarray(n_per_pair, dtype=np.int64).ravel() if ragged else np.full(n_pairs_total, int(n_per_pair), np.int64)
+    if len(counts) != n_pairs_total:
+        raise ValueError("need one size per pair")
     if world == 1:
-        return models, stats, masks.view(-1, n_per_pair)
-    pmax = (n_pairs_total + world - 1) // world
+        return models, stats, (masks if ragged else masks.view(-1, int(n_per_pair)))
     dev = models.device
-    rec = 72 + 64 + n_per_pair                                  # bytes per pair
-    packed = torch.zeros((pmax, rec), dtype=torch.uint8, device=dev)
+    rng = [shard_range(n_pairs_total, r, world) for r in range(world)]
+    mbytes = [int(counts[lo:hi].sum()) for lo, hi in rng]
+    rec = [(hi - lo) * 136 + mb for (lo, hi), mb in zip(rng, mbytes)]      # 72 B model + 64 B stats per pair, then the masks
+    cap = max(rec)
+    rank = dist.get_rank(group)
     p_r = models.shape[0]
-    packed[:p_r, :72] = models.contiguous().view(torch.uint8).view(p_r, 72)
-    packed[:p_r, 72:136] = stats.contiguous().view(torch.uint8).view(p_r, 64)
-    packed[:p_r, 136:] = masks.view(p_r, n_per_pair)
-    out = torch.empty((world, pmax, rec), dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(out.view(-1), packed.view(-1), group=group)
-    rows = []
+    if p_r != rng[rank][1] - rng[rank][0] or masks.numel() != mbytes[rank]:
+        raise ValueError("this rank's tensors do not match its shard of the batch")
+    packed = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    packed[:p_r * 72] = models.contiguous().view(torch.uint8).view(-1)
+    packed[p_r * 72:p_r * 136] = stats.contiguous().view(torch.uint8).view(-1)
+    packed[p_r * 136:p_r * 136 + mbytes[rank]] = masks.view(-1)
+    out = torch.empty((world, cap), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out.view(-1), packed, group=group)
+    ms, ss, ks = [], [], []
     for r in range(world):
-        lo, hi = shard_range(n_pairs_total, r, world)
-        rows.append(out[r, :hi - lo])
-    allp = torch.cat(rows, 0)
-    m = allp[:, :72].contiguous().view(torch.float64).view(-1, 9)
-    s = allp[:, 72:136].contiguous().view(torch.int32).view(-1, 16)
-    return m, s, allp[:, 136:]
+        pr = rng[r][1] - rng[r][0]
+        ms.append(out[r, :pr * 72]); ss.append(out[r, pr * 72:pr * 136]); ks.append(out[r, pr * 136:pr * 136 + mbytes[r]])
+    m = torch.cat(ms).contiguous().view(torch.float64).view(-1, 9)
+    st = torch.cat(ss).contiguous().view(torch.int32).view(-1, 16)
+    k = torch.cat(ks)
+    return m, st, (k if ragged else k.view(-1, int(n_per_pair)))

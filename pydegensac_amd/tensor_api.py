@@ -5,7 +5,7 @@ correspondences on the GPU.  These functions take `torch` tensors on a ROCm devi
 `data_ptr()`, float64, C-contiguous), run the same persistent kernels through the `*_batch_dev` entry points
 of include/mi_degensac.h on the tensor's current stream, and return tensors — no host staging, no
 synchronisation.  Marshalling rules follow bindings.cpp:126-198 (rows are [x, y] or [x, y, a11, a12, a21,
-a22]); seeds follow pydegensac_amd.parallel.pair_seeds unless given.
+a22]); seeds follow pydegensac_amd.parallel.pair_seeds unless given (any uint32 value is allowed).
 """
 import ctypes as C
 
@@ -42,7 +42,8 @@ def _run(which, pts1, pts2, counts, prm, seeds, min_n):
     dev = pts1.device
     if seeds is None:
         seeds = parallel.pair_seeds(0, P)
-    d_seeds = torch.as_tensor(np.asarray(seeds, dtype=np.int64) & 0xFFFFFFFF, device=dev).to(torch.int32)
+    # uint32 seeds travel as their int32 bit pattern (torch has no uint32 arithmetic; the kernel reads them as unsigned)
+    d_seeds = torch.from_numpy((np.asarray(seeds, dtype=np.int64) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)).to(dev)
     d_off = torch.from_numpy(offs).to(dev)
     model = torch.zeros((P, 9), dtype=torch.float64, device=dev)
     mask = torch.zeros(int(offs[-1]), dtype=torch.uint8, device=dev)

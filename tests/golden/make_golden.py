@@ -32,6 +32,9 @@ F_CASES = [
     ("F_n8", dict(n=8, inlier_ratio=1.0, sigma=0.1, seed=4), dict(max_iters=200)),
     ("F_all_outliers", dict(n=300, inlier_ratio=0.0, sigma=0.5, seed=6), dict(max_iters=3000)),
     ("F_c5_small", dict(n=5000, inlier_ratio=0.1, sigma=0.1, seed=7), dict(max_iters=4000)),
+    # BASELINE configs at their stated size (round 2)
+    ("F_c5_full", dict(n=50000, inlier_ratio=0.1, sigma=0.1, seed=0), dict(max_iters=200000, conf=0.9999)),
+    ("F_c2b_full", dict(n=2000, inlier_ratio=0.4, sigma=0.1, seed=1, plane_fraction=0.7), dict(max_iters=100000)),
 ]
 H_CASES = [
     ("H_c3_sampson", dict(n=5000, inlier_ratio=0.4, sigma=0.5, seed=0), dict(px_th=2.0, error_type=0)),
@@ -43,26 +46,38 @@ H_CASES = [
     ("H_c1_plumbing", dict(n=400, inlier_ratio=0.4, sigma=0.5, seed=3), dict(px_th=4.0, conf=0.99, max_iters=2000)),
     ("H_n4", dict(n=4, inlier_ratio=1.0, sigma=0.0, seed=3), dict(px_th=1.0, max_iters=100)),
     ("H_all_outliers", dict(n=200, inlier_ratio=0.0, sigma=0.5, seed=5), dict(px_th=1.0, max_iters=2000)),
+    # C3 at its stated size: 5000 correspondences WITH LAFs, LAF + symmetric checks (round 2)
+    ("H_c3_full_laf_sampson", dict(n=5000, inlier_ratio=0.4, sigma=0.5, seed=0, laf=True), dict(px_th=2.0, error_type=0, laf_coef=3.0)),
+    ("H_c3_full_laf_symm_max", dict(n=5000, inlier_ratio=0.4, sigma=0.5, seed=0, laf=True), dict(px_th=2.0, error_type=2, laf_coef=3.0)),
 ]
 SEEDS = [1, 7]
 
 
 def main():
+    only = sys.argv[1:]                       # optional: fixture-name prefixes to (re)generate
+    sel = lambda name: not only or any(name.startswith(o) for o in only)
+    n_written = 0
     for name, g, kw in F_CASES:
+        if not sel(name):
+            continue
         p1, p2, _, _ = syn.two_view_fundamental(**g)
         for s in SEEDS:
             F, m, st = ref.find_fundamental(p1, p2, seed=s, count_models=True, **kw)
             np.savez_compressed(os.path.join(HERE, f"{name}_s{s}.npz"), kind="F", gen=repr(g), call=repr(kw), seed=s,
                                 model=F, mask=np.packbits(m), n=len(m), samples=st["samples"], lo_runs=st["lo_runs"],
                                 full_passes=st["full_passes"], ex_passes=st["ex_passes"], I=st["I"])
+            n_written += 1
     for name, g, kw in H_CASES:
+        if not sel(name):
+            continue
         p1, p2, _, _ = syn.homography_pairs(**g)
         for s in SEEDS:
             H, m, st = ref.find_homography(p1, p2, seed=s, count_models=True, **kw)
             np.savez_compressed(os.path.join(HERE, f"{name}_s{s}.npz"), kind="H", gen=repr(g), call=repr(kw), seed=s,
                                 model=H, mask=np.packbits(m), n=len(m), samples=st["samples"], lo_runs=st["lo_runs"],
                                 full_passes=st["full_passes"], rejected=st["rejected"], I=st["I"])
-    print("wrote", len(F_CASES) * len(SEEDS) + len(H_CASES) * len(SEEDS), "fixtures")
+            n_written += 1
+    print("wrote", n_written, "fixtures")
 
 
 if __name__ == "__main__":

@@ -33,8 +33,7 @@ def test_full_size_batch_properties():
     A = [base[i % 20][0] for i in range(P)]; B = [base[i % 20][1] for i in range(P)]
     seeds = [1 + (i % 20) for i in range(P)]                     # pair i == pair i + 20: identical problems
     F, m = pd.findFundamentalMatrixBatch(A, B, seeds=seeds)
-    th, md = C.c_int(0), C.c_int(0); _lib.lib().mi_degensac_debug_last_launch(C.byref(th), C.byref(md))
-    assert th.value == 256, "a batch of >= 3 pairs per CU must take the throughput variant"
+    assert all(s_["threads"] == 256 for s_ in pd.last_stats()), "a batch of >= 3 pairs per CU must take the throughput variant"
     F = np.asarray(F)
     for i in range(20, P):
         assert np.array_equal(F[i], F[i % 20]) and np.array_equal(np.asarray(m[i]), np.asarray(m[i % 20]))

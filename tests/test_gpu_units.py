@@ -1,0 +1,161 @@
+"""GPU: the unit-level entry points of include/mi_degensac.h against the oracle's building blocks, and the
+boundary's concurrency contract (threads x streams on one device)."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import pydegensac_amd as pd
+from pydegensac_amd import _lib, synthetic as syn
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def test_solve7_matches_oracle_nullspace_cubic_and_orientation(oracle_port):
+    """mi_degensac_solve7 = the per-lane 7-point solver of the main kernel: null space (utools.c:97-167), cubic
+    (Ftools.c:39-81), real roots (Ftools.c:251-298), oriented epipolar test (Ftools.c:463-494), exp_ranF.c:1351-1372."""
+    L = _lib.lib(); P = oracle_port.lib(); dp = oracle_port.dp; ip = oracle_port.ip
+    n = 1500
+    p1, p2, lab, _ = syn.two_view_fundamental(n, 0.5, 0.1, seed=4)
+    u = np.ones((n, 6)); u[:, 0:2] = p1; u[:, 3:5] = p2
+    rng = np.random.default_rng(1)
+    S = 2000
+    samples = np.stack([rng.choice(n, 7, replace=False) for _ in range(S)]).astype(np.int32)
+    inl = np.flatnonzero(lab)
+    samples[:300] = np.stack([rng.choice(inl, 7, replace=False) for _ in range(300)])      # all-inlier samples: valid models
+    samples[300, 1] = samples[300, 0]                                                       # a rank-deficient sample
+    nsol = np.zeros(S, np.int32); ridx = np.zeros((S, 3), np.int32); models = np.zeros((S, 27))
+    _lib.check(L.mi_degensac_solve7(_lib.dptr(p1), _lib.dptr(p2), n, 2, samples.ctypes.data_as(C.POINTER(C.c_int32)), S, 0,
+                                    nsol.ctypes.data_as(C.POINTER(C.c_int32)), ridx.ctypes.data_as(C.POINTER(C.c_int32)), _lib.dptr(models)))
+    n_models = 0
+    for t in range(S):
+        A = np.zeros(81)
+        for i, q in enumerate(samples[t]):                                   # rows in draw order (rtools.c:74-92)
+            A[9 * i:9 * i + 9] = np.outer(u[q, 3:6], u[q, 0:3]).ravel()
+        ns = np.zeros(81)
+        dim = P.dg_oracle_nullspace(dp(A), dp(ns), 9)
+        if dim != 2:
+            assert nsol[t] == -1, t
+            continue
+        f1 = ns[0:9].copy(); f2 = ns[9:18].copy(); poly = np.zeros(4); roots = np.zeros(3)
+        P.dg_oracle_slcm(dp(f1), dp(f2), dp(poly))                           # f2 := f1 - f2 (Ftools.c:70)
+        nr = P.dg_oracle_rroots3(dp(poly), dp(roots))
+        samidx = np.ascontiguousarray(samples[t][::-1])                      # pool tail = reverse draw order (rtools.c:17-20)
+        want = []
+        for i in range(nr):
+            f = f1 * roots[i] + f2 * (1 - roots[i])                          # exp_ranF.c:1365-1368
+            if P.dg_oracle_all_ori_valid(dp(np.ascontiguousarray(f)), dp(u), ip(samidx), 7):
+                want.append((i, f))
+        assert nsol[t] == len(want), (t, nsol[t], len(want))
+        for k, (i, f) in enumerate(want):
+            assert ridx[t, k] == i and np.array_equal(models[t, 9 * k:9 * k + 9], f), (t, k)
+        n_models += len(want)
+    assert n_models > 200 and (nsol == -1).any()
+
+
+def test_score_models_symmetric_h_metrics_bit_exact(oracle_port):
+    """mi_degensac_score_models kinds 10..14 (H Sampson and the four symmetric transfer errors, Htools.c:161-370):
+    residuals bit-exact, I exact, J = the reference's sequential MSAC sum"""
+    L = _lib.lib(); P = oracle_port.lib(); dp = oracle_port.dp; ip = oracle_port.ip
+    n = 2500
+    p1, p2, lab, Hgt = syn.homography_pairs(n=n, inlier_ratio=0.4, sigma=0.5, seed=8)
+    u = np.ones((n, 6)); u[:, 0:2] = p1; u[:, 3:5] = p2
+    rng = np.random.default_rng(2)
+    Hc = np.linalg.inv(Hgt).T.ravel()
+    models = np.stack([Hc] + [Hc * (1 + 0.003 * rng.normal(size=9)) for _ in range(7)] + [rng.normal(size=9) for _ in range(4)]).copy()
+    M = len(models)
+    for kind, th in [(0, 4.0), (1, 4.0), (2, 2.0), (3, 4.0), (4, 2.0)]:
+        I = np.zeros(M, np.uint32); J = np.zeros(M); res = np.zeros((M, n))
+        _lib.check(L.mi_degensac_score_models(_lib.dptr(p1), _lib.dptr(p2), n, 2, _lib.dptr(models), M, 10 + kind, th, 0,
+                                              I.ctypes.data_as(C.POINTER(C.c_uint32)), _lib.dptr(J), _lib.dptr(res)))
+        for k in range(M):
+            d = np.zeros(n)
+            P.dg_oracle_HDS_full(kind, dp(u), dp(models[k].copy()), dp(d), n)
+            lst = np.zeros(n, np.int32)
+            S = P.dg_oracle_inlidxs(dp(d), n, C.c_double(th), ip(lst))
+            assert np.array_equal(d, res[k], equal_nan=True), (kind, k)
+            assert S.I == I[k] and (S.J == J[k] or (np.isnan(S.J) and np.isnan(J[k]))), (kind, k, S.J, J[k])
+        assert I[0] > 0.3 * n
+
+
+def test_two_threads_two_streams_equal_serial_runs(oracle_port):
+    """thread-safe boundary.  Two host threads, each driving two streams of the same device through the
+    asynchronous *_dev entry points (ragged batches of different sizes so the per-stream scratch differs), plus the
+    host-pointer API from both threads at once: every result equals the serial run bit for bit."""
+    import torch
+    from pydegensac_amd import tensor_api
+    dev = torch.device("cuda", 0)
+    jobs = []
+    for j in range(4):
+        sizes = [300 + 137 * ((j + k) % 5) for k in range(6 + 3 * j)]
+        A = []; B = []
+        for i, n in enumerate(sizes):
+            p1, p2, _, _ = syn.two_view_fundamental(n, 0.5, 0.1, seed=100 * j + i); A.append(p1); B.append(p2)
+        jobs.append((sizes, torch.from_numpy(np.concatenate(A)).to(dev), torch.from_numpy(np.concatenate(B)).to(dev),
+                     [17 * j + i + 1 for i in range(len(sizes))], A, B))
+    serial = []
+    for sizes, a, b, seeds, _, _ in jobs:
+        F, m, st, _ = tensor_api.find_fundamental_batch_tensors(a, b, sizes, max_iters=5000, seeds=seeds)
+        torch.cuda.synchronize()
+        serial.append((F.cpu().numpy().copy(), m.cpu().numpy().copy()))
+    # spot check of the serial run itself against the oracle
+    Fo, mo, _ = oracle_port.find_fundamental(jobs[0][4][0], jobs[0][5][0], 0.5, 0.9999, 5000, seed=jobs[0][3][0])
+    assert np.array_equal(serial[0][1][:jobs[0][0][0]], mo) and gu.rel(serial[0][0][0], Fo) < 1e-6
+    hostF, hostm = pd.findFundamentalMatrixBatch(jobs[1][4], jobs[1][5], max_iters=5000, seeds=jobs[1][3])
+    results = {}; errors = []
+
+    def worker(tid):
+        try:
+            torch.cuda.set_device(0)
+            streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+            for rep in range(3):
+                outs = []
+                for k in range(2):
+                    sizes, a, b, seeds, _, _ = jobs[2 * tid + k]
+                    with torch.cuda.stream(streams[k]):
+                        outs.append(tensor_api.find_fundamental_batch_tensors(a, b, sizes, max_iters=5000, seeds=seeds))
+                hf, hm = pd.findFundamentalMatrixBatch(jobs[1][4], jobs[1][5], max_iters=5000, seeds=jobs[1][3])   # host API, same time
+                for k in range(2):
+                    streams[k].synchronize()
+                    results[(tid, rep, k)] = (outs[k][0].cpu().numpy().copy(), outs[k][1].cpu().numpy().copy())
+                results[(tid, rep, "host")] = (np.asarray(hf).copy(), [np.asarray(x).copy() for x in hm])
+        except Exception as e:                                  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errors, errors
+    for tid in range(2):
+        for rep in range(3):
+            for k in range(2):
+                F, m = results[(tid, rep, k)]
+                assert np.array_equal(F, serial[2 * tid + k][0]) and np.array_equal(m, serial[2 * tid + k][1]), (tid, rep, k)
+            hf, hm = results[(tid, rep, "host")]
+            assert np.array_equal(hf, np.asarray(hostF)) and all(np.array_equal(x, np.asarray(y)) for x, y in zip(hm, hostm))
+
+
+def test_explicit_context_and_device_is_restored():
+    """mi_degensac_ctx_*: an explicit context gives the same bits as the thread's implicit one; the calling thread's
+    current HIP device is untouched (here: checked through torch's notion of the current device)."""
+    import torch
+    L = _lib.lib()
+    p1, p2, _, _ = syn.two_view_fundamental(600, 0.5, 0.1, seed=9)
+    F0, m0 = pd.findFundamentalMatrix(p1, p2, max_iters=4000, seed=21)
+    ctx = C.c_void_p()
+    _lib.check(L.mi_degensac_ctx_create(0, C.byref(ctx)))
+    try:
+        assert L.mi_degensac_ctx_stream(ctx) is not None
+        prm = _lib.make_params(0.5, 0.9999, 4000, 0, True, 0.0, True)
+        off = np.array([0, 600], np.int64); sd = np.array([21], np.uint32)
+        F = np.zeros(9); mk = np.zeros(600, np.uint8); st = np.zeros(16, np.int32)
+        for _ in range(2):                                           # second call reuses the staging buffers
+            _lib.check(L.mi_degensac_ctx_find_fundamental_batch(ctx, _lib.dptr(p1), _lib.dptr(p2), off.ctypes.data_as(C.POINTER(C.c_int64)), 1, 2,
+                                                               C.byref(prm), sd.ctypes.data_as(C.POINTER(C.c_uint32)), _lib.dptr(F),
+                                                               mk.ctypes.data_as(C.POINTER(C.c_uint8)), st.ctypes.data_as(C.POINTER(C.c_int32))))
+            assert np.array_equal(F.reshape(3, 3), F0) and np.array_equal(mk.astype(bool), np.asarray(m0))
+    finally:
+        L.mi_degensac_ctx_destroy(ctx)
+    assert torch.cuda.current_device() == 0
+    assert L.mi_degensac_release_scratch(0, None) == 0

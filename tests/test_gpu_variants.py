@@ -1,21 +1,20 @@
 """GPU: every kernel variant (512 / 256 threads per workgroup) and placement mode (0: points + pool in the HBM
 workspace, 1: both in LDS, 2: pool in LDS) returns the same bits, and the oracle agrees with them."""
-import os
-
 import numpy as np
 import pytest
 
 import pydegensac_amd as pd
-from pydegensac_amd import synthetic as syn
+from pydegensac_amd import _lib, synthetic as syn
 
 pytestmark = pytest.mark.gpu
 
+VARIANT = {512: _lib.TUNE_LATENCY, 256: _lib.TUNE_THROUGHPUT}
+PLACE = {0: _lib.TUNE_PLACE_HBM, 1: _lib.TUNE_PLACE_LDS, 2: _lib.TUNE_PLACE_POOL_LDS}
 
-@pytest.fixture
-def force(monkeypatch):
-    def _set(variant, mode):
-        monkeypatch.setenv("MI_DEGENSAC_VARIANT", str(variant)); monkeypatch.setenv("MI_DEGENSAC_MODE", str(mode))
-    yield _set
+
+def tune(variant, mode, seq_pool=False):
+    """params.tuning word (include/mi_degensac.h): kernel variant, placement, sampler stage"""
+    return VARIANT[variant] | PLACE[mode] | (_lib.TUNE_SEQ_POOL if seq_pool else 0)
 
 
 def _f_batch():
@@ -25,13 +24,14 @@ def _f_batch():
     return A, B
 
 
-def test_fundamental_variants_and_modes_agree(force, oracle_port):
+def test_fundamental_variants_and_modes_agree(oracle_port):
     A, B = _f_batch(); seeds = [1, 2, 3, 4]
     ref = None
     for variant in (512, 256):
         for mode in (1, 2, 0):
-            force(variant, mode)
-            F, m = pd.findFundamentalMatrixBatch(A, B, max_iters=20000, seeds=seeds)
+            F, m = pd.findFundamentalMatrixBatch(A, B, max_iters=20000, seeds=seeds, tuning=tune(variant, mode))
+            st = pd.last_stats()
+            assert all(s_["threads"] == variant and s_["placement"] == mode for s_ in st), (variant, mode, st[0])
             if ref is None:
                 ref = (np.asarray(F).copy(), [np.asarray(x).copy() for x in m])
             else:
@@ -44,17 +44,49 @@ def test_fundamental_variants_and_modes_agree(force, oracle_port):
         assert np.linalg.norm(a - b) <= 1e-9 * np.linalg.norm(b)
 
 
-def test_homography_variants_and_modes_agree(force):
+def test_homography_variants_and_modes_agree():
     A, B = [], []
     for i, n in enumerate([1200, 400, 2500]):
         p1, p2, _, _ = syn.homography_pairs(n, 0.4, 0.5, seed=30 + i, laf=True); A.append(p1); B.append(p2)
     ref = None
     for variant in (512, 256):
         for mode in (1, 2, 0):
-            force(variant, mode)
-            H, m = pd.findHomographyBatch(A, B, 1.0, 0.999, 20000, 3.0, "sampson", True, seeds=[5, 6, 7])
+            H, m = pd.findHomographyBatch(A, B, 1.0, 0.999, 20000, 3.0, "sampson", True, seeds=[5, 6, 7], tuning=tune(variant, mode))
+            assert all(s_["threads"] == variant for s_ in pd.last_stats())      # n = 2500 does not fit "both in LDS" at 512 threads
             if ref is None:
                 ref = (np.asarray(H).copy(), [np.asarray(x).copy() for x in m])
             else:
                 assert np.array_equal(np.asarray(H), ref[0]), (variant, mode)
                 assert all(np.array_equal(np.asarray(x), y) for x, y in zip(m, ref[1])), (variant, mode)
+
+
+def test_sequential_pool_stage_fallback_matches_goldens():
+    """The parallel pool-swap stage relies on the LDS exchange order that the library probes once per device
+    (mi_degensac_pool_stage_parallel); when the probe fails every launch uses the sequential stage.  Forcing that
+    fallback must reproduce the reference goldens, and the device this suite runs on must pass the probe."""
+    import ctypes as C
+    from tests import golden_util as gu
+    assert _lib.lib().mi_degensac_pool_stage_parallel(0) == 1
+    for path in gu.fixtures("F")[:6] + gu.fixtures("H")[:6]:
+        g = gu.load(path); kw = g["call"]
+        if g["n"] <= 10:
+            continue
+        for variant in (512, 256):
+            t = VARIANT[variant] | _lib.TUNE_SEQ_POOL
+            if g["kind"] == "F":
+                M, m = pd.findFundamentalMatrix_(g["p1"], g["p2"], kw.get("px_th", 0.5), kw.get("conf", 0.9999), kw.get("max_iters", 100000),
+                                                 kw.get("error_type", 0), kw.get("sym_check", True), kw.get("laf_coef", 0.0),
+                                                 kw.get("degen", True), seed=g["seed"], tuning=t)
+            else:
+                M, m = pd.findHomography_(g["p1"], g["p2"], kw.get("px_th", 1.0), kw.get("conf", 0.999), kw.get("max_iters", 50000),
+                                          kw.get("error_type", 0), kw.get("sym_check", True), kw.get("laf_coef", 0.0), seed=g["seed"], tuning=t)
+            st = pd.last_stats()
+            assert st["samples"] == g["samples"] and st["lo_runs"] == g["lo_runs"], path
+            if np.abs(g["model"]).sum():
+                assert np.array_equal(np.asarray(m), g["mask"]) and gu.rel(M, g["model"]) < 1e-6, path
+    # the unit-level sample stream, both stages
+    out = np.zeros((600, 7), np.int32); out2 = np.zeros((600, 7), np.int32)
+    L = _lib.lib()
+    _lib.check(L.mi_degensac_sample_stream_ex(777, 2000, 7, 600, 0, 0, out.ctypes.data_as(C.POINTER(C.c_int32))))
+    _lib.check(L.mi_degensac_sample_stream_ex(777, 2000, 7, 600, 0, 1, out2.ctypes.data_as(C.POINTER(C.c_int32))))
+    assert np.array_equal(out, out2)

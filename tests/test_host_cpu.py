@@ -96,8 +96,17 @@ for i, pid in enumerate(range(lo, hi)):
     f, m, s = port.find_fundamental(p1, p2, max_iters=2000, seed=parallel.pair_seed(pid))
     F[i] = f.ravel(); mk[i * N:(i + 1) * N] = m; st[i, 0] = s["samples"]; st[i, 3] = s["I"]
 gm, gs, gk = parallel.gather_results(torch.from_numpy(F), torch.from_numpy(st), torch.from_numpy(mk), N, NP)
+# ragged batch: pair p has 100 + 37 p correspondences
+sizes = [100 + 37 * p for p in range(NP)]
+Fr = np.zeros((hi - lo, 9)); sr = np.zeros((hi - lo, 16), np.int32); mr = []
+for i, pid in enumerate(range(lo, hi)):
+    p1, p2, _, _ = synthetic.two_view_fundamental(sizes[pid], 0.6, 0.1, seed=50 + pid)
+    f, m, s = port.find_fundamental(p1, p2, max_iters=1000, seed=parallel.pair_seed(pid))
+    Fr[i] = f.ravel(); mr.append(m.astype(np.uint8)); sr[i, 0] = s["samples"]
+rm, rs, rk = parallel.gather_results(torch.from_numpy(Fr), torch.from_numpy(sr), torch.from_numpy(np.concatenate(mr)), sizes, NP)
 if rank == 0:
-    np.savez(sys.argv[2], F=gm.numpy(), st=gs.numpy(), mk=gk.numpy())
+    assert rk.numel() == sum(sizes)
+    np.savez(sys.argv[2], F=gm.numpy(), st=gs.numpy(), mk=gk.numpy(), Fr=rm.numpy(), sr=rs.numpy(), mr=rk.numpy())
 dist.destroy_process_group()
 '''
 
@@ -117,7 +126,7 @@ def test_gather_invariant_to_world_size(tmp_path):
             subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                                    "--master-addr", "127.0.0.1", "--master-port", str(port_no), str(script), ROOT, out])
         outs.append(np.load(out))
-    for k in ["F", "st", "mk"]:
+    for k in ["F", "st", "mk", "Fr", "sr", "mr"]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
     assert outs[0]["st"][:, 0].min() > 0
 
@@ -131,3 +140,45 @@ def test_tensor_api_rejects_host_and_wrong_dtype_inputs():
         tensor_api.find_fundamental_batch_tensors(a, a, [16])                     # not on a GPU
     with pytest.raises(ValueError):
         tensor_api.find_fundamental_batch_tensors(a.numpy(), a.numpy(), [16])     # not tensors
+
+
+def test_pydegensac_alias_runs_the_reference_example_call_pattern():
+    """`import pydegensac` resolves to this implementation with the reference's surface (src/pydegensac/__init__.py:1-4);
+    the call pattern of examples/simple-example.py:18-37 (float32 [n,2] arrays, positional th / conf / n_iter) goes
+    through unchanged — up to the device: without a GPU the call must fail loudly, never fall back."""
+    import inspect
+    import torch
+    import pydegensac
+    import pydegensac_amd
+    from pydegensac_amd import _lib
+    for name in ["findHomography", "findFundamentalMatrix", "convert_cv2_kpts_to_xyA", "findHomography_", "findFundamentalMatrix_"]:
+        assert getattr(pydegensac, name) is getattr(pydegensac_amd, name)
+    s = inspect.signature(pydegensac.findFundamentalMatrix_)
+    assert [s.parameters[k].default for k in ["px_th", "conf", "max_iters"]] == [0.5, 0.9999, 200000]     # bindings.cpp:494-503
+    s = inspect.signature(pydegensac.findHomography_)
+    assert [s.parameters[k].default for k in ["px_th", "conf", "max_iters"]] == [1.0, 0.999, 10000]       # bindings.cpp:484-492
+    from pydegensac_amd import synthetic
+    p1, p2, lab, _ = synthetic.homography_pairs(n=300, inlier_ratio=0.6, sigma=0.5, seed=1)
+    src_pts = np.float32(p1).reshape(-1, 2); dst_pts = np.float32(p2).reshape(-1, 2)
+    if torch.cuda.is_available():
+        H, mask = pydegensac.findHomography(src_pts, dst_pts, 4.0, 0.99, 2000)                   # simple-example.py:21
+        F, maskf = pydegensac.findFundamentalMatrix(src_pts, dst_pts, 1.0, 0.999, 10000, enable_degeneracy_check=True)   # :35
+        assert H.shape == (3, 3) and int(np.asarray(mask).astype(np.float32).sum()) > 100
+    else:
+        with pytest.raises(_lib.MiDegensacError):
+            pydegensac.findHomography(src_pts, dst_pts, 4.0, 0.99, 2000)
+
+
+def test_batch_api_validates_every_pair():
+    import pydegensac_amd as pd
+    a = np.zeros((20, 2)); b = np.zeros((20, 2))
+    with pytest.raises(ValueError):
+        pd.findFundamentalMatrixBatch([a, a], [b, b[:19]], seeds=[1, 2])          # shorter pts2 in pair 1
+    with pytest.raises(ValueError):
+        pd.findFundamentalMatrixBatch([a, np.zeros((20, 6))], [b, np.zeros((20, 6))], seeds=[1, 2])   # mixed dims
+    with pytest.raises(ValueError):
+        pd.findFundamentalMatrixBatch([a], [b], error_type="bogus", seeds=[1])    # ValueError like the single-pair API
+    with pytest.raises(ValueError):
+        pd.findHomographyBatch([np.zeros((20, 3))], [np.zeros((20, 3))], seeds=[1])
+    with pytest.raises(ValueError):
+        pd.findFundamentalMatrixBatch([a, a], [b, b], seeds=[1])                  # one seed per pair

@@ -123,3 +123,21 @@ def test_port_matches_reference_random_sweep(oracle_port, oracle_ref):
     bad, loose, worst, _ = cpu_port_vs_ref.run(150, 5, verbose=True)
     assert bad == 0
     assert worst < 1e-5          # ill-conditioned (plane-dominated) final fits may differ beyond rounding, never grossly
+
+
+def test_h_symmetric_metrics_match_reference(oracle_port, oracle_ref):
+    """the four symmetric transfer errors of the restatement (HDS_full kinds 1..4) against the reference's own
+    HDsSymMaxSq / HDsSymMax / HDsSymSumSq / HDsSymSum (Htools.c:202-370), bit for bit"""
+    R = oracle_ref.lib(); P = oracle_port.lib(); dp = oracle_port.dp
+    p1, p2, lab, Hgt = syn.homography_pairs(n=700, inlier_ratio=0.5, sigma=0.5, seed=3)
+    n = 700
+    u = np.ones((n, 6)); u[:, 0:2] = p1; u[:, 3:5] = p2
+    rng = np.random.default_rng(5)
+    Hc = np.linalg.inv(Hgt).T.ravel().copy()          # the driver's column-wise image2->image1 form (utils.py:108)
+    for H in [Hc, Hc * (1 + 0.01 * rng.normal(size=9)), rng.normal(size=9)]:
+        H = np.ascontiguousarray(H)
+        for kind, name in [(1, "HDsSymMaxSq"), (2, "HDsSymMax"), (3, "HDsSymSumSq"), (4, "HDsSymSum")]:
+            d1 = np.zeros(n); d2 = np.zeros(n)
+            getattr(R, name)(None, dp(u), dp(H), dp(d1), n)      # lin (Z) is unused by these metrics
+            P.dg_oracle_HDS_full(kind, dp(u), dp(H), dp(d2), n)
+            assert np.array_equal(d1, d2), name

@@ -1,4 +1,4 @@
-"""Batch throughput probe: python tools/gpu_batch.py P [reps]  -> ms per batch, models/s."""
+"""Batch throughput probe: python tools/gpu_batch.py P [tuning]  -> ms per batch, models/s."""
 import sys, numpy as np, ctypes as C, torch, time
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pydegensac_amd import synthetic as syn, _lib, parallel
@@ -14,12 +14,12 @@ dev=torch.device('cuda',0)
 d_a=torch.from_numpy(a).to(dev); d_b=torch.from_numpy(b).to(dev); d_off=torch.from_numpy(offs).to(dev)
 d_seeds=torch.from_numpy(parallel.pair_seeds(0,P).astype(np.int64)).to(dev).to(torch.int32)
 d_F=torch.zeros((P,9),dtype=torch.float64,device=dev); d_mask=torch.zeros(P*N,dtype=torch.uint8,device=dev); d_st=torch.zeros((P,16),dtype=torch.int32,device=dev)
-prm=_lib.make_params(0.5,0.9999,100000,0,True,0.0,True)
+TUNE=int(sys.argv[2],0) if len(sys.argv)>2 else 0      # params.tuning (include/mi_degensac.h): 1 = latency variant, 2 = throughput
+prm=_lib.make_params(0.5,0.9999,100000,0,True,0.0,True,0,TUNE)
 best=1e9
 for it in range(3):
     torch.cuda.synchronize(); t=time.perf_counter()
     rc=L.mi_degensac_find_fundamental_batch_dev(d_a.data_ptr(),d_b.data_ptr(),d_off.data_ptr(),offs.ctypes.data_as(C.POINTER(C.c_int64)),P,2,C.byref(prm),d_seeds.data_ptr(),0,None,d_F.data_ptr(),d_mask.data_ptr(),d_st.data_ptr())
     torch.cuda.synchronize(); dt=time.perf_counter()-t; best=min(best,dt)
 st=d_st.cpu().numpy()
-th=C.c_int(0); md=C.c_int(0); L.mi_degensac_debug_last_launch(C.byref(th),C.byref(md))
-print(f"variant={th.value} mode={md.value} P={P} rc={rc} batch_ms={best*1e3:.1f} models/s={st[:,4].sum()/best/1e6:.2f}M pairs/s={P/best:.0f} sumI={st[:,3].sum()} ticks_total mean ms={st[:,13].mean()/1e5:.2f} max={st[:,13].max()/1e5:.1f}")
+print(f"variant={st[0,14]} mode={st[0,15]} P={P} rc={rc} batch_ms={best*1e3:.1f} models/s={st[:,4].sum()/best/1e6:.2f}M pairs/s={P/best:.0f} sumI={st[:,3].sum()} ticks_total mean ms={st[:,13].mean()/1e5:.2f} max={st[:,13].max()/1e5:.1f}")

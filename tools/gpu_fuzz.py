@@ -11,17 +11,17 @@ def run(N, rng_seed, verbose=True):
     """Returns (cases with different results, cases where only sample / LO counters differ)."""
     rng = np.random.default_rng(rng_seed)
     bad = 0; bad_res = 0
-    saved = {k: os.environ.get(k) for k in ("MI_DEGENSAC_VARIANT", "MI_DEGENSAC_MODE")}
-    try:
+    if True:
         for case in range(N):
-            os.environ["MI_DEGENSAC_VARIANT"] = str(rng.choice([512, 256])); os.environ["MI_DEGENSAC_MODE"] = str(rng.choice([0, 1, 2]))
+            variant = int(rng.choice([512, 256])); mode = int(rng.choice([0, 1, 2]))
+            tn = {512: 1, 256: 2}[variant] | ((mode + 1) << 2)          # params.tuning: variant, placement (include/mi_degensac.h)
             seed = int(rng.integers(1, 2**31 - 1)); n = int(rng.choice([8, 20, 64, 150, 400, 1000, 2000, 3000]))
             mi = int(rng.choice([500, 3000, 20000]))
             if rng.random() < 0.6:
                 ir = float(rng.uniform(0.1, 0.8)); sg = float(rng.choice([0.05, 0.1, 0.5, 1.0])); pf = float(rng.choice([0.0, 0.0, 0.6, 0.9]))
                 et = int(rng.choice([0, 1])); sym = bool(rng.random() < 0.7); dg = bool(rng.random() < 0.7); th = float(rng.choice([0.5, 1.0, 2.0]))
                 p1, p2, _, _ = syn.two_view_fundamental(n, ir, sg, seed=case, plane_fraction=pf)
-                Mg, mg = pd.findFundamentalMatrix_(p1, p2, th, 0.9999, mi, et, sym, 0.0, dg, seed=seed); sg_ = pd.last_stats()
+                Mg, mg = pd.findFundamentalMatrix_(p1, p2, th, 0.9999, mi, et, sym, 0.0, dg, seed=seed, tuning=tn); sg_ = pd.last_stats()
                 Mo, mo, so = port.find_fundamental(p1, p2, th, 0.9999, mi, et, sym, 0.0, dg, seed=seed)
                 tag = f"F n={n} ir={ir:.2f} sig={sg} pf={pf} et={et} sym={sym} dg={dg} th={th} mi={mi}"
             else:
@@ -29,7 +29,7 @@ def run(N, rng_seed, verbose=True):
                 ir = float(rng.uniform(0.15, 0.8)); sg = float(rng.choice([0.2, 0.5, 1.0])); laf = bool(rng.random() < 0.5)
                 et = int(rng.integers(0, 5)); sym = bool(rng.random() < 0.7); th = float(rng.choice([1.0, 2.0, 4.0])); lc = 3.0 if laf else 0.0
                 p1, p2, _, _ = syn.homography_pairs(n, ir, sg, seed=case, laf=laf)
-                Mg, mg = pd.findHomography_(p1, p2, th, 0.999, mi, et, sym, lc, seed=seed); sg_ = pd.last_stats()
+                Mg, mg = pd.findHomography_(p1, p2, th, 0.999, mi, et, sym, lc, seed=seed, tuning=tn); sg_ = pd.last_stats()
                 Mo, mo, so = port.find_homography(p1, p2, th, 0.999, mi, et, sym, lc, seed=seed)
                 tag = f"H n={n} ir={ir:.2f} sig={sg} laf={laf} et={et} sym={sym} th={th} mi={mi}"
             Mg = np.asarray(Mg, dtype=float).ravel(); Mo = np.asarray(Mo, dtype=float).ravel()
@@ -41,12 +41,8 @@ def run(N, rng_seed, verbose=True):
             if not (res_ok and traj_ok):
                 bad += 1
                 if verbose:
-                    print("MISMATCH" if not res_ok else "trajectory-only", tag, "seed", seed, "variant", os.environ["MI_DEGENSAC_VARIANT"], "mode",
-                          os.environ["MI_DEGENSAC_MODE"], "gpu", sg_["samples"], sg_["lo_runs"], sg_["I"], "oracle", so["samples"], so["lo_runs"], so["I"], "rel", rel)
-    finally:
-        for k, v in saved.items():
-            if v is None: os.environ.pop(k, None)
-            else: os.environ[k] = v
+                    print("MISMATCH" if not res_ok else "trajectory-only", tag, "seed", seed, "variant", variant, "mode",
+                          mode, "gpu", sg_["samples"], sg_["lo_runs"], sg_["I"], "oracle", so["samples"], so["lo_runs"], so["I"], "rel", rel)
     return bad_res, bad - bad_res
 
 
