@@ -547,10 +547,16 @@ __global__ __launch_bounds__(DG_T, 2) void dg_find_homography_kernel(dg_args A)
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
     __shared__ dg_f_shared Sh;
     __shared__ int next_pair;
+    /* the device code reads the arguments through a pointer (dg_f_ctx::A, also inside non-inlined functions): give it an
+     * LDS copy, so the by-value kernel argument's address is never taken (that would make the compiler keep a private
+     * per-lane copy of the whole block in scratch memory and turn every uniform argument into a vector value) */
+    __shared__ dg_args As;
+    if (threadIdx.x == 0) As = A;
+    __syncthreads();
     for (;;) {
-        const int pair = dg_next_pair(A, &next_pair);
+        const int pair = dg_next_pair(As, &next_pair);
         if (pair < 0) break;
-        dg_h_pair<T, LDSPTS>(A, &Sh, dyn_smem, pair, (int)blockIdx.x);
+        dg_h_pair<T, LDSPTS>(As, &Sh, dyn_smem, pair, (int)blockIdx.x);
     }
 }
 
