@@ -53,7 +53,8 @@ extern "C" {
                                                  guards with an uninitialised variable (exp_ranF.c:1254,1725) */
 
 /* tuning word (0 = let the library decide; results never depend on it, only speed does):
- *   bits 0-1  kernel variant    1 = latency (512-thread workgroups)   2 = throughput (256-thread)
+ *   bits 0-1  kernel variant    1 = latency (512-thread workgroups)   2 = throughput (256-thread, 2 pairs per CU)
+ *                               3 = high throughput (128-thread, up to 4 pairs per CU)
  *   bits 2-3  placement         1 = points + sampler pool in HBM      2 = both in LDS      3 = pool in LDS
  *             (a placement that does not fit the device's LDS is ignored)
  *   bit  4    sampler           1 = always use the sequential pool-swap stage

@@ -4,7 +4,12 @@
 #define DG_KERNEL_COMMON_H
 #include "dg_geom.h"
 
-#define DG_CHUNK   256         /* minimal samples speculated per round (one per lane of the first 256)  */
+#ifndef DG_CHUNK
+#define DG_CHUNK   256         /* minimal samples speculated per round (one per lane of the first DG_CHUNK); a variant may choose less */
+#endif
+#ifndef DG_MINW
+#define DG_MINW    2           /* __launch_bounds__: minimum waves per SIMD the kernels are compiled for (register budget 512 / DG_MINW) */
+#endif
 #define DG_MCAP    96          /* models scored per LDS sub-batch                                  */
 #define DG_HT_CAP  4096        /* LO inlier-set hash entries per pair                              */
 

@@ -352,13 +352,16 @@ __device__ __noinline__ void dg_sample_pool_seq(int cn, int n, int *pool, int (*
 /* which wave scores group g (4 consecutive models).  With >= 6 waves the scoring waves 2.. share the groups round-robin
  * and the two sampler waves do not score (their stages are the critical path).  With 4 waves the pool-swap wave 0
  * (~57 us per chunk) still does not score; wave 1 (seeds + draws, ~44 us) takes 2 of every 16 groups (~7 us each),
- * waves 2 and 3 seven each. */
+ * waves 2 and 3 seven each.  With 2 waves (128-thread workgroups: four resident pairs per CU) both waves score,
+ * alternating groups, after their sampler stage. */
 __device__ __forceinline__ int dg_group_owner(int g)
 {
 #if DG_NW >= 6
     return 2 + g % (DG_NW - 2);
-#else
+#elif DG_NW >= 4
     return (int)((0x1132323232323232ull >> (4 * (g & 15))) & 15ull);   /* g & 15 = 0..15 -> 2,3,2,3,...,2,3,1,1 */
+#else
+    return g & 1;                                                      /* two waves: both score once their sampler stage is done */
 #endif
 }
 
@@ -723,7 +726,7 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
             } else if (wave == 1) {
                 if (cn2 > 0) { unsigned sd = dg_sample_draws<7>(seed, cn2, n, S->seeds3[nx2], S->draws3[nx2], S->alm3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }
             }
-            if (wave >= 2 || (DG_NW < 6 && wave == 1))
+            if (wave >= 2 || (DG_NW < 6 && wave == 1) || DG_NW < 4)
                 dg_score_chunk_F<LDSPTS>(P, n, c.gmodels, S->mslot, Mtot, wave, mk_full, th,
                                          maxS.J < maxSs.J ? maxS.J : maxSs.J, S->ext, (double *)(c.wstage + (size_t)wave * c.n_max), c.res_I, c.res_J, lane);
         }
@@ -1019,7 +1022,7 @@ __device__ __forceinline__ int dg_next_pair(const dg_args &A, int *bc /* LDS */)
 }
 
 template <int T, int LDSPTS>
-__global__ __launch_bounds__(DG_T, 2) void dg_find_fundamental_kernel(dg_args A)
+__global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_fundamental_kernel(dg_args A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
     __shared__ dg_f_shared Sh;

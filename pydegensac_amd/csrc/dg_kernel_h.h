@@ -9,6 +9,7 @@
 #ifndef DG_KERNEL_H_H
 #define DG_KERNEL_H_H
 #include "dg_kernel_f_main.h"
+#define DG_SW0 (DG_NW > 2 ? 2 : 0)          /* first scoring wave of the main loop */
 
 /* u2h (Htools.c:115-131) over a list of ids, reference summation order (see dg_lsq_seq) */
 template <class PtFn>
@@ -390,9 +391,10 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
                 if (chunk_s[nxt] > 0) dg_sample_pool<4, LDSPTS>(chunk_s[nxt], n, pool, S->draws3[nxt], S->alm3[nxt], pscr, lane, S->dbg);
             } else if (wave == 1) {
                 if (cn2 > 0) { unsigned sd = dg_sample_draws<4>(seed, cn2, n, S->seeds3[nx2], S->draws3[nx2], S->alm3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }
-            } else {
-                /* static round-robin over the scoring waves */
-                for (int mi = wave - 2; mi < Mtot; mi += DG_NW - 2) {
+            }
+            /* static round-robin over the scoring waves: waves 2.. when there are more than two, else both waves after their sampler stage */
+            if (wave >= DG_SW0) {
+                for (int mi = wave - DG_SW0; mi < Mtot; mi += DG_NW - DG_SW0) {
 
                     double H[9], Hinv[9], H1[9];
                     const double *g = c.gmodels + (size_t)mi * 18;
@@ -542,7 +544,7 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
 }
 
 template <int T, int LDSPTS>
-__global__ __launch_bounds__(DG_T, 2) void dg_find_homography_kernel(dg_args A)
+__global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_homography_kernel(dg_args A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
     __shared__ dg_f_shared Sh;

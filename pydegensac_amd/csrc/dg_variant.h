@@ -1,5 +1,6 @@
 /* Host-visible interface of one compiled kernel variant (workgroup size is a compile-time constant of the device
- * code, so each variant is its own translation unit: mi_degensac.hip = 512 threads, mi_degensac_t256.hip = 256). */
+ * code, so each variant is its own translation unit: mi_degensac.hip = 512 threads, mi_degensac_t256.hip = 256,
+ * mi_degensac_t128.hip = 128). */
 #ifndef DG_VARIANT_H
 #define DG_VARIANT_H
 #include <hip/hip_runtime.h>
@@ -18,4 +19,5 @@ enum { DG_MODE_HBM = 0, DG_MODE_LDS = 1, DG_MODE_POOL_LDS = 2 };
     hipError_t dg_variant_##T_##_launch(int homography, int mode, int grid, size_t dyn, hipStream_t stream, const dg_args &A);
 DG_VARIANT_DECL(512)
 DG_VARIANT_DECL(256)
+DG_VARIANT_DECL(128)
 #endif /* DG_VARIANT_H */

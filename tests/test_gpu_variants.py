@@ -1,4 +1,4 @@
-"""GPU: every kernel variant (512 / 256 threads per workgroup) and placement mode (0: points + pool in the HBM
+"""GPU: every kernel variant (512 / 256 / 128 threads per workgroup) and placement mode (0: points + pool in the HBM
 workspace, 1: both in LDS, 2: pool in LDS) returns the same bits, and the oracle agrees with them."""
 import numpy as np
 import pytest
@@ -8,7 +8,7 @@ from pydegensac_amd import _lib, synthetic as syn
 
 pytestmark = pytest.mark.gpu
 
-VARIANT = {512: _lib.TUNE_LATENCY, 256: _lib.TUNE_THROUGHPUT}
+VARIANT = {512: _lib.TUNE_LATENCY, 256: _lib.TUNE_THROUGHPUT, 128: _lib.TUNE_THROUGHPUT4}
 PLACE = {0: _lib.TUNE_PLACE_HBM, 1: _lib.TUNE_PLACE_LDS, 2: _lib.TUNE_PLACE_POOL_LDS}
 
 
@@ -27,7 +27,7 @@ def _f_batch():
 def test_fundamental_variants_and_modes_agree(oracle_port):
     A, B = _f_batch(); seeds = [1, 2, 3, 4]
     ref = None
-    for variant in (512, 256):
+    for variant in (512, 256, 128):
         for mode in (1, 2, 0):
             F, m = pd.findFundamentalMatrixBatch(A, B, max_iters=20000, seeds=seeds, tuning=tune(variant, mode))
             st = pd.last_stats()
@@ -49,7 +49,7 @@ def test_homography_variants_and_modes_agree():
     for i, n in enumerate([1200, 400, 2500]):
         p1, p2, _, _ = syn.homography_pairs(n, 0.4, 0.5, seed=30 + i, laf=True); A.append(p1); B.append(p2)
     ref = None
-    for variant in (512, 256):
+    for variant in (512, 256, 128):
         for mode in (1, 2, 0):
             H, m = pd.findHomographyBatch(A, B, 1.0, 0.999, 20000, 3.0, "sampson", True, seeds=[5, 6, 7], tuning=tune(variant, mode))
             assert all(s_["threads"] == variant for s_ in pd.last_stats())      # n = 2500 does not fit "both in LDS" at 512 threads
@@ -71,7 +71,7 @@ def test_sequential_pool_stage_fallback_matches_goldens():
         g = gu.load(path); kw = g["call"]
         if g["n"] <= 10:
             continue
-        for variant in (512, 256):
+        for variant in (512, 256, 128):
             t = VARIANT[variant] | _lib.TUNE_SEQ_POOL
             if g["kind"] == "F":
                 M, m = pd.findFundamentalMatrix_(g["p1"], g["p2"], kw.get("px_th", 0.5), kw.get("conf", 0.9999), kw.get("max_iters", 100000),

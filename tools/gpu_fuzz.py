@@ -13,8 +13,8 @@ def run(N, rng_seed, verbose=True):
     bad = 0; bad_res = 0
     if True:
         for case in range(N):
-            variant = int(rng.choice([512, 256])); mode = int(rng.choice([0, 1, 2]))
-            tn = {512: 1, 256: 2}[variant] | ((mode + 1) << 2)          # params.tuning: variant, placement (include/mi_degensac.h)
+            variant = int(rng.choice([512, 256, 128])); mode = int(rng.choice([0, 1, 2]))
+            tn = {512: 1, 256: 2, 128: 3}[variant] | ((mode + 1) << 2)          # params.tuning: variant, placement (include/mi_degensac.h)
             seed = int(rng.integers(1, 2**31 - 1)); n = int(rng.choice([8, 20, 64, 150, 400, 1000, 2000, 3000]))
             mi = int(rng.choice([500, 3000, 20000]))
             if rng.random() < 0.6:
