@@ -104,7 +104,7 @@ __device__ __forceinline__ dg_pass_res dg_f_pass(CTX &c, const double *Fm /* LDS
     const dg_pt *P = c.P;
     /* ordered MSAC terms: the per-wave solver scratch is idle during a workgroup pass (LDS); HBM staging area otherwise */
     cfg.jbuf = (size_t)cfg.n * sizeof(double) <= DG_JBUF_LDS_BYTES ? (double *)c.S->ww : (double *)c.stage;
-    return dg_pass(&c.S->red, cfg, [&](int pid, int) { return dg_Ferr(kind, F, P[pid]); }, c.tid);
+    return dg_pass(&c.S->red, cfg, [&](int pid, int) { return dg_Ferr(kind, F, dg_ldpt<LDSPTS>(P, pid)); }, c.tid);
 }
 template <int LDSPTS>
 __device__ __forceinline__ dg_pass_res dg_h_pass(CTX &c, const double *Hm /* LDS */, dg_pass_cfg cfg)
@@ -115,7 +115,7 @@ __device__ __forceinline__ dg_pass_res dg_h_pass(CTX &c, const double *Hm /* LDS
     const dg_pt *P = c.P;
     /* ordered MSAC terms: the per-wave solver scratch is idle during a workgroup pass (LDS); HBM staging area otherwise */
     cfg.jbuf = (size_t)cfg.n * sizeof(double) <= DG_JBUF_LDS_BYTES ? (double *)c.S->ww : (double *)c.stage;
-    return dg_pass(&c.S->red, cfg, [&](int pid, int) { dg_pt p = P[pid]; return dg_HDs(H, p.x1, p.y1, p.x2, p.y2); }, c.tid);
+    return dg_pass(&c.S->red, cfg, [&](int pid, int) { dg_pt p = dg_ldpt<LDSPTS>(P, pid); return dg_HDs(H, p.x1, p.y1, p.x2, p.y2); }, c.tid);
 }
 __device__ __forceinline__ dg_pass_cfg dg_cfg0(int n)
 {
@@ -127,14 +127,14 @@ __device__ __forceinline__ dg_pass_cfg dg_cfg0(int n)
 template <int LDSPTS>
 __device__ __forceinline__ void dg_gather(CTX &c, const int *ids, int len, double *px)
 {
-    for (int i = 0; i < len; i++) { dg_pt p = c.P[ids[i]]; px[4*i] = p.x1; px[4*i+1] = p.y1; px[4*i+2] = p.x2; px[4*i+3] = p.y2; }
+    for (int i = 0; i < len; i++) { dg_pt p = dg_ldpt<LDSPTS>(c.P, ids[i]); px[4*i] = p.x1; px[4*i+1] = p.y1; px[4*i+2] = p.x2; px[4*i+3] = p.y2; }
 }
 
 /* lane j < len writes the coordinates of point `id` (its own) to row j of px */
 template <int LDSPTS>
 __device__ __forceinline__ void dg_gather_wave(CTX &c, int id, int len, double *px, int lane)
 {
-    if (lane < len) { dg_pt p = c.P[id]; px[4*lane] = p.x1; px[4*lane+1] = p.y1; px[4*lane+2] = p.x2; px[4*lane+3] = p.y2; }
+    if (lane < len) { dg_pt p = dg_ldpt<LDSPTS>(c.P, id); px[4*lane] = p.x1; px[4*lane+1] = p.y1; px[4*lane+2] = p.x2; px[4*lane+3] = p.y2; }
 }
 
 /* u2f on a global id list of any length -> S->f  (exp_ranF.c's u2f(u, inliers, n, f, buffer) calls) */
@@ -148,7 +148,7 @@ __device__ __forceinline__ void dg_u2f_list(CTX &c, const int *list, int len, co
             const int lane = c.tid;
             dg_gather_wave(c, lane < len ? list[lane] : 0, len, S->lsq.px, lane);
             if (wmodel && lane < len) {
-                dg_pt q = c.P[list[lane]];
+                dg_pt q = dg_ldpt<LDSPTS>(c.P, list[lane]);
                 if (wkind == DG_K_FDS) S->lsq.part[0][lane] = dg_exFDs_w(wmodel, q.x1, q.y1, q.x2, q.y2);
                 else { double w; dg_exFDsSym(wmodel, q.x1, q.y1, q.x2, q.y2, &w); S->lsq.part[0][lane] = w; }
             }
@@ -158,7 +158,7 @@ __device__ __forceinline__ void dg_u2f_list(CTX &c, const int *list, int len, co
         __syncthreads();
     } else {
         const dg_pt *P = c.P;
-        dg_u2f_big(&S->red, &S->lsq, [&](int i) { return P[i]; }, list, len, c.tid, Fout, c.stage, c.n_max);
+        dg_u2f_big(&S->red, &S->lsq, [&](int i) { return dg_ldpt<LDSPTS>(P, i); }, list, len, c.tid, Fout, c.stage, c.n_max);
     }
 }
 
@@ -339,7 +339,7 @@ __device__ __noinline__ unsigned dg_innerH(CTX &c, double *H /* LDS, in/out */, 
         unsigned cnt = 0;
         for (int base = 0; base < n; base += DG_T) {
             int j = base + tid; bool in = false;
-            if (j < n) { dg_pt p = P[j]; in = dg_HDs(Hr, p.x1, p.y1, p.x2, p.y2) <= th; inl_flags[j] = in ? 1 : 0; }
+            if (j < n) { dg_pt p = dg_ldpt<LDSPTS>(P, j); in = dg_HDs(Hr, p.x1, p.y1, p.x2, p.y2) <= th; inl_flags[j] = in ? 1 : 0; }
             cnt += in ? 1u : 0u;
         }
         cnt = dg_block_sum_u(&c.S->red, cnt, tid);
@@ -349,23 +349,37 @@ __device__ __noinline__ unsigned dg_innerH(CTX &c, double *H /* LDS, in/out */, 
 }
 
 /* ---- wave-level passes (one wave, no workgroup barriers) ------------------------------------------ */
-/* #points with Sampson error < thr (strict, DegUtils.c style) */
+/* #points with Sampson error < thr (strict, DegUtils.c style); DG_PU points per lane and step (loads in flight together) */
+template <int LDSPTS>
 __device__ __forceinline__ unsigned dg_wave_count_lt(const dg_pt *P, int n, const double *F, double thr, int lane)
 {
     unsigned cnt = 0;
-    for (int p = lane; p < n; p += 64) { dg_pt q = P[p]; cnt += dg_FDs(F, q.x1, q.y1, q.x2, q.y2) < thr ? 1u : 0u; }
+    for (int p0 = lane; p0 < n; p0 += 64 * DG_PU) {
+        dg_pt q[DG_PU];
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) { const int p = p0 + 64 * u; q[u] = dg_ldpt<LDSPTS>(P, p < n ? p : p0); }
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) cnt += (p0 + 64 * u < n && dg_FDs(F, q[u].x1, q[u].y1, q[u].x2, q[u].y2) < thr) ? 1u : 0u;
+    }
     return dg_wave_sum_u(cnt);
 }
 /* ordered id list of the points with error < thr; returns the count */
+template <int LDSPTS>
 __device__ __forceinline__ unsigned dg_wave_list_lt(const dg_pt *P, int n, const double *F, double thr, int *list, int lane)
 {
     unsigned off = 0;
-    for (int base = 0; base < n; base += 64) {
-        int p = base + lane; bool in = false;
-        if (p < n) { dg_pt q = P[p]; in = dg_FDs(F, q.x1, q.y1, q.x2, q.y2) < thr; }
-        unsigned long long b = __ballot(in);
-        if (in) list[off + (unsigned)__popcll(b & ((1ull << lane) - 1ull))] = p;
-        off += (unsigned)__popcll(b);
+    for (int base = 0; base < n; base += 64 * DG_PU) {
+        dg_pt q[DG_PU]; bool in[DG_PU];
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) { const int p = base + 64 * u + lane; q[u] = dg_ldpt<LDSPTS>(P, p < n ? p : 0); }
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) in[u] = base + 64 * u + lane < n && dg_FDs(F, q[u].x1, q[u].y1, q[u].x2, q[u].y2) < thr;
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) {
+            const unsigned long long b = __ballot(in[u]);
+            if (in[u]) list[off + (unsigned)__popcll(b & ((1ull << lane) - 1ull))] = base + 64 * u + lane;
+            off += (unsigned)__popcll(b);
+        }
     }
     return off;
 }
@@ -373,6 +387,7 @@ __device__ __forceinline__ unsigned dg_wave_list_lt(const dg_pt *P, int n, const
 /* ---- DegUtils.c:635-690 u2Fit, run by ONE wave on its own scratch -----------------------------------
  * F (LDS, 9) in/out.  Returns the count and *thf = the threshold the reference's `inl` flags correspond to
  * (th after the full schedule, the current ths on the "fewer than 8 inliers" early return). */
+template <int LDSPTS>
 __device__ __noinline__ unsigned dg_u2Fit_wave(dg_wave_ws *w, const dg_pt *P, int n, double *F, double th, double ths, unsigned iters,
                                               int *list, dg_pt *stage, int stage_cap, int lane, double *thf, int *n_aux)
 {
@@ -381,11 +396,11 @@ __device__ __noinline__ unsigned dg_u2Fit_wave(dg_wave_ws *w, const dg_pt *P, in
         double Fr[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) Fr[i] = F[i];
-        unsigned cnt = dg_wave_list_lt(P, n, Fr, ths, list, lane); (*n_aux)++;
+        unsigned cnt = dg_wave_list_lt<LDSPTS>(P, n, Fr, ths, list, lane); (*n_aux)++;
         if (cnt < 8) { *thf = ths; return cnt; }
         DG_WSYNC();
         if (cnt <= 14) {
-            if (lane < (int)cnt) { dg_pt q = P[list[lane]]; w->px[4*lane] = q.x1; w->px[4*lane+1] = q.y1; w->px[4*lane+2] = q.x2; w->px[4*lane+3] = q.y2; }
+            if (lane < (int)cnt) { dg_pt q = dg_ldpt<LDSPTS>(P, list[lane]); w->px[4*lane] = q.x1; w->px[4*lane+1] = q.y1; w->px[4*lane+2] = q.x2; w->px[4*lane+3] = q.y2; }
             DG_WSYNC();
             if (cnt > 8) dg_u2f_norm_w(w, w->px, (const double *)0, (int)cnt, F, lane);
             else {
@@ -397,7 +412,7 @@ __device__ __noinline__ unsigned dg_u2Fit_wave(dg_wave_ws *w, const dg_pt *P, in
                 DG_WSYNC();
             }
         } else {
-            for (int j = lane; j < (int)cnt; j += 64) stage[j] = P[list[j]];
+            for (int j = lane; j < (int)cnt; j += 64) stage[j] = dg_ldpt<LDSPTS>(P, list[j]);
             DG_WSYNC();
             if (2 * stage_cap >= 3 * (int)cnt) dg_lsq_seq_par(w, stage, (int)cnt, lane, 64, 0, w->A1, w->A2, [] { DG_WSYNC(); });
             else dg_lsq_seq_core(w, stage, (int)cnt, lane, 0, w->A1, w->A2);
@@ -416,7 +431,7 @@ __device__ __noinline__ unsigned dg_u2Fit_wave(dg_wave_ws *w, const dg_pt *P, in
     double Fr[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) Fr[i] = F[i];
-    unsigned cnt = dg_wave_count_lt(P, n, Fr, th, lane); (*n_aux)++;
+    unsigned cnt = dg_wave_count_lt<LDSPTS>(P, n, Fr, th, lane); (*n_aux)++;
     *thf = th;
     return cnt;
 }
@@ -472,13 +487,13 @@ __device__ __noinline__ void dg_innerFH(CTX &c, const int *idxH, unsigned lenH, 
     /* 10-point model + its consensus, one wave per repetition */
     for (unsigned rep = wave; rep < repCount; rep += DG_NW) {
         dg_wave_ws *w = &S->ww[wave];
-        if (lane < 10) { dg_pt q = P[S->fhIds[rep][lane]]; w->px[4*lane] = q.x1; w->px[4*lane+1] = q.y1; w->px[4*lane+2] = q.x2; w->px[4*lane+3] = q.y2; }
+        if (lane < 10) { dg_pt q = dg_ldpt<LDSPTS>(P, S->fhIds[rep][lane]); w->px[4*lane] = q.x1; w->px[4*lane+1] = q.y1; w->px[4*lane+2] = q.x2; w->px[4*lane+3] = q.y2; }
         DG_WSYNC();
         dg_u2f_norm_w(w, w->px, (const double *)0, 10, S->fhF[rep], lane);
         double Fr[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) Fr[i] = S->fhF[rep][i];
-        unsigned cnt = dg_wave_count_lt(P, n, Fr, th, lane);
+        unsigned cnt = dg_wave_count_lt<LDSPTS>(P, n, Fr, th, lane);
         if (lane == 0) { S->fhCnt[rep] = (int)cnt; S->fhCnt2[rep] = -1; }
         DG_WSYNC();
     }
@@ -493,7 +508,7 @@ __device__ __noinline__ void dg_innerFH(CTX &c, const int *idxH, unsigned lenH, 
         if (lane < 9) S->fhF2[rep][lane] = S->fhF[rep][lane];
         DG_WSYNC();
         double thf;
-        unsigned cnt = dg_u2Fit_wave(&S->ww[wave], P, n, S->fhF2[rep], th, th*3, 4, c.wlist + (size_t)wave * c.n_max, c.wstage + (size_t)wave * c.n_max, c.n_max, lane, &thf, &aux_local);
+        unsigned cnt = dg_u2Fit_wave<LDSPTS>(&S->ww[wave], P, n, S->fhF2[rep], th, th*3, 4, c.wlist + (size_t)wave * c.n_max, c.wstage + (size_t)wave * c.n_max, c.n_max, lane, &thf, &aux_local);
         if (lane == 0) { S->fhCnt2[rep] = (int)cnt; S->fhTh[rep] = thf; S->itmp[8 + wave] = aux_local; }
         DG_WSYNC();
     }
@@ -518,7 +533,7 @@ __device__ __noinline__ void dg_innerFH(CTX &c, const int *idxH, unsigned lenH, 
 #pragma unroll
         for (int i = 0; i < 9; i++) Fr[i] = Fb[i];
         if (tid < 9) F[tid] = Fr[tid];
-        for (int j = tid; j < n; j += DG_T) { dg_pt q = P[j]; inl[j] = dg_FDs(Fr, q.x1, q.y1, q.x2, q.y2) < thb ? 1 : 0; }
+        for (int j = tid; j < n; j += DG_T) { dg_pt q = dg_ldpt<LDSPTS>(P, j); inl[j] = dg_FDs(Fr, q.x1, q.y1, q.x2, q.y2) < thb ? 1 : 0; }
     }
     __syncthreads();
 }
@@ -557,7 +572,7 @@ __device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, doub
     unsigned nhinlCount, hinlCount;
     {
         dg_pass_cfg cfg = dg_cfg0(n); cfg.list = idxN; cfg.thL = 0.5; cfg.flags = nhinl; cfg.thF = 0.5;
-        dg_pass_res r = dg_pass(&S->red, cfg, [&](int pid, int) { dg_pt p = P[pid]; return dg_HDs(Hr, p.x1, p.y1, p.x2, p.y2) > 100*th ? 0.0 : 1.0; }, tid);
+        dg_pass_res r = dg_pass(&S->red, cfg, [&](int pid, int) { dg_pt p = dg_ldpt<LDSPTS>(P, pid); return dg_HDs(Hr, p.x1, p.y1, p.x2, p.y2) > 100*th ? 0.0 : 1.0; }, tid);
         c.n_hds++;
         nhinlCount = r.nL;
         dg_pass_cfg cfg2 = dg_cfg0(n); cfg2.list = idxH; cfg2.thL = 0.5;
@@ -592,9 +607,17 @@ __device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, doub
         /* one wave per candidate: #off-plane points with Sampson error < 2 th */
         for (int b = wave; b < B; b += DG_NW) {
             double aFt[9];
-            dg_rFtH_aFt<LDSPTS>(Hr, P[c.rf[b][0]], P[c.rf[b][1]], aFt);
+            dg_rFtH_aFt<LDSPTS>(Hr, dg_ldpt<LDSPTS>(P, c.rf[b][0]), dg_ldpt<LDSPTS>(P, c.rf[b][1]), aFt);
             unsigned cnt = 0;
-            for (int j = lane; j < (int)nhinlCount; j += 64) { dg_pt p = P[idxN[j]]; cnt += dg_FDs(aFt, p.x1, p.y1, p.x2, p.y2) < th*2 ? 1u : 0u; }
+            for (int j0 = lane; j0 < (int)nhinlCount; j0 += 64 * DG_PU) {     /* ids, then points, of DG_PU tiles in flight together */
+                int id[DG_PU]; dg_pt q[DG_PU];
+#pragma unroll
+                for (int u = 0; u < DG_PU; u++) { const int j = j0 + 64 * u; id[u] = idxN[j < (int)nhinlCount ? j : j0]; }
+#pragma unroll
+                for (int u = 0; u < DG_PU; u++) q[u] = dg_ldpt<LDSPTS>(P, id[u]);
+#pragma unroll
+                for (int u = 0; u < DG_PU; u++) cnt += (j0 + 64 * u < (int)nhinlCount && dg_FDs(aFt, q[u].x1, q[u].y1, q[u].x2, q[u].y2) < th*2) ? 1u : 0u;
+            }
             cnt = dg_wave_sum_u(cnt);
             if (lane == 0) c.rf[b][4] = (int)cnt;
         }
@@ -621,10 +644,10 @@ __device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, doub
         no_sam += bE + 1; c.n_aux += (int)bE + 1;
         {
             double aFt[9];
-            dg_rFtH_aFt<LDSPTS>(Hr, P[c.rf[bE][0]], P[c.rf[bE][1]], aFt);
+            dg_rFtH_aFt<LDSPTS>(Hr, dg_ldpt<LDSPTS>(P, c.rf[bE][0]), dg_ldpt<LDSPTS>(P, c.rf[bE][1]), aFt);
             /* v = Ds < 2 th ; uV = uN(:, v) */
             dg_pass_cfg cfg = dg_cfg0((int)nhinlCount); cfg.src = idxN; cfg.flags = vN; cfg.thF = th*2;
-            dg_pass(&S->red, cfg, [&](int pid, int) { dg_pt p = P[pid]; return dg_FDs(aFt, p.x1, p.y1, p.x2, p.y2); }, tid);
+            dg_pass(&S->red, cfg, [&](int pid, int) { dg_pt p = dg_ldpt<LDSPTS>(P, pid); return dg_FDs(aFt, p.x1, p.y1, p.x2, p.y2); }, tid);
             const unsigned char *vf = vN;
             dg_pass_cfg cf2 = dg_cfg0((int)nhinlCount); cf2.src = idxN; cf2.list = idxV; cf2.thL = 0.5;
             dg_pass_res rv = dg_pass(&S->red, cf2, [&](int, int pos) { return vf[pos] ? 0.0 : 1.0; }, tid);

@@ -113,7 +113,7 @@ __device__ __forceinline__ dg_score dg_iterF(CTX &c, int *inliers, double th, do
             else id = tid < cnt ? alt[tid] : 0;
             /* u2fw: weights are exFDs' w of the current model at the subset points */
             if (tid < use) {
-                dg_pt q = c.P[id];
+                dg_pt q = dg_ldpt<LDSPTS>(c.P, id);
                 double *px = S->lsq.px + 4*tid; px[0] = q.x1; px[1] = q.y1; px[2] = q.x2; px[3] = q.y2;
                 if (mk_ex == DG_K_FDS) S->lsq.part[0][tid] = dg_exFDs_w(fl, q.x1, q.y1, q.x2, q.y2);
                 else { double w; dg_exFDsSym(fl, q.x1, q.y1, q.x2, q.y2, &w); S->lsq.part[0][tid] = w; }
@@ -414,16 +414,22 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
                 for (int j = 0; j < 9; j++) Ff[g][j] = (float)f[j];
             }
             unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-            for (int p = lane; p < n; p += 64) {
-                const dg_pt q = P[p];
-                const float x1 = (float)q.x1, y1 = (float)q.y1, x2 = (float)q.x2, y2 = (float)q.y2;
 #define DG_R32(f_) fabsf(__builtin_fmaf(x1, __builtin_fmaf((f_)[0], x2, __builtin_fmaf((f_)[3], y2, (f_)[6])), \
                          __builtin_fmaf(y1, __builtin_fmaf((f_)[1], x2, __builtin_fmaf((f_)[4], y2, (f_)[7])), \
                                         __builtin_fmaf((f_)[2], x2, __builtin_fmaf((f_)[5], y2, (f_)[8])))))
-                c0 += !(DG_R32(Ff[0]) >= thr[0]) ? 1u : 0u; c1 += !(DG_R32(Ff[1]) >= thr[1]) ? 1u : 0u;
-                c2 += !(DG_R32(Ff[2]) >= thr[2]) ? 1u : 0u; c3 += !(DG_R32(Ff[3]) >= thr[3]) ? 1u : 0u;
-#undef DG_R32
+            for (int p0 = lane; p0 < n; p0 += 64 * DG_PU) {
+                dg_pt qq[DG_PU];
+#pragma unroll
+                for (int u = 0; u < DG_PU; u++) { const int p = p0 + 64 * u; qq[u] = dg_ldpt<LDSPTS>(P, p < n ? p : p0); }
+#pragma unroll
+                for (int u = 0; u < DG_PU; u++) {
+                    const unsigned on = p0 + 64 * u < n ? 1u : 0u;
+                    const float x1 = (float)qq[u].x1, y1 = (float)qq[u].y1, x2 = (float)qq[u].x2, y2 = (float)qq[u].y2;
+                    c0 += !(DG_R32(Ff[0]) >= thr[0]) ? on : 0u; c1 += !(DG_R32(Ff[1]) >= thr[1]) ? on : 0u;
+                    c2 += !(DG_R32(Ff[2]) >= thr[2]) ? on : 0u; c3 += !(DG_R32(Ff[3]) >= thr[3]) ? on : 0u;
+                }
             }
+#undef DG_R32
             const unsigned C1[4] = {dg_wave_sum_u(c0), dg_wave_sum_u(c1), dg_wave_sum_u(c2), dg_wave_sum_u(c3)};
 #pragma unroll
             for (int g = 0; g < 4; g++)
@@ -431,10 +437,16 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
         }
         if (use_bound && surv) {
             unsigned cb0 = 0, cb1 = 0, cb2 = 0, cb3 = 0;
-            for (int p = lane; p < n; p += 64) {
-                const dg_pt q = P[p];
-                cb0 += dg_Fbound(kind, F[0], q, t94b); cb1 += dg_Fbound(kind, F[1], q, t94b);
-                cb2 += dg_Fbound(kind, F[2], q, t94b); cb3 += dg_Fbound(kind, F[3], q, t94b);
+            for (int p0 = lane; p0 < n; p0 += 64 * DG_PU) {
+                dg_pt qq[DG_PU];
+#pragma unroll
+                for (int u = 0; u < DG_PU; u++) { const int p = p0 + 64 * u; qq[u] = dg_ldpt<LDSPTS>(P, p < n ? p : p0); }
+#pragma unroll
+                for (int u = 0; u < DG_PU; u++) {
+                    const unsigned on = p0 + 64 * u < n ? 1u : 0u;
+                    cb0 += dg_Fbound(kind, F[0], qq[u], t94b) & on; cb1 += dg_Fbound(kind, F[1], qq[u], t94b) & on;
+                    cb2 += dg_Fbound(kind, F[2], qq[u], t94b) & on; cb3 += dg_Fbound(kind, F[3], qq[u], t94b) & on;
+                }
             }
             const unsigned CB[4] = {dg_wave_sum_u(cb0), dg_wave_sum_u(cb1), dg_wave_sum_u(cb2), dg_wave_sum_u(cb3)};
 #pragma unroll
@@ -447,15 +459,22 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
             /* exact score: I, and J as the reference's sequential sum (dg_seq_sum): the wave stores the nonzero terms in
              * point order, lane 0 adds them one after the other */
             unsigned cI = 0, cnt = 0;
-            for (int base = 0; base < n; base += 64) {
-                const int p = base + lane; const bool act = p < n; double d = 0;
-                if (act) { dg_pt q = P[p]; d = dg_Ferr(kind, F[g], q); }
-                double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
-                cI += (act && d <= th) ? 1u : 0u;
-                const bool nz = !(term == 0.0);
-                const unsigned long long bJ = __ballot(nz);
-                if (nz) jbuf[cnt + (unsigned)__popcll(bJ & ((1ull << lane) - 1ull))] = term;
-                cnt += (unsigned)__popcll(bJ);
+            for (int base = 0; base < n; base += 64 * DG_PU) {
+                dg_pt qq[DG_PU]; double dd[DG_PU];
+#pragma unroll
+                for (int u = 0; u < DG_PU; u++) { const int p = base + 64 * u + lane; qq[u] = dg_ldpt<LDSPTS>(P, p < n ? p : 0); }
+#pragma unroll
+                for (int u = 0; u < DG_PU; u++) dd[u] = dg_Ferr(kind, F[g], qq[u]);
+#pragma unroll
+                for (int u = 0; u < DG_PU; u++) {
+                    const bool act = base + 64 * u + lane < n; const double d = dd[u];
+                    double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
+                    cI += (act && d <= th) ? 1u : 0u;
+                    const bool nz = !(term == 0.0);
+                    const unsigned long long bJ = __ballot(nz);
+                    if (nz) jbuf[cnt + (unsigned)__popcll(bJ & ((1ull << lane) - 1ull))] = term;
+                    cnt += (unsigned)__popcll(bJ);
+                }
             }
             DG_WSYNC();
             double J = 0.0; if (lane == 0) J = dg_seq_sum(jbuf, (int)cnt);
@@ -796,7 +815,7 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
                     if (pr.degen) {
                         __syncthreads();
                         if (tid < 7) {                                 /* u7 in samidx order = reverse draw order */
-                            dg_pt q = P[c.draws[k][6 - tid]];
+                            dg_pt q = dg_ldpt<LDSPTS>(P, c.draws[k][6 - tid]);
                             S->u7[tid][0] = q.x1; S->u7[tid][1] = q.y1; S->u7[tid][2] = q.x2; S->u7[tid][3] = q.y2;
                         }
                         __syncthreads();
@@ -901,7 +920,7 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
         {
             int dgn = 0;
             if (pr.degen) {
-                if (tid < 7) { dg_pt q = P[S->samidxBest[tid]]; S->u7[tid][0] = q.x1; S->u7[tid][1] = q.y1; S->u7[tid][2] = q.x2; S->u7[tid][3] = q.y2; }
+                if (tid < 7) { dg_pt q = dg_ldpt<LDSPTS>(P, S->samidxBest[tid]); S->u7[tid][0] = q.x1; S->u7[tid][1] = q.y1; S->u7[tid][2] = q.x2; S->u7[tid][3] = q.y2; }
                 __syncthreads();
                 dgn = dg_checksample(c, S->FBest, S->u7, 3*th, S->H);
             }
@@ -972,7 +991,7 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
     } else {
         double F[9];
         for (int i = 0; i < 9; i++) F[i] = S->F[i];
-        for (int j = tid; j < n; j += DG_T) mask[j] = dg_Ferr(finKind, F, P[j]) <= th ? 1 : 0;
+        for (int j = tid; j < n; j += DG_T) mask[j] = dg_Ferr(finKind, F, dg_ldpt<LDSPTS>(P, j)) <= th ? 1 : 0;
         __syncthreads();
         if (doSym || (doLaf && pr.final_laf_filter)) {
             dg_pass_cfg cl = dg_cfg0(n); cl.list = c.L[0]; cl.thL = th;
@@ -980,7 +999,7 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
             const int cnt = (int)rl.nL; const int *lst = c.L[0];
             /* clears list POSITION j, not lst[j]: exp_ranF.c:1719-1721 */
             if (doSym)
-                for (int j = tid; j < cnt; j += DG_T) if (dg_Ferr(DG_K_FSYM, F, P[lst[j]]) > pr.sym_th) mask[j] = 0;
+                for (int j = tid; j < cnt; j += DG_T) if (dg_Ferr(DG_K_FSYM, F, dg_ldpt<LDSPTS>(P, lst[j])) > pr.sym_th) mask[j] = 0;
             if (doLaf && pr.final_laf_filter) {
                 double thl = pr.laf_coef * th;
                 for (int j = tid; j < cnt; j += DG_T) {

@@ -36,7 +36,7 @@ __device__ __forceinline__ void dg_u2h_list(CTX &c, const int *list, int len, do
         __syncthreads();
     } else {
         const dg_pt *P = c.P;
-        dg_u2h_big(&S->red, &S->lsq, [&](int i) { return P[i]; }, list, len, c.tid, Hout, c.stage, c.n_max);
+        dg_u2h_big(&S->red, &S->lsq, [&](int i) { return dg_ldpt<LDSPTS>(P, i); }, list, len, c.tid, Hout, c.stage, c.n_max);
     }
 }
 
@@ -56,7 +56,7 @@ __device__ __forceinline__ dg_pass_res dg_hm_pass(CTX &c, int kind, const double
     const dg_pt *P = c.P;
     /* ordered MSAC terms: the per-wave solver scratch is idle during a workgroup pass (LDS); HBM staging area otherwise */
     cfg.jbuf = (size_t)cfg.n * sizeof(double) <= DG_JBUF_LDS_BYTES ? (double *)c.S->ww : (double *)c.stage;
-    return dg_pass(&S->red, cfg, [&](int pid, int) { return dg_Herr(kind, H, Hinv, H1, P[pid]); }, c.tid);
+    return dg_pass(&S->red, cfg, [&](int pid, int) { return dg_Herr(kind, H, Hinv, H1, dg_ldpt<LDSPTS>(P, pid)); }, c.tid);
 }
 
 /* symmetric (HDsSymMaxidx, eps variant) and LAF (HDSi1 on u_1, u_2) consistency of model h over the ids
@@ -76,7 +76,7 @@ __device__ __forceinline__ int dg_h_checks(CTX &c, int kind, const double *h /* 
     const dg_pt *P = c.P;
     if (pr.sym_th > 0) {
         dg_pass_cfg cfg = dg_cfg0(cnt); cfg.src = list; cfg.wantC = 1; cfg.thC = pr.sym_th;
-        dg_pass_res r = dg_pass(&Sh->red, cfg, [&](int pid, int) { dg_pt p = P[pid]; return dg_Hsym(Hinv, H1, p.x1, p.y1, p.x2, p.y2, 2, 1); }, c.tid);
+        dg_pass_res r = dg_pass(&Sh->red, cfg, [&](int pid, int) { dg_pt p = dg_ldpt<LDSPTS>(P, pid); return dg_Hsym(Hinv, H1, p.x1, p.y1, p.x2, p.y2, 2, 1); }, c.tid);
         S.Is = r.C;
         if (S.Is < maxS.Is) return 0;
     }
@@ -84,12 +84,12 @@ __device__ __forceinline__ int dg_h_checks(CTX &c, int kind, const double *h /* 
         double thl = pr.laf_coef * pr.th;
         dg_pass_cfg cfg = dg_cfg0(cnt); cfg.src = list; cfg.wantC = 1; cfg.thC = thl;
         dg_pass_res r1 = dg_pass(&Sh->red, cfg, [&](int pid, int) {
-            dg_pt o = P[pid], l = c.laf_pt(pid, 1);
+            dg_pt o = dg_ldpt<LDSPTS>(P, pid), l = c.laf_pt(pid, 1);
             return kind == 0 ? dg_HDs_mixed(H, o.x1, o.y1, o.x2, o.y2, l.x1, l.y1, l.x2, l.y2) : dg_Hsym(Hinv, H1, l.x1, l.y1, l.x2, l.y2, kind, 1); }, c.tid);
         *p1_inliers += (int)r1.C;
         if (early_p1 && *p1_inliers < (int)maxS.Ilafs) return 0;
         dg_pass_res r2 = dg_pass(&Sh->red, cfg, [&](int pid, int) {
-            dg_pt o = P[pid], l = c.laf_pt(pid, 2);
+            dg_pt o = dg_ldpt<LDSPTS>(P, pid), l = c.laf_pt(pid, 2);
             return kind == 0 ? dg_HDs_mixed(H, o.x1, o.y1, o.x2, o.y2, l.x1, l.y1, l.x2, l.y2) : dg_Hsym(Hinv, H1, l.x1, l.y1, l.x2, l.y2, kind, 1); }, c.tid);
         S.Ilafs = (int)r2.C < *p1_inliers ? r2.C : (unsigned)*p1_inliers;
         if (S.Ilafs < maxS.Ilafs) return 0;
@@ -404,15 +404,22 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
                     /* I, and J as the reference's sequential sum (dg_seq_sum) over the nonzero terms in point order */
                     unsigned cI = 0, cnt = 0; const double t94 = th * 9 / 4;
                     double *jbuf = (double *)(c.wstage + (size_t)wave * c.n_max);
-                    for (int base = 0; base < n; base += 64) {
-                        const int p = base + lane; const bool act = p < n; double d = 0;
-                        if (act) { dg_pt q = P[p]; d = dg_Herr(kind, H, Hinv, H1, q); }
-                        double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
-                        cI += (act && d <= th) ? 1u : 0u;
-                        const bool nz = !(term == 0.0);
-                        const unsigned long long bJ = __ballot(nz);
-                        if (nz) jbuf[cnt + (unsigned)__popcll(bJ & ((1ull << lane) - 1ull))] = term;
-                        cnt += (unsigned)__popcll(bJ);
+                    for (int base = 0; base < n; base += 64 * DG_PU) {
+                        dg_pt qq[DG_PU]; double dd[DG_PU];
+#pragma unroll
+                        for (int u = 0; u < DG_PU; u++) { const int p = base + 64 * u + lane; qq[u] = dg_ldpt<LDSPTS>(P, p < n ? p : 0); }
+#pragma unroll
+                        for (int u = 0; u < DG_PU; u++) dd[u] = dg_Herr(kind, H, Hinv, H1, qq[u]);
+#pragma unroll
+                        for (int u = 0; u < DG_PU; u++) {
+                            const bool act = base + 64 * u + lane < n; const double d = dd[u];
+                            double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
+                            cI += (act && d <= th) ? 1u : 0u;
+                            const bool nz = !(term == 0.0);
+                            const unsigned long long bJ = __ballot(nz);
+                            if (nz) jbuf[cnt + (unsigned)__popcll(bJ & ((1ull << lane) - 1ull))] = term;
+                            cnt += (unsigned)__popcll(bJ);
+                        }
                     }
                     DG_WSYNC();
                     double J = 0.0; if (lane == 0) J = dg_seq_sum(jbuf, (int)cnt);
@@ -520,7 +527,7 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
         for (int i = 0; i < 9; i++) { H[i] = S->F[i]; Hinv[i] = S->lsq.Z8[i]; H1[i] = S->lsq.Z8[9+i]; }
         const double thl = pr.laf_coef * th;
         for (int j = tid; j < n; j += DG_T) {
-            dg_pt p = P[j];
+            dg_pt p = dg_ldpt<LDSPTS>(P, j);
             int in = dg_Herr(kind, H, Hinv, H1, p) <= th;
             if (in && pr.sym_th > 0 && dg_Hsym(Hinv, H1, p.x1, p.y1, p.x2, p.y2, 2, 1) > pr.sym_th) in = 0;
             if (in && pr.laf_coef > 0) {

@@ -19,6 +19,26 @@
 
 struct dg_pt { double x1, y1, x2, y2; };           /* 32 B per correspondence */
 
+/* Load correspondence i of a point set whose placement is a compile-time property of the kernel instantiation
+ * (LDSPTS == 1: LDS, else the per-pair HBM workspace): address-space-qualified, so the access is a ds_read /
+ * global_load instead of a flat load through a generic pointer. */
+template <int LDSPTS>
+__device__ __forceinline__ dg_pt dg_ldpt(const dg_pt *P, int i)
+{
+    dg_pt r;
+    if (LDSPTS == 1) {
+        const __attribute__((address_space(3))) double *q = (const __attribute__((address_space(3))) double *)(P + i);
+        r.x1 = q[0]; r.y1 = q[1]; r.x2 = q[2]; r.y2 = q[3];
+    } else {
+        const __attribute__((address_space(1))) double *q = (const __attribute__((address_space(1))) double *)(P + i);
+        r.x1 = q[0]; r.y1 = q[1]; r.x2 = q[2]; r.y2 = q[3];
+    }
+    return r;
+}
+/* points per lane and step of the point loops: the loads of one step are issued back to back, so a pass over n points
+ * costs n / (64 * DG_PU) memory round trips per wave instead of n / 64 (the loops are latency-bound, not ALU-bound) */
+#define DG_PU 4
+
 /* ---- wave reductions on the VALU (DPP row rotates + 4 readlanes), no LDS traffic -------------------
  * Row step: rotate-add by 8,4,2,1 inside each 16-lane row leaves the row total in every lane of the row
  * (bitwise the same value in all 16 lanes: each step adds two values that are equal up to commutation).
@@ -77,7 +97,7 @@ __device__ __forceinline__ double dg_seq_sum(const double *t, int cnt)
 /* LDS block used by the reductions below (declared once per kernel) */
 struct dg_red {
     double   d[2][DG_NW][4];
-    unsigned u[2][DG_NW][4];
+    unsigned u[2][DG_NW][2 * DG_PU];   /* per-wave counts of one step of dg_pass (list, J) x DG_PU tiles; [0][w][0..3] also final counts */
     double   bc[96];          /* broadcast slots */
     int      bi[16];
 };
@@ -150,33 +170,51 @@ __device__ __forceinline__ dg_pass_res dg_pass(dg_red *r, const dg_pass_cfg &c, 
     const double t94 = c.thJ * 9 / 4;
     unsigned cI = 0, cC = 0, cF = 0, nJ = 0;
     int par = 0;
-    for (int base = 0; base < c.n; base += DG_T) {
-        int j = base + tid;
-        bool act = j < c.n;
-        int pid = act ? (c.src ? c.src[j] : j) : 0;
-        double d = act ? err(pid, j) : 0.0;
-        double term = 0.0; bool nz = false;
-        if (c.wantJ) {
-            if (act && c.thJ != 0 && !(d >= t94)) term = 1 - (d / t94);
-            nz = !(term == 0.0);                                   /* also true for NaN */
-            cI += (act && d <= c.thJ) ? 1u : 0u;
-        }
-        if (c.wantC) cC += (act && d <= c.thC) ? 1u : 0u;
-        if (c.flags) { bool f = act && d < c.thF; cF += f ? 1u : 0u; if (act) c.flags[j] = f ? 1 : 0; }
-        if (c.list || c.wantJ) {
-            /* ordered compaction (inlier ids, nonzero MSAC terms) needs the block's per-wave counts: one barrier per DG_T items */
-            bool in = c.list && act && (c.listStrict ? d < c.thL : d <= c.thL);
-            unsigned long long bL = __ballot(in), bJ = __ballot(nz);
-            if (lane == 0) { r->u[par][wave][2] = (unsigned)__popcll(bL); r->u[par][wave][3] = (unsigned)__popcll(bJ); }
-            __syncthreads();
-            unsigned lbase = out.nL, jbase = nJ;
+    /* one step = DG_PU consecutive tiles of DG_T items (item j of tile u belongs to thread j - u * DG_T): the id and
+     * point loads of the whole step are in flight together, and the ordered compactions of its tiles share one barrier */
+    for (int base = 0; base < c.n; base += DG_PU * DG_T) {
+        int jj[DG_PU], pid[DG_PU]; bool act[DG_PU]; double d[DG_PU];
 #pragma unroll
-            for (int w = 0; w < DG_NW; w++) {
-                if (w < wave) { lbase += r->u[par][w][2]; jbase += r->u[par][w][3]; }
-                out.nL += r->u[par][w][2]; nJ += r->u[par][w][3];
+        for (int u = 0; u < DG_PU; u++) { jj[u] = base + u * DG_T + tid; act[u] = jj[u] < c.n; }
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) pid[u] = act[u] ? (c.src ? c.src[jj[u]] : jj[u]) : 0;
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) d[u] = act[u] ? err(pid[u], jj[u]) : 0.0;
+        double term[DG_PU]; bool nz[DG_PU], in[DG_PU];
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) {
+            term[u] = 0.0; nz[u] = false;
+            if (c.wantJ) {
+                if (act[u] && c.thJ != 0 && !(d[u] >= t94)) term[u] = 1 - (d[u] / t94);
+                nz[u] = !(term[u] == 0.0);                          /* also true for NaN */
+                cI += (act[u] && d[u] <= c.thJ) ? 1u : 0u;
             }
-            if (in) c.list[lbase + (unsigned)__popcll(bL & ((1ull << lane) - 1ull))] = pid;
-            if (nz) c.jbuf[jbase + (unsigned)__popcll(bJ & ((1ull << lane) - 1ull))] = term;
+            if (c.wantC) cC += (act[u] && d[u] <= c.thC) ? 1u : 0u;
+            if (c.flags) { bool f = act[u] && d[u] < c.thF; cF += f ? 1u : 0u; if (act[u]) c.flags[jj[u]] = f ? 1 : 0; }
+            in[u] = c.list && act[u] && (c.listStrict ? d[u] < c.thL : d[u] <= c.thL);
+        }
+        if (c.list || c.wantJ) {
+            /* ordered compaction (inlier ids, nonzero MSAC terms) needs the per-wave counts of every tile: one barrier per step */
+            unsigned long long bL[DG_PU], bJ[DG_PU];
+#pragma unroll
+            for (int u = 0; u < DG_PU; u++) { bL[u] = __ballot(in[u]); bJ[u] = __ballot(nz[u]); }
+            if (lane == 0) {
+#pragma unroll
+                for (int u = 0; u < DG_PU; u++) { r->u[par][wave][2*u] = (unsigned)__popcll(bL[u]); r->u[par][wave][2*u+1] = (unsigned)__popcll(bJ[u]); }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < DG_PU; u++) {
+                unsigned lbase = out.nL, jbase = nJ;
+#pragma unroll
+                for (int w = 0; w < DG_NW; w++) {
+                    const unsigned a = r->u[par][w][2*u], b = r->u[par][w][2*u+1];
+                    if (w < wave) { lbase += a; jbase += b; }
+                    out.nL += a; nJ += b;
+                }
+                if (in[u]) c.list[lbase + (unsigned)__popcll(bL[u] & ((1ull << lane) - 1ull))] = pid[u];
+                if (nz[u]) c.jbuf[jbase + (unsigned)__popcll(bJ[u] & ((1ull << lane) - 1ull))] = term[u];
+            }
             par ^= 1;
         }
     }
