@@ -169,6 +169,11 @@ int mi_degensac_sample_stream_ex(uint32_t seed, int n, int sample_size, int iter
 int mi_degensac_solve7(const double *pts1, const double *pts2, int n, int dim,
                        const int32_t *samples, int n_samples, int device,
                        int32_t *nsol, int32_t *root_idx /*[3*n_samples]*/, double *models /*[27*n_samples]*/);
+/* the lane-level 3x3 routines of the DEGENSAC branch, one problem per lane: op 0 = in-place inverse (matutls/minv.c
+ * order; in/out 9 doubles, flag = -1 when singular), op 1 = right singular vectors and singular values (matutls/svduv.c
+ * order; in 9, out 9 + 3), op 2 = Hdetect (DegUtils.c:84-161; in F (9) + seven correspondences x1 y1 x2 y2 (28) + the
+ * triplet as three doubles, out 9). */
+int mi_degensac_mat3(int op, const double *in, int count, int device, double *out, int32_t *flag);
 
 /* ---- misc -------------------------------------------------------------------------------------- */
 int         mi_degensac_device_count(void);

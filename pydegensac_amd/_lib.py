@@ -95,6 +95,8 @@ def lib():
         l.mi_degensac_sample_stream.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, ip]
         l.mi_degensac_solve7.restype = C.c_int
         l.mi_degensac_solve7.argtypes = [dp, dp, C.c_int, C.c_int, ip, C.c_int, C.c_int, ip, ip, dp]
+        l.mi_degensac_mat3.restype = C.c_int
+        l.mi_degensac_mat3.argtypes = [C.c_int, dp, C.c_int, C.c_int, dp, ip]
         l.mi_degensac_last_error.restype = C.c_char_p
         l.mi_degensac_version.restype = C.c_char_p
         l.mi_degensac_kernel_name.restype = C.c_char_p

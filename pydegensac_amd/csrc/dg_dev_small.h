@@ -16,6 +16,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "dg_mat3.h"
 
 #define DG_FN static __device__ __forceinline__
 #define DG_BIG static __device__ __noinline__
@@ -54,339 +55,6 @@ DG_FN int dg_rand(dg_rng *g)
     if (++g->f >= 31) g->f = 0;
     if (++g->b >= 31) g->b = 0;
     return (int)(v >> 1);
-}
-
-/* ------------------------------------------------------------------------------------------------
- * CCMATH helpers (matutls/trnm.c, mmul.c, mattr.c, rmmult.c, minv.c)
- * ---------------------------------------------------------------------------------------------- */
-DG_FN void dg_trnm(double *a, int n)                      /* matutls/trnm.c: in-place transpose */
-{
-    int i, j; double s;
-    for (i = 0; i < n - 1; i++)
-        for (j = i + 1; j < n; j++) { s = a[i*n+j]; a[i*n+j] = a[j*n+i]; a[j*n+i] = s; }
-}
-
-DG_FN void dg_mmul(double *c, const double *a, const double *b, int n)   /* matutls/mmul.c: c = a*b */
-{
-    int i, j, k; double s;
-    for (i = 0; i < n; i++)
-        for (j = 0; j < n; j++) {
-            for (k = 0, s = 0.; k < n; k++) s += a[i*n+k] * b[k*n+j];
-            c[i*n+j] = s;
-        }
-}
-
-DG_FN void dg_mattr(double *a, const double *b, int m, int n)   /* matutls/mattr.c: a[n x m] = b[m x n]^T */
-{
-    int i, j;
-    for (i = 0; i < n; i++)
-        for (j = 0; j < m; j++) *a++ = b[j*n + i];
-}
-
-DG_FN void dg_rmmult(double *rm, const double *a, const double *b, int n, int m, int l)
-{                                                        /* matutls/rmmult.c: rm[n x l] = a[n x m] b[m x l] */
-    int i, j, k; double z;
-    for (i = 0; i < l; i++)
-        for (j = 0; j < n; j++) {
-            for (k = 0, z = 0.; k < m; k++) z += a[j*m+k] * b[k*l+i];
-            rm[j*l+i] = z;
-        }
-}
-
-/* matutls/minv.c restricted to n<=3 usage: in-place inverse by LU with partial pivoting
- * (Crout, pivot tolerance zr=1e-15 relative to the largest pivot seen).  Returns -1 if singular. */
-DG_BIG int dg_minv(double *a, int n)
-{
-    DG_LDS int le[9]; DG_LDS double q0[9];
-    int lc; double s, t, tq = 0., zr = 1.e-15;
-    double *pa, *pd, *ps, *p, *q;
-    int i, j, k, m, nle = 0;
-    for (j = 0, pa = pd = a; j < n; ++j, ++pa, pd += n + 1) {
-        if (j > 0) {
-            for (i = 0, q = q0, p = pa; i < n; ++i, p += n) *q++ = *p;
-            for (i = 1; i < n; ++i) {
-                lc = i < j ? i : j;
-                for (k = 0, p = pa + i*n - j, q = q0, t = 0.; k < lc; ++k) t += *p++ * *q++;
-                q0[i] -= t;
-            }
-            for (i = 0, q = q0, p = pa; i < n; ++i, p += n) *p = *q++;
-        }
-        s = fabs(*pd); lc = j;
-        for (k = j + 1, ps = pd; k < n; ++k) {
-            if ((t = fabs(*(ps += n))) > s) { s = t; lc = k; }
-        }
-        tq = tq > s ? tq : s;
-        if (s < zr * tq) return -1;
-        le[nle++] = lc;
-        if (lc != j) {
-            for (k = 0, p = a + n*j, q = a + n*lc; k < n; ++k) { t = *p; *p++ = *q; *q++ = t; }
-        }
-        for (k = j + 1, ps = pd, t = 1. / *pd; k < n; ++k) *(ps += n) *= t;
-        *pd = t;
-    }
-    for (j = 1, pd = ps = a; j < n; ++j) {
-        for (k = 0, pd += n + 1, q = ++ps; k < j; ++k, q += n) *q *= *pd;
-    }
-    for (j = 1, pa = a; j < n; ++j) {
-        ++pa;
-        for (i = 0, q = q0, p = pa; i < j; ++i, p += n) *q++ = *p;
-        for (k = 0; k < j; ++k) {
-            t = 0.;
-            for (i = k, p = pa + k*n + k - j, q = q0 + k; i < j; ++i) t -= *p++ * *q++;
-            q0[k] = t;
-        }
-        for (i = 0, q = q0, p = pa; i < j; ++i, p += n) *p = *q++;
-    }
-    for (j = n - 2, pd = pa = a + n*n - 1; j >= 0; --j) {
-        --pa; pd -= n + 1;
-        for (i = 0, m = n - j - 1, q = q0, p = pd + n; i < m; ++i, p += n) *q++ = *p;
-        for (k = n - 1, ps = pa; k > j; --k, ps -= n) {
-            t = -(*ps);
-            for (i = j + 1, p = ps, q = q0; i < k; ++i) t -= *++p * *q++;
-            q0[--m] = t;
-        }
-        for (i = 0, m = n - j - 1, q = q0, p = pd + n; i < m; ++i, p += n) *p = *q++;
-    }
-    for (k = 0, pa = a; k < n - 1; ++k, ++pa) {
-        for (i = 0, q = q0, p = pa; i < n; ++i, p += n) *q++ = *p;
-        for (j = 0, ps = a; j < n; ++j, ps += n) {
-            if (j > k) { t = 0.; p = ps + j; i = j; }
-            else { t = q0[j]; p = ps + k + 1; i = k + 1; }
-            for (; i < n;) t += *p++ * q0[i++];
-            q0[j] = t;
-        }
-        for (i = 0, q = q0, p = pa; i < n; ++i, p += n) *p = *q++;
-    }
-    for (j = n - 2, nle--; j >= 0; --j) {
-        --nle;
-        for (k = 0, p = a + j, q = a + le[nle]; k < n; ++k, p += n, q += n) { t = *p; *p = *q; *q = t; }
-    }
-    return 0;
-}
-
-/* ------------------------------------------------------------------------------------------------
- * CCMATH svduv (matutls/svduv.c + ldvmat.c + ldumat.c + qrbdv.c): a[m x n] (row-major, m>=n,
- * destroyed) = u[m x m] * diag(d) * v[n x n]^T.  Singular values are NOT sorted.  m<=9, n<=8.
- * ---------------------------------------------------------------------------------------------- */
-DG_FN void dg_ldvmat(double *a, double *v, int n)        /* matutls/ldvmat.c */
-{
-    double *p0, *q0, *p, *q, *qq; double h, s; int i, j, k, mm;
-    for (i = 0, mm = n*n, q = v; i < mm; ++i) *q++ = 0.;
-    *v = 1.; q0 = v + n*n - 1; *q0 = 1.; q0 -= n + 1;
-    p0 = a + n*n - n - n - 1;
-    for (i = n - 2, mm = 1; i > 0; --i, p0 -= n + 1, q0 -= n + 1, ++mm) {
-        if (*(p0 - 1) != 0.) {
-            h = *(p0 - 1); *q0 = 1. - h;
-            for (j = 0, q = q0 + n, p = p0; j < mm; ++j, q += n) *q = -h * *p++;
-            for (k = i + 1, q = q0 + 1; k < n; ++k) {
-                for (j = 0, qq = q + n, p = p0, s = 0.; j < mm; ++j, qq += n) s += *qq * *p++;
-                s *= h;
-                for (j = 0, qq = q + n, p = p0; j < mm; ++j, qq += n) *qq -= s * *p++;
-                *q++ = -s;
-            }
-        } else {
-            *q0 = 1.;
-            for (j = 0, p = q0 + 1, q = q0 + n; j < mm; ++j, q += n) *q = *p++ = 0.;
-        }
-    }
-}
-
-DG_FN void dg_ldumat(double *a, double *u, int m, int n, double *w /* >= 9 */)  /* matutls/ldumat.c */
-{
-    double *p0, *q0, *p, *q; int i, j, k, mm; double s, h;
-    for (i = 0; i < m; i++) w[i] = 0.;
-    for (i = 0, mm = m*m, q = u; i < mm; ++i) *q++ = 0.;
-    p0 = a + n*n - 1; q0 = u + m*m - 1; mm = m - n; i = n - 1;
-    for (j = 0; j < mm; ++j, q0 -= m + 1) *q0 = 1.;
-    if (mm == 0) { p0 -= n + 1; *q0 = 1.; q0 -= m + 1; --i; ++mm; }
-    for (; i >= 0; --i, ++mm, p0 -= n + 1, q0 -= m + 1) {
-        if (*p0 != 0.) {
-            for (j = 0, p = p0 + n; j < mm; p += n) w[j++] = *p;
-            h = *p0; *q0 = 1. - h;
-            for (j = 0, q = q0 + m; j < mm; q += m) *q = -h * w[j++];
-            for (k = i + 1, q = q0 + 1; k < m; ++k) {
-                for (j = 0, p = q + m, s = 0.; j < mm; p += m) s += w[j++] * *p;
-                s *= h;
-                for (j = 0, p = q + m; j < mm; p += m) *p -= s * w[j++];
-                *q++ = -s;
-            }
-        } else {
-            *q0 = 1.;
-            for (j = 0, p = q0 + 1, q = q0 + m; j < mm; ++j, q += m) *q = *p++ = 0.;
-        }
-    }
-}
-
-DG_FN int dg_qrbdv(double *dm, double *em, double *um, int mm, double *vm, int m)  /* matutls/qrbdv.c */
-{
-    int i, j, k, n, jj, nm;
-    double u, x, y, a, b, c, s, t, w, *p, *q;
-    for (j = 1, t = fabs(dm[0]); j < m; ++j)
-        if ((s = fabs(dm[j]) + fabs(em[j-1])) > t) t = s;
-    t *= 1.e-15; n = 100*m; nm = m;
-    for (j = 0; m > 1 && j < n; ++j) {
-        for (k = m - 1; k > 0; --k) {
-            if (fabs(em[k-1]) < t) break;
-            if (fabs(dm[k-1]) < t) {
-                for (i = k, s = 1., c = 0.; i < m; ++i) {
-                    a = s*em[i-1]; b = dm[i]; em[i-1] *= c;
-                    dm[i] = u = sqrt(a*a + b*b); s = -a/u; c = b/u;
-                    for (jj = 0, p = um + k - 1; jj < mm; ++jj, p += mm) {
-                        q = p + i - k + 1;
-                        w = c * *p + s * *q; *q = c * *q - s * *p; *p = w;
-                    }
-                }
-                break;
-            }
-        }
-        y = dm[k]; x = dm[m-1]; u = em[m-2];
-        a = (y + x)*(y - x) - u*u; s = y*em[k]; b = s + s;
-        u = sqrt(a*a + b*b);
-        if (u != 0.) {
-            c = sqrt((u + a)/(u + u));
-            if (c != 0.) s /= (c*u); else s = 1.;
-            for (i = k; i < m - 1; ++i) {
-                b = em[i];
-                if (i > k) {
-                    a = s*em[i]; b *= c;
-                    em[i-1] = u = sqrt(x*x + a*a);
-                    c = x/u; s = a/u;
-                }
-                a = c*y + s*b; b = c*b - s*y;
-                for (jj = 0, p = vm + i; jj < nm; ++jj, p += nm) {
-                    w = c * *p + s * *(p+1); *(p+1) = c * *(p+1) - s * *p; *p = w;
-                }
-                s *= dm[i+1]; dm[i] = u = sqrt(a*a + s*s);
-                y = c*dm[i+1]; c = a/u; s /= u;
-                x = c*b + s*y; y = c*y - s*b;
-                for (jj = 0, p = um + i; jj < mm; ++jj, p += mm) {
-                    w = c * *p + s * *(p+1); *(p+1) = c * *(p+1) - s * *p; *p = w;
-                }
-            }
-        }
-        em[m-2] = x; dm[m-1] = y;
-        if (fabs(x) < t) --m;
-        if (m == k + 1) --m;
-    }
-    return j;
-}
-
-DG_BIG int dg_svduv(double *d, double *a, double *u, int m, double *v, int n, double *w /* >= 29, caller-owned */)   /* matutls/svduv.c */
-{
-    double *p, *p1, *q, *pp, *e;
-    double s, h, r, t, sv;
-    int i, j, k, mm, nm, ms;
-    if (m < n) return -1;
-    for (i = 0; i < m + n; i++) w[i] = 0.;
-    e = w + m;
-    for (i = 0, mm = m, nm = n - 1, p = a; i < n; ++i, --mm, --nm, p += n + 1) {
-        if (mm > 1) {
-            sv = h = 0.;
-            for (j = 0, q = p, s = 0.; j < mm; ++j, q += n) { w[j] = *q; s += *q * *q; }
-            if (s > 0.) {
-                h = sqrt(s); if (*p < 0.) h = -h;
-                s += *p * h; s = 1./s; t = 1./(w[0] += h);
-                sv = 1. + fabs(*p/h);
-                for (k = 1, ms = n - i; k < ms; ++k) {
-                    for (j = 0, q = p + k, r = 0.; j < mm; q += n) r += w[j++] * *q;
-                    r *= s;
-                    for (j = 0, q = p + k; j < mm; q += n) *q -= r * w[j++];
-                }
-                for (j = 1, q = p; j < mm;) *(q += n) = t * w[j++];
-            }
-            *p = sv; d[i] = -h;
-        }
-        if (mm == 1) d[i] = *p;
-        p1 = p + 1; sv = h = 0.;
-        if (nm > 1) {
-            for (j = 0, q = p1, s = 0.; j < nm; ++j, ++q) s += *q * *q;
-            if (s > 0.) {
-                h = sqrt(s); if (*p1 < 0.) h = -h;
-                sv = 1. + fabs(*p1/h);
-                s += *p1 * h; s = 1./s; t = 1./(*p1 += h);
-                for (k = n, ms = n*(m - i); k < ms; k += n) {
-                    for (j = 0, q = p1, pp = p1 + k, r = 0.; j < nm; ++j) r += *q++ * *pp++;
-                    r *= s;
-                    for (j = 0, q = p1, pp = p1 + k; j < nm; ++j) *pp++ -= r * *q++;
-                }
-                for (j = 1, q = p1 + 1; j < nm; ++j) *q++ *= t;
-            }
-            *p1 = sv; e[i] = -h;
-        }
-        if (nm == 1) e[i] = *p1;
-    }
-    dg_ldvmat(a, v, n); dg_ldumat(a, u, m, n, w + 20);
-    dg_qrbdv(d, e, u, m, v, n);
-    for (i = 0; i < n; ++i) {
-        if (d[i] < 0.) {
-            d[i] = -d[i];
-            for (j = 0, p = v + i; j < n; ++j, p += n) *p = -*p;
-        }
-    }
-    return 0;
-}
-
-
-/* Left null vector of a 9x8 system the way Ftools.c:372-384 obtains it: svduv(D,Z,V,9,U,8) and then the
- * LAST column of the 9x9 left factor.  That column is produced by the Householder bidiagonalisation and the
- * backward accumulation of the left reflectors (ldumat) alone: qrbdv only rotates columns 0..7 of the left
- * factor (and the right factor), ldvmat only builds the right factor.  So this routine runs svduv's
- * reduction loop verbatim and accumulates just column 8 — the same floating-point operations, in the same
- * order, as the reference performs for those nine numbers. */
-DG_BIG void dg_svd_lastcol_9x8(double *a /* 9x8 row-major, destroyed */, double *col /* 9 */)
-{
-    DG_LDS double w[20];
-    const int m = 9, n = 8;
-    double *p, *p1, *q, *pp; double s, h, r, t, sv; int i, j, k, mm, nm, ms;
-    for (i = 0; i < m + n; i++) w[i] = 0.;
-    for (i = 0, mm = m, nm = n - 1, p = a; i < n; ++i, --mm, --nm, p += n + 1) {
-        if (mm > 1) {
-            sv = h = 0.;
-            for (j = 0, q = p, s = 0.; j < mm; ++j, q += n) { w[j] = *q; s += *q * *q; }
-            if (s > 0.) {
-                h = sqrt(s); if (*p < 0.) h = -h;
-                s += *p * h; s = 1./s; t = 1./(w[0] += h);
-                sv = 1. + fabs(*p/h);
-                for (k = 1, ms = n - i; k < ms; ++k) {
-                    for (j = 0, q = p + k, r = 0.; j < mm; q += n) r += w[j++] * *q;
-                    r *= s;
-                    for (j = 0, q = p + k; j < mm; q += n) *q -= r * w[j++];
-                }
-                for (j = 1, q = p; j < mm;) *(q += n) = t * w[j++];
-            }
-            *p = sv;
-        }
-        p1 = p + 1; sv = h = 0.;
-        if (nm > 1) {
-            for (j = 0, q = p1, s = 0.; j < nm; ++j, ++q) s += *q * *q;
-            if (s > 0.) {
-                h = sqrt(s); if (*p1 < 0.) h = -h;
-                sv = 1. + fabs(*p1/h);
-                s += *p1 * h; s = 1./s; t = 1./(*p1 += h);
-                for (k = n, ms = n*(m - i); k < ms; k += n) {
-                    for (j = 0, q = p1, pp = p1 + k, r = 0.; j < nm; ++j) r += *q++ * *pp++;
-                    r *= s;
-                    for (j = 0, q = p1, pp = p1 + k; j < nm; ++j) *pp++ -= r * *q++;
-                }
-                for (j = 1, q = p1 + 1; j < nm; ++j) *q++ *= t;
-            }
-            *p1 = sv;
-        }
-    }
-    /* ldumat (matutls/ldumat.c) restricted to column 8 of u */
-    for (i = 0; i < 9; i++) col[i] = 0.;
-    col[8] = 1.;
-    for (i = n - 1, mm = 1; i >= 0; --i, ++mm) {
-        double p0 = a[i*n + i];
-        if (p0 != 0.) {
-            for (j = 0; j < mm; j++) w[j] = a[(i + 1 + j)*n + i];
-            h = p0;
-            for (j = 0, s = 0.; j < mm; j++) s += w[j] * col[i + 1 + j];
-            s *= h;
-            for (j = 0; j < mm; j++) col[i + 1 + j] -= s * w[j];
-            col[i] = -s;
-        } else col[i] = 0.;
-    }
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -469,203 +137,6 @@ DG_FN void dg_laev2(double a, double b, double c, double *rt1, double *rt2, doub
 }
 
 /* z is n x n column-major (z[j*n+i] = Z(i,j)); applies rotations to columns j0..j0+cnt-1 */
-DG_FN void dg_lasr_rv(double *z, int n, int j0, int cnt, const double *c, const double *s, int backward)
-{
-    int j, i, jj; double ct, st, temp;
-    for (jj = 0; jj < cnt - 1; jj++) {
-        j = backward ? (cnt - 2 - jj) : jj;
-        ct = c[j]; st = s[j];
-        if (ct != 1. || st != 0.) {
-            double *zj = z + (size_t)(j0 + j) * n, *zj1 = zj + n;
-            for (i = 0; i < n; i++) {
-                temp = zj1[i];
-                zj1[i] = ct*temp - st*zj[i];
-                zj[i] = st*temp + ct*zj[i];
-            }
-        }
-    }
-}
-
-DG_BIG int dg_eig_sym(double *a, double *w, int n)
-{
-    DG_LDS double d[9], e[9], tau[9], work[18];
-    int i, j, k, l, m, ii;
-#define A_(r,c) a[(size_t)(c)*n + (r)]
-    /* ---- dsytd2, UPLO='U' ---- */
-    for (i = n - 2; i >= 0; i--) {
-        /* reflector H(i) annihilates A(0:i-1, i+1); alpha = A(i,i+1) */
-        double alpha = A_(i, i+1), xnorm = 0., taui, beta;
-        for (k = 0; k < i; k++) xnorm += A_(k, i+1) * A_(k, i+1);
-        xnorm = sqrt(xnorm);
-        if (xnorm == 0.) taui = 0.;
-        else {
-            beta = -dg_sign(dg_lapy2(alpha, xnorm), alpha);
-            taui = (beta - alpha) / beta;
-            { double sc = 1. / (alpha - beta); for (k = 0; k < i; k++) A_(k, i+1) *= sc; }
-            alpha = beta;
-        }
-        e[i] = alpha;
-        if (taui != 0.) {
-            double dot, al;
-            A_(i, i+1) = 1.;
-            /* tau(0:i) = taui * A(0:i,0:i) * v   (dsymv, upper) */
-            for (k = 0; k <= i; k++) {
-                double sum = 0.;
-                for (j = 0; j <= i; j++) sum += (j >= k ? A_(k, j) : A_(j, k)) * A_(j, i+1);
-                tau[k] = taui * sum;
-            }
-            dot = 0.; for (k = 0; k <= i; k++) dot += tau[k] * A_(k, i+1);
-            al = -.5 * taui * dot;
-            for (k = 0; k <= i; k++) tau[k] += al * A_(k, i+1);
-            /* dsyr2: A := A - v w' - w v' on the upper triangle */
-            for (j = 0; j <= i; j++)
-                for (k = 0; k <= j; k++)
-                    A_(k, j) = A_(k, j) - A_(k, i+1) * tau[j] - tau[k] * A_(j, i+1);
-            A_(i, i+1) = e[i];
-        }
-        d[i+1] = A_(i+1, i+1);
-        tau[i] = taui;
-    }
-    d[0] = A_(0, 0);
-    /* ---- dorgtr 'U' -> dorg2l(n-1,n-1,n-1) ---- */
-    for (j = 0; j < n - 1; j++) {
-        for (i = 0; i < j; i++) A_(i, j) = A_(i, j+1);
-        A_(n-1, j) = 0.;
-    }
-    for (i = 0; i < n - 1; i++) A_(i, n-1) = 0.;
-    A_(n-1, n-1) = 1.;
-    {
-        int mq = n - 1;              /* Q is mq x mq, k = mq reflectors */
-        for (i = 0; i < mq; i++) {
-            ii = i;                  /* column ii, reflector length ii+1 (rows 0..ii) */
-            A_(ii, ii) = 1.;
-            /* apply H(i) to A(0:ii, 0:ii-1) from the left */
-            for (j = 0; j < ii; j++) {
-                double sum = 0.;
-                for (k = 0; k <= ii; k++) sum += A_(k, j) * A_(k, ii);
-                sum *= tau[i];
-                for (k = 0; k <= ii; k++) A_(k, j) -= sum * A_(k, ii);
-            }
-            for (k = 0; k < ii; k++) A_(k, ii) *= -tau[i];
-            A_(ii, ii) = 1. - tau[i];
-            for (l = ii + 1; l < mq; l++) A_(l, ii) = 0.;
-        }
-    }
-    /* ---- dsteqr 'V' ---- */
-    {
-        const double eps = DG_EPS, eps2 = eps*eps, safmin = DG_SAFMIN;
-        int nmaxit = n * 30, jtot = 0, l1 = 0, lsv, lend, lendsv, mm;
-        double p, g, r, c, s, f, b, rt1, rt2, tst;
-        while (l1 < n) {
-            if (l1 > 0) e[l1-1] = 0.;
-            for (m = l1; m < n - 1; m++) {
-                tst = fabs(e[m]);
-                if (tst == 0.) break;
-                if (tst <= (sqrt(fabs(d[m])) * sqrt(fabs(d[m+1]))) * eps) { e[m] = 0.; break; }
-            }
-            /* m == n-1 if no break */
-            l = l1; lsv = l; lend = m; lendsv = lend; l1 = m + 1;
-            if (lend == l) continue;
-            if (fabs(d[lend]) < fabs(d[l])) { lend = lsv; l = lendsv; }
-            if (lend > l) {
-                /* QL iteration */
-                for (;;) {
-                    if (l != lend) {
-                        for (m = l; m < lend; m++) {
-                            tst = fabs(e[m]); tst *= tst;
-                            if (tst <= (eps2 * fabs(d[m])) * fabs(d[m+1]) + safmin) break;
-                        }
-                    } else m = lend;
-                    if (m < lend) e[m] = 0.;
-                    p = d[l];
-                    if (m == l) { d[l] = p; l++; if (l <= lend) continue; break; }
-                    if (m == l + 1) {
-                        dg_laev2(d[l], e[l], d[l+1], &rt1, &rt2, &c, &s);
-                        work[l] = c; work[n-1+l] = s;
-                        dg_lasr_rv(a, n, l, 2, work + l, work + n - 1 + l, 1);
-                        d[l] = rt1; d[l+1] = rt2; e[l] = 0.;
-                        l += 2; if (l <= lend) continue; break;
-                    }
-                    if (jtot == nmaxit) break;
-                    jtot++;
-                    g = (d[l+1] - p) / (2. * e[l]);
-                    r = dg_lapy2(g, 1.);
-                    g = d[m] - p + (e[l] / (g + dg_sign(r, g)));
-                    s = 1.; c = 1.; p = 0.;
-                    for (i = m - 1; i >= l; i--) {
-                        f = s * e[i]; b = c * e[i];
-                        dg_lartg(g, f, &c, &s, &r);
-                        if (i != m - 1) e[i+1] = r;
-                        g = d[i+1] - p;
-                        r = (d[i] - g)*s + 2.*c*b;
-                        p = s * r;
-                        d[i+1] = g + p;
-                        g = c*r - b;
-                        work[i] = c; work[n-1+i] = -s;
-                    }
-                    mm = m - l + 1;
-                    dg_lasr_rv(a, n, l, mm, work + l, work + n - 1 + l, 1);
-                    d[l] = d[l] - p; e[l] = g;
-                }
-            } else {
-                /* QR iteration */
-                for (;;) {
-                    if (l != lend) {
-                        for (m = l; m > lend; m--) {
-                            tst = fabs(e[m-1]); tst *= tst;
-                            if (tst <= (eps2 * fabs(d[m])) * fabs(d[m-1]) + safmin) break;
-                        }
-                    } else m = lend;
-                    if (m > lend) e[m-1] = 0.;
-                    p = d[l];
-                    if (m == l) { d[l] = p; l--; if (l >= lend) continue; break; }
-                    if (m == l - 1) {
-                        dg_laev2(d[l-1], e[l-1], d[l], &rt1, &rt2, &c, &s);
-                        work[m] = c; work[n-1+m] = s;
-                        dg_lasr_rv(a, n, l - 1, 2, work + m, work + n - 1 + m, 0);
-                        d[l-1] = rt1; d[l] = rt2; e[l-1] = 0.;
-                        l -= 2; if (l >= lend) continue; break;
-                    }
-                    if (jtot == nmaxit) break;
-                    jtot++;
-                    g = (d[l-1] - p) / (2. * e[l-1]);
-                    r = dg_lapy2(g, 1.);
-                    g = d[m] - p + (e[l-1] / (g + dg_sign(r, g)));
-                    s = 1.; c = 1.; p = 0.;
-                    for (i = m; i <= l - 1; i++) {
-                        f = s * e[i]; b = c * e[i];
-                        dg_lartg(g, f, &c, &s, &r);
-                        if (i != m) e[i-1] = r;
-                        g = d[i] - p;
-                        r = (d[i+1] - g)*s + 2.*c*b;
-                        p = s * r;
-                        d[i] = g + p;
-                        g = c*r - b;
-                        work[i] = c; work[n-1+i] = s;
-                    }
-                    mm = l - m + 1;
-                    dg_lasr_rv(a, n, m, mm, work + m, work + n - 1 + m, 0);
-                    d[l] = d[l] - p; e[l-1] = g;
-                }
-            }
-            if (jtot >= nmaxit) break;
-        }
-        /* selection sort, ascending */
-        for (ii = 1; ii < n; ii++) {
-            i = ii - 1; k = i; p = d[i];
-            for (j = ii; j < n; j++) if (d[j] < p) { k = j; p = d[j]; }
-            if (k != i) {
-                d[k] = d[i]; d[i] = p;
-                for (j = 0; j < n; j++) { double t = A_(j, i); A_(j, i) = A_(j, k); A_(j, k) = t; }
-            }
-        }
-        for (i = 0; i < n; i++) w[i] = d[i];
-        return jtot >= nmaxit ? 1 : 0;
-    }
-#undef A_
-}
-
-
 /* ------------------------------------------------------------------------------------------------
  * Wave-cooperative dsyev: the same arithmetic as dg_eig_sym (same per-element operations, same
  * summation order inside every dot product), but the independent loops run in different lanes of ONE
@@ -1082,47 +553,6 @@ static __device__ __noinline__ void dg_svd_lastcol_9x8_wave(double *a /* LDS 9x8
 /* ------------------------------------------------------------------------------------------------
  * degensac/utools.c
  * ---------------------------------------------------------------------------------------------- */
-/* utools.c:97-167  Gauss-Jordan null space of an n x n row-major matrix, tol 1e-12; buffer 2n ints */
-DG_BIG int dg_nullspace(double *matrix, double *nullspace, int n, int *buffer)
-{
-    int *pnopivot = buffer, nonpivot = 0;
-    int *ppivot = buffer + n;
-    int i, j, k, l, max;
-    double pivot, t, tol = 1e-12;
-    i = 0;
-    for (j = 0; j < n; j++) {
-        pivot = fabs(matrix[n*i+j]); max = i;
-        for (k = i + 1; k < n; k++) {
-            t = fabs(matrix[n*k+j]);
-            if (pivot < t) { pivot = t; max = k; }
-        }
-        if (pivot < tol) {
-            *(pnopivot++) = j; nonpivot++;
-            for (k = i; k < n; k++) matrix[n*k+j] = 0;
-        } else {
-            *(ppivot++) = j;
-            for (k = j; k < n; k++) { t = matrix[i*n+k]; matrix[i*n+k] = matrix[max*n+k]; matrix[max*n+k] = t; }
-            pivot = matrix[i*n+j];
-            for (k = j; k < n; k++) matrix[i*n+k] /= pivot;
-            for (k = 0; k < i; k++) {
-                pivot = -matrix[k*n+j];
-                for (l = j; l < n; l++) matrix[k*n+l] += pivot*matrix[i*n+l];
-            }
-            for (k = i + 1; k < n; k++) {
-                pivot = matrix[k*n+j];
-                for (l = j; l < n; l++) matrix[k*n+l] -= pivot*matrix[i*n+l];
-            }
-            i++;
-        }
-    }
-    for (k = 0; k < nonpivot; k++) {
-        j = buffer[k];
-        for (l = 0; l < n - nonpivot; l++) nullspace[k*n + buffer[n+l]] = -matrix[l*n+j];
-        for (l = 0; l < nonpivot; l++) nullspace[k*n + buffer[l]] = (j == buffer[l]) ? 1 : 0;
-    }
-    return nonpivot;
-}
-
 DG_FN double dg_det3(const double *A)                      /* utools.c:196-202 */
 {
     double r;

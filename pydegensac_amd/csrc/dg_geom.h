@@ -4,6 +4,7 @@
 #ifndef DG_GEOM_H
 #define DG_GEOM_H
 #include "dg_dev_small.h"
+#include "dg_mat3.h"
 #include "dg_wg.h"
 
 /* ---- Ftools.c:83-101 (FDs), :124-146 (exFDs), :147-168 (FDsSym), :228-250 (exFDsSym) --------- */
@@ -280,59 +281,13 @@ __device__ __forceinline__ int dg_gj8(double (&m)[8][9], double *h)
     return 1;
 }
 
-/* matutls/minv.c for n = 3 with private temporaries (re-entrant: one call per lane) */
-__device__ __noinline__ int dg_minv3(double *a)
-{
-    const int n = 3;
-    int lc, le[3]; double s, t, tq = 0., zr = 1.e-15, q0[3];
-    double *pa, *pd, *ps, *p, *q; int i, j, k, m, nle = 0;
-    for (j = 0, pa = pd = a; j < n; ++j, ++pa, pd += n + 1) {
-        if (j > 0) {
-            for (i = 0, q = q0, p = pa; i < n; ++i, p += n) *q++ = *p;
-            for (i = 1; i < n; ++i) { lc = i < j ? i : j; for (k = 0, p = pa + i*n - j, q = q0, t = 0.; k < lc; ++k) t += *p++ * *q++; q0[i] -= t; }
-            for (i = 0, q = q0, p = pa; i < n; ++i, p += n) *p = *q++;
-        }
-        s = fabs(*pd); lc = j;
-        for (k = j + 1, ps = pd; k < n; ++k) { if ((t = fabs(*(ps += n))) > s) { s = t; lc = k; } }
-        tq = tq > s ? tq : s;
-        if (s < zr * tq) return -1;
-        le[nle++] = lc;
-        if (lc != j) { for (k = 0, p = a + n*j, q = a + n*lc; k < n; ++k) { t = *p; *p++ = *q; *q++ = t; } }
-        for (k = j + 1, ps = pd, t = 1. / *pd; k < n; ++k) *(ps += n) *= t;
-        *pd = t;
-    }
-    for (j = 1, pd = ps = a; j < n; ++j) { for (k = 0, pd += n + 1, q = ++ps; k < j; ++k, q += n) *q *= *pd; }
-    for (j = 1, pa = a; j < n; ++j) {
-        ++pa;
-        for (i = 0, q = q0, p = pa; i < j; ++i, p += n) *q++ = *p;
-        for (k = 0; k < j; ++k) { t = 0.; for (i = k, p = pa + k*n + k - j, q = q0 + k; i < j; ++i) t -= *p++ * *q++; q0[k] = t; }
-        for (i = 0, q = q0, p = pa; i < j; ++i, p += n) *p = *q++;
-    }
-    for (j = n - 2, pd = pa = a + n*n - 1; j >= 0; --j) {
-        --pa; pd -= n + 1;
-        for (i = 0, m = n - j - 1, q = q0, p = pd + n; i < m; ++i, p += n) *q++ = *p;
-        for (k = n - 1, ps = pa; k > j; --k, ps -= n) { t = -(*ps); for (i = j + 1, p = ps, q = q0; i < k; ++i) t -= *++p * *q++; q0[--m] = t; }
-        for (i = 0, m = n - j - 1, q = q0, p = pd + n; i < m; ++i, p += n) *p = *q++;
-    }
-    for (k = 0, pa = a; k < n - 1; ++k, ++pa) {
-        for (i = 0, q = q0, p = pa; i < n; ++i, p += n) *q++ = *p;
-        for (j = 0, ps = a; j < n; ++j, ps += n) {
-            if (j > k) { t = 0.; p = ps + j; i = j; } else { t = q0[j]; p = ps + k + 1; i = k + 1; }
-            for (; i < n;) t += *p++ * q0[i++];
-            q0[j] = t;
-        }
-        for (i = 0, q = q0, p = pa; i < n; ++i, p += n) *p = *q++;
-    }
-    for (j = n - 2, nle--; j >= 0; --j) { --nle; for (k = 0, p = a + j, q = a + le[nle]; k < n; ++k, p += n, q += n) { t = *p; *p = *q; *q = t; } }
-    return 0;
-}
 __device__ __forceinline__ void dg_hsym_prepare(const double *H, double *Hinv, double *H1)
 {
     Hinv[0] = H[0]; Hinv[1] = H[3]; Hinv[2] = H[6];
     Hinv[3] = H[1]; Hinv[4] = H[4]; Hinv[5] = H[7];
     Hinv[6] = H[2]; Hinv[7] = H[5]; Hinv[8] = H[8];
     for (int i = 0; i < 9; i++) H1[i] = Hinv[i];
-    dg_minv3(H1);
+    dg_inv3(H1);
 }
 
 #endif /* DG_GEOM_H */

@@ -16,6 +16,8 @@
 
 struct dg_score { unsigned I; double J; unsigned Is; unsigned Ilafs; };
 
+/* doubles that ww[] lacks for the parallel pool stage's touch table */
+#define DG_WPAD ((2 * DG_CHUNK * 7 * 4 > DG_NW * (int)sizeof(dg_wave_ws)) ? (2 * DG_CHUNK * 7 * 4 - DG_NW * (int)sizeof(dg_wave_ws) + 7) / 8 : 1)
 struct dg_f_shared {
     dg_red red;
     dg_lsq_scratch lsq;
@@ -26,7 +28,7 @@ struct dg_f_shared {
     int      draws3[3][DG_CHUNK][8];    /* raw draws, then drawn ids (draw order) */
     unsigned long long alm3[3][DG_CHUNK / 64];   /* per-sample alias flags (order-dependent swaps) */
     dg_wave_ws ww[DG_NW];                /* per-wave scratch of the wave-parallel sections */
-    double   hw5[5][17 * 9 + 32];        /* Hdetect temporaries of checksample's five triplets */
+    double   wpad[DG_WPAD];              /* extends ww[] to the size the parallel pool stage needs (2 * DG_CHUNK * 7 ints) */
     double   csH[5][9]; int csRes[5];    /* checksample: per-triplet homography and verdict */
     double   fhF[16][9], fhF2[16][9], fhTh[16];   /* innerFH: per-repetition model, its u2Fit refinement, flag threshold */
     int      fhIds[16][10], fhCnt[16], fhCnt2[16], fhRaw[160];
@@ -82,10 +84,11 @@ struct dg_f_ctx {
     }
 };
 
-/* ww[] and hw5[] are adjacent double arrays that only the single-wave solver sections use: during a workgroup pass
- * they hold the ordered MSAC terms */
-#define DG_JBUF_LDS_BYTES (offsetof(dg_f_shared, hw5) + sizeof(((dg_f_shared *)0)->hw5) - offsetof(dg_f_shared, ww))
-static_assert(offsetof(dg_f_shared, hw5) == offsetof(dg_f_shared, ww) + sizeof(((dg_f_shared *)0)->ww), "ww and hw5 must be contiguous");
+/* ww[] and wpad[] are adjacent double arrays that only the single-wave solver sections use: during a workgroup pass
+ * they hold the ordered MSAC terms, during the main loop's scoring phase the parallel pool stage's touch table */
+#define DG_JBUF_LDS_BYTES (offsetof(dg_f_shared, wpad) + sizeof(((dg_f_shared *)0)->wpad) - offsetof(dg_f_shared, ww))
+static_assert(offsetof(dg_f_shared, wpad) == offsetof(dg_f_shared, ww) + sizeof(((dg_f_shared *)0)->ww), "ww and wpad must be contiguous");
+static_assert(DG_JBUF_LDS_BYTES >= 2 * DG_CHUNK * 7 * sizeof(int), "pool-stage scratch does not fit");
 
 #define CTX dg_f_ctx<LDSPTS>
 
@@ -187,45 +190,6 @@ __device__ __forceinline__ int dg_f_checks(CTX &c, const double *f, const int *l
     return 1;
 }
 
-/* ---- DegUtils.c:42-161 checksample / Hdetect on lane 0 ----------------------------------------- */
-__device__ __noinline__ void dg_Hdetect(const double *F, const double (*u7)[4], const unsigned char *IDXS, double *H, double *hw /* 17*9 + 32 doubles */)
-{
-    double *D = hw, *U = hw + 9, *V = hw + 18, *ec = hw + 27, *Ex = hw + 36, *A = hw + 45, *u3a = hw + 54, *u3b = hw + 63, *u3aT = hw + 72,
-           *u3bT = hw + 81, *Au3b = hw + 90, *Ft = hw + 99, *F1 = hw + 108, *p1 = hw + 117, *p1T = hw + 126, *p2 = hw + 135, *b = hw + 144, *wk = hw + 153;
-    int i, j, sing;
-    dg_mattr(Ft, F, 3, 3);
-    for (i = 0; i < 9; i++) F1[i] = F[i];
-    dg_svduv(D, F1, U, 3, V, 3, wk);
-    ec[0] = V[2]; ec[1] = V[5]; ec[2] = V[8];
-    Ex[0] = 0; Ex[1] = -ec[2]; Ex[2] = ec[1]; Ex[3] = ec[2]; Ex[4] = 0; Ex[5] = -ec[0]; Ex[6] = -ec[1]; Ex[7] = ec[0]; Ex[8] = 0;
-    dg_mmul(A, Ex, Ft, 3);
-    for (i = 0; i < 3; ++i) {
-        const double *q = u7[IDXS[i]];
-        double ua[3] = {q[0], q[1], 1.0}, ub[3] = {q[2], q[3], 1.0};
-        for (j = 0; j < 3; ++j) { u3a[i+j*3] = ua[j]; u3b[i+j*3] = ub[j]; }
-    }
-    dg_mmul(Au3b, A, u3b, 3);
-    dg_mattr(u3aT, u3a, 3, 3);
-    dg_mattr(u3bT, Au3b, 3, 3);
-    for (i = 0; i < 3; i++) {
-        const double *u = u3aT + 3*i, *v = u3bT + 3*i; double *h = p1T + 3*i;
-        h[0] = u[1]*v[2] - u[2]*v[1]; h[1] = u[2]*v[0] - u[0]*v[2]; h[2] = u[0]*v[1] - u[1]*v[0];
-    }
-    dg_mattr(p1, p1T, 3, 3);
-    for (i = 0; i < 9; ++i) Ex[i] *= -1;
-    dg_mmul(p2, Ex, u3a, 3);
-    b[0] = (p1[0]*p2[0] + p1[3]*p2[3] + p1[6]*p2[6]) / (p2[0]*p2[0] + p2[3]*p2[3] + p2[6]*p2[6]);
-    b[1] = (p1[1]*p2[1] + p1[4]*p2[4] + p1[7]*p2[7]) / (p2[1]*p2[1] + p2[4]*p2[4] + p2[7]*p2[7]);
-    b[2] = (p1[2]*p2[2] + p1[5]*p2[5] + p1[8]*p2[8]) / (p2[2]*p2[2] + p2[5]*p2[5] + p2[8]*p2[8]);
-    dg_mattr(u3bT, u3b, 3, 3);
-    sing = dg_minv3(u3bT);
-    dg_rmmult(u3b, u3bT, b, 3, 3, 1);
-    dg_mattr(u3bT, u3b, 3, 1);
-    dg_rmmult(u3b, ec, u3bT, 3, 1, 3);
-    for (i = 0; i < 3; ++i) for (j = 0; j < 3; ++j) H[i+j*3] = A[i*3+j] - u3b[i*3+j];
-    if (isnan(*H) || isinf(*H) || sing) { H[1] = H[2] = H[3] = H[5] = H[6] = H[7] = 0; H[0] = H[4] = H[8] = 1; }
-}
-
 /* DegUtils.c:42-82 checksample.  The five triplets are independent until the "first success wins" rule:
  * waves 0..4 each evaluate one (Hdetect + sort on lane 0, the 5-point re-fit wave-cooperatively), then the
  * lowest successful index is taken — the same H the sequential loop returns.  Called by the whole workgroup. */
@@ -238,7 +202,7 @@ __device__ __noinline__ int dg_checksample(CTX &c, const double *F /* LDS */, co
         dg_wave_ws *w = &S->ww[wave];
         const unsigned char IDXS[5][3] = {{0,1,2}, {3,4,5}, {0,1,6}, {3,4,6}, {2,5,6}};
         if (lane == 0) {
-            dg_Hdetect(F, u7, IDXS[tr], w->H, S->hw5[tr]);
+            dg_Hdetect(F, u7, IDXS[tr], w->H);
             for (int j = 0; j < 7; j++) { w->Ds[j] = dg_HDs(w->H, u7[j][0], u7[j][1], u7[j][2], u7[j][3]); w->sDs[j] = w->Ds[j]; w->idx[j] = j; }
             for (int a = 0; a < 7; ++a)                                  /* sortDs, DegUtils.c:164-183 */
                 for (int b = a + 1; b < 7; ++b)
@@ -554,10 +518,12 @@ __device__ __forceinline__ void dg_rFtH_aFt(const double *Hr, const dg_pt &p0, c
     ec[0] = c1[1]*c2[2] - c1[2]*c2[1]; ec[1] = c1[2]*c2[0] - c1[0]*c2[2]; ec[2] = c1[0]*c2[1] - c1[1]*c2[0];
     double ecNorm = sqrt(ec[0]*ec[0] + ec[1]*ec[1] + ec[2]*ec[2]);
     ec[0] = ec[0]/ecNorm; ec[1] = ec[1]/ecNorm; ec[2] = ec[2]/ecNorm;
-    double sk[9] = {0, -ec[2], ec[1], ec[2], 0, -ec[0], -ec[1], ec[0], 0}, Ht[9], aFtH[9];
-    dg_mattr(Ht, Hr, 3, 3);
-    dg_mmul(aFtH, sk, Ht, 3);
-    dg_mattr(aFt, aFtH, 3, 3);
+    /* aFt = ([e]x H^T)^T, every entry a three-term sum over the inner index in ascending order from 0.0 (DegUtils.c:337-345) */
+    const double sk[9] = {0, -ec[2], ec[1], ec[2], 0, -ec[0], -ec[1], ec[0], 0};
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) { double z = 0.; z += sk[3*i] * Hr[3*j]; z += sk[3*i + 1] * Hr[3*j + 1]; z += sk[3*i + 2] * Hr[3*j + 2]; aFt[3*j + i] = z; }
 }
 
 template <int LDSPTS>

@@ -198,7 +198,7 @@ __device__ __noinline__ dg_score dg_inFrani(CTX &c, int ninl, double th, double 
  * ids: the 7 drawn ids in draw order.  Writes up to 3 models (9 doubles each) to out[0..27), packs their
  * root indices (2 bits each) into *rix and returns the number of valid models, or -1 when the null space
  * of the 7x9 system is not 2-dimensional (exp_ranF.c:1355-1358). */
-__device__ __noinline__ int dg_solve7_lane(const dg_pt *P, const int *ids, double *out, unsigned *rix)
+__device__ __noinline__ int dg_solve7_lane(const dg_pt *P, const int *ids, double *out, unsigned *rix, double *wscr /* LDS, this wave's, >= 81 doubles */)
 {
     dg_pt sp[7];
     double m[7][9];
@@ -213,19 +213,18 @@ __device__ __noinline__ int dg_solve7_lane(const dg_pt *P, const int *ids, doubl
     }
     double f1[9], f2[9];
     int ok = dg_gj7(m, f1, f2);
-    if (!ok) {
-        /* general utools.c:97-167 path on a private 9x9 copy (degenerate samples only) */
-        double Ag[81], sol[81]; int nb[18];
+    /* degenerate samples only: a column without a usable pivot.  Those lanes take turns on the wave's LDS scratch
+     * with the general elimination (no per-lane copy of the system in scratch memory) */
+    for (unsigned long long need = __ballot(!ok); need; need &= need - 1) {
+        if ((int)(threadIdx.x & 63) != __ffsll((long long)need) - 1) continue;
         for (int i = 0; i < 7; i++) {
-            double a[3] = {sp[i].x1, sp[i].y1, 1.0}, b[3] = {sp[i].x2, sp[i].y2, 1.0};
-            for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) Ag[9*i+3*k+l] = b[k] * a[l];
+            const double a[3] = {sp[i].x1, sp[i].y1, 1.0}, b[3] = {sp[i].x2, sp[i].y2, 1.0};
+            for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) wscr[9*i + 3*k + l] = b[k] * a[l];
         }
-        for (int i = 63; i < 81; i++) Ag[i] = 0;
-        for (int i = 0; i < 81; i++) sol[i] = 0;
-        int ns = dg_nullspace(Ag, sol, 9, nb);
-        if (ns == 2) { for (int i = 0; i < 9; i++) { f1[i] = sol[i]; f2[i] = sol[9+i]; } ok = 1; }
-        else return -1;
+        if (dg_null9<7, 2>(wscr, wscr + 63) == 2) { for (int i = 0; i < 9; i++) { f1[i] = wscr[63 + i]; f2[i] = wscr[72 + i]; } ok = 1; }
+        else ok = -1;
     }
+    if (ok < 0) return -1;
     double poly[4], roots[3];
     dg_slcm(f1, f2, poly);
     int nsol = dg_rroots3(poly, roots);
@@ -707,7 +706,7 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
         /* ================= solve: one 7-point problem per lane ================= */
         int nvalid = 0, nullbad = 0; unsigned rixp = 0;
         if (tid < chunk) {
-            int r_ = dg_solve7_lane(P, c.draws[tid], c.gmodels + (size_t)tid * 27, &rixp);
+            int r_ = dg_solve7_lane(P, c.draws[tid], c.gmodels + (size_t)tid * 27, &rixp, (double *)&S->ww[wave]);
             if (r_ < 0) nullbad = 1; else nvalid = r_;
         }
         /* ordered slots: exclusive scan of nvalid over the lanes of the chunk */

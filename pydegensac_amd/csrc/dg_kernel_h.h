@@ -254,7 +254,7 @@ __device__ __noinline__ int dg_h_lo(CTX &c, int kind, const double *e4, double t
 
 /* One 4-point problem per lane (own register allocation): orientation test, 8x9 null vector, near-singularity
  * test and, for the symmetric metrics, H1 = inverse of the transposed H.  Returns 1 when the sample yields a model. */
-__device__ __noinline__ int dg_solve4_lane(const dg_pt *P, const int *ids, int kind, double *hm, double *H1m)
+__device__ __noinline__ int dg_solve4_lane(const dg_pt *P, const int *ids, int kind, double *hm, double *H1m, double *wscr /* LDS, this wave's, >= 81 doubles */)
 {
     dg_pt sp[4];
 #pragma unroll
@@ -270,17 +270,16 @@ __device__ __noinline__ int dg_solve4_lane(const dg_pt *P, const int *ids, int k
         for (int j = 0; j < 9; j++) { m[2*i][j] = z0[j]; m[2*i+1][j] = z1[j]; }
     }
     int ok = dg_gj8(m, hm);
-    if (!ok) {
-        double Ag[81], sol[81]; int nb[18];
+    /* degenerate samples only: those lanes take turns on the wave's LDS scratch with the general elimination */
+    for (unsigned long long need = __ballot(!ok); need; need &= need - 1) {
+        if ((int)(threadIdx.x & 63) != __ffsll((long long)need) - 1) continue;
         for (int i = 0; i < 4; i++) {
-            double s0 = sp[i].x1, s1 = sp[i].y1, s3 = sp[i].x2, s4 = sp[i].y2;
-            double z0[9] = {s3, 0, -s0*s3, s4, 0, -s0*s4, 1.0, 0, -s0*1.0};
-            double z1[9] = {0, s3, -s1*s3, 0, s4, -s1*s4, 0, 1.0, -s1*1.0};
-            for (int j = 0; j < 9; j++) { Ag[18*i+j] = z0[j]; Ag[18*i+9+j] = z1[j]; }
+            const double s0 = sp[i].x1, s1 = sp[i].y1, s3 = sp[i].x2, s4 = sp[i].y2;
+            const double z0[9] = {s3, 0, -s0*s3, s4, 0, -s0*s4, 1.0, 0, -s0*1.0};
+            const double z1[9] = {0, s3, -s1*s3, 0, s4, -s1*s4, 0, 1.0, -s1*1.0};
+            for (int j = 0; j < 9; j++) { wscr[18*i + j] = z0[j]; wscr[18*i + 9 + j] = z1[j]; }
         }
-        for (int i = 72; i < 81; i++) Ag[i] = 0;
-        for (int i = 0; i < 81; i++) sol[i] = 0;
-        if (dg_nullspace(Ag, sol, 9, nb) == 1) { for (int i = 0; i < 9; i++) hm[i] = sol[i]; ok = 1; }
+        if (dg_null9<8, 1>(wscr, wscr + 72) == 1) { for (int i = 0; i < 9; i++) hm[i] = wscr[72 + i]; ok = 1; }
     }
     if (!ok || dg_HcloseToSingular(hm)) return 0;
     if (kind != 0) { double Hi[9]; dg_hsym_prepare(hm, Hi, H1m); }
@@ -357,7 +356,7 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
         c.seeds = S->seeds3[cur]; c.draws = S->draws3[cur]; chunk_base = no_sam;
         /* ---- solve: orientation test, 8x9 null vector, near-singularity test; <= 1 model per lane ---- */
         double hm[9], H1m[9]; int valid = 0;
-        if (tid < chunk) valid = dg_solve4_lane(P, c.draws[tid], kind, hm, H1m);
+        if (tid < chunk) valid = dg_solve4_lane(P, c.draws[tid], kind, hm, H1m, (double *)&S->ww[wave]);
         {
             unsigned v = (unsigned)valid, incl = v;
 #pragma unroll

@@ -1,6 +1,6 @@
 /* Non-minimal solvers (normalised least squares) of the LO / DEGENSAC steps.
- *   - "small" variants (<= 16 correspondences): lane 0, reference statement order, bit-compatible
- *     with the scalar reference up to the restated dsyev / SVD.
+ *   - "small" variants (<= 16 correspondences): one wave, the reference's operation order per output number,
+ *     bit-compatible with the scalar reference up to the restated dsyev / SVD.
  *   - "big" variants (an inlier list of any length): the whole workgroup accumulates the Hartley
  *     normalisation and the 9x9 normal matrix in parallel, lane 0 finishes (eig, rank-2, denorm).
  */
@@ -46,87 +46,30 @@ __device__ __forceinline__ void dg_normu_small(const double *p, int len, double 
     A2[1] *= -A2[0]; A2[2] *= -A2[0];
 }
 
-/* utools.c:170-184 cov_mat, rows x 9 */
-__device__ __forceinline__ void dg_cov9(double *Cv, const double *Z, int rows)
+/* Htools.c:101-114 u2h on exactly 4 gathered points (one lane): the 8 x 9 DLT system laid out as the reference
+ * lays it out (entry (j, r) of the 9 x 8 array lin_hg fills, read back as a 9 x 9 array after an in-place 9 x 9
+ * transpose; entries the reference never writes are zero here), then its null vector. */
+__device__ __noinline__ void dg_u2h_4pt(dg_lsq_scratch *s, const double *p, double *H)
 {
-    for (int i = 0; i < 9; i++)
-        for (int j = 0; j <= i; j++) {
-            double val = 0;
-            for (int k = 0; k < rows; k++) val += Z[9*k+i] * Z[9*k+j];
-            Cv[9*i+j] = val; Cv[i+9*j] = val;
+    double *M = s->U9;
+    for (int i = 0; i < 81; i++) { M[i] = 0.; s->V[i] = 0.; }
+    for (int i = 0; i < 4; i++) {
+        const double s0 = p[4*i], s1 = p[4*i+1], s3 = p[4*i+2], s4 = p[4*i+3];
+        const double z0[9] = {s3, 0, -s0*s3, s4, 0, -s0*s4, 1.0, 0, -s0*1.0};
+        const double z1[9] = {0, s3, -s1*s3, 0, s4, -s1*s4, 0, 1.0, -s1*1.0};
+        /* flat index e = 8 j + r of the 9 x 8 array is element (e / 9, e % 9) of the 9 x 9 view; transposed */
+        for (int j = 0; j < 9; j++) {
+            const int e0 = 8*j + 2*i, e1 = e0 + 1;
+            M[9*(e0 % 9) + e0 / 9] = z0[j]; M[9*(e1 % 9) + e1 / 9] = z1[j];
         }
-}
-
-/* Ftools.c:350-458 u2f / u2fw on `len` gathered points (lane 0 only).  wts: per-point weights or 0. */
-__device__ __noinline__ void dg_u2f_small(dg_lsq_scratch *s, const double *p, const double *wts, int len, double *F)
-{
-    int i, j, k, l;
-    if (len > 8) {
-        dg_normu_small(p, len, s->A1, s->A2);
-        for (i = 0; i < len; i++) {                                   /* lin_fmN, Ftools.c:300-328 */
-            double a[3], b[3];
-            a[2] = 1; b[2] = 1;
-            a[0] = p[4*i]   * s->A1[0] + s->A1[1]; a[1] = p[4*i+1] * s->A1[0] + s->A1[2];
-            b[0] = p[4*i+2] * s->A2[0] + s->A2[1]; b[1] = p[4*i+3] * s->A2[0] + s->A2[2];
-            for (k = 0; k < 3; k++) for (l = 0; l < 3; l++) s->Z[9*i + 3*k + l] = a[l] * b[k];
-        }
-        if (wts) for (i = 0; i < len; i++) for (k = 0; k < 9; k++) s->Z[9*i+k] *= wts[i];
-        dg_cov9(s->V, s->Z, len);
-        dg_eig_sym(s->V, s->D, 9);
-        j = 0; for (i = 1; i < 9; i++) if (s->D[i] < s->D[j]) j = i;
-        for (i = 0; i < 9; i++) F[i] = s->V[j*9 + i];
-    } else {
-        for (i = 0; i < 72; i++) s->Z8[i] = 0.;
-        for (i = 0; i < len && i < 8; i++) {
-            double a[3] = {p[4*i], p[4*i+1], 1.0}, b[3] = {p[4*i+2], p[4*i+3], 1.0};
-            for (k = 0; k < 3; k++) for (l = 0; l < 3; l++) s->Z8[(k*3+l)*8 + i] = b[k] * a[l];
-        }
-        /* Ftools.c:427-432: scalmul(Z+i, w, 9, 9) strides by 9 over a row stride of 8 (reproduced) */
-        if (wts) for (i = 0; i < len && i < 8; i++) for (k = 0; k < 9; k++) if (i + 9*k < 72) s->Z8[i + 9*k] *= wts[i];
-        dg_svd_lastcol_9x8(s->Z8, s->U9);   /* left null vector -> U9[0..8] */
-        for (i = 0; i < 9; i++) F[i] = s->U9[i];
     }
-    dg_singulF(F);
-    if (len > 8) dg_denormF(F, s->A1, s->A2);
-}
-
-/* Htools.c:101-133 u2h on `len` gathered points (lane 0 only) */
-__device__ __noinline__ void dg_u2h_small(dg_lsq_scratch *s, const double *p, int len, double *H)
-{
-    int i, j;
-    if (len < 4) return;
-    if (len == 4) {
-        /* Htools.c:106-114 incl. the 9x8-as-9x9 transposition (never-written entries zeroed) */
-        int nb[18];
-        for (i = 0; i < 81; i++) { s->V[i] = 0.; s->U9[i] = 0.; }
-        for (i = 0; i < 4; i++) {
-            double s0 = p[4*i], s1 = p[4*i+1], s3 = p[4*i+2], s4 = p[4*i+3];
-            double z0[9] = {s3, 0, -s0*s3, s4, 0, -s0*s4, 1.0, 0, -s0*1.0};
-            double z1[9] = {0, s3, -s1*s3, 0, s4, -s1*s4, 0, 1.0, -s1*1.0};
-            for (j = 0; j < 9; j++) { s->U9[j*8 + 2*i] = z0[j]; s->U9[j*8 + 2*i + 1] = z1[j]; }
-        }
-        dg_trnm(s->U9, 9);
-        for (i = 72; i < 81; i++) s->U9[i] = 0.;
-        dg_nullspace(s->U9, s->V, 9, nb);
-        for (i = 0; i < 9; i++) H[i] = s->V[i];
-    } else {
-        dg_normu_small(p, len, s->A1, s->A2);
-        for (i = 0; i < len; i++) {                                   /* lin_hgN, Htools.c:60-99 */
-            double a0 = p[4*i]   * s->A1[0] + s->A1[1], a1 = p[4*i+1] * s->A1[0] + s->A1[2];
-            double b[3] = {p[4*i+2] * s->A2[0] + s->A2[1], p[4*i+3] * s->A2[0] + s->A2[2], 1.0};
-            double *z = s->Z + 18*i;
-            for (j = 0; j < 3; j++) { z[3*j] = b[j]; z[3*j+1] = 0; z[3*j+2] = -a0 * b[j]; }
-            for (j = 0; j < 3; j++) { z[9+3*j] = 0; z[9+3*j+1] = b[j]; z[9+3*j+2] = -a1 * b[j]; }
-        }
-        dg_cov9(s->V, s->Z, 2*len);
-        dg_eig_sym(s->V, s->D, 9);
-        for (i = 0; i < 9; i++) H[i] = s->V[i];
-        dg_denormH(H, s->A1, s->A2);
-    }
+    for (int i = 72; i < 81; i++) M[i] = 0.;
+    dg_null9<9, 1>(M, s->V);
+    for (int i = 0; i < 9; i++) H[i] = s->V[i];
 }
 
 /* ---- wave-cooperative variants of the small solvers (all 64 lanes of wave 0 call these) ----------------
- * Same arithmetic as dg_u2f_small / dg_u2h_small; the design-matrix rows, the 45 normal-matrix entries and
+ * Same arithmetic as the reference's u2f / u2h (Ftools.c:350-458, Htools.c:101-133); the design-matrix rows, the 45 normal-matrix entries and
  * the eigen-solver's inner loops are spread over lanes.  p (gathered coordinates) is in LDS. */
 __device__ __forceinline__ void dg_cov9_wave(double *Cv, const double *Z, int rows, int lane)
 {
@@ -216,7 +159,8 @@ __device__ __forceinline__ void dg_u2h_norm_w(SC *s, const double *p, int len, d
 
 __device__ __noinline__ void dg_u2h_small_w(dg_lsq_scratch *s, const double *p, int len, double *H, int lane)
 {
-    if (len <= 4) { if (lane == 0) dg_u2h_small(s, p, len, H); DG_WSYNC(); return; }
+    if (len < 4) return;
+    if (len == 4) { if (lane == 0) dg_u2h_4pt(s, p, H); DG_WSYNC(); return; }
     dg_u2h_norm_w(s, p, len, H, lane);
 }
 

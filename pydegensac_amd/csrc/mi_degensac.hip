@@ -128,12 +128,11 @@ __global__ void dg_solve7_kernel(const double *p1, const double *p2, int dim, co
     }
     double f1[9], f2[9]; int nv = 0;
     int ok = dg_gj7(m, f1, f2);
-    if (!ok) {
-        double Ag[81], sol[81]; int nb[18];
-        for (int i = 0; i < 7; i++) { double a[3] = {sp[i].x1, sp[i].y1, 1.0}, b[3] = {sp[i].x2, sp[i].y2, 1.0}; for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) Ag[9*i+3*k+l] = b[k] * a[l]; }
-        for (int i = 63; i < 81; i++) Ag[i] = 0;
-        for (int i = 0; i < 81; i++) sol[i] = 0;
-        if (dg_nullspace(Ag, sol, 9, nb) == 2) { for (int i = 0; i < 9; i++) { f1[i] = sol[i]; f2[i] = sol[9+i]; } ok = 1; }
+    __shared__ double wscr[81];                  /* one wave per block: the general elimination, one lane at a time */
+    for (unsigned long long need = __ballot(!ok); need; need &= need - 1) {
+        if ((int)(threadIdx.x & 63) != __ffsll((long long)need) - 1) continue;
+        for (int i = 0; i < 7; i++) { double a[3] = {sp[i].x1, sp[i].y1, 1.0}, b[3] = {sp[i].x2, sp[i].y2, 1.0}; for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) wscr[9*i+3*k+l] = b[k] * a[l]; }
+        if (dg_null9<7, 2>(wscr, wscr + 63) == 2) { for (int i = 0; i < 9; i++) { f1[i] = wscr[63+i]; f2[i] = wscr[72+i]; } ok = 1; }
     }
     if (ok) {
         double poly[4], roots[3];
@@ -169,6 +168,50 @@ extern "C" int mi_degensac_solve7(const double *pts1, const double *pts2, int n,
     return 0;
 }
 
+
+/* one problem per lane through the lane-level 3x3 routines of dg_mat3.h (op 0: inverse, 1: right singular vectors,
+ * 2: Hdetect) */
+__global__ void dg_mat3_kernel(int op, const double *in, int count, double *out, int *flag)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    if (op == 0) {
+        double a[9]; for (int i = 0; i < 9; i++) a[i] = in[(size_t)t * 9 + i];
+        flag[t] = dg_inv3(a);
+        for (int i = 0; i < 9; i++) out[(size_t)t * 9 + i] = a[i];
+    } else if (op == 1) {
+        double a[9], v[9], d[3]; for (int i = 0; i < 9; i++) a[i] = in[(size_t)t * 9 + i];
+        dg_svd3_right(a, v, d);
+        for (int i = 0; i < 9; i++) out[(size_t)t * 12 + i] = v[i];
+        for (int i = 0; i < 3; i++) out[(size_t)t * 12 + 9 + i] = d[i];
+        flag[t] = 0;
+    } else {
+        /* in: F (9), seven correspondences x1 y1 x2 y2 (28), triplet (3, as doubles) */
+        double F[9], u7[7][4]; unsigned char ids[3];
+        const double *q = in + (size_t)t * 40;
+        for (int i = 0; i < 9; i++) F[i] = q[i];
+        for (int i = 0; i < 7; i++) for (int j = 0; j < 4; j++) u7[i][j] = q[9 + 4*i + j];
+        for (int i = 0; i < 3; i++) ids[i] = (unsigned char)q[37 + i];
+        double H[9]; dg_Hdetect(F, u7, ids, H);
+        for (int i = 0; i < 9; i++) out[(size_t)t * 9 + i] = H[i];
+        flag[t] = 0;
+    }
+}
+
+extern "C" int mi_degensac_mat3(int op, const double *in, int count, int device, double *out, int32_t *flag)
+{
+    DG_UNIT_ENTER(device);
+    if (op < 0 || op > 2 || count < 0) { set_err("bad op"); return MI_DEGENSAC_EINVAL; }
+    const size_t ni = op == 2 ? 40 : 9, no = op == 1 ? 12 : 9;
+    DevBuf<double> di, dout; DevBuf<int> df;
+    if (di.alloc(count * ni) || dout.alloc(count * no) || df.alloc(count)) { set_err("device allocation failed"); return MI_DEGENSAC_ENOMEM; }
+    HIPCHK(hipMemcpy(di.p, in, count * ni * 8, hipMemcpyHostToDevice));
+    if (count) hipLaunchKernelGGL(dg_mat3_kernel, dim3((count + 63) / 64), dim3(64), 0, 0, op, di.p, count, dout.p, df.p);
+    HIPCHK(hipGetLastError()); HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, dout.p, count * no * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(flag, df.p, (size_t)count * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
 
 #ifdef MI_DEGENSAC_DEV
 #include "mi_degensac_dev.inc"

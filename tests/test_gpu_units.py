@@ -163,3 +163,40 @@ def test_explicit_context_and_device_is_restored():
         L.mi_degensac_ctx_destroy(ctx)
     assert torch.cuda.current_device() == 0
     assert L.mi_degensac_release_scratch(0, None) == 0
+
+
+def test_mat3_device_routines_equal_reference(oracle_ref):
+    """mi_degensac_mat3: the lane-level 3x3 inverse / right singular vectors / Hdetect as compiled for gfx950, against
+    the unmodified reference's minv / svduv / Hdetect (oracle/_ref) on 10^4 random inputs each: bit for bit"""
+    from tests.test_mat3_cpu import _mats
+    L = _lib.lib(); R = oracle_ref.lib()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    rng = np.random.default_rng(21)
+    A = np.stack(list(_mats(rng, 10000)))
+    out = np.zeros((len(A), 9)); flag = np.zeros(len(A), np.int32)
+    _lib.check(L.mi_degensac_mat3(0, dp(A), len(A), 0, dp(out), flag.ctypes.data_as(C.POINTER(C.c_int32))))
+    for a, o, f in zip(A, out, flag):
+        y = a.copy(); r = R.minv(dp(y), 3)
+        assert (r != 0) == (f != 0) and np.array_equal(o, y.ravel(), equal_nan=True)
+    out = np.zeros((len(A), 12))
+    _lib.check(L.mi_degensac_mat3(1, dp(A), len(A), 0, dp(out), flag.ctypes.data_as(C.POINTER(C.c_int32))))
+    for a, o in zip(A, out):
+        y = a.copy(); d = np.zeros(3); u = np.zeros(9); v = np.zeros(9)
+        R.svduv(dp(d), dp(y), dp(u), 3, dp(v), 3)
+        assert np.array_equal(o[:9], v, equal_nan=True) and np.array_equal(o[9:], d, equal_nan=True)
+    trip = np.array([[0, 1, 2], [3, 4, 5], [0, 1, 6], [3, 4, 6], [2, 5, 6]], np.uint8)
+    N = 10000; inp = np.zeros((N, 40)); want = np.zeros((N, 9))
+    for t in range(N):
+        F = rng.normal(size=(3, 3))
+        if t % 3:
+            u, s, vt = np.linalg.svd(F); s[2] = 0; F = (u * s) @ vt
+        pts = rng.uniform(-500, 500, size=(7, 4))
+        if t % 7 == 0:
+            pts[2] = pts[0] + (pts[1] - pts[0]) * 0.3
+        ids = np.ascontiguousarray(trip[t % 5])
+        inp[t, :9] = F.ravel(); inp[t, 9:37] = pts.ravel(); inp[t, 37:] = ids
+        u7 = np.ones((7, 6)); u7[:, 0:2] = pts[:, 0:2]; u7[:, 3:5] = pts[:, 2:4]
+        R.Hdetect(dp(np.ascontiguousarray(F).copy()), dp(u7), ids.ctypes.data_as(C.POINTER(C.c_ubyte)), dp(want[t]))
+    out = np.zeros((N, 9)); flag = np.zeros(N, np.int32)
+    _lib.check(L.mi_degensac_mat3(2, dp(inp), N, 0, dp(out), flag.ctypes.data_as(C.POINTER(C.c_int32))))
+    assert np.array_equal(out, want, equal_nan=True), np.flatnonzero((out != want).any(axis=1))[:10]
