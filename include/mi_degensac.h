@@ -150,6 +150,28 @@ int mi_degensac_find_homography_batch_dev(const double *d_pts1, const double *d_
  * `stream_or_null` is NULL, else only that stream's); call before destroying a stream */
 int mi_degensac_release_scratch(int device, void *stream_or_null);
 
+/* ---- tentative correspondences: the stage in front of the estimators -------------------
+ * Replaces the matcher calls of the reference's example, examples/simple-example.py:46-53
+ * (cv2.BFMatcher().knnMatch(descs1, descs2, k=2) followed by `m.distance < 0.9 * n.distance`):
+ * brute-force 2-nearest-neighbour search of every row of desc1 among the rows of desc2, the
+ * second-nearest-neighbour ratio test and an optional mutual-nearest-neighbour check.
+ *   norm L2:      float32 descriptors [n, dim]; distance = sqrt(sum_k (a_k - b_k)^2), fp32, summed in ascending k
+ *   norm HAMMING: uint8 descriptors [n, dim] with dim % 4 == 0 (pad with zero bytes); distance = differing bits
+ * idx[i] = the two nearest train rows of query i (ties: lower index first; -1 when desc2 has fewer rows),
+ * dist[i] their distances, keep[i] = dist[i][0] < ratio * dist[i][1] (and, with mutual, the nearest neighbour of
+ * desc2[idx[i][0]] in desc1 is i). */
+#define MI_DEGENSAC_NORM_L2       0
+#define MI_DEGENSAC_NORM_HAMMING  1
+int mi_degensac_match(int norm, const void *desc1, int n1, const void *desc2, int n2, int dim, float ratio, int mutual,
+                      int device, int32_t *idx /*[n1,2]*/, float *dist /*[n1,2]*/, uint8_t *keep /*[n1], nullable*/);
+/* device pointers, asynchronous on `stream` */
+int mi_degensac_match_knn2_dev(int norm, const void *d_desc1, int n1, const void *d_desc2, int n2, int dim, int device,
+                               void *stream, int32_t *d_idx, float *d_dist);
+int mi_degensac_match_filter_dev(const int32_t *d_idx, const float *d_dist, int n1, float ratio,
+                                 const int32_t *d_back_idx_or_null /*[n2,2]: knn2 of desc2 in desc1*/, int device, void *stream,
+                                 uint8_t *d_keep);
+const char *mi_degensac_match_last_error(void);
+
 /* ---- unit-level device entry points (parity tests of the kernels' building blocks) ------------ */
 /* score n_models fundamental (kind 0: Sampson, 1: symmetric epipolar) or homography (kind 10..14:
  * H Sampson, symm_sq_max, symm_max, symm_sq_sum, symm_sum) models against all n points: I (<= th)
