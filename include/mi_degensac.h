@@ -58,7 +58,8 @@ extern "C" {
  *   bits 2-3  placement         1 = points + sampler pool in HBM      2 = both in LDS      3 = pool in LDS
  *             (a placement that does not fit the device's LDS is ignored)
  *   bit  4    sampler           1 = always use the sequential pool-swap stage
- *   bits 8-15 helper workgroups per pair of the cooperative large-n mode (0 = automatic) */
+ *   bits 8-15 helper workgroups per pair of the cooperative large-n mode (fundamental matrix, placement HBM):
+ *             0 = automatic (15 helpers when n >= 8192 and the batch leaves the device mostly idle), 255 = off */
 #define MI_DEGENSAC_TUNE_VARIANT(v)   ((uint32_t)(v) & 3u)
 #define MI_DEGENSAC_TUNE_PLACEMENT(p) (((uint32_t)(p) & 3u) << 2)
 #define MI_DEGENSAC_TUNE_SEQ_POOL     (1u << 4)

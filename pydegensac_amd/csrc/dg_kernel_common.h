@@ -43,8 +43,28 @@ struct dg_ws_layout {
     size_t off_stage;     /* dg_pt[n_max] staging of long least-squares lists                     */
     size_t off_wave;      /* per-wave buffers of the wave-parallel sections: int[NW][n_max] + dg_pt[NW][n_max] */
     size_t off_res;       /* per-model results of a chunk: double J[768], unsigned I[768], int rf[256][5] */
+    size_t off_mslot;     /* cooperative mode: the chunk's compact model index -> slot table, unsigned short[3*DG_CHUNK] */
+    size_t off_hjbuf;     /* cooperative mode: ordered MSAC terms of each helper workgroup, double[coop_k][n_max]        */
     int    n_max;
 };
+
+/* Cooperative large-n mode (placement HBM, fundamental matrix): every pair owner has coop_k helper workgroups that
+ * score groups of the current chunk's models against the point set in the owner's HBM workspace.  One control block
+ * per owner slot (zeroed by the host per launch): the owner publishes a chunk with an agent-scope release and a new
+ * `gen`, helpers acquire, score their groups, release and count themselves in `done` (MI355X_MICROARCH.md, inter-workgroup
+ * visibility: plain payload, lane-0 agent release / acquire, relaxed agent flag). */
+struct dg_coop_cb {
+    /* line 0: the two flags, touched ONLY with agent-scope atomics (a plain access would leave a copy of the line in the
+     * toucher's XCD L2, which later polls would hit: per-XCD L2s are not coherent with each other) */
+    int gen;              /* chunk generation, -1 = no more work for this slot's helpers */
+    int done;             /* helpers that finished generation `gen` */
+    int fpad[30];
+    /* line 1: the chunk's parameters, plain stores before the owner's release, plain loads after the helpers' acquire */
+    int Mtot, n, kind, err;
+    double th, tau, ext[4];
+    double ppad[8];
+};
+static_assert(sizeof(dg_coop_cb) == 256, "control block = two 128-byte lines");
 
 struct dg_args {
     const double *pts1, *pts2;       /* [total, dim] */
@@ -59,6 +79,8 @@ struct dg_args {
     int dim, n_pairs, pts_in_lds;
     int *ticket;                     /* device counter, zeroed per launch: persistent workgroups pull the next pair from it */
     const int *order;                /* optional processing order (ticket t -> pair order[t]); null = identity              */
+    int coop_k;                      /* helper workgroups per owner (0 = every workgroup owns pairs)            */
+    dg_coop_cb *coop;                /* [owner slots] control blocks (coop_k > 0)                              */
     int pool_seq;                    /* 1 = always use the sequential pool-swap stage (LDS exchange-order self-check failed, or forced) */
     int variant_threads, mode;       /* reported in the stats block */
     int *trace;                      /* debug: [0] = count, then (tag, I, J lo, J hi) records; null = off */

@@ -364,6 +364,29 @@ __device__ __forceinline__ int dg_group_owner(int g)
 #endif
 }
 
+/* |epipolar residual| of (x1, y1, x2, y2) under the fp32 model f_ with 4 nested FMAs (level-1 screen) */
+#define DG_R32(f_) fabsf(__builtin_fmaf(x1, __builtin_fmaf((f_)[0], x2, __builtin_fmaf((f_)[3], y2, (f_)[6])), \
+                         __builtin_fmaf(y1, __builtin_fmaf((f_)[1], x2, __builtin_fmaf((f_)[4], y2, (f_)[7])), \
+                                        __builtin_fmaf((f_)[2], x2, __builtin_fmaf((f_)[5], y2, (f_)[8])))))
+
+/* Level-1 screen of one model (see dg_score_chunk_F): fp32 copy of the coefficients and the threshold on |r32| below
+ * which a point may still be inside the 9/4 th band; +inf (everything passes) when the bound is not a normal fp32 number */
+__device__ __forceinline__ float dg_l1_setup(int kind, const double *f, const double *ext, double t94b, float *Ff)
+{
+    const double X1 = ext[0], Y1 = ext[1], X2 = ext[2], Y2 = ext[3];
+    const double u1 = fabs(f[0]) * X2 + fabs(f[3]) * Y2 + fabs(f[6]), u2 = fabs(f[1]) * X2 + fabs(f[4]) * Y2 + fabs(f[7]);
+    const double u3 = fabs(f[0]) * X1 + fabs(f[1]) * Y1 + fabs(f[2]), u4 = fabs(f[3]) * X1 + fabs(f[4]) * Y1 + fabs(f[5]);
+    const double uw = fabs(f[2]) * X2 + fabs(f[5]) * Y2 + fabs(f[8]);
+    const double am = u1*u1 + u2*u2, bm = u3*u3 + u4*u4;
+    const double lim = t94b * (1.0 + 1e-9) * (kind == DG_K_FDS ? am + bm : fmin(am, bm));
+    const double M = X1 * u1 + Y1 * u2 + uw;
+    const double tg = sqrt(lim) + M * (32.0 / 16777216.0);
+#pragma unroll
+    for (int j = 0; j < 9; j++) Ff[j] = (float)f[j];
+    /* unusable bound (overflow / underflow / NaN): make the level pass everything for this model */
+    return (tg > 1e-30 && tg < 1e30 && M < 1e30) ? (float)tg * (1.0f + 1.1920929e-7f) : __builtin_inff();
+}
+
 template <int LDSPTS>
 __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const double *gmodels, const unsigned short *mslot,
                                              int Mtot, int wave, int kind, double th, double tauJ, const double *ext /* LDS[4] */,
@@ -395,27 +418,10 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
              * |r32 - r| <= 8 u M,  M = X1 u1 + Y1 u2 + (|F02| X2 + |F12| Y2 + |F22|) >= sum of |terms|;  32 u M is used.
              * So every point with r^2 < t Dmax has |r32| < sqrt(t Dmax) + 32 u M.  Models whose bound is not a normal
              * fp32 number skip this level. */
-            const double X1 = ext[0], Y1 = ext[1], X2 = ext[2], Y2 = ext[3];
             float thr[4], Ff[4][9];
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const double *f = F[g];
-                const double u1 = fabs(f[0]) * X2 + fabs(f[3]) * Y2 + fabs(f[6]), u2 = fabs(f[1]) * X2 + fabs(f[4]) * Y2 + fabs(f[7]);
-                const double u3 = fabs(f[0]) * X1 + fabs(f[1]) * Y1 + fabs(f[2]), u4 = fabs(f[3]) * X1 + fabs(f[4]) * Y1 + fabs(f[5]);
-                const double uw = fabs(f[2]) * X2 + fabs(f[5]) * Y2 + fabs(f[8]);
-                const double am = u1*u1 + u2*u2, bm = u3*u3 + u4*u4;
-                const double lim = t94b * (1.0 + 1e-9) * (kind == DG_K_FDS ? am + bm : fmin(am, bm));
-                const double M = X1 * u1 + Y1 * u2 + uw;
-                const double tg = sqrt(lim) + M * (32.0 / 16777216.0);
-                /* unusable bound (overflow / underflow / NaN): make the level pass everything for this model */
-                thr[g] = (tg > 1e-30 && tg < 1e30 && M < 1e30) ? (float)tg * (1.0f + 1.1920929e-7f) : __builtin_inff();
-#pragma unroll
-                for (int j = 0; j < 9; j++) Ff[g][j] = (float)f[j];
-            }
+            for (int g = 0; g < 4; g++) thr[g] = dg_l1_setup(kind, F[g], ext, t94b, Ff[g]);
             unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-#define DG_R32(f_) fabsf(__builtin_fmaf(x1, __builtin_fmaf((f_)[0], x2, __builtin_fmaf((f_)[3], y2, (f_)[6])), \
-                         __builtin_fmaf(y1, __builtin_fmaf((f_)[1], x2, __builtin_fmaf((f_)[4], y2, (f_)[7])), \
-                                        __builtin_fmaf((f_)[2], x2, __builtin_fmaf((f_)[5], y2, (f_)[8])))))
             for (int p0 = lane; p0 < n; p0 += 64 * DG_PU) {
                 dg_pt qq[DG_PU];
 #pragma unroll
@@ -428,7 +434,6 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
                     c2 += !(DG_R32(Ff[2]) >= thr[2]) ? on : 0u; c3 += !(DG_R32(Ff[3]) >= thr[3]) ? on : 0u;
                 }
             }
-#undef DG_R32
             const unsigned C1[4] = {dg_wave_sum_u(c0), dg_wave_sum_u(c1), dg_wave_sum_u(c2), dg_wave_sum_u(c3)};
 #pragma unroll
             for (int g = 0; g < 4; g++)
@@ -608,8 +613,10 @@ __device__ __forceinline__ unsigned dg_sample_chunk(unsigned seed, int cn, int n
 
 /* the whole driver for ONE pair, run by one workgroup on scratch slot `slot` */
 template <int T, int LDSPTS>
-__device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsigned char *dyn_smem, const int pair, const int slot)
+__device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsigned char *dyn_smem, const int pair, const int slot, int &coop_gen)
 {
+    const int coopK = LDSPTS == 0 ? A.coop_k : 0;
+    dg_coop_cb *const cb = coopK > 0 ? A.coop + slot : (dg_coop_cb *)0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long off = A.offsets[pair];
     const int n = (int)(A.offsets[pair + 1] - off);
@@ -731,6 +738,23 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
             __syncthreads();
         }
         const int Mtot = __builtin_amdgcn_readfirstlane((int)S->moff[DG_CHUNK]);
+        if (LDSPTS == 0 && coopK > 0) {
+            /* publish the chunk to the helpers: model table (already in the workspace), slot table, parameters */
+            unsigned short *gms = (unsigned short *)(ws + A.wl.off_mslot);
+            for (int i = tid; i < Mtot; i += DG_T) gms[i] = S->mslot[i];
+            __syncthreads();
+            if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
+                if (tid == 0) {
+                    cb->Mtot = Mtot; cb->n = n; cb->kind = mk_full; cb->th = th; cb->tau = maxS.J < maxSs.J ? maxS.J : maxSs.J;
+                    for (int i = 0; i < 4; i++) cb->ext[i] = S->ext[i];
+                    __hip_atomic_store(&cb->done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (tid == 0) __hip_atomic_store(&cb->gen, coop_gen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            coop_gen++;
+        }
 
         DG_PH(1);
         /* ====== score chunk c (waves 2.., one wave per model, points streamed from LDS)  ||  pool swaps of chunk c+1 (wave 0)  ||  seeds + draws of chunk c+2 (wave 1) ====== */
@@ -744,11 +768,21 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
             } else if (wave == 1) {
                 if (cn2 > 0) { unsigned sd = dg_sample_draws<7>(seed, cn2, n, S->seeds3[nx2], S->draws3[nx2], S->alm3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }
             }
-            if (wave >= 2 || (DG_NW < 6 && wave == 1) || DG_NW < 4)
+            /* cooperative mode: the helpers score every group (a whole workgroup per group); the owner's waves only sample */
+            if (!(LDSPTS == 0 && coopK > 0) && (wave >= 2 || (DG_NW < 6 && wave == 1) || DG_NW < 4))
                 dg_score_chunk_F<LDSPTS>(P, n, c.gmodels, S->mslot, Mtot, wave, mk_full, th,
                                          maxS.J < maxSs.J ? maxS.J : maxSs.J, S->ext, (double *)(c.wstage + (size_t)wave * c.n_max), c.res_I, c.res_J, lane);
         }
         c.n_fds += Mtot;   /* provisional: models past the termination point are subtracted below */
+        if (LDSPTS == 0 && coopK > 0) {
+            /* wait for the helpers' groups of this chunk (their results are in c.res_I / c.res_J).  The WHOLE first wave
+             * polls, behind a scalar branch: a spin loop under a per-lane `if` would let the compiler re-order the lanes of
+             * that wave around the barriers of the enclosing loop (a wave then arrives at s_barrier twice) */
+            if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
+                while (__hip_atomic_load(&cb->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < coopK) __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+        }
         __syncthreads();
         if (cn2 > 0) seed = (unsigned)S->itmp[31];
         DG_PH(2);
@@ -1026,6 +1060,121 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
 #undef DG_PH
 }
 
+/* ---- cooperative large-n mode: a helper workgroup ---------------------------------------------------------
+ * One group of four models scored by a WHOLE workgroup on the owner's HBM-resident point set: the two screening levels
+ * of dg_score_chunk_F with the points split over all threads (counts are sums, so the split is free), then every
+ * survivor through dg_pass, which yields I and the reference-order J exactly as the owner's own passes do. */
+template <int T>
+__device__ __forceinline__ void dg_score_group_wg(dg_f_shared *S, const dg_pt *P, int n, const double *gmodels, const unsigned short *gms,
+                                                  int Mtot, int grp, int kind, double th, double tauJ, const double *ext, double *jbuf,
+                                                  unsigned *res_I, double *res_J, int tid)
+{
+    const double t94 = th * 9 / 4, t94b = t94 * (1.0 + 1e-6);
+    const bool use_bound = th != 0 && kind != DG_K_EXFSYM && tauJ >= 4.0;
+    const int m0 = 4 * grp;
+    int mi[4], ng = 0; double F[4][9];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int idx = m0 + g;
+        mi[g] = idx < Mtot ? idx : m0;
+        if (idx < Mtot) ng = g + 1;
+        const double *gp = gmodels + (size_t)gms[mi[g]] * 9;
+#pragma unroll
+        for (int j = 0; j < 9; j++) F[g][j] = gp[j];
+    }
+    unsigned surv = (1u << ng) - 1u;
+    if (use_bound && tauJ >= 64.0) {
+        float thr[4], Ff[4][9];
+#pragma unroll
+        for (int g = 0; g < 4; g++) thr[g] = dg_l1_setup(kind, F[g], ext, t94b, Ff[g]);
+        unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        for (int p0 = tid; p0 < n; p0 += T * DG_PU) {
+            dg_pt qq[DG_PU];
+#pragma unroll
+            for (int u = 0; u < DG_PU; u++) { const int p = p0 + T * u; qq[u] = dg_ldpt<0>(P, p < n ? p : p0); }
+#pragma unroll
+            for (int u = 0; u < DG_PU; u++) {
+                const unsigned on = p0 + T * u < n ? 1u : 0u;
+                const float x1 = (float)qq[u].x1, y1 = (float)qq[u].y1, x2 = (float)qq[u].x2, y2 = (float)qq[u].y2;
+                c0 += !(DG_R32(Ff[0]) >= thr[0]) ? on : 0u; c1 += !(DG_R32(Ff[1]) >= thr[1]) ? on : 0u;
+                c2 += !(DG_R32(Ff[2]) >= thr[2]) ? on : 0u; c3 += !(DG_R32(Ff[3]) >= thr[3]) ? on : 0u;
+            }
+        }
+        const unsigned C1[4] = {dg_block_sum_u(&S->red, c0, tid), dg_block_sum_u(&S->red, c1, tid), dg_block_sum_u(&S->red, c2, tid), dg_block_sum_u(&S->red, c3, tid)};
+#pragma unroll
+        for (int g = 0; g < 4; g++) if (g < ng && !((double)C1[g] > tauJ)) surv &= ~(1u << g);
+    }
+    if (use_bound && surv) {
+        unsigned cb0 = 0, cb1 = 0, cb2 = 0, cb3 = 0;
+        for (int p0 = tid; p0 < n; p0 += T * DG_PU) {
+            dg_pt qq[DG_PU];
+#pragma unroll
+            for (int u = 0; u < DG_PU; u++) { const int p = p0 + T * u; qq[u] = dg_ldpt<0>(P, p < n ? p : p0); }
+#pragma unroll
+            for (int u = 0; u < DG_PU; u++) {
+                const unsigned on = p0 + T * u < n ? 1u : 0u;
+                cb0 += dg_Fbound(kind, F[0], qq[u], t94b) & on; cb1 += dg_Fbound(kind, F[1], qq[u], t94b) & on;
+                cb2 += dg_Fbound(kind, F[2], qq[u], t94b) & on; cb3 += dg_Fbound(kind, F[3], qq[u], t94b) & on;
+            }
+        }
+        const unsigned CB[4] = {dg_block_sum_u(&S->red, cb0, tid), dg_block_sum_u(&S->red, cb1, tid), dg_block_sum_u(&S->red, cb2, tid), dg_block_sum_u(&S->red, cb3, tid)};
+#pragma unroll
+        for (int g = 0; g < 4; g++) if (((surv >> g) & 1u) && !((double)CB[g] > tauJ)) surv &= ~(1u << g);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        if (g >= ng) continue;
+        unsigned I = 0; double J = 0;
+        if ((surv >> g) & 1u) {
+            dg_pass_cfg cfg = dg_cfg0(n); cfg.wantJ = 1; cfg.thJ = th; cfg.jbuf = jbuf;
+            const double *Fg = F[g];
+            dg_pass_res r = dg_pass(&S->red, cfg, [&](int pid, int) { return dg_Ferr(kind, Fg, dg_ldpt<0>(P, pid)); }, tid);
+            I = r.I; J = r.J;
+        }
+        if (tid == 0) { res_I[mi[g]] = I; res_J[mi[g]] = J; }
+    }
+}
+
+/* helper h (1..coop_k) of owner slot `slot`: follows the owner's chunk generations until the owner retires the slot */
+template <int T>
+__device__ __forceinline__ void dg_f_helper(const dg_args &A, dg_f_shared *S, const int slot, const int h)
+{
+    const int tid = threadIdx.x;
+    char *ws = A.ws + (size_t)slot * A.wl.stride;
+    const dg_pt *P = (const dg_pt *)(ws + A.wl.off_pts);
+    const double *gmodels = (const double *)(ws + A.wl.off_models);
+    const unsigned short *gms = (const unsigned short *)(ws + A.wl.off_mslot);
+    double *res_J = (double *)(ws + A.wl.off_res); unsigned *res_I = (unsigned *)(res_J + 3 * DG_CHUNK);
+    double *jbuf = (double *)(ws + A.wl.off_hjbuf) + (size_t)(h - 1) * A.wl.n_max;
+    dg_coop_cb *cb = A.coop + slot;
+    const bool wave0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;      /* scalar: see the owner's wait */
+    int last = 0;
+    for (;;) {
+        if (wave0) {
+            int g;
+            while ((g = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&cb->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) == last) __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            S->itmp[0] = g;                                                  /* every lane stores the same value */
+        }
+        __syncthreads();
+        const int g = S->itmp[0];
+        __syncthreads();
+        if (g < 0) break;
+        last = g;
+        const int Mtot = cb->Mtot, n = cb->n, kind = cb->kind; const double th = cb->th, tau = cb->tau;
+        if (tid < 4) S->ext[tid] = cb->ext[tid];
+        __syncthreads();
+        for (int grp = h - 1; 4 * grp < Mtot; grp += A.coop_k)
+            dg_score_group_wg<T>(S, P, n, gmodels, gms, Mtot, grp, kind, th, tau, S->ext, jbuf, res_I, res_J, tid);
+        __syncthreads();
+        if (wave0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tid == 0) __hip_atomic_fetch_add(&cb->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 /* Persistent workgroups: the grid is at most the number of workgroups the device keeps resident, every workgroup owns
  * one scratch slot and pulls pairs from a device-wide ticket counter until the batch is exhausted (optionally in a
  * caller-given order, e.g. expected-cost descending). */
@@ -1051,11 +1200,21 @@ __global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_fundamental_kernel(dg_a
     __shared__ dg_args As;
     if (threadIdx.x == 0) As = A;
     __syncthreads();
+    int slot = (int)blockIdx.x, coop_gen = 0;
+    if (LDSPTS == 0 && As.coop_k > 0) {
+        /* cooperative large-n mode: block b = owner of slot b / (k+1) when b % (k+1) == 0, else one of its helpers */
+        slot = (int)blockIdx.x / (As.coop_k + 1);
+        const int h = (int)blockIdx.x % (As.coop_k + 1);
+        if (h != 0) { dg_f_helper<T>(As, &Sh, slot, h); return; }
+    }
     for (;;) {
         const int pair = dg_next_pair(As, &next_pair);
         if (pair < 0) break;
-        dg_f_pair<T, LDSPTS>(As, &Sh, dyn_smem, pair, (int)blockIdx.x);
+        dg_f_pair<T, LDSPTS>(As, &Sh, dyn_smem, pair, slot, coop_gen);
     }
+    if (LDSPTS == 0 && As.coop_k > 0 && threadIdx.x == 0)          /* retire the slot: its helpers leave */
+        __hip_atomic_store(&As.coop[slot].gen, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
 }
 
 #endif /* DG_KERNEL_F_MAIN_H */

@@ -44,6 +44,22 @@ def test_fundamental_variants_and_modes_agree(oracle_port):
         assert np.linalg.norm(a - b) <= 1e-9 * np.linalg.norm(b)
 
 
+def test_cooperative_helpers_do_not_change_results():
+    """cooperative large-n mode forced on a small batch (placement HBM, 1 / 3 / 7 helper workgroups per pair, several pairs
+    per owner): bit-identical to the plain run, counters included"""
+    A, B = _f_batch(); A = A * 3; B = B * 3; seeds = list(range(1, 13))
+    ref = None
+    for variant in (512, 256):
+        for helpers in (255, 1, 3, 7):
+            F, m = pd.findFundamentalMatrixBatch(A, B, max_iters=20000, seeds=seeds, tuning=tune(variant, 0) | (helpers << 8))
+            st = [(s_["samples"], s_["lo_runs"], s_["models"], s_["degen"]) for s_ in pd.last_stats()]
+            if ref is None:
+                ref = (np.asarray(F).copy(), [np.asarray(x).copy() for x in m], st)
+            else:
+                assert np.array_equal(np.asarray(F), ref[0]) and st == ref[2], (variant, helpers)
+                assert all(np.array_equal(np.asarray(x), y) for x, y in zip(m, ref[1])), (variant, helpers)
+
+
 def test_homography_variants_and_modes_agree():
     A, B = [], []
     for i, n in enumerate([1200, 400, 2500]):
