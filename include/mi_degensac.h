@@ -151,6 +151,34 @@ int mi_degensac_find_homography_batch_dev(const double *d_pts1, const double *d_
  * `stream_or_null` is NULL, else only that stream's); call before destroying a stream */
 int mi_degensac_release_scratch(int device, void *stream_or_null);
 
+/* ---- structured diagnostics ----------------------------------------------------------------
+ * The reference's drivers fill a residual dump per local-optimisation run and the binding throws it away
+ * (`double *resids`, exp_ranF.c:1503-1511 / :776-779 / :670-672 / :729-730, exp_ranH.c:679-698 / :445-446 / :344 /
+ * :400; freed at bindings.cpp:242-243, :458-459).  Per LO run RESIDS_M = 62 rows of n residuals (rtools.h:15):
+ *   row 0      the so-far-the-best sample's model (errs[4])        row 1      the least-squares model before the LO
+ *   row 2+6i   repetition i: the model of its random subset        rows 3+6i .. 6+6i  its inner iterations (LO metric)
+ *   row 7+6i   its final full-metric pass
+ * resids[(pair_offset * resid_runs + run * n) * 62 + row * n + j]; rows the reference never writes for a run (early
+ * exits: it leaves them uninitialised) are NaN here, rows it memsets keep its byte pattern (0 for F, 0xFF for H); the
+ * after-loop LO of the F driver leaves row 0 NaN.  LO runs beyond resid_runs are not recorded. */
+#define MI_DEGENSAC_RESIDS_M 62
+typedef struct mi_degensac_diag {
+    double  *d_resids;        /* device buffer of total_points * resid_runs * 62 doubles, or NULL              */
+    int32_t  resid_runs;      /* LO runs per pair the buffer has room for                                     */
+    int32_t  reserved;
+} mi_degensac_diag;
+int mi_degensac_find_fundamental_batch_dev_ex(const double *d_pts1, const double *d_pts2, const int64_t *d_offsets,
+        const int64_t *offsets_host, int n_pairs, int dim, const mi_degensac_params *prm, const uint32_t *d_seeds, int device,
+        void *stream, double *d_F, uint8_t *d_mask, int32_t *d_stats, const mi_degensac_diag *diag /*nullable*/);
+int mi_degensac_find_homography_batch_dev_ex(const double *d_pts1, const double *d_pts2, const int64_t *d_offsets,
+        const int64_t *offsets_host, int n_pairs, int dim, const mi_degensac_params *prm, const uint32_t *d_seeds, int device,
+        void *stream, double *d_H, uint8_t *d_mask, int32_t *d_stats, const mi_degensac_diag *diag /*nullable*/);
+/* one pair, host pointers: resids[resid_runs * 62 * n] */
+int mi_degensac_find_fundamental_resids(const double *pts1, const double *pts2, int n, int dim, const mi_degensac_params *prm,
+        uint32_t seed, int device, double *F, uint8_t *mask, int32_t *stats /*nullable*/, double *resids, int resid_runs);
+int mi_degensac_find_homography_resids(const double *pts1, const double *pts2, int n, int dim, const mi_degensac_params *prm,
+        uint32_t seed, int device, double *H, uint8_t *mask, int32_t *stats /*nullable*/, double *resids, int resid_runs);
+
 /* ---- tentative correspondences: the stage in front of the estimators -------------------
  * Replaces the matcher calls of the reference's example, examples/simple-example.py:46-53
  * (cv2.BFMatcher().knnMatch(descs1, descs2, k=2) followed by `m.distance < 0.9 * n.distance`):
@@ -171,6 +199,10 @@ int mi_degensac_match_knn2_dev(int norm, const void *d_desc1, int n1, const void
 int mi_degensac_match_filter_dev(const int32_t *d_idx, const float *d_dist, int n1, float ratio,
                                  const int32_t *d_back_idx_or_null /*[n2,2]: knn2 of desc2 in desc1*/, int device, void *stream,
                                  uint8_t *d_keep);
+/* utils.py:24-41 convert_cv2_kpts_to_xyA on the device: kpts [n,4] float32 = (pt.x, pt.y, size, angle in degrees) ->
+ * out [n,6] float64 = (x, y, s cos a, s sin a, -s sin a, s cos a), the LAF rows of the estimators' [n,6] input */
+int mi_degensac_kpts_to_xyA(const float *kpts, int n, int device, double *out);
+int mi_degensac_kpts_to_xyA_dev(const float *d_kpts, int n, int device, void *stream, double *d_out);
 const char *mi_degensac_match_last_error(void);
 
 /* ---- unit-level device entry points (parity tests of the kernels' building blocks) ------------ */

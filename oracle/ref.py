@@ -30,6 +30,8 @@ def lib(flavour=""):
                                           C.c_int, C.c_int, C.c_double, C.c_uint, C.c_int,
                                           dp, C.POINTER(C.c_ubyte), C.POINTER(C.c_int)]
         l.ref_find_homography.restype = C.c_int
+        l.ref_capture_resids.argtypes = [dp, C.c_int]
+        l.ref_capture_resids.restype = None
         l.ref_counters_reset.argtypes = [C.c_int]
         l.ref_counters_get.argtypes = [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
         l._flavour = flavour
@@ -79,3 +81,14 @@ def find_homography(pts1, pts2, px_th=1.0, conf=0.999, max_iters=50000, error_ty
     stats = dict(samples=st[0], lo_runs=st[1], rejected=st[2], I=st[3], full_passes=full.value,
                  models=full.value, pass_seconds=sec.value)
     return H.reshape(3, 3), mask.astype(bool), stats
+
+
+def resids_of(which, pts1, pts2, runs, **kw):
+    """The residual dump the reference's driver fills per LO run and its binding frees unseen (RESIDS_M = 62 rows of n per
+    run): the first `runs` LO runs as an array [runs, 62, n] (runs that did not happen stay NaN; rows the reference never
+    writes inside a run hold whatever realloc returned), plus the usual result tuple."""
+    n = np.asarray(pts1).shape[0]
+    buf = np.full((runs, 62, n), np.nan)
+    lib(kw.get("flavour", "")).ref_capture_resids(_dp(buf), runs)
+    out = (find_fundamental if which == "F" else find_homography)(pts1, pts2, **kw)
+    return buf, out

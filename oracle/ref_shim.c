@@ -86,6 +86,19 @@ static void build_u(const double *x1, const double *x2, int n, int dim, int laf,
     }
 }
 
+/* optional capture of the drivers' per-LO residual dump (`resids`, RESIDS_M rows of n per LO run), which the
+ * reference's binding frees unseen: set a destination before the call, cleared after it */
+static double *g_resids_dst = 0; static int g_resids_cap = 0;
+void ref_capture_resids(double *dst, int cap_runs) { g_resids_dst = dst; g_resids_cap = cap_runs; }
+static void capture_resids(const double *resids, int runs, int n)
+{
+    if (g_resids_dst && resids) {
+        int r = runs < g_resids_cap ? runs : g_resids_cap;
+        if (r > 0) memcpy(g_resids_dst, resids, sizeof(double) * (size_t)r * RESIDS_M * (size_t)n);
+    }
+    g_resids_dst = 0; g_resids_cap = 0;
+}
+
 /* stats: [0]=samples drawn, [1]=LO runs, [2]=(H) rejected samples, [3]=returned inlier count I */
 int ref_find_fundamental(const double *x1, const double *x2, int n, int dim,
                          double px_th, double conf, int max_iters, int error_type,
@@ -113,6 +126,7 @@ int ref_find_fundamental(const double *x1, const double *x2, int n, int dim,
     ret = exp_ransacFcustomLAF(u, ulaf1, ulaf2, n, th, laf_coef, conf, max_iters, F, mask, data_out,
                                1, 0, &resids, HinF, &I_H, EXFDS1, FDS1, FDSidx1, sym_th, degen);
     if (stats) { stats[0] = data_out[0]; stats[1] = data_out[1]; stats[2] = I_H; stats[3] = ret; }
+    capture_resids(resids, data_out[1], n);
     free(resids); free(data_out); free(u); free(ulaf1); free(ulaf2);
     return ret;
 }
@@ -149,6 +163,7 @@ int ref_find_homography(const double *x1, const double *x2, int n, int dim,
     S = exp_ransacHcustomLAF(u, ulaf1, ulaf2, n, th, laf_coef, conf, max_iters, H, mask, 4, data_out,
                              1, 0, &resids, HDS1, HDSi1, HDSidx1, sym_th);
     if (stats) { stats[0] = data_out[0]; stats[1] = data_out[1]; stats[2] = data_out[2]; stats[3] = (int)S.I; }
+    capture_resids(resids, data_out[1], n);
     free(resids); free(data_out); free(u); free(ulaf1); free(ulaf2);
     return (int)S.I;
 }

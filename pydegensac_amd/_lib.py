@@ -95,6 +95,9 @@ def lib():
         l.mi_degensac_sample_stream.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, ip]
         l.mi_degensac_solve7.restype = C.c_int
         l.mi_degensac_solve7.argtypes = [dp, dp, C.c_int, C.c_int, ip, C.c_int, C.c_int, ip, ip, dp]
+        for name in ("mi_degensac_find_fundamental_resids", "mi_degensac_find_homography_resids"):
+            f = getattr(l, name); f.restype = C.c_int
+            f.argtypes = [dp, dp, C.c_int, C.c_int, pp, C.c_uint32, C.c_int, dp, bp, ip, dp, C.c_int]
         l.mi_degensac_match.restype = C.c_int
         l.mi_degensac_match.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, ip,
                                         C.POINTER(C.c_float), bp]
@@ -102,6 +105,10 @@ def lib():
         l.mi_degensac_match_knn2_dev.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         l.mi_degensac_match_filter_dev.restype = C.c_int
         l.mi_degensac_match_filter_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        l.mi_degensac_kpts_to_xyA.restype = C.c_int
+        l.mi_degensac_kpts_to_xyA.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, dp]
+        l.mi_degensac_kpts_to_xyA_dev.restype = C.c_int
+        l.mi_degensac_kpts_to_xyA_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         l.mi_degensac_match_last_error.restype = C.c_char_p
         l.mi_degensac_mat3.restype = C.c_int
         l.mi_degensac_mat3.argtypes = [C.c_int, dp, C.c_int, C.c_int, dp, ip]

@@ -77,6 +77,10 @@ struct dg_args {
     dg_ws_layout wl;
     dg_params prm;
     int dim, n_pairs, pts_in_lds;
+    double *resids_out;              /* optional diagnostics: the reference's per-LO residual dump (exp_ranF.c:1503-1511, :776-779,
+                                        :670-672, :729-730; exp_ranH.c likewise), [offsets[pair] * resid_runs * 62 + (run * 62 + row) * n + j];
+                                        rows the reference never writes for a run are NaN; null = off                        */
+    int resid_runs;                  /* LO runs per pair the dump has room for                                   */
     int *ticket;                     /* device counter, zeroed per launch: persistent workgroups pull the next pair from it */
     const int *order;                /* optional processing order (ticket t -> pair order[t]); null = identity              */
     int coop_k;                      /* helper workgroups per owner (0 = every workgroup owns pairs)            */

@@ -72,6 +72,7 @@ struct dg_f_ctx {
     int n_max;
     /* counters */
     int n_fds, n_exfds, n_hds, n_aux;
+    double *rrun;            /* diagnostics: the 62 x n residual rows of the current LO run, or null */
 
     __device__ __forceinline__ dg_pt pt(int i) const { return P[i]; }
     /* LAF point sets u_1 (which=1: +a12,+a22) and u_2 (which=2: +a11,+a21): bindings.cpp:337-409 */
@@ -91,6 +92,34 @@ static_assert(offsetof(dg_f_shared, wpad) == offsetof(dg_f_shared, ww) + sizeof(
 static_assert(DG_JBUF_LDS_BYTES >= 2 * DG_CHUNK * 7 * sizeof(int), "pool-stage scratch does not fit");
 
 #define CTX dg_f_ctx<LDSPTS>
+#define DG_RESIDS_M 62           /* rtools.h:15: 2 + RAN_REP * (1 + ILSQ_ITERS + 1) residual vectors per LO run */
+
+/* diagnostics: row `row` of the current LO run's dump := residuals of model M (LDS) under metric `kind`
+ * (kind < 10: fundamental-matrix metrics of dg_Ferr; >= 10: homography metric kind - 10) */
+template <int LDSPTS>
+__device__ __forceinline__ void dg_dump_resid(CTX &c, int row, const double *M, int kind)
+{
+    if (!c.rrun) return;
+    double m[9], Hinv[9], H1[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { m[i] = M[i]; Hinv[i] = 0; H1[i] = 0; }
+    if (kind > 10) dg_hsym_prepare(m, Hinv, H1);
+    double *out = c.rrun + (size_t)row * c.n;
+    for (int j = c.tid; j < c.n; j += DG_T) {
+        const dg_pt q = dg_ldpt<LDSPTS>(c.P, j);
+        out[j] = kind < 10 ? dg_Ferr(kind, m, q) : dg_Herr(kind - 10, m, Hinv, H1, q);
+    }
+}
+/* a new LO run: point c.rrun at its rows (null when the dump is off or full) and mark every row "never written" */
+template <int LDSPTS>
+__device__ __forceinline__ void dg_resid_begin(CTX &c, int run /* 0-based */)
+{
+    c.rrun = 0;
+    if (!c.A->resids_out || run >= c.A->resid_runs) return;
+    c.rrun = c.A->resids_out + ((size_t)c.off * c.A->resid_runs + (size_t)run * c.n) * DG_RESIDS_M;
+    const double nan_ = __longlong_as_double(0x7ff8000000000000ll);
+    for (size_t j = c.tid; j < (size_t)DG_RESIDS_M * c.n; j += DG_T) c.rrun[j] = nan_;
+}
 
 /* debug checkpoints (tag, I, J), mirrored by the oracle's TRACE2 hook; active only when A.trace != 0 */
 #define DG_TRACE(c, tag, I, J) do { if ((c).A->trace && (c).tid == 0) { int *t_ = (c).A->trace; int k_ = t_[0]; \

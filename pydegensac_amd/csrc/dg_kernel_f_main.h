@@ -49,7 +49,7 @@ __device__ __forceinline__ unsigned dg_hash_list(const int *list, int count, boo
  * metric variant (FDS1 / EXFDS1) whose residuals the reference would hold in errs[0] for that model. */
 template <int LDSPTS>
 __device__ __forceinline__ dg_score dg_iterF(CTX &c, int *inliers, double th, double ths, double *f, int iterID,
-                                             int mk_full, int mk_ex, int *kind0)
+                                             int mk_full, int mk_ex, int *kind0, int rrow /* first diagnostics row of this repetition's iterations */)
 {
     dg_f_shared *S = c.S; const int n = c.n, tid = c.tid;
     double *fl = S->fLO;
@@ -81,6 +81,7 @@ __device__ __forceinline__ dg_score dg_iterF(CTX &c, int *inliers, double th, do
     for (int it = 0; it < DG_ILSQ_ITERS; it++) {
         dg_pass_cfg c1 = dg_cfg0(n); c1.wantJ = 1; c1.thJ = th; c1.list = inliers; c1.thL = th;
         dg_pass_res r1 = dg_f_pass(c, fl, mk_ex, c1); c.n_exfds++;
+        dg_dump_resid(c, rrow + it, fl, mk_ex);
         DG_LT(3);
         Sc = zero; Sc.I = r1.I; Sc.J = r1.J;
         DG_TRACE(c, 11, Sc.I, Sc.J);
@@ -145,6 +146,7 @@ __device__ __forceinline__ dg_score dg_iterF(CTX &c, int *inliers, double th, do
     dg_pass_cfg c3 = dg_cfg0(n); c3.wantJ = 1; c3.thJ = th; c3.list = inliers; c3.thL = th;
     DG_LT(0);
     dg_pass_res r3 = dg_f_pass(c, fl, mk_full, c3); c.n_fds++;
+    dg_dump_resid(c, rrow + 4, fl, mk_full);
     DG_LT(7);
     DG_TRACE(c, 12, r3.I, r3.J);
     if (maxS.J < r3.J) {
@@ -165,7 +167,10 @@ __device__ __noinline__ dg_score dg_inFrani(CTX &c, int ninl, double th, double 
     int *inliers = c.L[0], *intbuff = c.L[1], *intbuff_best = c.L[2];
     dg_score maxS = {0, 0, 0, 0};
     *kindBest = mk_full;
-    if (ninl < 16) return maxS;
+    if (ninl < 16) {
+        if (c.rrun) { for (size_t j = tid; j < (size_t)(DG_RESIDS_M - 2) * c.n; j += DG_T) c.rrun[2 * (size_t)c.n + j] = 0.; __syncthreads(); }   /* exp_ranF.c:761 */
+        return maxS;
+    }
     int ssiz = ninl / 2; if (ssiz > 14) ssiz = 14;
     for (int i = 0; i < DG_RAN_REP; i++) {
         DG_LT(0);
@@ -179,7 +184,8 @@ __device__ __noinline__ dg_score dg_inFrani(CTX &c, int ninl, double th, double 
         __syncthreads();
         int k0;
         ++*iterID;
-        dg_score Sc = dg_iterF(c, intbuff, th, DG_TC * th, S->f, *iterID, mk_full, mk_ex, &k0);
+        dg_dump_resid(c, 2 + 6 * i, S->f, mk_full);                       /* errs[0] = FDS1(f): exp_ranF.c:776-779 */
+        dg_score Sc = dg_iterF(c, intbuff, th, DG_TC * th, S->f, *iterID, mk_full, mk_ex, &k0, 2 + 6 * i + 1);
         if (maxS.J < Sc.J) {
             maxS = Sc; *kindBest = k0;
             __syncthreads();
@@ -635,7 +641,7 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
     c.res_J = (double *)(ws + A.wl.off_res); c.res_I = (unsigned *)(c.res_J + 3 * DG_CHUNK); c.rf = (int (*)[5])(c.res_I + 3 * DG_CHUNK);
     c.seeds = S->seeds3[0]; c.draws = S->draws3[0];
     c.n_max = A.wl.n_max; c.wlist = (int *)(ws + A.wl.off_wave); c.wstage = (dg_pt *)(ws + A.wl.off_wave + (size_t)DG_NW * A.wl.n_max * sizeof(int));
-    c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0;
+    c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0; c.rrun = 0;
     dg_pt *Pw; int *pool;
     /* LDSPTS: 1 = point set and sampler pool in LDS, 2 = pool in LDS / points in the HBM workspace (L2), 0 = both in HBM */
     if (LDSPTS == 1) { Pw = (dg_pt *)dyn_smem; pool = (int *)(dyn_smem + (size_t)n * sizeof(dg_pt)); }
@@ -912,6 +918,8 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
                 }
                 iter_cnt++; track = 0;
                 DG_PH(3);
+                dg_resid_begin(c, iter_cnt - 1); __syncthreads();
+                dg_dump_resid(c, 0, e4F, e4kind);                              /* errs[4], exp_ranF.c:1503-1504 */
                 /* LSQ before LO: S = inlidxs(errs[4], TC*th*MWM); u2f; FDS1; inlidxs(th)  (:1506-1511) */
                 dg_pass_cfg ca = dg_cfg0(n); ca.list = c.L[0]; ca.thL = DG_TC * th * DG_MWM;
                 dg_pass_res ra = dg_f_pass(c, e4F, e4kind, ca);
@@ -919,6 +927,7 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
                 dg_u2f_list(c, c.L[0], (int)ra.nL, 0, 0, S->f);
                 dg_pass_cfg cb = dg_cfg0(n); cb.wantJ = 1; cb.thJ = th; cb.list = c.L[0]; cb.thL = th;
                 dg_pass_res rb = dg_f_pass(c, S->f, mk_full, cb); c.n_fds++;
+                dg_dump_resid(c, 1, S->f, mk_full);                            /* d after the LSQ, :1511 */
                 DG_TRACE(c, 2, rb.nL, rb.J);
                 int kb;
                 dg_score Sl = dg_inFrani(c, (int)rb.nL, th, S->Hx /* LO result model */, &iterID, mk_full, mk_ex, &kb);
@@ -997,11 +1006,15 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
             }
         } else {
             iter_cnt++;
+            dg_resid_begin(c, iter_cnt - 1); __syncthreads();
+            /* row 0 (errs[4], exp_ranF.c:1634) stays NaN here: which sample's residuals that physical buffer holds after the
+             * loop is not tracked past sample 50 */
             dg_pass_cfg ca = dg_cfg0(n); ca.list = c.L[0]; ca.thL = DG_TC * th * DG_MWM;
             dg_pass_res ra = dg_f_pass(c, S->FBest, mk_full, ca);
             dg_u2f_list(c, c.L[0], (int)ra.nL, 0, 0, S->f);
             dg_pass_cfg cb = dg_cfg0(n); cb.list = c.L[0]; cb.thL = th;
             dg_pass_res rb = dg_f_pass(c, S->f, mk_full, cb); c.n_fds++;
+            dg_dump_resid(c, 1, S->f, mk_full);
             int kb;
             dg_score Sl = dg_inFrani(c, (int)rb.nL, th, S->Hx, &iterID, mk_full, mk_ex, &kb);
             if (maxS.J < Sl.J) {

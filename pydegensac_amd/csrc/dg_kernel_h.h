@@ -104,7 +104,8 @@ struct dg_hbufs { int pe[3]; };
 
 /* exp_ranH.c:291-412 exp_iterHcustom; h (LDS) = in/out parameter H */
 template <int LDSPTS>
-__device__ __forceinline__ dg_score dg_iterHc(CTX &c, int kind, int *inliers, double th, double ths, double *h, int iterID, unsigned inlLimit, dg_hbufs &B)
+__device__ __forceinline__ dg_score dg_iterHc(CTX &c, int kind, int *inliers, double th, double ths, double *h, int iterID, unsigned inlLimit, dg_hbufs &B,
+                                              int rrow /* first diagnostics row of this repetition's iterations */)
 {
     dg_f_shared *S = c.S; const int n = c.n, tid = c.tid;
     double *hl = S->fLO;
@@ -132,6 +133,7 @@ __device__ __forceinline__ dg_score dg_iterHc(CTX &c, int kind, int *inliers, do
     for (int it = 0; it < DG_ILSQ_ITERS; it++) {
         dg_pass_cfg c1 = dg_cfg0(n); c1.wantJ = 1; c1.thJ = th; c1.list = inliers; c1.thL = th;
         dg_pass_res r1 = dg_hm_pass(c, kind, hl, c1); c.n_hds++;
+        dg_dump_resid(c, rrow + it, hl, 10 + kind);                       /* exp_ranH.c:344 */
         DG_BUFSET(S, pd, hl);
         dg_score Ss = zero; Ss.I = r1.I; Ss.J = r1.J;
         DG_TRACE(c, 21, Ss.I, Ss.J);
@@ -169,6 +171,7 @@ __device__ __forceinline__ dg_score dg_iterHc(CTX &c, int kind, int *inliers, do
     }
     dg_pass_cfg c3 = dg_cfg0(n); c3.wantJ = 1; c3.thJ = th; c3.list = inliers; c3.thL = th;
     dg_pass_res r3 = dg_hm_pass(c, kind, hl, c3); c.n_hds++;
+    dg_dump_resid(c, rrow + 4, hl, 10 + kind);                            /* exp_ranH.c:400 */
     DG_BUFSET(S, pd, hl);
     DG_TRACE(c, 22, r3.I, r3.J);
     if (maxS.J < r3.J) {
@@ -188,7 +191,14 @@ __device__ __forceinline__ dg_score dg_inHranic(CTX &c, int kind, int ninl, doub
     dg_f_shared *S = c.S; const int tid = c.tid;
     int *inliers = c.L[0], *intbuff = c.L[1];
     dg_score maxS = {0, 0, 0, 0};
-    if (ninl < 8) return maxS;
+    if (ninl < 8) {
+        if (c.rrun) {                                                    /* exp_ranH.c:429: memset(.., 0xFF, ..) */
+            const double ff = __longlong_as_double(-1ll);
+            for (size_t j = tid; j < (size_t)(DG_RESIDS_M - 2) * c.n; j += DG_T) c.rrun[2 * (size_t)c.n + j] = ff;
+            __syncthreads();
+        }
+        return maxS;
+    }
     int ssiz = ninl / 2; if (ssiz > 12) ssiz = 12;
     { int t = B.pe[2]; B.pe[2] = B.pe[0]; B.pe[0] = t; }
     for (int i = 0; i < DG_RAN_REP; i++) {
@@ -200,8 +210,9 @@ __device__ __forceinline__ dg_score dg_inHranic(CTX &c, int kind, int ninl, doub
         }
         __syncthreads();
         DG_BUFSET(S, B.pe[0], S->f);                          /* HDS1(h) -> errs[0] (scored inside dg_iterHc) */
+        dg_dump_resid(c, 2 + 6 * i, S->f, 10 + kind);         /* exp_ranH.c:445-446 */
         ++*iterID;
-        dg_score Sc = dg_iterHc(c, kind, intbuff, th, DG_TC * th, S->f, *iterID, inlLimit, B);
+        dg_score Sc = dg_iterHc(c, kind, intbuff, th, DG_TC * th, S->f, *iterID, inlLimit, B, 2 + 6 * i + 1);
         if (maxS.J < Sc.J) {
             maxS = Sc;
             { int t = B.pe[2]; B.pe[2] = B.pe[0]; B.pe[0] = t; }
@@ -216,11 +227,13 @@ __device__ __forceinline__ dg_score dg_inHranic(CTX &c, int kind, int ninl, doub
 
 /* one LO run of the driver (exp_ranH.c:678-747 / :795-861).  e4 = model behind errs[4].  Returns 1 if accepted. */
 template <int LDSPTS>
-__device__ __noinline__ int dg_h_lo(CTX &c, int kind, const double *e4, double th, dg_score &maxS, int *iterID, int *p1_inliers, int no_sam)
+__device__ __noinline__ int dg_h_lo(CTX &c, int kind, const double *e4, double th, dg_score &maxS, int *iterID, int *p1_inliers, int no_sam, int lo_run /* 0-based */)
 {
     dg_f_shared *S = c.S; const int n = c.n, tid = c.tid;
     dg_hbufs B; B.pe[0] = 0; B.pe[1] = 1; B.pe[2] = 2;
     const int B0 = B.pe[0];                                   /* d = errs[0] */
+    dg_resid_begin(c, lo_run); __syncthreads();
+    dg_dump_resid(c, 0, e4, 10 + kind);                                   /* errs[4], exp_ranH.c:679 / :794 */
     dg_pass_cfg ca = dg_cfg0(n); ca.list = c.L[0]; ca.thL = DG_TC * th * DG_MWM;
     dg_pass_res ra = dg_hm_pass(c, kind, e4, ca);
     DG_TRACE(c, 1, ra.nL, no_sam);
@@ -228,6 +241,7 @@ __device__ __noinline__ int dg_h_lo(CTX &c, int kind, const double *e4, double t
     DG_BUFSET(S, B0, S->f);
     dg_pass_cfg cb = dg_cfg0(n); cb.wantJ = 1; cb.thJ = th; cb.list = c.L[0]; cb.thL = th;
     dg_pass_res rb = dg_hm_pass(c, kind, S->f, cb); c.n_hds++;
+    dg_dump_resid(c, 1, S->f, 10 + kind);                                 /* d after the LSQ, exp_ranH.c:694 / :810 */
     DG_TRACE(c, 2, rb.nL, rb.J);
     /* h (the driver's `sol`) = S->Hx: u2h wrote the LSQ model there; inHrani overwrites it on improvement */
     __syncthreads();
@@ -309,7 +323,7 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
     c.res_J = (double *)(ws + A.wl.off_res); c.res_I = (unsigned *)(c.res_J + 3 * DG_CHUNK); c.rf = (int (*)[5])(c.res_I + 3 * DG_CHUNK);
     c.seeds = S->seeds3[0]; c.draws = S->draws3[0];
     c.n_max = A.wl.n_max; c.wlist = (int *)(ws + A.wl.off_wave); c.wstage = (dg_pt *)(ws + A.wl.off_wave + (size_t)DG_NW * A.wl.n_max * sizeof(int));
-    c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0;
+    c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0; c.rrun = 0;
     dg_pt *Pw; int *pool;
     /* LDSPTS: 1 = point set and sampler pool in LDS, 2 = pool in LDS / points in the HBM workspace (L2), 0 = both in HBM */
     if (LDSPTS == 1) { Pw = (dg_pt *)dyn_smem; pool = (int *)(dyn_smem + (size_t)n * sizeof(dg_pt)); }
@@ -492,7 +506,7 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
                 if (tid == 0) { dg_srand(&S->rng, c.seeds[k]); for (int i = 0; i < 5; i++) dg_rand(&S->rng); }
                 __syncthreads();
                 iter_cnt++;
-                if (dg_h_lo(c, kind, e4, th, maxS, &iterID, &p1_inliers, no_sam)) { new_max = 1; accepted = 1; best_sample = no_sam; t_best = wall_clock64(); }
+                if (dg_h_lo(c, kind, e4, th, maxS, &iterID, &p1_inliers, no_sam, iter_cnt - 1)) { new_max = 1; accepted = 1; best_sample = no_sam; t_best = wall_clock64(); }
             }
             if (new_max) {
                 int new_sam = dg_nsamples((int)maxS.I + 1, n, 4, pr.conf);
@@ -511,7 +525,7 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
         if (tid == 0 && no_sam > 0) { int li = no_sam - 1 - chunk_base; if (li < 0) li = 0; dg_srand(&S->rng, c.seeds[li]); for (int i = 0; i < 5; i++) dg_rand(&S->rng); }
         __syncthreads();
         iter_cnt++;
-        if (dg_h_lo(c, kind, e4, th, maxS, &iterID, &p1_inliers, no_sam)) { accepted = 1; best_sample = no_sam; t_best = wall_clock64(); }
+        if (dg_h_lo(c, kind, e4, th, maxS, &iterID, &p1_inliers, no_sam, iter_cnt - 1)) { accepted = 1; best_sample = no_sam; t_best = wall_clock64(); }
     }
 
     /* ---- final mask: exp_ranH.c:864-907 (this driver indexes the filters correctly) ---- */

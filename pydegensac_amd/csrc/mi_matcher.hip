@@ -110,6 +110,18 @@ __global__ void mt_filter_kernel(const int32_t *idx, const float *dist, int n1, 
     keep[i] = ok ? 1 : 0;
 }
 
+/* utils.py:24-41 convert_cv2_kpts_to_xyA on the device: (x, y, size, angle in degrees) -> (x, y, s cos a, s sin a,
+ * -s sin a, s cos a) in float64, the [n, 6] rows the estimators take for the LAF consistency checks */
+__global__ void mt_kpts_to_xyA_kernel(const float *kp, int n, double *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = kp[4 * i], y = kp[4 * i + 1], s = kp[4 * i + 2], a = kp[4 * i + 3];
+    const double r = a * 3.141592653589793 / 180.0, cs = cos(r), sn = sin(r);
+    double *o = out + (size_t)i * 6;
+    o[0] = x; o[1] = y; o[2] = s * cs; o[3] = s * sn; o[4] = -s * sn; o[5] = s * cs;
+}
+
 static thread_local char mt_err[256] = "";
 extern "C" const char *mi_degensac_match_last_error(void) { return mt_err; }
 #define MTCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(mt_err, sizeof mt_err, "%s failed: %s", #x, hipGetErrorString(e_)); (void)hipGetLastError(); return MI_DEGENSAC_EHIP; } } while (0)
@@ -186,5 +198,29 @@ extern "C" int mi_degensac_match(int norm, const void *desc1, int n1, const void
     MTCHK(hipDeviceSynchronize());
     MTCHK(hipMemcpy(idx, di, (size_t)n1 * 8, hipMemcpyDeviceToHost)); MTCHK(hipMemcpy(dist, dd, (size_t)n1 * 8, hipMemcpyDeviceToHost));
     if (keep) MTCHK(hipMemcpy(keep, dk, (size_t)n1, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int mi_degensac_kpts_to_xyA_dev(const float *d_kpts, int n, int device, void *stream, double *d_out)
+{
+    if (n < 0) { snprintf(mt_err, sizeof mt_err, "bad argument"); return MI_DEGENSAC_EINVAL; }
+    MtDevGuard g; int rc = g.enter(device); if (rc) return rc;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(mt_kpts_to_xyA_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_kpts, n, d_out);
+    MTCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int mi_degensac_kpts_to_xyA(const float *kpts, int n, int device, double *out)
+{
+    if (!kpts || !out || n < 0) { snprintf(mt_err, sizeof mt_err, "bad argument"); return MI_DEGENSAC_EINVAL; }
+    MtDevGuard g; int rc = g.enter(device); if (rc) return rc;
+    if (n == 0) return 0;
+    float *dk = nullptr; double *dout = nullptr;
+    struct Free { float *&a; double *&b; ~Free() { (void)hipFree(a); (void)hipFree(b); } } fr{dk, dout};
+    MTCHK(hipMalloc((void **)&dk, (size_t)n * 16)); MTCHK(hipMalloc((void **)&dout, (size_t)n * 48));
+    MTCHK(hipMemcpy(dk, kpts, (size_t)n * 16, hipMemcpyHostToDevice));
+    rc = mi_degensac_kpts_to_xyA_dev(dk, n, device, nullptr, dout); if (rc) return rc;
+    MTCHK(hipDeviceSynchronize());
+    MTCHK(hipMemcpy(out, dout, (size_t)n * 48, hipMemcpyDeviceToHost));
     return 0;
 }

@@ -70,3 +70,16 @@ def tentative_points(kps1, kps2, desc1, desc2, ratio=0.9, mutual=False, norm=Non
     q, t, _ = match_snn(desc1, desc2, ratio, mutual, norm, device)
     a = np.asarray(kps1, np.float64); b = np.asarray(kps2, np.float64)
     return a[q], b[t]
+
+
+def kpts_to_xyA(kpts, device=0):
+    """utils.py:24-41 `convert_cv2_kpts_to_xyA` on the GPU for keypoints given as an array [n, 4] = (x, y, size, angle in
+    degrees) (cv2.KeyPoint.pt / .size / .angle): the [n, 6] float64 rows (x, y, a11, a12, a21, a22) the estimators accept."""
+    k = np.ascontiguousarray(kpts, np.float32)
+    if k.ndim != 2 or k.shape[1] != 4:
+        raise ValueError("keypoints should be an array [n, 4] = (x, y, size, angle)")
+    out = np.zeros((k.shape[0], 6))
+    rc = _lib.lib().mi_degensac_kpts_to_xyA(k.ctypes.data_as(C.POINTER(C.c_float)), k.shape[0], int(device), _lib.dptr(out))
+    if rc != 0:
+        raise _lib.MiDegensacError(f"mi_degensac error {rc}: {_lib.lib().mi_degensac_match_last_error().decode()}")
+    return out

@@ -1,0 +1,59 @@
+"""GPU: the per-LO residual dump (include/mi_degensac.h MI_DEGENSAC_RESIDS_M) against the dump the UNMODIFIED
+reference fills and frees (oracle/_ref, captured by ref_shim.c).  Row 0 of the first run (a minimal-sample model) is
+bit-exact; the other rows are residuals of least-squares models (also row 0 of a run started from the DEGENSAC branch), which agree with the reference's to the last bits of its LAPACK
+build's dsyev (models within 1e-9), so they are compared to 2e-5 relative; rows the reference memsets keep
+its byte pattern; asking for the dump changes nothing else."""
+import numpy as np
+import pytest
+
+import pydegensac_amd as pd
+from pydegensac_amd import diagnostics as dg, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(res, ref, lo_runs, n):
+    runs = min(lo_runs, res.shape[0])
+    assert runs > 0
+    written = ~np.isnan(res[:runs]).all(axis=2)                       # rows the kernel computed (or memset)
+    assert written[:, 1].all()                                        # the LSQ-before-LO row exists in every run
+    for r in range(runs):
+        for row in np.flatnonzero(written[r]):
+            a, b = res[r, row], ref[r, row]
+            if (row == 0 and r == 0) or not np.isfinite(b).all():
+                assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (r, row)
+            else:
+                assert np.allclose(a, b, rtol=2e-5, atol=1e-9 * max(1.0, float(np.abs(b).max()))), (r, row, np.abs(a - b).max())
+    assert np.isnan(res[runs:]).all()
+    return int(written.sum())
+
+
+@pytest.mark.parametrize("et", [0, 1])
+def test_fundamental_residual_dump_equals_reference(oracle_ref, et):
+    p1, p2, _, _ = syn.two_view_fundamental(1200, 0.4, 0.1, seed=3)
+    F, m, st, res = dg.find_fundamental_with_residuals(p1, p2, 0.5, 0.9999, 20000, et, seed=5, lo_runs=12)
+    ref, (Fo, mo, so) = oracle_ref.resids_of("F", p1, p2, 12, px_th=0.5, conf=0.9999, max_iters=20000, error_type=et, seed=5)
+    assert st["lo_runs"] == so["lo_runs"] and np.array_equal(m, mo)
+    rows = _check(res, ref, st["lo_runs"], 1200)
+    assert rows > 20 * min(st["lo_runs"], 12)
+    F2, m2 = pd.findFundamentalMatrix_(p1, p2, 0.5, 0.9999, 20000, et, seed=5)
+    assert np.array_equal(F, F2) and np.array_equal(m, m2)           # asking for the dump changes nothing else
+
+
+@pytest.mark.parametrize("et", [0, 2, 3])
+def test_homography_residual_dump_equals_reference(oracle_ref, et):
+    p1, p2, _, _ = syn.homography_pairs(900, 0.4, 0.5, seed=4)
+    H, m, st, res = dg.find_homography_with_residuals(p1, p2, 2.0, 0.999, 20000, et, seed=7, lo_runs=6)
+    ref, (Ho, mo, so) = oracle_ref.resids_of("H", p1, p2, 6, px_th=2.0, conf=0.999, max_iters=20000, error_type=et, seed=7)
+    assert st["lo_runs"] == so["lo_runs"] and np.array_equal(m, mo)
+    _check(res, ref, st["lo_runs"], 900)
+
+
+def test_few_inliers_rows_keep_the_reference_memset():
+    """fewer than 16 (F) inliers after the LSQ: the reference zero-fills the 60 repetition rows (exp_ranF.c:761)"""
+    p1, p2, _, _ = syn.two_view_fundamental(60, 0.2, 0.1, seed=9)
+    F, m, st, res = dg.find_fundamental_with_residuals(p1, p2, 0.5, 0.9999, 3000, 0, seed=2, lo_runs=4)
+    if st["lo_runs"] > 0:
+        r0 = res[0]
+        assert not np.isnan(r0[1]).any()
+        assert (r0[2:] == 0).all() or not np.isnan(r0[2]).all()

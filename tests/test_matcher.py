@@ -77,3 +77,21 @@ def test_gpu_example_pipeline_from_descriptors_to_homography(oracle_port):
     assert np.array_equal(src, p1[q]) and np.array_equal(dst, kps2[t]) and len(q) > 400
     H, mask = pydegensac.findHomography(src, dst, 4.0, 0.99, 2000, seed=2)
     assert np.asarray(mask).sum() > 0.8 * len(q)
+
+
+@pytest.mark.gpu
+def test_gpu_keypoints_to_laf_rows_equal_the_reference_conversion():
+    """mi_degensac_kpts_to_xyA against utils.py:24-41 (pydegensac_amd.convert_cv2_kpts_to_xyA on keypoint objects)"""
+    import math
+    import pydegensac_amd as pd
+    from pydegensac_amd import matcher
+
+    class KP:                                                     # what utils.py reads of a cv2.KeyPoint
+        def __init__(self, x, y, s, a): self.pt = (x, y); self.size = s; self.angle = a
+    rng = np.random.default_rng(5)
+    k = np.c_[rng.uniform(0, 800, 500), rng.uniform(0, 600, 500), rng.uniform(2, 60, 500), rng.uniform(0, 360, 500)].astype(np.float32)
+    k[0, 3] = 0.0; k[1, 3] = 90.0; k[2, 3] = 180.0
+    want = pd.convert_cv2_kpts_to_xyA([KP(float(a), float(b), float(c), float(d)) for a, b, c, d in k])
+    got = matcher.kpts_to_xyA(k)
+    assert np.array_equal(got[:, :2], want[:, :2])
+    assert np.allclose(got, want, rtol=0, atol=4e-14 * 60)         # cos / sin of the device library vs libm: last-bit agreement
