@@ -355,16 +355,16 @@ __device__ __noinline__ void dg_sample_pool_seq(int cn, int n, int *pool, int (*
  * the load latency per model); only survivors are scored exactly, the others get J = 0 (never an event in the commit,
  * so decisions are unchanged).  With tau < 4 nearly every model survives and the screen is skipped. */
 /* which wave scores group g (4 consecutive models).  With >= 6 waves the scoring waves 2.. share the groups round-robin
- * and the two sampler waves do not score (their stages are the critical path).  With 4 waves the pool-swap wave 0
- * (~57 us per chunk) still does not score; wave 1 (seeds + draws, ~44 us) takes 2 of every 16 groups (~7 us each),
- * waves 2 and 3 seven each.  With 2 waves (128-thread workgroups: four resident pairs per CU) both waves score,
+ * and the two sampler waves do not score (their stages are the critical path).  With 4 waves, wave 1 (seed chain
+ * 33 us + draws 16 us per chunk: the longest stage) does not score, wave 0 (pool swaps, 45 us) takes 1 of every 16
+ * groups (~7 us each), waves 2 and 3 eight and seven.  With 2 waves (128-thread workgroups: four resident pairs per CU) both waves score,
  * alternating groups, after their sampler stage. */
 __device__ __forceinline__ int dg_group_owner(int g)
 {
 #if DG_NW >= 6
     return 2 + g % (DG_NW - 2);
 #elif DG_NW >= 4
-    return (int)((0x1132323232323232ull >> (4 * (g & 15))) & 15ull);   /* g & 15 = 0..15 -> 2,3,2,3,...,2,3,1,1 */
+    return (int)((0x2032323232323232ull >> (4 * (g & 15))) & 15ull);   /* g & 15 = 0..15 -> 2,3,2,3,...,2,3,0,2 */
 #else
     return g & 1;                                                      /* two waves: both score once their sampler stage is done */
 #endif
@@ -775,7 +775,7 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
                 if (cn2 > 0) { unsigned sd = dg_sample_draws<7>(seed, cn2, n, S->seeds3[nx2], S->draws3[nx2], S->alm3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }
             }
             /* cooperative mode: the helpers score every group (a whole workgroup per group); the owner's waves only sample */
-            if (!(LDSPTS == 0 && coopK > 0) && (wave >= 2 || (DG_NW < 6 && wave == 1) || DG_NW < 4))
+            if (!(LDSPTS == 0 && coopK > 0) && (wave >= 2 || DG_NW < 6))
                 dg_score_chunk_F<LDSPTS>(P, n, c.gmodels, S->mslot, Mtot, wave, mk_full, th,
                                          maxS.J < maxSs.J ? maxS.J : maxSs.J, S->ext, (double *)(c.wstage + (size_t)wave * c.n_max), c.res_I, c.res_J, lane);
         }
