@@ -166,6 +166,11 @@ typedef struct mi_degensac_diag {
     double  *d_resids;        /* device buffer of total_points * resid_runs * 62 doubles, or NULL              */
     int32_t  resid_runs;      /* LO runs per pair the buffer has room for                                     */
     int32_t  reserved;
+    int32_t *d_hist;          /* fundamental matrix only: the drivers' `data_out` (exp_ranF.c:1495, :1758-1759; allocated and freed at
+                                 bindings.cpp:412, :459): per pair n + 3 ints at d_hist[offsets[pair] + 3 * pair]: [0] samples drawn,
+                                 [1] LO runs, [2 + I] number of samples whose best model had I inliers.  Device buffer of
+                                 total_points + 3 * n_pairs ints, or NULL.  Every model is scored exactly when this is set (the
+                                 screening passes are skipped): results are unchanged, the call is slower.               */
 } mi_degensac_diag;
 int mi_degensac_find_fundamental_batch_dev_ex(const double *d_pts1, const double *d_pts2, const int64_t *d_offsets,
         const int64_t *offsets_host, int n_pairs, int dim, const mi_degensac_params *prm, const uint32_t *d_seeds, int device,
@@ -178,6 +183,9 @@ int mi_degensac_find_fundamental_resids(const double *pts1, const double *pts2, 
         uint32_t seed, int device, double *F, uint8_t *mask, int32_t *stats /*nullable*/, double *resids, int resid_runs);
 int mi_degensac_find_homography_resids(const double *pts1, const double *pts2, int n, int dim, const mi_degensac_params *prm,
         uint32_t seed, int device, double *H, uint8_t *mask, int32_t *stats /*nullable*/, double *resids, int resid_runs);
+/* one pair, host pointers: hist[n + 3] (see mi_degensac_diag.d_hist) */
+int mi_degensac_find_fundamental_hist(const double *pts1, const double *pts2, int n, int dim, const mi_degensac_params *prm,
+        uint32_t seed, int device, double *F, uint8_t *mask, int32_t *stats /*nullable*/, int32_t *hist);
 
 /* ---- tentative correspondences: the stage in front of the estimators -------------------
  * Replaces the matcher calls of the reference's example, examples/simple-example.py:46-53

@@ -30,6 +30,8 @@ def lib(flavour=""):
                                           C.c_int, C.c_int, C.c_double, C.c_uint, C.c_int,
                                           dp, C.POINTER(C.c_ubyte), C.POINTER(C.c_int)]
         l.ref_find_homography.restype = C.c_int
+        l.ref_capture_data_out.argtypes = [C.POINTER(C.c_int), C.c_int]
+        l.ref_capture_data_out.restype = None
         l.ref_capture_resids.argtypes = [dp, C.c_int]
         l.ref_capture_resids.restype = None
         l.ref_counters_reset.argtypes = [C.c_int]
@@ -91,4 +93,14 @@ def resids_of(which, pts1, pts2, runs, **kw):
     buf = np.full((runs, 62, n), np.nan)
     lib(kw.get("flavour", "")).ref_capture_resids(_dp(buf), runs)
     out = (find_fundamental if which == "F" else find_homography)(pts1, pts2, **kw)
+    return buf, out
+
+
+def data_out_of(pts1, pts2, **kw):
+    """The F driver's `data_out` ([0] samples, [1] LO runs, [2 + I] samples whose best root had I inliers; allocated and freed
+    unseen at bindings.cpp:412, :459): the first n + 3 ints, plus the usual result tuple."""
+    n = np.asarray(pts1).shape[0]
+    buf = np.zeros(n + 3, np.int32)
+    lib(kw.get("flavour", "")).ref_capture_data_out(buf.ctypes.data_as(C.POINTER(C.c_int)), n + 3)
+    out = find_fundamental(pts1, pts2, **kw)
     return buf, out

@@ -89,6 +89,8 @@ static void build_u(const double *x1, const double *x2, int n, int dim, int laf,
 /* optional capture of the drivers' per-LO residual dump (`resids`, RESIDS_M rows of n per LO run), which the
  * reference's binding frees unseen: set a destination before the call, cleared after it */
 static double *g_resids_dst = 0; static int g_resids_cap = 0;
+static int *g_dataout_dst = 0; static int g_dataout_len = 0;
+void ref_capture_data_out(int *dst, int len) { g_dataout_dst = dst; g_dataout_len = len; }
 void ref_capture_resids(double *dst, int cap_runs) { g_resids_dst = dst; g_resids_cap = cap_runs; }
 static void capture_resids(const double *resids, int runs, int n)
 {
@@ -127,6 +129,7 @@ int ref_find_fundamental(const double *x1, const double *x2, int n, int dim,
                                1, 0, &resids, HinF, &I_H, EXFDS1, FDS1, FDSidx1, sym_th, degen);
     if (stats) { stats[0] = data_out[0]; stats[1] = data_out[1]; stats[2] = I_H; stats[3] = ret; }
     capture_resids(resids, data_out[1], n);
+    if (g_dataout_dst) { memcpy(g_dataout_dst, data_out, sizeof(int) * (size_t)g_dataout_len); g_dataout_dst = 0; }
     free(resids); free(data_out); free(u); free(ulaf1); free(ulaf2);
     return ret;
 }

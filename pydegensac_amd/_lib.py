@@ -98,6 +98,8 @@ def lib():
         for name in ("mi_degensac_find_fundamental_resids", "mi_degensac_find_homography_resids"):
             f = getattr(l, name); f.restype = C.c_int
             f.argtypes = [dp, dp, C.c_int, C.c_int, pp, C.c_uint32, C.c_int, dp, bp, ip, dp, C.c_int]
+        l.mi_degensac_find_fundamental_hist.restype = C.c_int
+        l.mi_degensac_find_fundamental_hist.argtypes = [dp, dp, C.c_int, C.c_int, pp, C.c_uint32, C.c_int, dp, bp, ip, ip]
         l.mi_degensac_match.restype = C.c_int
         l.mi_degensac_match.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, ip,
                                         C.POINTER(C.c_float), bp]

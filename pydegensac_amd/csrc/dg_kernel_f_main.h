@@ -666,6 +666,7 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
     }
     if (lane == 0) { S->extw[wave][0] = ex0; S->extw[wave][1] = ex1; S->extw[wave][2] = ex2; S->extw[wave][3] = ex3; }
     dg_ht_init(c.ht, tid);
+    if (A.hist_out) for (int j = tid; j < n + 3; j += DG_T) A.hist_out[(size_t)off + 3 * (size_t)pair + j] = 0;
     if (tid < 9) { S->F[tid] = 0; S->FBest[tid] = 0; }
     __syncthreads();
     if (tid < 4) { double e = 0.; for (int w = 0; w < DG_NW; w++) e = fmax(e, S->extw[w][tid]); S->ext[tid] = e; }
@@ -751,7 +752,7 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
             __syncthreads();
             if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
                 if (tid == 0) {
-                    cb->Mtot = Mtot; cb->n = n; cb->kind = mk_full; cb->th = th; cb->tau = maxS.J < maxSs.J ? maxS.J : maxSs.J;
+                    cb->Mtot = Mtot; cb->n = n; cb->kind = mk_full; cb->th = th; cb->tau = A.hist_out ? 0.0 : (maxS.J < maxSs.J ? maxS.J : maxSs.J);
                     for (int i = 0; i < 4; i++) cb->ext[i] = S->ext[i];
                     __hip_atomic_store(&cb->done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -777,7 +778,7 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
             /* cooperative mode: the helpers score every group (a whole workgroup per group); the owner's waves only sample */
             if (!(LDSPTS == 0 && coopK > 0) && (wave >= 2 || DG_NW < 6))
                 dg_score_chunk_F<LDSPTS>(P, n, c.gmodels, S->mslot, Mtot, wave, mk_full, th,
-                                         maxS.J < maxSs.J ? maxS.J : maxSs.J, S->ext, (double *)(c.wstage + (size_t)wave * c.n_max), c.res_I, c.res_J, lane);
+                                         A.hist_out ? 0.0 : (maxS.J < maxSs.J ? maxS.J : maxSs.J), S->ext, (double *)(c.wstage + (size_t)wave * c.n_max), c.res_I, c.res_J, lane);
         }
         c.n_fds += Mtot;   /* provisional: models past the termination point are subtracted below */
         if (LDSPTS == 0 && coopK > 0) {
@@ -873,7 +874,7 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
                         dg_pass_cfg ch = dg_cfg0(n); ch.flags = c.Fl[1]; ch.thF = th*3;
                         dg_pass_res rh = dg_h_pass(c, S->H, ch); c.n_hds++;
                         unsigned I = rh.nF;
-                        if (I < 8) { brk = 1; c.n_fds -= (nvk - 1 - r); break; }   /* exp_ranF.c:1437-1439: later roots are never scored */
+                        if (I < 8) { brk = 1; c.n_fds -= (nvk - 1 - r); if (A.hist_out) { __syncthreads(); if (tid == 0) S->nv[k] = (unsigned char)(r + 1); __syncthreads(); } break; }   /* exp_ranF.c:1437-1439: later roots are never scored */
                         { long long ti0 = wall_clock64(); I = dg_innerH(c, S->H, 16*th, 10, c.Fl[0]); if (tid == 0) S->dbg[0] += wall_clock64() - ti0; }
                         if ((int)I > Ihmax) Ihmax = (int)I;
                         if (I > 6) {
@@ -948,6 +949,17 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
             }
         }
         /* models of samples that were never committed do not count as scored */
+        if (A.hist_out) {
+            /* data_out[LmaxI + 2]++ for every sample of the chunk that was reached (exp_ranF.c:1495; samples whose null
+             * space is not 2-dimensional `continue` before it, :1355-1358) */
+            int *hist = A.hist_out + (size_t)off + 3 * (size_t)pair;
+            const int reached = no_sam - chunk_base;
+            if (tid < reached && tid < chunk && S->nv[tid] != 255) {
+                unsigned best = 0;
+                for (int r = 0; r < S->nv[tid]; r++) { const unsigned I_ = c.res_I[S->moff[tid] + r]; best = I_ > best ? I_ : best; }
+                atomicAdd(&hist[2 + best], 1);
+            }
+        }
         if (k < chunk) { c.n_fds -= (Mtot - (int)S->moff[k]); done = 1; }
         else if (no_sam >= max_sam) done = 1;
         __syncthreads();
@@ -1056,6 +1068,7 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
         }
     }
     if (tid < 9) A.model_out[(size_t)pair * 9 + tid] = accepted ? S->F[tid] : 0.0;
+    if (A.hist_out && tid == 0) { int *hist = A.hist_out + (size_t)off + 3 * (size_t)pair; hist[0] = no_sam; hist[1] = iter_cnt; }
     if (A.stats_out && tid == 0) {
         int *st = A.stats_out + (size_t)pair * 16;
         long long t_end = wall_clock64();

@@ -42,3 +42,20 @@ def find_homography_with_residuals(x1y1, x2y2, px_th=1.0, conf=0.999, max_iters=
                                    laf_coef=0.0, seed=1, device=0, lo_runs=16):
     """(H, mask, stats, resids [lo_runs, 62, n]) — H as findHomography_ returns it (the driver's raw model)"""
     return _run("H", x1y1, x2y2, px_th, conf, max_iters, error_type, sym_check_enable, laf_coef, True, seed, device, lo_runs)
+
+
+def find_fundamental_with_support_histogram(x1y1, x2y2, px_th=0.5, conf=0.9999, max_iters=200000, error_type=0, sym_check_enable=True,
+                                            laf_coef=0.0, enable_degeneracy_check=True, seed=1, device=0):
+    """(F, mask, stats, hist) — hist = the reference driver's `data_out` (exp_ranF.c:1495, :1758-1759): hist[0] samples drawn,
+    hist[1] LO runs, hist[2 + I] = number of samples whose best model had exactly I inliers.  Every model is scored exactly
+    for this (no screening): same result, slower call."""
+    a = np.ascontiguousarray(x1y1, np.float64); b = np.ascontiguousarray(x2y2, np.float64)
+    if a.ndim != 2 or a.shape != b.shape or a.shape[1] not in (2, 6):
+        raise ValueError("x1y1 and x2y2 should be arrays of the same shape [n,2] or [n,6]")
+    n, dim = a.shape
+    prm = _lib.make_params(px_th, conf, max_iters, error_type, sym_check_enable, laf_coef, enable_degeneracy_check)
+    model = np.zeros(9); mask = np.zeros(n, np.uint8); st = np.zeros(_lib.STATS_LEN, np.int32); hist = np.zeros(n + 3, np.int32)
+    _lib.check(_lib.lib().mi_degensac_find_fundamental_hist(_lib.dptr(a), _lib.dptr(b), n, dim, C.byref(prm), int(seed) & 0xFFFFFFFF, int(device),
+                                                            _lib.dptr(model), mask.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                            st.ctypes.data_as(C.POINTER(C.c_int32)), hist.ctypes.data_as(C.POINTER(C.c_int32))))
+    return model.reshape(3, 3), mask.astype(bool), _lib.stats_dict(st), hist

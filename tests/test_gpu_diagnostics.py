@@ -57,3 +57,15 @@ def test_few_inliers_rows_keep_the_reference_memset():
         r0 = res[0]
         assert not np.isnan(r0[1]).any()
         assert (r0[2:] == 0).all() or not np.isnan(r0[2]).all()
+
+
+@pytest.mark.parametrize("n,ir,mi", [(800, 0.4, 6000), (300, 0.6, 2000), (1500, 0.3, 12000)])
+def test_support_histogram_equals_reference_data_out(oracle_ref, n, ir, mi):
+    """the F driver's data_out histogram (exp_ranF.c:1495): exact, incl. the sample / LO counters in front"""
+    p1, p2, _, _ = syn.two_view_fundamental(n, ir, 0.1, seed=6, plane_fraction=0.5 if n == 1500 else 0.0)
+    F, m, st, hist = dg.find_fundamental_with_support_histogram(p1, p2, 0.5, 0.9999, mi, seed=3)
+    ref, (Fo, mo, so) = oracle_ref.data_out_of(p1, p2, px_th=0.5, conf=0.9999, max_iters=mi, seed=3)
+    assert np.array_equal(hist, ref), np.flatnonzero(hist != ref)[:10]
+    assert hist[0] == so["samples"] and hist[1] == so["lo_runs"] and np.array_equal(m, mo)
+    F2, m2 = pd.findFundamentalMatrix_(p1, p2, 0.5, 0.9999, mi, seed=3)
+    assert np.array_equal(F, F2) and np.array_equal(m, m2)           # switching the screens off changes nothing
