@@ -83,3 +83,68 @@ def find_homography_batch_tensors(pts1, pts2, counts, px_th=1.0, conf=0.999, max
     if bool(found.any()):
         out[found] = torch.linalg.inv(Hc[found].transpose(1, 2))
     return out, mask, stats, offs
+
+
+# ---- the stage in front of the estimators on the device: matcher and keypoint conversion -------------
+def knn_match_tensors(desc1, desc2):
+    """cv2 `BFMatcher().knnMatch(descs1, descs2, k=2)` (examples/simple-example.py:46-47) on device tensors: float32
+    descriptors [n, dim] -> L2, uint8 [n, dim] (dim % 4 == 0) -> Hamming.  Returns (idx [n1, 2] int32, dist [n1, 2] float32)
+    on the device, asynchronous on the current stream."""
+    import torch
+    if not (isinstance(desc1, torch.Tensor) and isinstance(desc2, torch.Tensor)) or desc1.device.type != "cuda" or desc2.device != desc1.device:
+        raise ValueError("descriptors must be torch tensors on the same ROCm device")
+    if desc1.dim() != 2 or desc2.dim() != 2 or desc1.shape[1] != desc2.shape[1] or desc1.dtype != desc2.dtype:
+        raise ValueError("descriptors should be [n1, dim] and [n2, dim] tensors of one dtype")
+    if desc1.dtype == torch.float32:
+        norm = 0
+    elif desc1.dtype == torch.uint8 and desc1.shape[1] % 4 == 0:
+        norm = 1
+    else:
+        raise ValueError("float32 descriptors (L2) or uint8 descriptors with dim % 4 == 0 (Hamming)")
+    a = desc1.contiguous(); b = desc2.contiguous(); dev = a.device
+    n1, n2, dim = a.shape[0], b.shape[0], a.shape[1]
+    idx = torch.full((n1, 2), -1, dtype=torch.int32, device=dev)
+    dist = torch.full((n1, 2), float("inf"), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    rc = _lib.lib().mi_degensac_match_knn2_dev(norm, a.data_ptr(), n1, b.data_ptr(), n2, dim, dev.index or 0, C.c_void_p(stream.cuda_stream),
+                                               idx.data_ptr(), dist.data_ptr())
+    if rc != 0:
+        raise _lib.MiDegensacError(f"mi_degensac error {rc}: {_lib.lib().mi_degensac_match_last_error().decode()}")
+    for t in (a, b):
+        t.record_stream(stream)
+    return idx, dist
+
+
+def match_snn_tensors(desc1, desc2, ratio=0.9, mutual=False):
+    """The ratio test of the example (`m.distance < ratio * n.distance`, simple-example.py:49-53), optionally restricted to
+    mutual nearest neighbours, on the device: (query indices, train indices, distances) of the tentative correspondences.
+    The only host synchronisation is the final boolean selection (the number of survivors sizes the outputs)."""
+    import torch
+    idx, dist = knn_match_tensors(desc1, desc2)
+    dev = idx.device; n1 = idx.shape[0]
+    keep = torch.zeros(n1, dtype=torch.uint8, device=dev)
+    back = knn_match_tensors(desc2, desc1)[0] if mutual and desc2.shape[0] > 0 else None
+    stream = torch.cuda.current_stream(dev)
+    rc = _lib.lib().mi_degensac_match_filter_dev(idx.data_ptr(), dist.data_ptr(), n1, float(ratio), back.data_ptr() if back is not None else None,
+                                                 dev.index or 0, C.c_void_p(stream.cuda_stream), keep.data_ptr())
+    if rc != 0:
+        raise _lib.MiDegensacError(f"mi_degensac error {rc}: {_lib.lib().mi_degensac_match_last_error().decode()}")
+    if back is not None:
+        back.record_stream(stream)
+    sel = torch.nonzero(keep, as_tuple=False).flatten()
+    return sel, idx[sel, 0].to(torch.int64), dist[sel, 0]
+
+
+def kpts_to_xyA_tensors(kpts):
+    """utils.py:24-41 `convert_cv2_kpts_to_xyA` on the device: [n, 4] float32 (x, y, size, angle in degrees) -> [n, 6] float64"""
+    import torch
+    if not isinstance(kpts, torch.Tensor) or kpts.device.type != "cuda" or kpts.dtype != torch.float32 or kpts.dim() != 2 or kpts.shape[1] != 4:
+        raise ValueError("keypoints should be a float32 tensor [n, 4] = (x, y, size, angle) on a ROCm device")
+    k = kpts.contiguous(); dev = k.device
+    out = torch.zeros((k.shape[0], 6), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    rc = _lib.lib().mi_degensac_kpts_to_xyA_dev(k.data_ptr(), k.shape[0], dev.index or 0, C.c_void_p(stream.cuda_stream), out.data_ptr())
+    if rc != 0:
+        raise _lib.MiDegensacError(f"mi_degensac error {rc}: {_lib.lib().mi_degensac_match_last_error().decode()}")
+    k.record_stream(stream)
+    return out

@@ -49,3 +49,27 @@ def test_homography_tensors_match_host_batch():
         assert np.array_equal(m[offs[p]:offs[p + 1]], np.asarray(mh[p]))
         # inv() runs in numpy on the host path and in torch.linalg on the device path: same to rounding
         assert np.linalg.norm(H[p] - Hh[p]) <= 1e-9 * max(np.linalg.norm(Hh[p]), 1e-300)
+
+
+def test_device_pipeline_descriptors_to_homography_matches_host_stages():
+    """keypoints + descriptors on the device -> matcher -> LAF rows -> findHomography, nothing staged through the host but
+    the survivor count; every stage equals its host-API counterpart"""
+    import torch
+    from pydegensac_amd import matcher
+    rng = np.random.default_rng(9)
+    p1, p2, lab, _ = syn.homography_pairs(n=1500, inlier_ratio=0.5, sigma=0.5, seed=21)
+    d1 = rng.normal(size=(1500, 64)).astype(np.float32)
+    d2 = d1 + 0.15 * rng.normal(size=d1.shape).astype(np.float32); d2[~lab] = rng.normal(size=((~lab).sum(), 64)).astype(np.float32)
+    k1 = np.c_[p1, rng.uniform(4, 30, 1500), rng.uniform(0, 360, 1500)].astype(np.float32)
+    k2 = np.c_[p2, rng.uniform(4, 30, 1500), rng.uniform(0, 360, 1500)].astype(np.float32)
+    dev = torch.device("cuda", 0)
+    q, t, d = tensor_api.match_snn_tensors(torch.from_numpy(d1).to(dev), torch.from_numpy(d2).to(dev), 0.9, mutual=True)
+    hq, ht, hd = matcher.match_snn(d1, d2, 0.9, mutual=True)
+    assert np.array_equal(q.cpu().numpy(), hq) and np.array_equal(t.cpu().numpy(), ht) and np.array_equal(d.cpu().numpy(), hd)
+    A1 = tensor_api.kpts_to_xyA_tensors(torch.from_numpy(k1).to(dev)); A2 = tensor_api.kpts_to_xyA_tensors(torch.from_numpy(k2).to(dev))
+    assert np.array_equal(A1.cpu().numpy(), matcher.kpts_to_xyA(k1))
+    src = A1[q]; dst = A2[t]
+    H, m, st, offs = tensor_api.find_homography_batch_tensors(src, dst, [int(q.numel())], 2.0, 0.999, 20000, -1.0, "sampson", True, seeds=[5])
+    Hh, mh = pd.findHomography(src.cpu().numpy()[:, :2], dst.cpu().numpy()[:, :2], 2.0, 0.999, 20000, seed=5)
+    assert np.array_equal(m.cpu().numpy(), np.asarray(mh)) and m.sum().item() > 0.8 * q.numel()
+    assert np.linalg.norm(H[0].cpu().numpy() - Hh) <= 1e-9 * np.linalg.norm(Hh)
