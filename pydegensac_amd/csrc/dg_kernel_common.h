@@ -7,6 +7,15 @@
 #ifndef DG_CHUNK
 #define DG_CHUNK   256         /* minimal samples speculated per round (one per lane of the first DG_CHUNK); a variant may choose less */
 #endif
+/* phase timers of the development build (tools/gpu_phases.py): a real-time-counter read plus a wait on the scalar
+ * memory queue each, on the critical path of the serial waves: compiled out of the product library */
+#ifdef MI_DEGENSAC_DEV
+#define DG_CLK() wall_clock64()
+#define DG_DEVT(x) x
+#else
+#define DG_CLK() 0ll
+#define DG_DEVT(x) do {} while (0)
+#endif
 #ifndef DG_MINW
 #define DG_MINW    2           /* __launch_bounds__: minimum waves per SIMD the kernels are compiled for (register budget 512 / DG_MINW) */
 #endif

@@ -585,7 +585,7 @@ __device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, doub
     while (no_sam < 2*max_sam) {
         int B = (int)(2*max_sam - no_sam); if (B > DG_CHUNK) B = DG_CHUNK;
         __syncthreads();
-        long long tg0 = wall_clock64();
+        long long tg0 = DG_CLK();
         if (tid == 0) {
             S->rng_save = S->rng;
             for (int b = 0; b < B; b++) {
@@ -598,7 +598,7 @@ __device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, doub
             }
         }
         __syncthreads();
-        long long tg1 = wall_clock64(); if (tid == 0) S->dbg[1] += tg1 - tg0;
+        long long tg1 = DG_CLK(); DG_DEVT(if (tid == 0) S->dbg[1] += tg1 - tg0);
         /* one wave per candidate: #off-plane points with Sampson error < 2 th */
         for (int b = wave; b < B; b += DG_NW) {
             double aFt[9];
@@ -617,7 +617,7 @@ __device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, doub
             if (lane == 0) c.rf[b][4] = (int)cnt;
         }
         __syncthreads();
-        long long tg2 = wall_clock64(); if (tid == 0) S->dbg[2] += tg2 - tg1;
+        long long tg2 = DG_CLK(); DG_DEVT(if (tid == 0) S->dbg[2] += tg2 - tg1);
         /* first candidate beating m_i */
         bool hit = tid < B && (unsigned)c.rf[tid][4] > m_i;
         unsigned long long bal = __ballot(hit);
@@ -663,7 +663,7 @@ __device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, doub
                 max_sam = max_sam > ns ? ns : max_sam;
             }
         }
-        if (tid == 0) S->dbg[3] += wall_clock64() - tg2;
+        DG_DEVT(if (tid == 0) S->dbg[3] += DG_CLK() - tg2);
     }
     __syncthreads();
     if (LDSPTS != 0) { for (int j = tid; j < n; j += DG_T) c.pool[j] = c.L[8][j]; __syncthreads(); }

@@ -258,7 +258,7 @@ template <int NDRAW>
 __device__ __noinline__ unsigned dg_sample_draws(unsigned seed, int cn, int n, unsigned *seeds, int (*draws)[8],
                                                  unsigned long long *almask, int lane, long long *dbg = 0)
 {
-    long long ts0 = wall_clock64();
+    long long ts0 = DG_CLK();
     __builtin_amdgcn_s_setprio(3);                        /* the serial waves must not queue behind the scoring waves */
     /* seed chain: lane j carries the term C[NDRAW][j] * r_j, r_j = seed * 16807^j mod (2^31-1) */
     const unsigned gk = lane < 31 ? dg_rng_G[lane] : 0u, ck = lane < 31 ? dg_rng_C[NDRAW][lane] : 0u;
@@ -270,7 +270,7 @@ __device__ __noinline__ unsigned dg_sample_draws(unsigned seed, int cn, int n, u
         sd = dg_wave_sum_u(ck * rj) >> 1;
     }
     DG_WSYNC();
-    long long ts1 = wall_clock64();
+    long long ts1 = DG_CLK();
     /* draws of every sample (lane = sample) + per-sample alias flag: two draws on the same position, or a draw
      * inside the tail block, make the swaps of that sample order-dependent -> replayed sequentially in stage 2 */
 #pragma unroll
@@ -292,7 +292,7 @@ __device__ __noinline__ unsigned dg_sample_draws(unsigned seed, int cn, int n, u
     }
     DG_WSYNC();
     __builtin_amdgcn_s_setprio(0);
-    if (dbg && lane == 0) { long long ts2 = wall_clock64(); dbg[4] += ts1 - ts0; dbg[5] += ts2 - ts1; }
+    DG_DEVT(if (dbg && lane == 0) { long long ts2 = DG_CLK(); dbg[4] += ts1 - ts0; dbg[5] += ts2 - ts1; });
     return sd;
 }
 
@@ -304,7 +304,7 @@ template <int NDRAW, int LDSPTS>
 __device__ __noinline__ void dg_sample_pool_seq(int cn, int n, int *pool, int (*draws)[8], const unsigned long long *almask_in,
                                                 int lane, long long *dbg = 0)
 {
-    long long ts2 = wall_clock64();
+    long long ts2 = DG_CLK();
     __builtin_amdgcn_s_setprio(3);
     unsigned long long almask[DG_CHUNK / 64];
 #pragma unroll
@@ -344,7 +344,7 @@ __device__ __noinline__ void dg_sample_pool_seq(int cn, int n, int *pool, int (*
     if (act) vp[n - 1 - lane] = t;
     DG_WSYNC();
     __builtin_amdgcn_s_setprio(0);
-    if (dbg && lane == 0) { long long ts3 = wall_clock64(); dbg[6] += ts3 - ts2; }
+    DG_DEVT(if (dbg && lane == 0) { long long ts3 = DG_CLK(); dbg[6] += ts3 - ts2; });
 }
 
 /* ---------------------------------------------------------------------------------------------- */
@@ -509,7 +509,7 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
 template <int NDRAW>
 __device__ __noinline__ void dg_sample_pool_par(int cn, int n, int *vp_generic, int (*draws)[8], int *ptr /* LDS, 2*cn*NDRAW ints */, int lane, long long *dbg)
 {
-    long long ts2 = wall_clock64();
+    long long ts2 = DG_CLK();
     __builtin_amdgcn_s_setprio(3);
     __attribute__((address_space(3))) int *vp = (__attribute__((address_space(3))) int *)vp_generic;
     const int M2 = 2 * cn * NDRAW;
@@ -595,7 +595,7 @@ __device__ __noinline__ void dg_sample_pool_par(int cn, int n, int *vp_generic, 
     }
     DG_WSYNC();
     __builtin_amdgcn_s_setprio(0);
-    if (dbg && lane == 0) { long long ts3 = wall_clock64(); dbg[6] += ts3 - ts2; }
+    DG_DEVT(if (dbg && lane == 0) { long long ts3 = DG_CLK(); dbg[6] += ts3 - ts2; });
 }
 
 /* stage 2 dispatch: the parallel form needs the pool in LDS with 16-bit ids and 2*cn*NDRAW ints of LDS scratch */
@@ -692,11 +692,11 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
     unsigned seed = (unsigned)S->itmp[31];
     __syncthreads();
 
-    if (tid == 0) { for (int i = 0; i < 8; i++) { S->ph[i] = 0; S->dbg[i] = 0; } S->tq = wall_clock64(); }
+    DG_DEVT(if (tid == 0) { for (int i = 0; i < 8; i++) { S->ph[i] = 0; S->dbg[i] = 0; } S->tq = DG_CLK(); });
 #ifdef DG_LO_PROF
     if (tid == 0) { for (int i = 0; i < 16; i++) S->lt[i] = 0; S->ltq = wall_clock64(); }
 #endif
-#define DG_PH(i) do { if (tid == 0) { long long tq2_ = wall_clock64(); S->ph[i] += tq2_ - S->tq; S->tq = tq2_; } } while (0)
+#define DG_PH(i) DG_DEVT(if (tid == 0) { long long tq2_ = DG_CLK(); S->ph[i] += tq2_ - S->tq; S->tq = tq2_; })
     /* software pipeline: chunk c is scored while chunk c+1 gets its pool swaps and chunk c+2 its seeds and draws */
     int cur = 0, chunk_s[3] = {0, 0, 0}, chunk_base = 0;
     {
@@ -875,7 +875,7 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
                         dg_pass_res rh = dg_h_pass(c, S->H, ch); c.n_hds++;
                         unsigned I = rh.nF;
                         if (I < 8) { brk = 1; c.n_fds -= (nvk - 1 - r); if (A.hist_out) { __syncthreads(); if (tid == 0) S->nv[k] = (unsigned char)(r + 1); __syncthreads(); } break; }   /* exp_ranF.c:1437-1439: later roots are never scored */
-                        { long long ti0 = wall_clock64(); I = dg_innerH(c, S->H, 16*th, 10, c.Fl[0]); if (tid == 0) S->dbg[0] += wall_clock64() - ti0; }
+                        { long long ti0 = DG_CLK(); I = dg_innerH(c, S->H, 16*th, 10, c.Fl[0]); DG_DEVT(if (tid == 0) S->dbg[0] += DG_CLK() - ti0); (void)ti0; }
                         if ((int)I > Ihmax) Ihmax = (int)I;
                         if (I > 6) {
                             I = dg_rFtH(c, c.Fl[0], th, S->H, S->f);
@@ -1082,7 +1082,7 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
     if (A.phase_out && tid == 0) { for (int i = 0; i < 16; i++) A.phase_out[(size_t)pair * 16 + i] = S->lt[i]; }
     if (0)
 #endif
-    if (A.phase_out && tid == 0) { S->ph[7] = wall_clock64() - t_start; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + i] = S->ph[i]; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + 8 + i] = S->dbg[i]; }
+    DG_DEVT(if (A.phase_out && tid == 0) { S->ph[7] = DG_CLK() - t_start; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + i] = S->ph[i]; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + 8 + i] = S->dbg[i]; });
 #undef DG_PH
 }
 
