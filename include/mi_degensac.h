@@ -59,11 +59,19 @@ extern "C" {
  *             (a placement that does not fit the device's LDS is ignored)
  *   bit  4    sampler           1 = always use the sequential pool-swap stage
  *   bits 8-15 helper workgroups per pair of the cooperative large-n mode (fundamental matrix, placement HBM):
- *             0 = automatic (15 helpers when n >= 8192 and the batch leaves the device mostly idle), 255 = off */
+ *             0 = automatic (15 helpers when n >= 8192 and the batch leaves the device mostly idle), 255 = off
+ *   bits 16-23 setting long pairs aside (fundamental matrix, batches larger than the resident grid): a pair still
+ *             running after this many samples (units of 256) while unstarted pairs remain is written back to its
+ *             workspace and resumed once every pair has been started, so that the batch ends one long pair after the
+ *             last pair was STARTED instead of one long pair after the last long pair was started.
+ *             0 = automatic (max_iters / 12, at least 4096 samples), 255 = off
+ *   bits 24-31 cap on the number of resident workgroups (0 = none; for tests of the queueing paths on small batches) */
 #define MI_DEGENSAC_TUNE_VARIANT(v)   ((uint32_t)(v) & 3u)
 #define MI_DEGENSAC_TUNE_PLACEMENT(p) (((uint32_t)(p) & 3u) << 2)
 #define MI_DEGENSAC_TUNE_SEQ_POOL     (1u << 4)
 #define MI_DEGENSAC_TUNE_HELPERS(h)   (((uint32_t)(h) & 255u) << 8)
+#define MI_DEGENSAC_TUNE_SET_ASIDE(t)  (((uint32_t)(t) & 255u) << 16)
+#define MI_DEGENSAC_TUNE_GRID_CAP(g)   (((uint32_t)(g) & 255u) << 24)
 
 typedef struct mi_degensac_params {
     double   px_th;                    /* pixel threshold (utils.py:76,113)                         */
@@ -93,7 +101,7 @@ enum {
     MI_ST_TICKS_BEST = 12,  /* 100 MHz device wall-clock ticks from the pair's start to that commit */
     MI_ST_TICKS_TOTAL = 13, /* ... to the pair's end                                                */
     MI_ST_THREADS = 14,     /* workgroup size of the kernel variant that ran (512 / 256)            */
-    MI_ST_PLACEMENT = 15    /* 0 = points + pool in HBM, 1 = both in LDS, 2 = pool in LDS           */
+    MI_ST_PLACEMENT = 15    /* bits 0-7: 0 = points + pool in HBM, 1 = both in LDS, 2 = pool in LDS; bit 8: the pair was set aside once */
 };
 
 /* ---- contexts ---------------------------------------------------------------------------------- */
@@ -235,7 +243,9 @@ int mi_degensac_solve7(const double *pts1, const double *pts2, int n, int dim,
 /* the lane-level 3x3 routines of the DEGENSAC branch, one problem per lane: op 0 = in-place inverse (matutls/minv.c
  * order; in/out 9 doubles, flag = -1 when singular), op 1 = right singular vectors and singular values (matutls/svduv.c
  * order; in 9, out 9 + 3), op 2 = Hdetect (DegUtils.c:84-161; in F (9) + seven correspondences x1 y1 x2 y2 (28) + the
- * triplet as three doubles, out 9). */
+ * triplet as three doubles, out 9).  op 3 = the 9x9 symmetric eigen-solver (LAPACK dsyev as lap_eig calls it,
+ * degensac/lapwrap.c:67-96), one problem per wave: in 81, out 9 eigenvalues (smallest first, the rest as the QL/QR
+ * iteration left them) + 81 (column-major vectors, column 0 = the one of the smallest eigenvalue), flag = info. */
 int mi_degensac_mat3(int op, const double *in, int count, int device, double *out, int32_t *flag);
 
 /* ---- misc -------------------------------------------------------------------------------------- */

@@ -14,6 +14,8 @@ FLAG_FINAL_LAF_FILTER = 1
 TUNE_LATENCY, TUNE_THROUGHPUT, TUNE_THROUGHPUT4 = 1, 2, 3   # kernel variant: 512- / 256- / 128-thread workgroups
 TUNE_PLACE_HBM, TUNE_PLACE_LDS, TUNE_PLACE_POOL_LDS = 1 << 2, 2 << 2, 3 << 2
 TUNE_SEQ_POOL = 1 << 4
+# bits 8-15: cooperative helper workgroups per pair (0 auto, 255 off); bits 16-23: samples after which a running pair is
+# set aside while unstarted pairs remain, in units of 256 (0 auto, 255 off); bits 24-31: cap on resident workgroups (tests)
 
 
 class Params(C.Structure):
@@ -140,4 +142,7 @@ def make_params(px_th, conf, max_iters, error_type, sym_check, laf_coef, degen=T
 
 
 def stats_dict(st):
-    return {k: int(v) for k, v in zip(STAT_NAMES, st)}
+    d = {k: int(v) for k, v in zip(STAT_NAMES, st)}
+    d["set_aside"] = d["placement"] >> 8          # the pair was written back to its workspace once and resumed later
+    d["placement"] &= 255
+    return d

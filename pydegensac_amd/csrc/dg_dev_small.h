@@ -115,6 +115,38 @@ __device__ __forceinline__ void dg_lartg_fast(double f, double g, double *c, dou
     *s = f < 0. ? -sq : sq;
 }
 
+/* dlartg without branches on the critical path: the scalar recurrence of dsteqr pays every compare -> exec-mask ->
+ * branch round trip in full (one wave, nothing to overlap with), so the two zero cases are selected at the end instead
+ * of branched on at the start (their lanes compute on garbage that is thrown away), and the out-of-range case — never
+ * seen in practice — is one wave-wide ballot that sends the whole wave through the plain routine.  Same values as
+ * dg_lartg bit for bit (checked by tools/gpu_micro.py on 1.28 M random pairs, and by the eigen-solver parity test). */
+__device__ __forceinline__ void dg_lartg_bf(double f, double g, double *c, double *s, double *r)
+{
+    const double f1 = fabs(f), g1 = fabs(g);
+    const bool gz = g == 0., fz = f == 0.;
+    const bool ok = f1 > 1e-140 && f1 < 1e140 && g1 > 1e-140 && g1 < 1e140;
+    if (__ballot(!ok && !gz && !fz) != 0ull) { dg_lartg(f, g, c, s, r); return; }
+    const double x = f*f + g*g;
+    double y = __builtin_amdgcn_rsq(x);
+    double sg = x * y, sh = y * 0.5;
+    double sr = __builtin_fma(-sh, sg, 0.5);
+    sg = __builtin_fma(sg, sr, sg); sh = __builtin_fma(sh, sr, sh);
+    double sd = __builtin_fma(-sg, sg, x); sg = __builtin_fma(sd, sh, sg);
+    sd = __builtin_fma(-sg, sg, x);        sg = __builtin_fma(sd, sh, sg);
+    const double d = sg;
+    double ry = __builtin_amdgcn_rcp(d);
+    double re = __builtin_fma(-d, ry, 1.0); ry = __builtin_fma(ry, re, ry);
+    re = __builtin_fma(-d, ry, 1.0);        ry = __builtin_fma(ry, re, ry);
+    double q0 = f1 * ry, rr = __builtin_fma(-d, q0, f1);
+    double cq = __builtin_fma(rr, ry, q0);
+    q0 = g * ry; rr = __builtin_fma(-d, q0, g);
+    const double sq = __builtin_fma(rr, ry, q0);
+    double rq = dg_sign(d, f), ss = f < 0. ? -sq : sq;
+    cq = fz ? 0. : cq; ss = fz ? dg_sign(1., g) : ss; rq = fz ? g1 : rq;
+    cq = gz ? 1. : cq; ss = gz ? 0. : ss;             rq = gz ? f : rq;      /* dlartg tests g == 0 first */
+    *c = cq; *s = ss; *r = rq;
+}
+
 DG_FN void dg_laev2(double a, double b, double c, double *rt1, double *rt2, double *cs1, double *sn1)
 {
     double sm = a + c, df = a - c, adf = fabs(df), tb = b + b, ab = fabs(tb);
@@ -160,6 +192,22 @@ static __device__ long long dg_eig_ticks[4];
 #else
 #define DG_ET(i)
 #endif
+/* dg_steqr9.h on the device: the reciprocal-sharing dlartg, wave-uniform conditions through a ballot, and the three
+ * searches for a negligible subdiagonal entry with one candidate per lane (lanes 8..63 repeat lanes 0..7) */
+#define DG_STEQR_FN static __device__ __forceinline__
+#define DG_STEQR_PTR __attribute__((address_space(3))) double *
+#define DG_STEQR_LARTG(f, g, c, s, r) dg_lartg_fast((f), (g), (c), (s), (r))
+#define DG_STEQR_ANY(cond) (__ballot(cond) != 0ull)
+#define DG_STEQR_FIND_SPLIT(d, e, l1, m) do { const int i_ = lane & 7; const double ae_ = fabs((e)[i_]); \
+        const bool c_ = i_ >= (l1) && (ae_ == 0. || ae_ <= (sqrt(fabs((d)[i_])) * sqrt(fabs((d)[i_+1]))) * DG_EPS); \
+        const unsigned long long bm_ = __ballot(c_) & 0xffull; (m) = bm_ ? __ffsll((long long)bm_) - 1 : 8; } while (0)
+#define DG_STEQR_FIND_QL(d, e, l, lend, m) do { const int i_ = lane & 7; double t2_ = fabs((e)[i_]); t2_ *= t2_; \
+        const bool c_ = i_ >= (l) && i_ < (lend) && t2_ <= ((DG_EPS*DG_EPS) * fabs((d)[i_])) * fabs((d)[i_+1]) + DG_SAFMIN; \
+        const unsigned long long bm_ = __ballot(c_) & 0xffull; (m) = bm_ ? __ffsll((long long)bm_) - 1 : (lend); } while (0)
+#define DG_STEQR_FIND_QR(d, e, l, lend, m) do { const int i_ = lane & 7; double t2_ = fabs((e)[i_]); t2_ *= t2_; \
+        const bool c_ = i_ >= (lend) && i_ < (l) && t2_ <= ((DG_EPS*DG_EPS) * fabs((d)[i_+1])) * fabs((d)[i_]) + DG_SAFMIN; \
+        const unsigned long long bm_ = __ballot(c_) & 0xffull; (m) = bm_ ? 64 - __clzll((long long)bm_) : (lend); } while (0)
+#include "dg_steqr9.h"
 struct dg_eig_ws { double d[9], e[9], tau[9], work[18]; };
 static __device__ __noinline__ int dg_eig_sym_wave(double *a, double *w, int lane, dg_eig_ws *ews)
 {
@@ -168,7 +216,7 @@ static __device__ __noinline__ int dg_eig_sym_wave(double *a, double *w, int lan
     long long t_et = wall_clock64();
 #endif
     double *d = ews->d, *e = ews->e, *tau = ews->tau;
-    int i, j, k, l, m, ii;
+    int i, j, k, ii;
 #define A_(r,c) a[(c)*n + (r)]
     /* ---- dsytd2, UPLO='U' ----
      * Lane r (< 9) keeps row r of the symmetric matrix in nine registers (both triangles, kept in step), every index
@@ -274,131 +322,13 @@ static __device__ __noinline__ int dg_eig_sym_wave(double *a, double *w, int lan
     }
     DG_ET(1);
     /* ---- dsteqr 'V' ----
-     * d, e and the saved rotations live in registers, one element per lane (lane i holds d[i], e[i], c_i, s_i);
-     * every lane replays the scalar recurrences on values broadcast with v_readlane (uniform indices).
-     * Lane r < 9 holds row r of Z in nine registers; a sweep's rotations are applied with a statically
-     * unrolled loop over the 8 column pairs, predicated on the (uniform) active range. */
+     * dg_steqr9.h: d / e stay in LDS (every lane runs the scalar recurrence and stores the same values), lane r < 9
+     * rotates row r of Z in place (a[c*9 + r]); lanes 9..63 repeat rows 0..8, same values to the same addresses. */
     {
-        const double eps = DG_EPS, eps2 = eps*eps, safmin = DG_SAFMIN;
-        int nmaxit = n * 30, jtot = 0, l1 = 0, lsv, lend, lendsv;
-        double p, g, r, c, s, f, b, rt1, rt2, tst;
+        double p;
         DG_WSYNC();
-        double dreg = lane < n ? d[lane] : 0., ereg = lane < n - 1 ? e[lane] : 0., creg = 1., sreg = 0.;
-        double z[9];
-#pragma unroll
-        for (int cc = 0; cc < 9; cc++) z[cc] = lane < n ? A_(lane, cc) : 0.;
-#define RD(reg, i_) dg_rdl_d(reg, (i_))
-#define WR(reg, i_, v_) do { double v__ = (v_); reg = (lane == (i_)) ? v__ : reg; } while (0)
-        /* rotations j = lo .. hi-1 (pairs (j, j+1)), c/s in creg/sreg at lane j; backward = high j first */
-#define DG_ROTREG(lo, hi, backward) do { \
-            _Pragma("unroll") for (int q_ = 0; q_ < 8; q_++) { const int j_ = (backward) ? 7 - q_ : q_; \
-                if (j_ >= (lo) && j_ < (hi)) { double ct_ = RD(creg, j_), st_ = RD(sreg, j_); \
-                    if (ct_ != 1. || st_ != 0.) { double temp_ = z[j_+1]; z[j_+1] = ct_*temp_ - st_*z[j_]; z[j_] = st_*temp_ + ct_*z[j_]; } } } } while (0)
-        while (l1 < n) {
-            if (l1 > 0) WR(ereg, l1 - 1, 0.);
-            {   /* first negligible subdiagonal at or after l1: every lane tests its own (e_i, d_i, d_{i+1}) */
-                const double dn = __shfl_down(dreg, 1, 64), ae = fabs(ereg);
-                const bool cnd = lane >= l1 && lane < n - 1 && (ae == 0. || ae <= (sqrt(fabs(dreg)) * sqrt(fabs(dn))) * eps);
-                const unsigned long long bm = __ballot(cnd);
-                m = bm ? __ffsll((long long)bm) - 1 : n - 1;
-                if (bm) WR(ereg, m, 0.);
-            }
-            l = l1; lsv = l; lend = m; lendsv = lend; l1 = m + 1;
-            if (lend == l) continue;
-            if (fabs(RD(dreg, lend)) < fabs(RD(dreg, l))) { lend = lsv; l = lendsv; }
-            if (lend > l) {
-                for (;;) {
-                    if (l != lend) {
-                        const double dn = __shfl_down(dreg, 1, 64); double t2 = fabs(ereg); t2 *= t2;
-                        const bool cnd = lane >= l && lane < lend && t2 <= (eps2 * fabs(dreg)) * fabs(dn) + safmin;
-                        const unsigned long long bm = __ballot(cnd);
-                        m = bm ? __ffsll((long long)bm) - 1 : lend;
-                    } else m = lend;
-                    if (m < lend) WR(ereg, m, 0.);
-                    p = RD(dreg, l);
-                    if (m == l) { l++; if (l <= lend) continue; break; }
-                    if (m == l + 1) {
-                        dg_laev2(RD(dreg, l), RD(ereg, l), RD(dreg, l+1), &rt1, &rt2, &c, &s);
-                        WR(creg, l, c); WR(sreg, l, s);
-                        DG_ROTREG(l, l + 1, 1);
-                        WR(dreg, l, rt1); WR(dreg, l+1, rt2); WR(ereg, l, 0.);
-                        l += 2; if (l <= lend) continue; break;
-                    }
-                    if (jtot == nmaxit) break;
-                    jtot++;
-                    { double el = RD(ereg, l);
-                      g = (RD(dreg, l+1) - p) / (2. * el);
-                      r = dg_lapy2(g, 1.);
-                      g = RD(dreg, m) - p + (el / (g + dg_sign(r, g))); }
-                    s = 1.; c = 1.; p = 0.;
-                    for (i = m - 1; i >= l; i--) {
-                        double ei = RD(ereg, i), di = RD(dreg, i), di1 = RD(dreg, i+1);
-                        f = s * ei; b = c * ei;
-                        dg_lartg_fast(g, f, &c, &s, &r);
-                        if (i != m - 1) WR(ereg, i+1, r);
-                        g = di1 - p;
-                        r = (di - g)*s + 2.*c*b;
-                        p = s * r;
-                        WR(dreg, i+1, g + p);
-                        g = c*r - b;
-                        WR(creg, i, c); WR(sreg, i, -s);
-                    }
-                    DG_ROTREG(l, m, 1);
-                    { double dl = RD(dreg, l); WR(dreg, l, dl - p); WR(ereg, l, g); }
-                }
-            } else {
-                for (;;) {
-                    if (l != lend) {
-                        /* lane i stands for m = i+1: e[m-1] = e_i, d[m] = d_{i+1}, d[m-1] = d_i; the highest hit wins */
-                        const double dn = __shfl_down(dreg, 1, 64); double t2 = fabs(ereg); t2 *= t2;
-                        const bool cnd = lane >= lend && lane < l && t2 <= (eps2 * fabs(dn)) * fabs(dreg) + safmin;
-                        const unsigned long long bm = __ballot(cnd);
-                        m = bm ? 64 - __clzll((long long)bm) : lend;
-                    } else m = lend;
-                    if (m > lend) WR(ereg, m-1, 0.);
-                    p = RD(dreg, l);
-                    if (m == l) { l--; if (l >= lend) continue; break; }
-                    if (m == l - 1) {
-                        dg_laev2(RD(dreg, l-1), RD(ereg, l-1), RD(dreg, l), &rt1, &rt2, &c, &s);
-                        WR(creg, m, c); WR(sreg, m, s);
-                        DG_ROTREG(l - 1, l, 0);
-                        WR(dreg, l-1, rt1); WR(dreg, l, rt2); WR(ereg, l-1, 0.);
-                        l -= 2; if (l >= lend) continue; break;
-                    }
-                    if (jtot == nmaxit) break;
-                    jtot++;
-                    { double el = RD(ereg, l-1);
-                      g = (RD(dreg, l-1) - p) / (2. * el);
-                      r = dg_lapy2(g, 1.);
-                      g = RD(dreg, m) - p + (el / (g + dg_sign(r, g))); }
-                    s = 1.; c = 1.; p = 0.;
-                    for (i = m; i <= l - 1; i++) {
-                        double ei = RD(ereg, i), di = RD(dreg, i), di1 = RD(dreg, i+1);
-                        f = s * ei; b = c * ei;
-                        dg_lartg_fast(g, f, &c, &s, &r);
-                        if (i != m) WR(ereg, i-1, r);
-                        g = di - p;
-                        r = (di1 - g)*s + 2.*c*b;
-                        p = s * r;
-                        WR(dreg, i, g + p);
-                        g = c*r - b;
-                        WR(creg, i, c); WR(sreg, i, s);
-                    }
-                    DG_ROTREG(m, l, 0);
-                    { double dl = RD(dreg, l); WR(dreg, l, dl - p); WR(ereg, l-1, g); }
-                }
-            }
-            if (jtot >= nmaxit) break;
-        }
-        /* back to LDS for the ordering step */
-        if (lane < n) {
-            d[lane] = dreg;
-#pragma unroll
-            for (int cc = 0; cc < 9; cc++) A_(lane, cc) = z[cc];
-        }
-#undef RD
-#undef WR
-#undef DG_ROTREG
+        const int info = dg_steqr9((DG_STEQR_PTR)d, (DG_STEQR_PTR)e, (DG_STEQR_PTR)(a + (lane % 9)), 9, lane);
+        const int jtot = info ? n * 30 : 0, nmaxit = n * 30;
         DG_WSYNC();
         DG_ET(2);
         /* dsteqr ends with an ascending selection sort; every caller only consumes the smallest pair (column 0,

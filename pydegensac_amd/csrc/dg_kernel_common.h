@@ -53,6 +53,7 @@ struct dg_ws_layout {
     size_t off_wave;      /* per-wave buffers of the wave-parallel sections: int[NW][n_max] + dg_pt[NW][n_max] */
     size_t off_res;       /* per-model results of a chunk: double J[768], unsigned I[768], int rf[256][5] */
     size_t off_mslot;     /* cooperative mode: the chunk's compact model index -> slot table, unsigned short[3*DG_CHUNK] */
+    size_t off_park;      /* parked-pair image: dg_f_shared + the dynamic LDS of the workgroup that set the pair aside (F driver) */
     size_t off_hjbuf;     /* cooperative mode: ordered MSAC terms of each helper workgroup, double[coop_k][n_max]        */
     int    n_max;
 };
@@ -97,6 +98,17 @@ struct dg_args {
     const int *order;                /* optional processing order (ticket t -> pair order[t]); null = identity              */
     int coop_k;                      /* helper workgroups per owner (0 = every workgroup owns pairs)            */
     dg_coop_cb *coop;                /* [owner slots] control blocks (coop_k > 0)                              */
+    /* Setting long pairs aside (F driver, batches larger than the resident grid).  A pair that is still running after
+     * park_sam samples while unstarted pairs remain is written back to its workspace (the LDS image goes to wl.off_park)
+     * and queued; its workgroup continues with a spare workspace and the next ticket, and the queued pairs are resumed —
+     * by whichever workgroup runs out of tickets first — once every pair has been started.  The batch then ends one
+     * long pair after the last pair was STARTED, instead of one long pair after the last long pair was started.
+     * Results do not depend on it (the image is the complete state between two chunks). */
+    int park_sam;                    /* 0 = off */
+    int n_res, n_ws;                 /* workspaces in `ws`: n_res = one per resident workgroup, then the spares up to n_ws */
+    int dyn_bytes;                   /* dynamic LDS per workgroup                                              */
+    int *park_ctl;                   /* [0] spares handed out, [32] queue entries claimed, [64] queue entries taken (one 128-byte line each) */
+    long long *park_q;               /* [n_ws - grid] entries: pair << 32 | workspace, -1 until published        */
     int pool_seq;                    /* 1 = always use the sequential pool-swap stage (LDS exchange-order self-check failed, or forced) */
     int variant_threads, mode;       /* reported in the stats block */
     int *trace;                      /* debug: [0] = count, then (tag, I, J lo, J hi) records; null = off */

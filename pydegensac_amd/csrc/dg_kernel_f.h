@@ -18,6 +18,17 @@ struct dg_score { unsigned I; double J; unsigned Is; unsigned Ilafs; };
 
 /* doubles that ww[] lacks for the parallel pool stage's touch table */
 #define DG_WPAD ((2 * DG_CHUNK * 7 * 4 > DG_NW * (int)sizeof(dg_wave_ws)) ? (2 * DG_CHUNK * 7 * 4 - DG_NW * (int)sizeof(dg_wave_ws) + 7) / 8 : 1)
+/* the F driver's workgroup-uniform state between two chunks (replicated in every lane while a pair runs; one copy in
+ * LDS travels with the image of a pair that is set aside, dg_args::park_sam) */
+struct dg_f_drv {
+    dg_score maxS, maxSs;
+    int no_sam, max_sam, iter_cnt, degen_cnt, iterID, Ihmax; unsigned non_degen;
+    int best_sample; long long t_best, t_start;
+    int finKind, accepted, perm[4], p4, e4kind, track, done;
+    unsigned seed; int cur, chunk_s[3], chunk_base;
+    int n_fds, n_exfds, n_hds, n_aux;
+};
+
 struct dg_f_shared {
     dg_red red;
     dg_lsq_scratch lsq;
@@ -48,6 +59,7 @@ struct dg_f_shared {
     int      samidxBest[7];
     int      itmp[32];
     double   dtmp[32];
+    dg_f_drv park;
 };
 
 /* ------------------------------------------------------------------------------------------------ */

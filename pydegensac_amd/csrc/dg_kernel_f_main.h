@@ -617,9 +617,68 @@ __device__ __forceinline__ unsigned dg_sample_chunk(unsigned seed, int cn, int n
     return sd;
 }
 
-/* the whole driver for ONE pair, run by one workgroup on scratch slot `slot` */
+/* ---- setting a long pair aside (dg_args::park_sam) -------------------------------------------------------------
+ * Cross-workgroup hand-off as in the cooperative mode: plain payload, then ONE agent-scope release by wave 0 after the
+ * workgroup barrier, then the flag (the queue entry) with a relaxed agent-scope atomic; the taker polls the entry with
+ * its whole first wave behind a scalar branch, then acquires. */
+#define DG_PARK_SPARE   0
+#define DG_PARK_CLAIMED 32
+#define DG_PARK_HEAD    64
+#define DG_PARK_DYN_OFF ((sizeof(dg_f_shared) + 255) & ~(size_t)255)   /* the dynamic LDS follows the dg_f_shared image */
+
+/* copies between LDS and the workspace, 16 bytes per thread and step (both sides 16-byte aligned) */
+__device__ __forceinline__ void dg_copy16(void *dst, const void *src, size_t bytes, int tid)
+{
+    const size_t nv = bytes / 16;
+    const uint4 *s4 = (const uint4 *)src; uint4 *d4 = (uint4 *)dst;
+    for (size_t i = tid; i < nv; i += DG_T) d4[i] = s4[i];
+    const size_t done = nv * 16;
+    for (size_t i = done + tid; i < bytes; i += DG_T) ((unsigned char *)dst)[i] = ((const unsigned char *)src)[i];
+}
+
+/* the next queued pair for a workgroup that found no ticket: pair << 32 | workspace, or -1 when the queue is empty.
+ * Entries are taken with compare-and-swap, never past the claimed count: a workgroup that sets a pair aside later
+ * finds its own entry when its tickets run out, so no entry is left behind. */
+__device__ __forceinline__ long long dg_park_take(const dg_args &A, long long *bc /* LDS */)
+{
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
+        int h;
+        for (;;) {
+            h = __builtin_amdgcn_readfirstlane(__hip_atomic_load(A.park_ctl + DG_PARK_HEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const int cl = __builtin_amdgcn_readfirstlane(__hip_atomic_load(A.park_ctl + DG_PARK_CLAIMED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (h >= cl) { h = -1; break; }
+            int ok = 0;
+            if (threadIdx.x == 0) {
+                int expect = h;
+                ok = __hip_atomic_compare_exchange_strong(A.park_ctl + DG_PARK_HEAD, &expect, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+            }
+            if (__builtin_amdgcn_readfirstlane(ok)) break;
+        }
+        long long e = -1;
+        if (h >= 0) {
+            for (;;) {
+                const long long v = __hip_atomic_load(A.park_q + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+                e = ((long long)hi << 32) | (unsigned)lo;
+                if (e >= 0) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        *bc = e;                                                             /* every lane stores the same value */
+    }
+    __syncthreads();
+    return *bc;
+}
+
+/* the whole driver for ONE pair, run by one workgroup on workspace `wsid` (a resident workgroup starts on the workspace
+ * of its own index).  resume != 0: `wsid` holds the image of a pair that was set aside, continue it.
+ * Returns -1 when the pair is finished, else the pair was set aside and the return value is the spare workspace the
+ * workgroup continues on. */
 template <int T, int LDSPTS>
-__device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsigned char *dyn_smem, const int pair, const int slot, int &coop_gen)
+__device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsigned char *dyn_smem, const int pair, const int slot, const int wsid,
+                                         const int resume, int &coop_gen)
 {
     const int coopK = LDSPTS == 0 ? A.coop_k : 0;
     dg_coop_cb *const cb = coopK > 0 ? A.coop + slot : (dg_coop_cb *)0;
@@ -628,9 +687,8 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
     const int n = (int)(A.offsets[pair + 1] - off);
     const dg_params &pr = A.prm;
     const double th = pr.th;
-    long long t_start = wall_clock64();
 
-    char *ws = A.ws + (size_t)slot * A.wl.stride;
+    char *ws = A.ws + (size_t)wsid * A.wl.stride;
     CTX c;
     c.S = S; c.n = n; c.tid = tid; c.A = &A; c.off = off;
     for (int i = 0; i < 10; i++) c.L[i] = (int *)(ws + A.wl.off_lists) + (size_t)i * A.wl.n_max;
@@ -650,6 +708,26 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
     const dg_pt *P = Pw;
     int *const pscr = A.pool_seq ? (int *)0 : (int *)S->ww;     /* LDS scratch of the parallel pool stage; null selects the sequential one */
 
+    const int mk_full = pr.error_type == 1 ? DG_K_FSYM : DG_K_FDS;
+    const int mk_ex   = pr.error_type == 1 ? DG_K_EXFSYM : DG_K_FDS;
+    const int doSym = pr.sym_th > 0, doLaf = pr.laf_coef > 0;
+
+    /* ---- driver state (workgroup-uniform, replicated in every lane) ---- */
+    dg_f_drv D;
+    dg_score &maxS = D.maxS, &maxSs = D.maxSs;
+    int &no_sam = D.no_sam, &max_sam = D.max_sam, &iter_cnt = D.iter_cnt, &degen_cnt = D.degen_cnt, &iterID = D.iterID, &Ihmax = D.Ihmax;
+    unsigned &non_degen = D.non_degen;
+    int &best_sample = D.best_sample; long long &t_best = D.t_best, &t_start = D.t_start;
+    int &finKind = D.finKind, &accepted = D.accepted;          /* errs[3] = residuals of S->F under finKind */
+    int (&perm)[4] = D.perm, &p4 = D.p4, &e4kind = D.e4kind, &track = D.track;   /* errs[] pointer bookkeeping */
+    double *e4F = S->bufF[0];                         /* model whose residuals errs[4] points at */
+    int &done = D.done;
+    unsigned &seed = D.seed;
+    int &cur = D.cur, (&chunk_s)[3] = D.chunk_s, &chunk_base = D.chunk_base;
+    int park_on = (A.park_sam > 0 && !resume) ? 1 : 0;
+
+  if (!resume) {
+    t_start = wall_clock64();
     /* ---- stage the correspondences (bindings.cpp:337-409: only x,y of each row are geometry) ---- */
     double ex0 = 0., ex1 = 0., ex2 = 0., ex3 = 0.;
     for (int i = tid; i < n; i += DG_T) {
@@ -672,24 +750,18 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
     if (tid < 4) { double e = 0.; for (int w = 0; w < DG_NW; w++) e = fmax(e, S->extw[w][tid]); S->ext[tid] = e; }
     __syncthreads();
 
-    const int mk_full = pr.error_type == 1 ? DG_K_FSYM : DG_K_FDS;
-    const int mk_ex   = pr.error_type == 1 ? DG_K_EXFSYM : DG_K_FDS;
-    const int doSym = pr.sym_th > 0, doLaf = pr.laf_coef > 0;
-
-    /* ---- driver state (workgroup-uniform, replicated in every lane) ---- */
-    dg_score maxS = {8, 0, 0, 0}, maxSs = {8, 0, 0, 0};
-    int no_sam = 0, max_sam = pr.max_iters, iter_cnt = 0, degen_cnt = 0, iterID = 0, Ihmax = 0;
-    unsigned non_degen = 0;
-    int best_sample = 0; long long t_best = t_start;
-    int finKind = mk_full, accepted = 0;              /* errs[3] = residuals of S->F under finKind */
-    int perm[4] = {0, 1, 2, 3}, p4 = 3, e4kind = mk_full, track = 1;   /* errs[] pointer bookkeeping */
-    double *e4F = S->bufF[0];                         /* model whose residuals errs[4] points at */
-    int done = 0;
+    maxS.I = 8; maxS.J = 0; maxS.Is = 0; maxS.Ilafs = 0; maxSs = maxS;
+    no_sam = 0; max_sam = pr.max_iters; iter_cnt = 0; degen_cnt = 0; iterID = 0; Ihmax = 0;
+    non_degen = 0;
+    best_sample = 0; t_best = t_start;
+    finKind = mk_full; accepted = 0;
+    perm[0] = 0; perm[1] = 1; perm[2] = 2; perm[3] = 3; p4 = 3; e4kind = mk_full; track = 1;
+    done = 0;
 
     /* srand(seed0); seed = rand() */
     if (tid == 0) { dg_srand(&S->rng, A.seeds[pair]); S->itmp[31] = dg_rand(&S->rng); }
     __syncthreads();
-    unsigned seed = (unsigned)S->itmp[31];
+    seed = (unsigned)S->itmp[31];
     __syncthreads();
 
     DG_DEVT(if (tid == 0) { for (int i = 0; i < 8; i++) { S->ph[i] = 0; S->dbg[i] = 0; } S->tq = DG_CLK(); });
@@ -698,7 +770,7 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
 #endif
 #define DG_PH(i) DG_DEVT(if (tid == 0) { long long tq2_ = DG_CLK(); S->ph[i] += tq2_ - S->tq; S->tq = tq2_; })
     /* software pipeline: chunk c is scored while chunk c+1 gets its pool swaps and chunk c+2 its seeds and draws */
-    int cur = 0, chunk_s[3] = {0, 0, 0}, chunk_base = 0;
+    cur = 0; chunk_s[0] = chunk_s[1] = chunk_s[2] = 0; chunk_base = 0;
     {
         int cn0 = max_sam - no_sam; if (cn0 > DG_CHUNK) cn0 = DG_CHUNK; if (cn0 < 0) cn0 = 0;
         int cn1 = max_sam - no_sam - cn0; if (cn1 > DG_CHUNK) cn1 = DG_CHUNK; if (cn1 < 0) cn1 = 0;
@@ -712,7 +784,52 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
         __syncthreads();
         seed = (unsigned)S->itmp[31];
     }
+  } else {
+    /* continue a pair that was set aside: its LDS image, then the driver state the image carries */
+    const char *pk = ws + A.wl.off_park;
+    dg_copy16(S, pk, sizeof(dg_f_shared), tid);
+    dg_copy16(dyn_smem, pk + DG_PARK_DYN_OFF, (size_t)A.dyn_bytes, tid);
+    __syncthreads();
+    D = S->park;
+    c.n_fds = D.n_fds; c.n_exfds = D.n_exfds; c.n_hds = D.n_hds; c.n_aux = D.n_aux;
+    DG_DEVT(if (tid == 0) S->tq = DG_CLK());
+    __syncthreads();
+  }
     while (!done && no_sam < max_sam) {
+        if (park_on && no_sam >= A.park_sam) {
+            /* still running after park_sam samples: set the pair aside if unstarted pairs remain and a spare workspace is left */
+            park_on = 0;
+            __syncthreads();
+            if (tid == 0) {
+                int nw = -1;
+                if (__hip_atomic_load(A.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < A.n_pairs) {
+                    nw = A.n_res + __hip_atomic_fetch_add(A.park_ctl + DG_PARK_SPARE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (nw >= A.n_ws) nw = -1;
+                }
+                S->itmp[30] = nw;
+            }
+            __syncthreads();
+            const int nw = S->itmp[30];
+            __syncthreads();
+            if (nw >= 0) {
+                D.n_fds = c.n_fds; D.n_exfds = c.n_exfds; D.n_hds = c.n_hds; D.n_aux = c.n_aux;
+                if (tid == 0) S->park = D;
+                __syncthreads();
+                char *pk = ws + A.wl.off_park;
+                dg_copy16(pk, S, sizeof(dg_f_shared), tid);
+                dg_copy16(pk + DG_PARK_DYN_OFF, dyn_smem, (size_t)A.dyn_bytes, tid);
+                __syncthreads();
+                if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
+                    int idx = 0;
+                    if (tid == 0) idx = __hip_atomic_fetch_add(A.park_ctl + DG_PARK_CLAIMED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    idx = __builtin_amdgcn_readfirstlane(idx);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (tid == 0) __hip_atomic_store(A.park_q + idx, ((long long)pair << 32) | (long long)(unsigned)wsid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                return nw;
+            }
+        }
         int chunk = chunk_s[cur]; if (chunk > max_sam - no_sam) chunk = max_sam - no_sam;
         c.seeds = S->seeds3[cur]; c.draws = S->draws3[cur]; chunk_base = no_sam;
         DG_PH(3);
@@ -1075,7 +1192,7 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
         st[0] = no_sam; st[1] = iter_cnt; st[2] = 0; st[3] = (int)maxS.I; st[4] = c.n_fds + c.n_exfds;
         st[5] = degen_cnt; st[6] = Ihmax; st[7] = best_sample; st[8] = c.n_fds; st[9] = c.n_exfds;
         st[10] = c.n_hds; st[11] = c.n_aux; st[12] = (int)(t_best - t_start); st[13] = (int)(t_end - t_start);
-        st[14] = A.variant_threads; st[15] = A.mode;
+        st[14] = A.variant_threads; st[15] = A.mode | (resume ? 256 : 0);      /* bit 8: the pair was set aside and resumed */
     }
     DG_PH(6);
 #ifdef DG_LO_PROF
@@ -1084,6 +1201,7 @@ __device__ __forceinline__ void dg_f_pair(const dg_args &A, dg_f_shared *S, unsi
 #endif
     DG_DEVT(if (A.phase_out && tid == 0) { S->ph[7] = DG_CLK() - t_start; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + i] = S->ph[i]; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + 8 + i] = S->dbg[i]; });
 #undef DG_PH
+    return -1;
 }
 
 /* ---- cooperative large-n mode: a helper workgroup ---------------------------------------------------------
@@ -1218,8 +1336,9 @@ template <int T, int LDSPTS>
 __global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_fundamental_kernel(dg_args A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
-    __shared__ dg_f_shared Sh;
+    __shared__ __attribute__((aligned(16))) dg_f_shared Sh;
     __shared__ int next_pair;
+    __shared__ long long next_parked;
     /* the device code reads the arguments through a pointer (dg_f_ctx::A, also inside non-inlined functions): give it an
      * LDS copy, so the by-value kernel argument's address is never taken (that would make the compiler keep a private
      * per-lane copy of the whole block in scratch memory and turn every uniform argument into a vector value) */
@@ -1233,10 +1352,20 @@ __global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_fundamental_kernel(dg_a
         const int h = (int)blockIdx.x % (As.coop_k + 1);
         if (h != 0) { dg_f_helper<T>(As, &Sh, slot, h); return; }
     }
+    int wsid = slot;
     for (;;) {
         const int pair = dg_next_pair(As, &next_pair);
-        if (pair < 0) break;
-        dg_f_pair<T, LDSPTS>(As, &Sh, dyn_smem, pair, slot, coop_gen);
+        if (pair >= 0) {
+            const int spare = dg_f_pair<T, LDSPTS>(As, &Sh, dyn_smem, pair, slot, wsid, 0, coop_gen);
+            if (spare >= 0) wsid = spare;            /* the pair was set aside with its workspace */
+            continue;
+        }
+        /* every pair has been started: continue the ones that were set aside */
+        if (As.park_sam <= 0) break;
+        const long long e = dg_park_take(As, &next_parked);
+        if (e < 0) break;
+        wsid = (int)(e & 0xffffffffll);
+        dg_f_pair<T, LDSPTS>(As, &Sh, dyn_smem, (int)(e >> 32), slot, wsid, 1, coop_gen);
     }
     if (LDSPTS == 0 && As.coop_k > 0 && threadIdx.x == 0)          /* retire the slot: its helpers leave */
         __hip_atomic_store(&As.coop[slot].gen, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

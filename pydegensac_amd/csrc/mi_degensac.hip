@@ -198,15 +198,33 @@ __global__ void dg_mat3_kernel(int op, const double *in, int count, double *out,
     }
 }
 
+/* op 3: the wave eigen-solver (dsyev restated; dg_dev_small.h dg_eig_sym_wave), one symmetric 9x9 problem per wave.
+ * out: the nine eigenvalues as the solver leaves them (smallest first, the rest unordered) + the 81 entries of the
+ * matrix it leaves behind (column 0 = the eigenvector of the smallest eigenvalue, which is all the estimator reads) */
+__global__ void dg_eig9_kernel(const double *in, int count, double *out, int *flag)
+{
+    __shared__ double a[81], w[9]; __shared__ dg_eig_ws ews;
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (t >= count) return;
+    for (int i = lane; i < 81; i += 64) a[i] = in[(size_t)t * 81 + i];
+    DG_WSYNC();
+    const int info = dg_eig_sym_wave(a, w, lane, &ews);
+    DG_WSYNC();
+    if (lane < 9) out[(size_t)t * 90 + lane] = w[lane];
+    for (int i = lane; i < 81; i += 64) out[(size_t)t * 90 + 9 + i] = a[i];
+    if (lane == 0) flag[t] = info;
+}
+
 extern "C" int mi_degensac_mat3(int op, const double *in, int count, int device, double *out, int32_t *flag)
 {
     DG_UNIT_ENTER(device);
-    if (op < 0 || op > 2 || count < 0) { set_err("bad op"); return MI_DEGENSAC_EINVAL; }
-    const size_t ni = op == 2 ? 40 : 9, no = op == 1 ? 12 : 9;
+    if (op < 0 || op > 3 || count < 0) { set_err("bad op"); return MI_DEGENSAC_EINVAL; }
+    const size_t ni = op == 3 ? 81 : op == 2 ? 40 : 9, no = op == 3 ? 90 : op == 1 ? 12 : 9;
     DevBuf<double> di, dout; DevBuf<int> df;
     if (di.alloc(count * ni) || dout.alloc(count * no) || df.alloc(count)) { set_err("device allocation failed"); return MI_DEGENSAC_ENOMEM; }
     HIPCHK(hipMemcpy(di.p, in, count * ni * 8, hipMemcpyHostToDevice));
-    if (count) hipLaunchKernelGGL(dg_mat3_kernel, dim3((count + 63) / 64), dim3(64), 0, 0, op, di.p, count, dout.p, df.p);
+    if (count && op == 3) hipLaunchKernelGGL(dg_eig9_kernel, dim3(count), dim3(64), 0, 0, di.p, count, dout.p, df.p);
+    else if (count) hipLaunchKernelGGL(dg_mat3_kernel, dim3((count + 63) / 64), dim3(64), 0, 0, op, di.p, count, dout.p, df.p);
     HIPCHK(hipGetLastError()); HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, dout.p, count * no * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(flag, df.p, (size_t)count * 4, hipMemcpyDeviceToHost));

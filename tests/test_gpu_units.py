@@ -200,3 +200,40 @@ def test_mat3_device_routines_equal_reference(oracle_ref):
     out = np.zeros((N, 9)); flag = np.zeros(N, np.int32)
     _lib.check(L.mi_degensac_mat3(2, dp(inp), N, 0, dp(out), flag.ctypes.data_as(C.POINTER(C.c_int32))))
     assert np.array_equal(out, want, equal_nan=True), np.flatnonzero((out != want).any(axis=1))[:10]
+
+
+def test_wave_eigensolver_equals_oracle_dsyev():
+    """mi_degensac_mat3 op 3: the wave eigen-solver (dsytd2 + dorg2l + the replicated-register dsteqr of dg_steqr9.h) on
+    symmetric 9x9 matrices — Gram matrices of normalised correspondence rows like the estimator's, random symmetric
+    ones over many scales, rank-deficient ones — against the CPU oracle's dsyev restatement: the smallest eigenvalue
+    and its eigenvector (all the estimator reads) bit for bit, and the whole spectrum as a set."""
+    from oracle import port
+    L = _lib.lib(); O = port.lib()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    rng = np.random.default_rng(33)
+    N = 4000; A = np.zeros((N, 9, 9))
+    for t in range(N):
+        k = t % 5
+        if k == 0:
+            m = rng.normal(size=(rng.integers(8, 60), 9)); a = m.T @ m
+        elif k == 1:
+            x1 = rng.normal(size=(14, 2)) * np.sqrt(2) / 2; x2 = x1 + rng.normal(size=(14, 2)) * 0.05
+            m = np.stack([np.r_[b[0] * np.r_[a_, 1.0], b[1] * np.r_[a_, 1.0], np.r_[a_, 1.0]] for a_, b in zip(x1, x2)]); a = m.T @ m
+        elif k == 2:
+            a = rng.normal(size=(9, 9)) * 10.0 ** rng.integers(-5, 6); a = a + a.T
+        elif k == 3:
+            m = rng.normal(size=(6, 9)); a = m.T @ m                       # rank 6
+        else:
+            a = np.diag(rng.normal(size=9)) + 1e-9 * rng.normal(size=(9, 9)); a = (a + a.T) / 2
+        A[t] = (a + a.T) / 2
+    out = np.zeros((N, 90)); flag = np.zeros(N, np.int32)
+    _lib.check(L.mi_degensac_mat3(3, dp(A), N, 0, dp(out), flag.ctypes.data_as(C.POINTER(C.c_int32))))
+    bad = []
+    for t in range(N):
+        a = A[t].copy(); w = np.zeros(9)
+        info = O.dg_oracle_eig_sym(dp(a), dp(w), 9)
+        ok = info == flag[t] and out[t, 0] == w[0] and np.array_equal(out[t, 9:18], a.ravel()[:9]) \
+            and np.array_equal(np.sort(out[t, :9]), w)
+        if not ok:
+            bad.append(t)
+    assert not bad, (len(bad), bad[:10], flag[bad[:10]])

@@ -60,6 +60,27 @@ def test_cooperative_helpers_do_not_change_results():
                 assert all(np.array_equal(np.asarray(x), y) for x, y in zip(m, ref[1])), (variant, helpers)
 
 
+def test_setting_long_pairs_aside_does_not_change_results():
+    """Long pairs are written back to their workspace and resumed after every pair has been started (dg_args::park_sam).
+    Forced on a small batch: 4 resident workgroups for 24 pairs, threshold = one chunk / four chunks / 2048 samples, all
+    three workgroup sizes and every placement: bit-identical models, masks and counters to the run without it."""
+    A, B = _f_batch(); A = A * 6; B = B * 6; seeds = list(range(1, 25))
+    ref = None
+    for variant in (256, 512, 128):
+        for mode in (2, 1, 0):
+            for park in (255, 1, 4, 8):                          # 255 = off; else units of 256 samples
+                F, m = pd.findFundamentalMatrixBatch(A, B, max_iters=20000, seeds=seeds,
+                                                     tuning=tune(variant, mode) | (255 << 8) | (park << 16) | (4 << 24))
+                st = [(s_["samples"], s_["lo_runs"], s_["models"], s_["degen"], s_["I"], s_["best_sample"]) for s_ in pd.last_stats()]
+                aside = sum(s_["set_aside"] for s_ in pd.last_stats())
+                assert (aside == 0) if park == 255 else (aside >= 4), (variant, mode, park, aside)
+                if ref is None:
+                    ref = (np.asarray(F).copy(), [np.asarray(x).copy() for x in m], st)
+                else:
+                    assert np.array_equal(np.asarray(F), ref[0]) and st == ref[2], (variant, mode, park)
+                    assert all(np.array_equal(np.asarray(x), y) for x, y in zip(m, ref[1])), (variant, mode, park)
+
+
 def test_homography_variants_and_modes_agree():
     A, B = [], []
     for i, n in enumerate([1200, 400, 2500]):
