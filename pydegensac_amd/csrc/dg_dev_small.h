@@ -207,6 +207,10 @@ static __device__ long long dg_eig_ticks[4];
 #define DG_STEQR_FIND_QR(d, e, l, lend, m) do { const int i_ = lane & 7; double t2_ = fabs((e)[i_]); t2_ *= t2_; \
         const bool c_ = i_ >= (lend) && i_ < (l) && t2_ <= ((DG_EPS*DG_EPS) * fabs((d)[i_+1])) * fabs((d)[i_]) + DG_SAFMIN; \
         const unsigned long long bm_ = __ballot(c_) & 0xffull; (m) = bm_ ? 64 - __clzll((long long)bm_) : (lend); } while (0)
+#ifdef DG_EIG_TIMING
+static __device__ long long dg_steqr_ticks[2], dg_steqr_tq;
+#define DG_STEQR_T(i) do { long long t__ = wall_clock64(); if (lane == 0) { dg_steqr_ticks[i] += t__ - dg_steqr_tq; dg_steqr_tq = t__; } } while (0)
+#endif
 #include "dg_steqr9.h"
 struct dg_eig_ws { double d[9], e[9], tau[9], work[18]; };
 static __device__ __noinline__ int dg_eig_sym_wave(double *a, double *w, int lane, dg_eig_ws *ews)
@@ -327,8 +331,12 @@ static __device__ __noinline__ int dg_eig_sym_wave(double *a, double *w, int lan
     {
         double p;
         DG_WSYNC();
+#ifdef DG_EIG_TIMING
+        if (lane == 0) dg_steqr_tq = wall_clock64();
+#endif
         const int info = dg_steqr9((DG_STEQR_PTR)d, (DG_STEQR_PTR)e, (DG_STEQR_PTR)(a + (lane % 9)), 9, lane);
         const int jtot = info ? n * 30 : 0, nmaxit = n * 30;
+        DG_STEQR_T(0);
         DG_WSYNC();
         DG_ET(2);
         /* dsteqr ends with an ascending selection sort; every caller only consumes the smallest pair (column 0,

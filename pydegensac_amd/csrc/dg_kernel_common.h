@@ -241,4 +241,34 @@ __device__ __forceinline__ int dg_randsubset_wave(dg_rng *g, int *pool, int max_
     return max_sz - siz;
 }
 
+/* dg_randsubset_wave on a private generator, leaving the list untouched: the canonical slots it would store are
+ * written to (pos[j], val[j]), j < 2*siz, pos = -1 for the slots that hold no store.  Used to prepare a sample ahead of
+ * time; storing the slots later (and adopting the generator) has the same effect as the call itself. */
+__device__ __forceinline__ void dg_randsubset_wave_ahead(dg_rng *g, const int *pool, int max_sz, int siz, int lane, int *id, int *pos_out, int *val_out)
+{
+    int myS = 0;
+    for (int i = 0; i < siz; i++) {
+        int s = 0;
+        if (lane == 0) s = dg_rand(g) % (max_sz - i);
+        s = __builtin_amdgcn_readfirstlane(s);
+        if (lane == i) myS = s;
+    }
+    const bool used = lane < 2 * siz;
+    const int drawn = __shfl(myS, lane >= siz ? lane - siz : 0, 64);
+    const int pos = lane < siz ? max_sz - 1 - lane : (used ? drawn : -1);
+    int val = used ? pool[pos] : 0;
+    for (int i = 0; i < siz; i++) {
+        const int s_i = __builtin_amdgcn_readlane(myS, i), t_i = max_sz - 1 - i;
+        const unsigned long long mA = __ballot(used && pos == s_i), mB = __ballot(used && pos == t_i);
+        const int la = __ffsll((long long)mA) - 1, lb = __ffsll((long long)mB) - 1;
+        const int va = __builtin_amdgcn_readlane(val, la), vb = __builtin_amdgcn_readlane(val, lb);
+        if (lane == la) val = vb;
+        if (lane == lb) val = va;
+    }
+    bool canon = used;
+    for (int j = 0; j < 2 * siz; j++) { const int pj = __builtin_amdgcn_readlane(pos, j); if (j < lane && pj == pos) canon = false; }
+    if (used) { pos_out[lane] = canon ? pos : -1; val_out[lane] = val; }
+    *id = __shfl(val, lane < siz ? siz - 1 - lane : 0, 64);
+}
+
 #endif /* DG_KERNEL_COMMON_H */

@@ -29,6 +29,11 @@ struct dg_f_drv {
     int n_fds, n_exfds, n_hds, n_aux;
 };
 
+/* A 14-point sample of the local optimisation prepared ahead of time by an idle wave (dg_inFrani): the generator state
+ * it assumes at the start of the repetition, the state after its draws, the list slots the draws would store, the model. */
+#define DG_LO_AHEAD (DG_NW - 1 < 5 ? DG_NW - 1 : 5)
+struct dg_lo_ahead { dg_rng before, after; int pos[32], val[32]; double F[9]; };
+
 struct dg_f_shared {
     dg_red red;
     dg_lsq_scratch lsq;
@@ -60,6 +65,7 @@ struct dg_f_shared {
     int      itmp[32];
     double   dtmp[32];
     dg_f_drv park;
+    dg_lo_ahead ahead[DG_LO_AHEAD]; int n_ahead;
 };
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -163,7 +169,7 @@ __device__ __forceinline__ dg_pass_res dg_h_pass(CTX &c, const double *Hm /* LDS
 }
 __device__ __forceinline__ dg_pass_cfg dg_cfg0(int n)
 {
-    dg_pass_cfg c; c.n = n; c.src = 0; c.wantJ = 0; c.thJ = 0; c.jbuf = 0; c.wantC = 0; c.thC = 0; c.list = 0; c.thL = 0; c.listStrict = 0; c.flags = 0; c.thF = 0;
+    dg_pass_cfg c; c.n = n; c.src = 0; c.wantJ = 0; c.thJ = 0; c.jbuf = 0; c.wantC = 0; c.thC = 0; c.list = 0; c.thL = 0; c.listStrict = 0; c.list2 = 0; c.thL2 = 0; c.flags = 0; c.thF = 0;
     return c;
 }
 

@@ -17,6 +17,7 @@
  *   DG_STEQR_FN                      function qualifiers
  *   DG_STEQR_PTR                     the pointer type of d / e / z (an LDS-qualified pointer on the device)
  *   DG_STEQR_LARTG(f, g, c, s, r)    dlartg (the device passes its reciprocal-sharing form)
+ *   DG_STEQR_ST / DG_STEQR_STZ       stores to d / e and to this lane's row of Z
  *   DG_STEQR_ANY(cond)               a wave-uniform condition as a scalar (ballot on the device)
  *   DG_STEQR_FIND_SPLIT / _QL / _QR  the three searches for a negligible subdiagonal entry (one candidate per lane and
  *                                    a ballot on the device)
@@ -25,6 +26,9 @@
 #ifndef DG_STEQR9_H
 #define DG_STEQR9_H
 
+#ifndef DG_STEQR_T
+#define DG_STEQR_T(i)
+#endif
 #ifndef DG_STEQR_FN
 #define DG_STEQR_FN static inline
 #endif
@@ -33,6 +37,12 @@
 #endif
 #ifndef DG_STEQR_LARTG
 #define DG_STEQR_LARTG(f, g, c, s, r) dg_lartg((f), (g), (c), (s), (r))
+#endif
+#ifndef DG_STEQR_ST
+/* stores to d / e and to this lane's row of Z.  On the device every lane stores (the same value to the same address):
+ * restricting them to one / nine lanes was measured 8 % slower (exec-mask round trips inside the chain) */
+#define DG_STEQR_ST(lhs, v) ((lhs) = (v))
+#define DG_STEQR_STZ(lhs, v) ((lhs) = (v))
 #endif
 #ifndef DG_STEQR_ANY
 #define DG_STEQR_ANY(cond) (cond)
@@ -61,9 +71,9 @@ DG_STEQR_FN int dg_steqr9(DG_STEQR_PTR d, DG_STEQR_PTR e, DG_STEQR_PTR z, const 
     double p, g, r, c, s, f, b, rt1, rt2;
     (void)lane;
     while (l1 < n) {
-        if (l1 > 0) e[l1 - 1] = 0.;
+        if (l1 > 0) DG_STEQR_ST(e[l1 - 1], 0.);
         DG_STEQR_FIND_SPLIT(d, e, l1, m);
-        if (m < n - 1) e[m] = 0.;
+        if (m < n - 1) DG_STEQR_ST(e[m], 0.);
         l = l1; lsv = l; lend = m; lendsv = lend; l1 = m + 1;
         if (lend == l) continue;
         if (DG_STEQR_ANY(fabs(d[lend]) < fabs(d[l]))) { lend = lsv; l = lendsv; }
@@ -71,13 +81,13 @@ DG_STEQR_FN int dg_steqr9(DG_STEQR_PTR d, DG_STEQR_PTR e, DG_STEQR_PTR z, const 
             /* ---- QL: chase the bulge from m-1 down to l ---- */
             for (;;) {
                 if (l != lend) DG_STEQR_FIND_QL(d, e, l, lend, m); else m = lend;
-                if (m < lend) e[m] = 0.;
+                if (m < lend) DG_STEQR_ST(e[m], 0.);
                 p = d[l];
                 if (m == l) { l++; if (l <= lend) continue; break; }
                 if (m == l + 1) {
                     dg_laev2(d[l], e[l], d[l+1], &rt1, &rt2, &c, &s);
-                    if (c != 1. || s != 0.) { const double t = z[(l+1)*zs], u = z[l*zs]; z[(l+1)*zs] = c*t - s*u; z[l*zs] = s*t + c*u; }
-                    d[l] = rt1; d[l+1] = rt2; e[l] = 0.;
+                    if (c != 1. || s != 0.) { const double t = z[(l+1)*zs], u = z[l*zs]; DG_STEQR_STZ(z[(l+1)*zs], c*t - s*u); DG_STEQR_STZ(z[l*zs], s*t + c*u); }
+                    DG_STEQR_ST(d[l], rt1); DG_STEQR_ST(d[l+1], rt2); DG_STEQR_ST(e[l], 0.);
                     l += 2; if (l <= lend) continue; break;
                 }
                 if (jtot == nmaxit) break;
@@ -87,39 +97,41 @@ DG_STEQR_FN int dg_steqr9(DG_STEQR_PTR d, DG_STEQR_PTR e, DG_STEQR_PTR z, const 
                   r = dg_lapy2(g, 1.);
                   g = d[m] - p + (el / (g + dg_sign(r, g))); }
                 s = 1.; c = 1.; p = 0.;
+                DG_STEQR_T(0);
                 double ei = e[m-1], di = d[m-1], di1 = d[m], zhi = z[m*zs], zlo = z[(m-1)*zs];
                 for (i = m - 1; i >= l; i--) {
                     double ei_n = 0., di_n = 0., zlo_n = 0.;
                     if (i > l) { ei_n = e[i-1]; di_n = d[i-1]; zlo_n = z[(i-1)*zs]; }
                     f = s * ei; b = c * ei;
                     DG_STEQR_LARTG(g, f, &c, &s, &r);
-                    if (i != m - 1) e[i+1] = r;
+                    if (i != m - 1) DG_STEQR_ST(e[i+1], r);
                     g = di1 - p;
                     r = (di - g)*s + 2.*c*b;
                     p = s * r;
-                    d[i+1] = g + p;
+                    DG_STEQR_ST(d[i+1], g + p);
                     g = c*r - b;
                     {   /* columns (i, i+1) with (c, -s); the new column i is the next step's column i+1 */
                         const double ct = c, st = -s; double nhi = zhi, carry = zlo;
                         if (ct != 1. || st != 0.) { nhi = ct*zhi - st*zlo; carry = st*zhi + ct*zlo; }
-                        z[(i+1)*zs] = nhi; zhi = carry;
+                        DG_STEQR_STZ(z[(i+1)*zs], nhi); zhi = carry;
                     }
                     ei = ei_n; di1 = di; di = di_n; zlo = zlo_n;
                 }
-                z[l*zs] = zhi;
-                d[l] = di1 - p; e[l] = g;
+                DG_STEQR_STZ(z[l*zs], zhi);
+                DG_STEQR_ST(d[l], di1 - p); DG_STEQR_ST(e[l], g);
+                DG_STEQR_T(1);
             }
         } else {
             /* ---- QR: chase the bulge from m up to l-1 ---- */
             for (;;) {
                 if (l != lend) DG_STEQR_FIND_QR(d, e, l, lend, m); else m = lend;
-                if (m > lend) e[m-1] = 0.;
+                if (m > lend) DG_STEQR_ST(e[m-1], 0.);
                 p = d[l];
                 if (m == l) { l--; if (l >= lend) continue; break; }
                 if (m == l - 1) {
                     dg_laev2(d[l-1], e[l-1], d[l], &rt1, &rt2, &c, &s);
-                    if (c != 1. || s != 0.) { const double t = z[l*zs], u = z[(l-1)*zs]; z[l*zs] = c*t - s*u; z[(l-1)*zs] = s*t + c*u; }
-                    d[l-1] = rt1; d[l] = rt2; e[l-1] = 0.;
+                    if (c != 1. || s != 0.) { const double t = z[l*zs], u = z[(l-1)*zs]; DG_STEQR_STZ(z[l*zs], c*t - s*u); DG_STEQR_STZ(z[(l-1)*zs], s*t + c*u); }
+                    DG_STEQR_ST(d[l-1], rt1); DG_STEQR_ST(d[l], rt2); DG_STEQR_ST(e[l-1], 0.);
                     l -= 2; if (l >= lend) continue; break;
                 }
                 if (jtot == nmaxit) break;
@@ -129,27 +141,29 @@ DG_STEQR_FN int dg_steqr9(DG_STEQR_PTR d, DG_STEQR_PTR e, DG_STEQR_PTR z, const 
                   r = dg_lapy2(g, 1.);
                   g = d[m] - p + (el / (g + dg_sign(r, g))); }
                 s = 1.; c = 1.; p = 0.;
+                DG_STEQR_T(0);
                 double ei = e[m], di = d[m], di1 = d[m+1], zlo = z[m*zs], zhi = z[(m+1)*zs];
                 for (i = m; i <= l - 1; i++) {
                     double ei_n = 0., di1_n = 0., zhi_n = 0.;
                     if (i < l - 1) { ei_n = e[i+1]; di1_n = d[i+2]; zhi_n = z[(i+2)*zs]; }
                     f = s * ei; b = c * ei;
                     DG_STEQR_LARTG(g, f, &c, &s, &r);
-                    if (i != m) e[i-1] = r;
+                    if (i != m) DG_STEQR_ST(e[i-1], r);
                     g = di - p;
                     r = (di1 - g)*s + 2.*c*b;
                     p = s * r;
-                    d[i] = g + p;
+                    DG_STEQR_ST(d[i], g + p);
                     g = c*r - b;
                     {   /* columns (i, i+1) with (c, s); the new column i+1 is the next step's column i */
                         double nlo = zlo, carry = zhi;
                         if (c != 1. || s != 0.) { carry = c*zhi - s*zlo; nlo = s*zhi + c*zlo; }
-                        z[i*zs] = nlo; zlo = carry;
+                        DG_STEQR_STZ(z[i*zs], nlo); zlo = carry;
                     }
                     ei = ei_n; di = di1; di1 = di1_n; zhi = zhi_n;
                 }
-                z[l*zs] = zlo;
-                d[l] = di - p; e[l-1] = g;
+                DG_STEQR_STZ(z[l*zs], zlo);
+                DG_STEQR_ST(d[l], di - p); DG_STEQR_ST(e[l-1], g);
+                DG_STEQR_T(1);
             }
         }
         if (jtot >= nmaxit) break;

@@ -97,7 +97,7 @@ __device__ __forceinline__ double dg_seq_sum(const double *t, int cnt)
 /* LDS block used by the reductions below (declared once per kernel) */
 struct dg_red {
     double   d[2][DG_NW][4];
-    unsigned u[2][DG_NW][2 * DG_PU];   /* per-wave counts of one step of dg_pass (list, J) x DG_PU tiles; [0][w][0..3] also final counts */
+    unsigned u[2][DG_NW][3 * DG_PU];   /* per-wave counts of one step of dg_pass (list, J, second list) x DG_PU tiles; [0][w][0..3] also final counts */
     double   bc[96];          /* broadcast slots */
     int      bi[16];
 };
@@ -157,16 +157,18 @@ struct dg_pass_cfg {
     int         wantC;  double thC;
     /* ordered list of ids with d <= thL  (inlidxs' index list) */
     int        *list;   double thL;  int listStrict;   /* listStrict: ids with d < thL instead of d <= thL */
+    /* optional second ordered list of the same residuals: ids with d <= thL2 */
+    int        *list2;  double thL2;
     /* flags[item position] = d < thF (strict, DegUtils.c style) and their count */
     unsigned char *flags; double thF;
 };
-struct dg_pass_res { unsigned I; double J; unsigned C; unsigned nL; unsigned nF; };
+struct dg_pass_res { unsigned I; double J; unsigned C; unsigned nL; unsigned nF; unsigned nL2; };
 
 template <class Err>
 __device__ __forceinline__ dg_pass_res dg_pass(dg_red *r, const dg_pass_cfg &c, Err err, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
-    dg_pass_res out; out.I = 0; out.J = 0; out.C = 0; out.nL = 0; out.nF = 0;
+    dg_pass_res out; out.I = 0; out.J = 0; out.C = 0; out.nL = 0; out.nF = 0; out.nL2 = 0;
     const double t94 = c.thJ * 9 / 4;
     unsigned cI = 0, cC = 0, cF = 0, nJ = 0;
     int par = 0;
@@ -180,7 +182,7 @@ __device__ __forceinline__ dg_pass_res dg_pass(dg_red *r, const dg_pass_cfg &c, 
         for (int u = 0; u < DG_PU; u++) pid[u] = act[u] ? (c.src ? c.src[jj[u]] : jj[u]) : 0;
 #pragma unroll
         for (int u = 0; u < DG_PU; u++) d[u] = act[u] ? err(pid[u], jj[u]) : 0.0;
-        double term[DG_PU]; bool nz[DG_PU], in[DG_PU];
+        double term[DG_PU]; bool nz[DG_PU], in[DG_PU], in2[DG_PU];
 #pragma unroll
         for (int u = 0; u < DG_PU; u++) {
             term[u] = 0.0; nz[u] = false;
@@ -192,28 +194,30 @@ __device__ __forceinline__ dg_pass_res dg_pass(dg_red *r, const dg_pass_cfg &c, 
             if (c.wantC) cC += (act[u] && d[u] <= c.thC) ? 1u : 0u;
             if (c.flags) { bool f = act[u] && d[u] < c.thF; cF += f ? 1u : 0u; if (act[u]) c.flags[jj[u]] = f ? 1 : 0; }
             in[u] = c.list && act[u] && (c.listStrict ? d[u] < c.thL : d[u] <= c.thL);
+            in2[u] = c.list2 && act[u] && d[u] <= c.thL2;
         }
         if (c.list || c.wantJ) {
             /* ordered compaction (inlier ids, nonzero MSAC terms) needs the per-wave counts of every tile: one barrier per step */
-            unsigned long long bL[DG_PU], bJ[DG_PU];
+            unsigned long long bL[DG_PU], bJ[DG_PU], bL2[DG_PU];
 #pragma unroll
-            for (int u = 0; u < DG_PU; u++) { bL[u] = __ballot(in[u]); bJ[u] = __ballot(nz[u]); }
+            for (int u = 0; u < DG_PU; u++) { bL[u] = __ballot(in[u]); bJ[u] = __ballot(nz[u]); bL2[u] = c.list2 ? __ballot(in2[u]) : 0ull; }
             if (lane == 0) {
 #pragma unroll
-                for (int u = 0; u < DG_PU; u++) { r->u[par][wave][2*u] = (unsigned)__popcll(bL[u]); r->u[par][wave][2*u+1] = (unsigned)__popcll(bJ[u]); }
+                for (int u = 0; u < DG_PU; u++) { r->u[par][wave][3*u] = (unsigned)__popcll(bL[u]); r->u[par][wave][3*u+1] = (unsigned)__popcll(bJ[u]); r->u[par][wave][3*u+2] = (unsigned)__popcll(bL2[u]); }
             }
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < DG_PU; u++) {
-                unsigned lbase = out.nL, jbase = nJ;
+                unsigned lbase = out.nL, jbase = nJ, l2base = out.nL2;
 #pragma unroll
                 for (int w = 0; w < DG_NW; w++) {
-                    const unsigned a = r->u[par][w][2*u], b = r->u[par][w][2*u+1];
-                    if (w < wave) { lbase += a; jbase += b; }
-                    out.nL += a; nJ += b;
+                    const unsigned a = r->u[par][w][3*u], b = r->u[par][w][3*u+1], a2 = r->u[par][w][3*u+2];
+                    if (w < wave) { lbase += a; jbase += b; l2base += a2; }
+                    out.nL += a; nJ += b; out.nL2 += a2;
                 }
                 if (in[u]) c.list[lbase + (unsigned)__popcll(bL[u] & ((1ull << lane) - 1ull))] = pid[u];
                 if (nz[u]) c.jbuf[jbase + (unsigned)__popcll(bJ[u] & ((1ull << lane) - 1ull))] = term[u];
+                if (in2[u]) c.list2[l2base + (unsigned)__popcll(bL2[u] & ((1ull << lane) - 1ull))] = pid[u];
             }
             par ^= 1;
         }

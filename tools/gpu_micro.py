@@ -18,7 +18,7 @@ for n,v in zip(names,t):
     elif n=="cov9+eig9 lane0": print(f"lartg_bf mismatches (of 1.28M): {v}")
     else: print(f"{n:16s} {v/reps/100:.1f} us")
 
-if os.environ.get("MI_DEGENSAC_LIB","").endswith("exp_et.so"): print("eig stages (us per call): tridiag %.1f  orgtr %.1f  steqr %.1f  sort %.1f" % tuple(t[4:8]/reps/100))
+if os.environ.get("MI_DEGENSAC_LIB","").endswith("exp_et.so"): print("steqr split (us per call): outside the rotation chains %.1f, inside %.1f" % (mo[12]/reps/100, mo[13]/reps/100)); print("eig stages (us per call): tridiag %.1f  orgtr %.1f  steqr %.1f  sort %.1f" % tuple(t[4:8]/reps/100))
 
 for k in range(8):
     o=mo[16+8*k:24+8*k]
