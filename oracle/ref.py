@@ -36,6 +36,9 @@ def lib(flavour=""):
         l.ref_capture_resids.restype = None
         l.ref_counters_reset.argtypes = [C.c_int]
         l.ref_counters_get.argtypes = [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
+        l.ref_find_fundamental_legacy.argtypes = [C.c_int, dp, dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_uint,
+                                                  dp, C.POINTER(C.c_ubyte), C.POINTER(C.c_int)]
+        l.ref_find_fundamental_legacy.restype = C.c_int
         l._flavour = flavour
         _LIB = l
     return _LIB
@@ -104,3 +107,15 @@ def data_out_of(pts1, pts2, **kw):
     lib(kw.get("flavour", "")).ref_capture_data_out(buf.ctypes.data_as(C.POINTER(C.c_int)), n + 3)
     out = find_fundamental(pts1, pts2, **kw)
     return buf, out
+
+
+def find_fundamental_legacy(variant, pts1, pts2, px_th=0.5, conf=0.9999, max_iters=100000, error_type=0, sym_check=False, seed=1):
+    """The reference's legacy drivers: variant 0 = exp_ransacFcustom (exp_ranF.c:811), 1 = exp_ransacF (:242, Sampson only).
+    Returns (F [3,3], mask [n] bool, stats dict)."""
+    l = lib()
+    a = np.ascontiguousarray(pts1, dtype=np.float64); b = np.ascontiguousarray(pts2, dtype=np.float64)
+    n, dim = a.shape
+    F = np.zeros(9); mask = np.zeros(n, np.uint8); st = (C.c_int * 4)()
+    l.ref_find_fundamental_legacy(int(variant), _dp(a), _dp(b), n, dim, px_th, conf, max_iters, error_type, int(sym_check), seed,
+                                  _dp(F), mask.ctypes.data_as(C.POINTER(C.c_ubyte)), st)
+    return F.reshape(3, 3), mask.astype(bool), dict(samples=st[0], lo_runs=st[1], Ih=st[2], I=st[3])

@@ -170,3 +170,35 @@ int ref_find_homography(const double *x1, const double *x2, int n, int dim,
     free(resids); free(data_out); free(u); free(ulaf1); free(ulaf2);
     return (int)S.I;
 }
+
+/* ---- the legacy fundamental-matrix drivers of exp_ranF.c: exp_ransacFcustom (:811, the custom-metric
+ * driver without the LAF arguments) and exp_ransacF (:242, fixed Sampson metric, never seeds the generator itself).
+ * Same marshalling as ref_find_fundamental; variant 0 = exp_ransacFcustom, 1 = exp_ransacF. */
+/* defined in exp_ranF.c:811 but not declared in exp_ranF.h */
+int exp_ransacFcustom(double *u, int len, double th, double conf, int max_sam, double *F, unsigned char *inl, int *data_out,
+                      int do_lo, unsigned inlLimit, double **resids, double *H_best, int *Ih, exFDsPtr EXFDS1, FDsPtr FDS1, int doSymCheck);
+int ref_find_fundamental_legacy(int variant, const double *x1, const double *x2, int n, int dim,
+                                double px_th, double conf, int max_iters, int error_type, int sym_check, unsigned seed,
+                                double *F, unsigned char *mask, int *stats)
+{
+    FDsPtr FDS1; exFDsPtr EXFDS1;
+    double th = px_th * px_th;
+    int ret, I_H = 0, i;
+    double *u, *ua, *ub, *resids = 0, HinF[9];
+    int *data_out;
+    if (error_type == 1) { FDS1 = &FDsSym; EXFDS1 = &exFDsSym; } else { FDS1 = &FDs; EXFDS1 = &exFDs; }
+    u = (double *)malloc(sizeof(double) * 6 * (size_t)n); ua = (double *)malloc(48); ub = (double *)malloc(48);
+    data_out = (int *)calloc((size_t)n * 18 + 8, sizeof(int));
+    build_u(x1, x2, n, dim, 0, u, ua, ub);
+    for (i = 0; i < 9; i++) F[i] = 0;
+    oracle_set_seed(seed);
+    if (variant == 0)
+        ret = exp_ransacFcustom(u, n, th, conf, max_iters, F, mask, data_out, 1, 0, &resids, HinF, &I_H, EXFDS1, FDS1, sym_check);
+    else {
+        srand(seed);                       /* exp_ransacF draws `seed = rand()` from whatever state the process is in */
+        ret = exp_ransacF(u, n, th, conf, max_iters, F, mask, data_out, 1, 0, &resids, HinF, &I_H);
+    }
+    if (stats) { stats[0] = data_out[0]; stats[1] = data_out[1]; stats[2] = I_H; stats[3] = ret; }
+    free(resids); free(data_out); free(u); free(ua); free(ub);
+    return ret;
+}

@@ -46,8 +46,14 @@ struct dg_f_shared {
     dg_wave_ws ww[DG_NW];                /* per-wave scratch of the wave-parallel sections */
     double   wpad[DG_WPAD];              /* extends ww[] to the size the parallel pool stage needs (2 * DG_CHUNK * 7 ints) */
     double   csH[5][9]; int csRes[5];    /* checksample: per-triplet homography and verdict */
-    double   fhF[16][9], fhF2[16][9], fhTh[16];   /* innerFH: per-repetition model, its u2Fit refinement, flag threshold */
-    int      fhIds[16][10], fhCnt[16], fhCnt2[16], fhRaw[160];
+    union {      /* never live at the same time: innerFH belongs to the DEGENSAC branch, `ahead` to one local optimisation */
+        struct {
+            double   fhF[16][9], fhF2[16][9], fhTh[16];   /* innerFH: per-repetition model, its u2Fit refinement, flag threshold */
+            int      fhIds[16][10], fhCnt[16], fhCnt2[16], fhRaw[160];
+        };
+        dg_lo_ahead ahead[DG_LO_AHEAD];
+    };
+    int n_ahead;
     long long ph[8], dbg[8], tq;
 #ifdef DG_LO_PROF
     long long lt[16], ltq;
@@ -65,7 +71,6 @@ struct dg_f_shared {
     int      itmp[32];
     double   dtmp[32];
     dg_f_drv park;
-    dg_lo_ahead ahead[DG_LO_AHEAD]; int n_ahead;
 };
 
 /* ------------------------------------------------------------------------------------------------ */
