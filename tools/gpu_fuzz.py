@@ -46,7 +46,35 @@ def run(N, rng_seed, verbose=True):
     return bad_res, bad - bad_res
 
 
+def run_set_aside(N, rng_seed):
+    """Random fundamental-matrix batches on a capped resident grid with long pairs set aside at random thresholds
+    (tuning bits 16-31) against the same batch without it: models, masks and counters must be identical."""
+    rng = np.random.default_rng(rng_seed); bad = 0; aside = 0
+    for case in range(N):
+        P = int(rng.integers(6, 40)); A = []; B = []
+        for i in range(P):
+            n = int(rng.choice([20, 150, 400, 1000, 2000])); pf = float(rng.choice([0.0, 0.0, 0.6, 0.9]))
+            p1, p2, _, _ = syn.two_view_fundamental(n, float(rng.uniform(0.15, 0.8)), float(rng.choice([0.1, 0.5])), seed=1000 * case + i, plane_fraction=pf)
+            A.append(p1); B.append(p2)
+        seeds = [int(x) for x in rng.integers(1, 2**31 - 1, P)]; mi = int(rng.choice([3000, 20000]))
+        variant = int(rng.choice([1, 2, 3])); mode = int(rng.choice([1, 2, 3])); et = int(rng.choice([0, 1])); sym = bool(rng.random() < 0.7)
+        base = variant | (mode << 2) | (255 << 8)
+        ets = ['sampson', 'symm_epipolar'][et]
+        F0, m0 = pd.findFundamentalMatrixBatch(A, B, 0.5, 0.9999, mi, error_type=ets, symmetric_error_check=sym, seeds=seeds, tuning=base | (255 << 16)); s0 = pd.last_stats()
+        tn = base | (int(rng.integers(1, 12)) << 16) | (int(rng.integers(1, 6)) << 24)
+        F1, m1 = pd.findFundamentalMatrixBatch(A, B, 0.5, 0.9999, mi, error_type=ets, symmetric_error_check=sym, seeds=seeds, tuning=tn); s1 = pd.last_stats()
+        aside += sum(x["set_aside"] for x in s1)
+        key = lambda st: [(x["samples"], x["lo_runs"], x["models"], x["degen"], x["I"], x["best_sample"]) for x in st]
+        ok = np.array_equal(np.asarray(F0), np.asarray(F1)) and all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(m0, m1)) and key(s0) == key(s1)
+        if not ok:
+            bad += 1; print("MISMATCH set-aside case", case, "P", P, "tuning", hex(tn))
+    print(f"set-aside: {N - bad}/{N} batches identical, {aside} pairs were set aside")
+    return bad
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "set-aside":
+        sys.exit(1 if run_set_aside(int(sys.argv[2]) if len(sys.argv) > 2 else 40, int(sys.argv[3]) if len(sys.argv) > 3 else 0) else 0)
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     t0 = time.time()
     br, bt = run(N, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
