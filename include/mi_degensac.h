@@ -52,6 +52,13 @@ extern "C" {
 #define MI_DEGENSAC_FLAG_FINAL_LAF_FILTER 1u  /* apply the F driver's final LAF filter, which the reference
                                                  guards with an uninitialised variable (exp_ranF.c:1254,1725) */
 
+#define MI_DEGENSAC_FLAG_LEGACY_F 2u          /* fundamental matrix: behave like the reference's older drivers exp_ransacF (exp_ranF.c:242)
+                                                 and exp_ransacFcustom (:811) instead of exp_ransacFcustomLAF: the sample budget
+                                                 follows EVERY new best model, also one found by the main loop or the DEGENSAC
+                                                 branch between two local optimisations (:1085-1090 sits outside the LO block
+                                                 there).  Needs symmetric_error_check = 0 and no LAF check (their symmetric
+                                                 check is a different one and is not built); error_type 0 = exp_ransacF */
+
 /* tuning word (0 = let the library decide; results never depend on it, only speed does):
  *   bits 0-1  kernel variant    1 = latency (512-thread workgroups)   2 = throughput (256-thread, 2 pairs per CU)
  *                               3 = high throughput (128-thread, up to 4 pairs per CU)

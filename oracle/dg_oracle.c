@@ -733,8 +733,9 @@ static int f_checks(const double *u, const double *u_1, const double *u_2, int l
 static int exp_ransacFcustomLAF(dg_ctx *c, const double *u, const double *u_1, const double *u_2, int len, double th,
                                 double laf_coef, double conf, int max_sam, double *F, unsigned char *inl,
                                 int do_lo, unsigned inlLimit, exfds_fn EXFDS1, fds_fn FDS1, fdsidx_fn FDS1idx,
-                                double SymCheck_th, int enable_degen_check, unsigned seed0, int final_laf_filter, int *stats)
+                                double SymCheck_th, int enable_degen_check, unsigned seed0, int final_flags, int *stats)
 {
+    const int final_laf_filter = final_flags & 1, legacy = (final_flags >> 1) & 1;   /* bit 1: legacy sample-budget rule (no LAF, no symmetric check) */
     unsigned seed; int *pool, no_sam, new_sam; double u7[42], H[9], FBest[9];
     double *f1, *f2, poly[4], roots[3], f[9], *err, *d, *d_check, *errs[5];
     int nsol, i = 0, j, *inliers, new_max = 0, do_iterate; unsigned I;
@@ -861,10 +862,16 @@ static int exp_ransacFcustomLAF(dg_ctx *c, const double *u, const double *u_1, c
                     new_max = 1; best_sample = no_sam;
                 }
             }
-            if (new_max) {
+            if (new_max && !legacy) {
                 new_sam = dg_nsamples(maxS.I + 1, len, 7, conf);
                 if (new_sam < max_sam) max_sam = new_sam;
             }
+        }
+        /* the legacy drivers exp_ransacF / exp_ransacFcustom (exp_ranF.c:242, :811) update the sample budget after EVERY
+         * sample that produced a new best model, whoever found it (:1085-1090 sits outside the do_iterate block there) */
+        if (new_max && legacy) {
+            new_sam = dg_nsamples(maxS.I + 1, len, 7, conf);
+            if (new_sam < max_sam) max_sam = new_sam;
         }
     }
 

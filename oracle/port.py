@@ -48,13 +48,14 @@ def ip(a):
 
 
 def find_fundamental(pts1, pts2, px_th=0.5, conf=0.9999, max_iters=100000, error_type=0, sym_check=True,
-                     laf_coef=0.0, degen=True, seed=1, final_laf_filter=False):
+                     laf_coef=0.0, degen=True, seed=1, final_laf_filter=False, legacy=False):
+    """legacy=True: the sample-budget rule of exp_ransacF / exp_ransacFcustom (exp_ranF.c:242, :811; needs sym_check=False, laf_coef=0)"""
     l = lib()
     a = np.ascontiguousarray(pts1, dtype=np.float64); b = np.ascontiguousarray(pts2, dtype=np.float64)
     n, dim = a.shape
     F = np.zeros(9); mask = np.zeros(n, np.uint8); st = np.zeros(ST_COUNT, np.int32)
     l.dg_oracle_find_fundamental(dp(a), dp(b), n, dim, px_th, conf, max_iters, error_type, int(sym_check),
-                                 max(0.0, laf_coef), int(degen), seed, int(final_laf_filter), dp(F),
+                                 max(0.0, laf_coef), int(degen), seed, int(final_laf_filter) | (2 if legacy else 0), dp(F),
                                  mask.ctypes.data_as(C.POINTER(C.c_ubyte)), ip(st))
     stats = dict(samples=int(st[0]), lo_runs=int(st[1]), rejected=int(st[2]), I=int(st[3]), models=int(st[4]),
                  degen=int(st[5]), Ih=int(st[6]), best_sample=int(st[7]), full_passes=int(st[8]),

@@ -10,6 +10,7 @@ STATS_LEN = 16
 STAT_NAMES = ["samples", "lo_runs", "rejected", "I", "models", "degen", "Ih", "best_sample",
               "full_passes", "ex_passes", "h_passes", "aux_passes", "ticks_best", "ticks_total", "threads", "placement"]
 FLAG_FINAL_LAF_FILTER = 1
+FLAG_LEGACY_F = 2            # exp_ransacF / exp_ransacFcustom sample-budget rule (include/mi_degensac.h)
 # params.tuning (include/mi_degensac.h MI_DEGENSAC_TUNE_*): speed knobs only, results never depend on them
 TUNE_LATENCY, TUNE_THROUGHPUT, TUNE_THROUGHPUT4 = 1, 2, 3   # kernel variant: 512- / 256- / 128-thread workgroups
 TUNE_PLACE_HBM, TUNE_PLACE_LDS, TUNE_PLACE_POOL_LDS = 1 << 2, 2 << 2, 3 << 2

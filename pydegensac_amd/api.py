@@ -189,7 +189,7 @@ def _error_type(table, error_type):
         raise ValueError("Error type should be on of {}. Got {} instead".format(list(table.keys()), error_type))
 
 
-def _batch(which, pts1_list, pts2_list, px_th, conf, max_iters, error_type_int, sym, laf, degen, seeds, device, tuning=0):
+def _batch(which, pts1_list, pts2_list, px_th, conf, max_iters, error_type_int, sym, laf, degen, seeds, device, tuning=0, flags=0):
     n_pairs = len(pts1_list)
     if n_pairs == 0 or len(pts2_list) != n_pairs:
         raise ValueError("pts1_list and pts2_list must hold the same, non-zero number of pairs")
@@ -209,7 +209,7 @@ def _batch(which, pts1_list, pts2_list, px_th, conf, max_iters, error_type_int, 
     offs = np.zeros(n_pairs + 1, np.int64)
     offs[1:] = np.cumsum([x.shape[0] for x in a])
     A = np.ascontiguousarray(np.concatenate(a, 0)); B = np.ascontiguousarray(np.concatenate(b, 0))
-    prm = _lib.make_params(px_th, conf, max_iters, error_type_int, sym, laf, degen, 0, tuning)
+    prm = _lib.make_params(px_th, conf, max_iters, error_type_int, sym, laf, degen, flags, tuning)
     model = np.zeros((n_pairs, 9)); mask = np.zeros(int(offs[-1]), np.uint8); st = np.zeros((n_pairs, 16), np.int32)
     sd = np.ascontiguousarray(seeds, dtype=np.uint32)
     fn = _lib.lib().mi_degensac_find_fundamental_batch if which == "F" else _lib.lib().mi_degensac_find_homography_batch
@@ -232,6 +232,25 @@ def findFundamentalMatrixBatch(pts1_list, pts2_list, px_th=0.5, conf=0.9999, max
         seeds = (_time_seed() + np.arange(len(pts1_list))) & 0xFFFFFFFF
     return _batch("F", pts1_list, pts2_list, px_th, conf, max_iters, et, symmetric_error_check,
                   max(0, laf_consistensy_coef), enable_degeneracy_check, seeds, device, tuning)
+
+
+def ransacF_legacy(pts1, pts2, px_th=0.5, conf=0.9999, max_iters=100000, error_type="sampson", seed=None, device=0, tuning=0):
+    """The reference's older fundamental-matrix drivers, which its Python module no longer reaches: `exp_ransacF`
+    (exp_ranF.c:242; error_type "sampson") and `exp_ransacFcustom` without its symmetric check (exp_ranF.c:811; either
+    metric).  They differ from findFundamentalMatrix in one rule: the sample budget follows every new best model, also one
+    found between two local optimisations (MI_DEGENSAC_FLAG_LEGACY_F).  Returns (F [3,3], mask [n] bool)."""
+    et = _error_type(error_type_dict_fundamental, error_type)
+    return _call_single("F", convert_and_check(pts1), convert_and_check(pts2), px_th, conf, max_iters, et, False, 0.0, True,
+                        _time_seed() if seed is None else seed, device, _lib.FLAG_LEGACY_F, tuning)
+
+
+def ransacF_legacy_batch(pts1_list, pts2_list, px_th=0.5, conf=0.9999, max_iters=100000, error_type="sampson", seeds=None,
+                         device=0, tuning=0):
+    """ransacF_legacy for independent pairs in one launch.  Returns (F [P,3,3], [mask_p])."""
+    et = _error_type(error_type_dict_fundamental, error_type)
+    if seeds is None:
+        seeds = (_time_seed() + np.arange(len(pts1_list))) & 0xFFFFFFFF
+    return _batch("F", pts1_list, pts2_list, px_th, conf, max_iters, et, False, 0.0, True, seeds, device, tuning, _lib.FLAG_LEGACY_F)
 
 
 def findHomographyBatch(pts1_list, pts2_list, px_th=1.0, conf=0.999, max_iters=50000, laf_consistensy_coef=-1.0,

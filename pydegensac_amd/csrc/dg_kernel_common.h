@@ -38,6 +38,7 @@ struct dg_params {
     int    error_type;
     int    degen;
     int    final_laf_filter;
+    int    legacy;        /* F: the sample-budget rule of exp_ransacF / exp_ransacFcustom (MI_DEGENSAC_FLAG_LEGACY_F) */
 };
 
 /* per-pair global scratch (L2-resident), sized for the pair's n */

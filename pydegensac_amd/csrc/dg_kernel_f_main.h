@@ -1104,11 +1104,15 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                         new_max = 1; accepted = 1; finKind = kb; best_sample = no_sam; t_best = wall_clock64();
                     }
                 }
-                if (new_max) {
+                if (new_max && !pr.legacy) {
                     int new_sam = dg_nsamples((int)maxS.I + 1, n, 7, pr.conf);
                     if (new_sam < max_sam) max_sam = new_sam;
                 }
                 DG_PH(4);
+            }
+            if (new_max && pr.legacy) {                 /* exp_ransacF / exp_ransacFcustom: after every sample with a new best model (exp_ranF.c:1085-1090) */
+                int new_sam = dg_nsamples((int)maxS.I + 1, n, 7, pr.conf);
+                if (new_sam < max_sam) max_sam = new_sam;
             }
         }
         /* models of samples that were never committed do not count as scored */

@@ -50,6 +50,16 @@ H_CASES = [
     ("H_c3_full_laf_sampson", dict(n=5000, inlier_ratio=0.4, sigma=0.5, seed=0, laf=True), dict(px_th=2.0, error_type=0, laf_coef=3.0)),
     ("H_c3_full_laf_symm_max", dict(n=5000, inlier_ratio=0.4, sigma=0.5, seed=0, laf=True), dict(px_th=2.0, error_type=2, laf_coef=3.0)),
 ]
+# the reference's older F drivers: variant 1 = exp_ransacF (exp_ranF.c:242), 0 = exp_ransacFcustom (:811) without
+# its symmetric check; fixtures L_*.npz, kind "L"
+LEGACY_CASES = [
+    ("L_ransacF_c2", 1, dict(n=2000, inlier_ratio=0.4, sigma=0.1, seed=0), dict()),
+    ("L_ransacF_c2b_plane", 1, dict(n=2000, inlier_ratio=0.4, sigma=0.1, seed=1, plane_fraction=0.7), dict()),
+    ("L_ransacF_plane9", 1, dict(n=1500, inlier_ratio=0.5, sigma=0.1, seed=3, plane_fraction=0.9), dict(max_iters=50000)),
+    ("L_ransacF_n100", 1, dict(n=100, inlier_ratio=0.3, sigma=0.3, seed=4), dict(max_iters=5000)),
+    ("L_custom_sampson_plane", 0, dict(n=2000, inlier_ratio=0.4, sigma=0.1, seed=2, plane_fraction=0.6), dict()),
+    ("L_custom_symm_epipolar", 0, dict(n=1000, inlier_ratio=0.4, sigma=0.1, seed=2, plane_fraction=0.6), dict(error_type=1)),
+]
 SEEDS = [1, 7]
 
 
@@ -76,6 +86,16 @@ def main():
             np.savez_compressed(os.path.join(HERE, f"{name}_s{s}.npz"), kind="H", gen=repr(g), call=repr(kw), seed=s,
                                 model=H, mask=np.packbits(m), n=len(m), samples=st["samples"], lo_runs=st["lo_runs"],
                                 full_passes=st["full_passes"], rejected=st["rejected"], I=st["I"])
+            n_written += 1
+    for name, variant, g, kw in LEGACY_CASES:
+        if not sel(name):
+            continue
+        p1, p2, _, _ = syn.two_view_fundamental(**g)
+        for s in SEEDS:
+            F, m, st = ref.find_fundamental_legacy(variant, p1, p2, seed=s, **kw)
+            np.savez_compressed(os.path.join(HERE, f"{name}_s{s}.npz"), kind="L", variant=variant, gen=repr(g), call=repr(kw), seed=s,
+                                model=F, mask=np.packbits(m), n=len(m), samples=st["samples"], lo_runs=st["lo_runs"],
+                                full_passes=0, I=st["I"])
             n_written += 1
     print("wrote", n_written, "fixtures")
 

@@ -17,13 +17,13 @@ def load(path):
     z = np.load(path, allow_pickle=False)
     g = ast.literal_eval(str(z["gen"])); call = ast.literal_eval(str(z["call"]))
     kind = str(z["kind"])
-    if kind == "F":
+    if kind in ("F", "L"):
         p1, p2, _, _ = syn.two_view_fundamental(**g)
     else:
         p1, p2, _, _ = syn.homography_pairs(**g)
     n = int(z["n"])
     mask = np.unpackbits(z["mask"])[:n].astype(bool)
-    return dict(kind=kind, n=n, p1=p1, p2=p2, call=call, seed=int(z["seed"]), model=z["model"], mask=mask,
+    return dict(kind=kind, variant=int(z["variant"]) if "variant" in z else None, n=n, p1=p1, p2=p2, call=call, seed=int(z["seed"]), model=z["model"], mask=mask,
                 samples=int(z["samples"]), lo_runs=int(z["lo_runs"]), full_passes=int(z["full_passes"]),
                 ex_passes=int(z["ex_passes"]) if "ex_passes" in z else None,
                 rejected=int(z["rejected"]) if "rejected" in z else None, I=int(z["I"]))
