@@ -337,7 +337,8 @@ def main():
                                  "LDS/L2-resident, so `traffic` (HBM bytes per launch from the committed PMC passes, profiles/) is far "
                                  "below it: inputs once, then model tables, lists and scratch"},
             "parity_checked": n_checked,
-            "kernel_variant": {"threads": int(local_st[0, 14]), "placement": int(local_st[0, 15])},
+            "kernel_variant": {"threads": int(local_st[0, 14]), "placement": int(local_st[0, 15]) & 255},
+            "pairs_set_aside": int((local_st[:, 15] >> 8).sum()),        # long pairs written back and resumed after the last start
         }
         if world == 1:
             out["single_call_ms"] = single_call_ms()

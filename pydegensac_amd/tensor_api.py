@@ -64,7 +64,8 @@ def find_fundamental_batch_tensors(pts1, pts2, counts, px_th=0.5, conf=0.9999, m
                                    laf_consistensy_coef=-1.0, error_type="sampson", symmetric_error_check=True,
                                    enable_degeneracy_check=True, seeds=None):
     """P independent pairs, rows of pair p = pts[offs[p]:offs[p+1]] with offs = cumsum(counts).
-    Returns (F [P,3,3] float64, mask [total] bool, stats [P,16] int32, offsets) — all but offsets on the device."""
+    Returns (F [P,3,3] float64, mask [total] bool, stats [P,16] int32, offsets) — all but offsets on the device.
+    stats columns = include/mi_degensac.h MI_ST_* (column 15: placement in bits 0-7, bit 8 = the pair was set aside once)."""
     et = error_type_dict_fundamental[error_type.lower()]
     prm = _lib.make_params(px_th, conf, max_iters, et, symmetric_error_check, max(0.0, laf_consistensy_coef), enable_degeneracy_check)
     return _run("F", pts1, pts2, counts, prm, seeds, 8)
