@@ -34,6 +34,9 @@ struct dg_f_drv {
 #define DG_LO_AHEAD (DG_NW - 1 < 5 ? DG_NW - 1 : 5)
 struct dg_lo_ahead { dg_rng before, after; int pos[32], val[32]; double F[9]; };
 
+/* LDS scratch of the long-list least squares (640 doubles): the per-wave solver scratch, idle while a workgroup fit runs */
+#define DG_LSQ_LTAB(S) (sizeof((S)->ww) + sizeof((S)->wpad) >= 640 * sizeof(double) ? (double *)(S)->ww : (double *)0)
+
 struct dg_f_shared {
     dg_red red;
     dg_lsq_scratch lsq;
@@ -213,7 +216,8 @@ __device__ __forceinline__ void dg_u2f_list(CTX &c, const int *list, int len, co
         __syncthreads();
     } else {
         const dg_pt *P = c.P;
-        dg_u2f_big(&S->red, &S->lsq, [&](int i) { return dg_ldpt<LDSPTS>(P, i); }, list, len, c.tid, Fout, c.stage, c.n_max);
+        dg_u2f_big(&S->red, &S->lsq, [&](int i) { return dg_ldpt<LDSPTS>(P, i); }, list, len, c.tid, Fout, c.stage, c.n_max,
+                   DG_LSQ_LTAB(S));
     }
 }
 

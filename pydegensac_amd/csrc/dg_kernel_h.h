@@ -10,13 +10,17 @@
 #define DG_KERNEL_H_H
 #include "dg_kernel_f_main.h"
 #define DG_SW0 (DG_NW > 2 ? 2 : 0)          /* first scoring wave of the main loop */
+/* development build only: time since the previous mark goes to dbg[i] (0 passes, 1 least squares + eigen-solve over a long
+ * list, 2 inlier-set hash, 3 small fits, 4 consistency checks); dbg[7] holds the previous mark */
+#define DG_HT(i) DG_DEVT(do { __syncthreads(); if (c.tid == 0) { long long t_ = DG_CLK(); c.S->dbg[i] += t_ - c.S->dbg[7]; c.S->dbg[7] = t_; } } while (0))
 
 /* u2h (Htools.c:115-131) over a list of ids, reference summation order (see dg_lsq_seq) */
 template <class PtFn>
-__device__ __forceinline__ void dg_u2h_big(dg_red *r, dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, double *Hout /* LDS */, dg_pt *stage, int stage_cap)
+__device__ __forceinline__ void dg_u2h_big(dg_red *r, dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, double *Hout /* LDS */, dg_pt *stage, int stage_cap,
+                                           double *ltab)
 {
     (void)r;
-    dg_lsq_seq(s, pt, list, len, tid, 1, s->A1, s->A2, stage, stage_cap);
+    dg_lsq_seq(s, pt, list, len, tid, 1, s->A1, s->A2, stage, stage_cap, ltab);
     if (tid < 64) dg_eig_sym_wave(s->V, s->D, tid, &s->ews);
     if (tid == 0) {
         for (int i = 0; i < 9; i++) Hout[i] = s->V[i];
@@ -36,7 +40,8 @@ __device__ __forceinline__ void dg_u2h_list(CTX &c, const int *list, int len, do
         __syncthreads();
     } else {
         const dg_pt *P = c.P;
-        dg_u2h_big(&S->red, &S->lsq, [&](int i) { return dg_ldpt<LDSPTS>(P, i); }, list, len, c.tid, Hout, c.stage, c.n_max);
+        dg_u2h_big(&S->red, &S->lsq, [&](int i) { return dg_ldpt<LDSPTS>(P, i); }, list, len, c.tid, Hout, c.stage, c.n_max,
+                   DG_LSQ_LTAB(S));
     }
 }
 
@@ -115,6 +120,7 @@ __device__ __forceinline__ dg_score dg_iterHc(CTX &c, int kind, int *inliers, do
     /* errs[4] = errs[0] holds HDS1(h): inlidxs(th) and the list at th*MWM in one pass */
     dg_pass_cfg c0 = dg_cfg0(n); c0.wantJ = 1; c0.thJ = th; c0.list = inliers; c0.thL = th * DG_MWM;
     dg_pass_res r0 = dg_hm_pass(c, kind, h, c0); c.n_hds++;
+    DG_HT(0);
     maxS.I = r0.I; maxS.J = r0.J;
     DG_TRACE(c, 20, maxS.I, maxS.J);
     if (maxS.I < 4) {
@@ -129,10 +135,12 @@ __device__ __forceinline__ dg_score dg_iterHc(CTX &c, int kind, int *inliers, do
         if (dc < (unsigned)cnt) { if (tid == 0) dg_randsubset(&S->rng, inliers, cnt, (int)dc); use = (int)dc; o = cnt - (int)dc; }
         __syncthreads();
         dg_u2h_list(c, inliers + o, use, hl);
+        DG_HT(1);
     }
     for (int it = 0; it < DG_ILSQ_ITERS; it++) {
         dg_pass_cfg c1 = dg_cfg0(n); c1.wantJ = 1; c1.thJ = th; c1.list = inliers; c1.thL = th;
         dg_pass_res r1 = dg_hm_pass(c, kind, hl, c1); c.n_hds++;
+        DG_HT(0);
         dg_dump_resid(c, rrow + it, hl, 10 + kind);                       /* exp_ranH.c:344 */
         DG_BUFSET(S, pd, hl);
         dg_score Ss = zero; Ss.I = r1.I; Ss.J = r1.J;
@@ -147,9 +155,11 @@ __device__ __forceinline__ dg_score dg_iterHc(CTX &c, int kind, int *inliers, do
             }
         }
         __syncthreads();
+        DG_HT(2);
         if (S->itmp[0]) { DG_TRACE(c, 23, 0, 0); return zero; }
         dg_pass_cfg c2 = dg_cfg0(n); c2.list = inliers; c2.thL = ths * DG_MWM;
         dg_pass_res r2 = dg_hm_pass(c, kind, hl, c2);
+        DG_HT(0);
         DG_TRACE(c, 24, r2.nL, 0);
         if (maxS.J < Ss.J) {
             maxS = Ss;
@@ -166,11 +176,13 @@ __device__ __forceinline__ dg_score dg_iterHc(CTX &c, int kind, int *inliers, do
             if (dc < (unsigned)cnt) { if (tid == 0) dg_randsubset(&S->rng, inliers, cnt, (int)dc); use = (int)dc; o = cnt - (int)dc; }
             __syncthreads();
             dg_u2h_list(c, inliers + o, use, hl);
+            DG_HT(1);
         }
         ths -= dth;
     }
     dg_pass_cfg c3 = dg_cfg0(n); c3.wantJ = 1; c3.thJ = th; c3.list = inliers; c3.thL = th;
     dg_pass_res r3 = dg_hm_pass(c, kind, hl, c3); c.n_hds++;
+    DG_HT(0);
     dg_dump_resid(c, rrow + 4, hl, 10 + kind);                            /* exp_ranH.c:400 */
     DG_BUFSET(S, pd, hl);
     DG_TRACE(c, 22, r3.I, r3.J);
@@ -209,6 +221,7 @@ __device__ __forceinline__ dg_score dg_inHranic(CTX &c, int kind, int ninl, doub
             dg_u2h_small_w(&S->lsq, S->lsq.px, ssiz, S->f, tid);
         }
         __syncthreads();
+        DG_HT(3);
         DG_BUFSET(S, B.pe[0], S->f);                          /* HDS1(h) -> errs[0] (scored inside dg_iterHc) */
         dg_dump_resid(c, 2 + 6 * i, S->f, 10 + kind);         /* exp_ranH.c:445-446 */
         ++*iterID;
@@ -233,14 +246,18 @@ __device__ __noinline__ int dg_h_lo(CTX &c, int kind, const double *e4, double t
     dg_hbufs B; B.pe[0] = 0; B.pe[1] = 1; B.pe[2] = 2;
     const int B0 = B.pe[0];                                   /* d = errs[0] */
     dg_resid_begin(c, lo_run); __syncthreads();
+    DG_DEVT(if (tid == 0) S->dbg[7] = DG_CLK());
     dg_dump_resid(c, 0, e4, 10 + kind);                                   /* errs[4], exp_ranH.c:679 / :794 */
     dg_pass_cfg ca = dg_cfg0(n); ca.list = c.L[0]; ca.thL = DG_TC * th * DG_MWM;
     dg_pass_res ra = dg_hm_pass(c, kind, e4, ca);
+    DG_HT(0);
     DG_TRACE(c, 1, ra.nL, no_sam);
     dg_u2h_list(c, c.L[0], (int)ra.nL, S->f);
+    DG_HT(1);
     DG_BUFSET(S, B0, S->f);
     dg_pass_cfg cb = dg_cfg0(n); cb.wantJ = 1; cb.thJ = th; cb.list = c.L[0]; cb.thL = th;
     dg_pass_res rb = dg_hm_pass(c, kind, S->f, cb); c.n_hds++;
+    DG_HT(0);
     dg_dump_resid(c, 1, S->f, 10 + kind);                                 /* d after the LSQ, exp_ranH.c:694 / :810 */
     DG_TRACE(c, 2, rb.nL, rb.J);
     /* h (the driver's `sol`) = S->Hx: u2h wrote the LSQ model there; inHrani overwrites it on improvement */
@@ -257,7 +274,9 @@ __device__ __noinline__ int dg_h_lo(CTX &c, int kind, const double *e4, double t
         dg_pass_cfg cl = dg_cfg0(n); cl.wantJ = 1; cl.thJ = th; cl.list = c.L[2]; cl.thL = th;
         dg_pass_res rl = dg_hm_pass(c, kind, S->bufF[B0], cl);
         DG_TRACE(c, 4, rl.nL, rl.J);
-        if (!dg_h_checks(c, kind, S->Hx, c.L[2], (int)rl.nL, Sl, maxS, p1_inliers, 0)) return 0;
+        const int ok_ = dg_h_checks(c, kind, S->Hx, c.L[2], (int)rl.nL, Sl, maxS, p1_inliers, 0);
+        DG_HT(4);
+        if (!ok_) return 0;
     }
     maxS = Sl;
     __syncthreads();
@@ -365,9 +384,12 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
         __syncthreads();
         seed = (unsigned)S->itmp[31];
     }
+    DG_DEVT(if (tid == 0) { for (int i = 0; i < 8; i++) { S->ph[i] = 0; S->dbg[i] = 0; } S->tq = DG_CLK(); });
+#define DG_PHH(i) DG_DEVT(if (tid == 0) { long long tq2_ = DG_CLK(); S->ph[i] += tq2_ - S->tq; S->tq = tq2_; })
     while (!done && no_sam < max_sam) {
         int chunk = chunk_s[cur]; if (chunk > max_sam - no_sam) chunk = max_sam - no_sam;
         c.seeds = S->seeds3[cur]; c.draws = S->draws3[cur]; chunk_base = no_sam;
+        DG_PHH(2);
         /* ---- solve: orientation test, 8x9 null vector, near-singularity test; <= 1 model per lane ---- */
         double hm[9], H1m[9]; int valid = 0;
         if (tid < chunk) valid = dg_solve4_lane(P, c.draws[tid], kind, hm, H1m, (double *)&S->ww[wave]);
@@ -393,6 +415,7 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
             __syncthreads();
         }
         const int Mtot = __builtin_amdgcn_readfirstlane((int)S->moff[DG_CHUNK]);
+        DG_PHH(0);
 
         /* ---- score chunk c (waves 2.., one wave per model)  ||  pool swaps of chunk c+1 (wave 0)  ||  seeds + draws of chunk c+2 (wave 1) ---- */
         const int nxt = cur == 2 ? 0 : cur + 1, nx2 = nxt == 2 ? 0 : nxt + 1;
@@ -446,6 +469,7 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
         c.n_hds += Mtot;
         __syncthreads();
         if (cn2 > 0) seed = (unsigned)S->itmp[31];
+        DG_PHH(1);
 
         /* ---- commit: replay exp_ranH.c:547-757 in order ---- */
         int k;
@@ -506,7 +530,9 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
                 if (tid == 0) { dg_srand(&S->rng, c.seeds[k]); for (int i = 0; i < 5; i++) dg_rand(&S->rng); }
                 __syncthreads();
                 iter_cnt++;
+                DG_PHH(2);
                 if (dg_h_lo(c, kind, e4, th, maxS, &iterID, &p1_inliers, no_sam, iter_cnt - 1)) { new_max = 1; accepted = 1; best_sample = no_sam; t_best = wall_clock64(); }
+                DG_PHH(3);
             }
             if (new_max) {
                 int new_sam = dg_nsamples((int)maxS.I + 1, n, 4, pr.conf);
@@ -525,7 +551,9 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
         if (tid == 0 && no_sam > 0) { int li = no_sam - 1 - chunk_base; if (li < 0) li = 0; dg_srand(&S->rng, c.seeds[li]); for (int i = 0; i < 5; i++) dg_rand(&S->rng); }
         __syncthreads();
         iter_cnt++;
+        DG_PHH(2);
         if (dg_h_lo(c, kind, e4, th, maxS, &iterID, &p1_inliers, no_sam, iter_cnt - 1)) { accepted = 1; best_sample = no_sam; t_best = wall_clock64(); }
+        DG_PHH(3);
     }
 
     /* ---- final mask: exp_ranH.c:864-907 (this driver indexes the filters correctly) ---- */
@@ -561,6 +589,9 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
         st[5] = 0; st[6] = 0; st[7] = best_sample; st[8] = c.n_hds; st[9] = 0; st[10] = 0; st[11] = 0;
         st[12] = (int)(t_best - t_start); st[13] = (int)(t_end - t_start); st[14] = A.variant_threads; st[15] = A.mode;
     }
+    DG_PHH(6);
+    DG_DEVT(if (A.phase_out && tid == 0) { S->ph[7] = DG_CLK() - t_start; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + i] = S->ph[i]; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + 8 + i] = S->dbg[i]; });
+#undef DG_PHH
 }
 
 template <int T, int LDSPTS>

@@ -255,7 +255,8 @@ __device__ __forceinline__ void dg_lsq_seq_core(SC *s, const dg_pt *stage, int l
  * `sync` separates the phases (__syncthreads for a workgroup, a wave barrier for one wave); tid < 64 is the wave that
  * runs the serial parts. */
 template <class SC, class Sync>
-__device__ __forceinline__ void dg_lsq_seq_par(SC *s, dg_pt *stage, int len, int tid, int nthr, int rows2, double *A1o, double *A2o, Sync sync)
+__device__ __forceinline__ void dg_lsq_seq_par(SC *s, dg_pt *stage, int len, int tid, int nthr, int rows2, double *A1o, double *A2o, Sync sync,
+                                               double *ltab = (double *)0 /* optional LDS scratch, 640 doubles, used by wave 0 only */)
 {
     double *aux = (double *)(stage + len);
     const int lane = tid & 63; const bool w0 = tid < 64;
@@ -303,6 +304,61 @@ __device__ __forceinline__ void dg_lsq_seq_par(SC *s, dg_pt *stage, int len, int
         }
     }
     sync();
+    if (w0 && ltab) {
+        /* Normal matrix with the per-point work shared: the wave first forms, 64 points at a time and one point per lane,
+         * the nine (F: z[3k+l] = a_l b_k, lin_fmN) or ten (H: b_q, -a0 b_q, -a1 b_q and a structural zero, lin_hgN)
+         * design-matrix entries of each point in LDS — the same products the lanes used to form for themselves behind
+         * run-time selects — and then every accumulating lane reads its two (F) or four (H) factors per point from there:
+         * same factors, same multiplies, same adds in list order. */
+        int ie = 0, je = 0;
+        { int e = 0; for (int i = 0; i < 9; i++) for (int q = 0; q <= i; q++) { if (e == lane) { ie = i; je = q; } e++; } }
+        const int ki = ie / 3, li = ie % 3, kj = je / 3, lj = je % 3;
+        const int x0 = !rows2 ? ie : (li == 0 ? ki : li == 1 ? 9 : 3 + ki), y0 = !rows2 ? je : (lj == 0 ? kj : lj == 1 ? 9 : 3 + kj);
+        const int x1 = li == 0 ? 9 : li == 1 ? ki : 6 + ki, y1 = lj == 0 ? 9 : lj == 1 ? kj : 6 + kj;
+        double val = 0;
+        for (int base = 0; base < len; base += 64) {
+            const int cnt = len - base < 64 ? len - base : 64;
+            if (lane < cnt) {
+                const dg_pt q = stage[base + lane]; double *t = ltab + 10 * lane;
+                if (!rows2) {
+                    const double a[3] = {q.x1, q.y1, 1.0}, b[3] = {q.x2, q.y2, 1.0};
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+#pragma unroll
+                        for (int l = 0; l < 3; l++) t[3*k + l] = a[l] * b[k];
+                } else {
+                    const double b[3] = {q.x2, q.y2, 1.0};
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { t[k] = b[k]; t[3 + k] = -q.x1 * b[k]; t[6 + k] = -q.y1 * b[k]; }
+                }
+                t[9] = 0.0;
+            }
+            DG_WSYNC();
+            if (lane < 45) {
+                int p = 0;
+                if (!rows2) {
+                    for (; p + 8 <= cnt; p += 8) {
+                        const double *t = ltab + 10 * p;
+                        const double u0 = t[x0], v0 = t[y0], u1 = t[10 + x0], v1 = t[10 + y0], u2 = t[20 + x0], v2 = t[20 + y0], u3 = t[30 + x0], v3 = t[30 + y0];
+                        const double u4 = t[40 + x0], v4 = t[40 + y0], u5 = t[50 + x0], v5 = t[50 + y0], u6 = t[60 + x0], v6 = t[60 + y0], u7 = t[70 + x0], v7 = t[70 + y0];
+                        val += u0 * v0; val += u1 * v1; val += u2 * v2; val += u3 * v3; val += u4 * v4; val += u5 * v5; val += u6 * v6; val += u7 * v7;
+                    }
+                    for (; p < cnt; p++) { const double *t = ltab + 10 * p; val += t[x0] * t[y0]; }
+                } else {
+                    for (; p + 4 <= cnt; p += 4) {
+                        const double *t = ltab + 10 * p;
+                        const double u0 = t[x0], v0 = t[y0], p0 = t[x1], q0 = t[y1], u1 = t[10 + x0], v1 = t[10 + y0], p1 = t[10 + x1], q1 = t[10 + y1];
+                        const double u2 = t[20 + x0], v2 = t[20 + y0], p2 = t[20 + x1], q2 = t[20 + y1], u3 = t[30 + x0], v3 = t[30 + y0], p3 = t[30 + x1], q3 = t[30 + y1];
+                        val += u0 * v0; val += p0 * q0; val += u1 * v1; val += p1 * q1; val += u2 * v2; val += p2 * q2; val += u3 * v3; val += p3 * q3;
+                    }
+                    for (; p < cnt; p++) { const double *t = ltab + 10 * p; val += t[x0] * t[y0]; val += t[x1] * t[y1]; }
+                }
+            }
+            DG_WSYNC();
+        }
+        if (lane < 45) { s->V[9*ie + je] = val; s->V[ie + 9*je] = val; }
+        return;
+    }
     if (w0 && lane < 45) {                                        /* normal matrix: lane e owns entry (ie, je), je <= ie */
         int ie = 0, je = 0;
         { int e = 0; for (int i = 0; i < 9; i++) for (int q = 0; q <= i; q++) { if (e == lane) { ie = i; je = q; } e++; } }
@@ -335,23 +391,25 @@ __device__ __forceinline__ void dg_lsq_seq_par(SC *s, dg_pt *stage, int len, int
 }
 
 template <class PtFn>
-__device__ __forceinline__ void dg_lsq_seq(dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, int rows2, double *A1o, double *A2o, dg_pt *stage, int stage_cap)
+__device__ __forceinline__ void dg_lsq_seq(dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, int rows2, double *A1o, double *A2o, dg_pt *stage, int stage_cap,
+                                           double *ltab = (double *)0)
 {
     /* gather the listed correspondences into a contiguous staging array (all lanes), so that the sequential
      * sums stream uniform addresses */
     __syncthreads();
     for (int j = tid; j < len; j += DG_T) stage[j] = pt(list[j]);
     __syncthreads();
-    if (2 * stage_cap >= 3 * len) dg_lsq_seq_par(s, stage, len, tid, DG_T, rows2, A1o, A2o, [] { __syncthreads(); });
+    if (2 * stage_cap >= 3 * len) dg_lsq_seq_par(s, stage, len, tid, DG_T, rows2, A1o, A2o, [] { __syncthreads(); }, ltab);
     else if (tid < 64) dg_lsq_seq_core(s, stage, len, tid, rows2, A1o, A2o);
     __syncthreads();
 }
 
 template <class PtFn>
-__device__ __forceinline__ void dg_u2f_big(dg_red *r, dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, double *Fout /* LDS */, dg_pt *stage, int stage_cap)
+__device__ __forceinline__ void dg_u2f_big(dg_red *r, dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, double *Fout /* LDS */, dg_pt *stage, int stage_cap,
+                                           double *ltab = (double *)0)
 {
     (void)r;
-    dg_lsq_seq(s, pt, list, len, tid, 0, s->A1, s->A2, stage, stage_cap);
+    dg_lsq_seq(s, pt, list, len, tid, 0, s->A1, s->A2, stage, stage_cap, ltab);
     if (tid < 64) dg_eig_sym_wave(s->V, s->D, tid, &s->ews);
     if (tid == 0) {
         int jm = 0; for (int i = 1; i < 9; i++) if (s->D[i] < s->D[jm]) jm = i;
