@@ -92,6 +92,26 @@ def test_throughput_variant_batch_of_1100_against_oracle(oracle_port):
         assert gu.rel(F[p], Fo) < 1e-6, p
 
 
+def test_c3_batch_of_1024_takes_the_small_workgroups_and_matches_the_oracle(oracle_port):
+    """The bench's C3 batch (1024 homography pairs, 5000 correspondences with LAFs): the host picks 128-thread workgroups
+    with the sampler pool in the workspace (four resident pairs per CU); 24 randomly chosen pairs against the oracle, and
+    the set-aside machinery of the F driver stays off."""
+    P = 1024
+    A, B = [], []
+    for i in range(P):
+        p1, p2, _, _ = syn.homography_pairs(5000, 0.4, 0.5, seed=i, laf=True); A.append(p1); B.append(p2)
+    seeds = [int(x) for x in parallel.pair_seeds(0, P)]
+    H, m = pd.findHomographyBatch(A, B, 2.0, 0.999, 50000, 3.0, "sampson", True, seeds=seeds)
+    st = pd.last_stats()
+    assert all(s_["threads"] == 128 and s_["placement"] == 0 and s_["set_aside"] == 0 for s_ in st), st[0]
+    for p in np.random.default_rng(5).choice(P, 24, replace=False):
+        Ho, mo, so = oracle_port.find_homography(A[p], B[p], 2.0, 0.999, 50000, 0, True, 3.0, seed=seeds[p])
+        assert (st[p]["samples"], st[p]["lo_runs"], st[p]["rejected"]) == (so["samples"], so["lo_runs"], so["rejected"]), p
+        assert np.array_equal(np.asarray(m[p]), mo), p
+        Hu = np.linalg.inv(Ho.T)                                    # utils.py:108
+        assert np.linalg.norm(np.asarray(H[p]) - Hu) <= 1e-6 * np.linalg.norm(Hu), p
+
+
 def test_tensor_api_against_oracle(oracle_port):
     """device-resident API (SURVEY 8f #1): a ragged F batch and an H batch with LAFs, every pair against the oracle"""
     import torch
