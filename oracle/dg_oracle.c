@@ -706,12 +706,18 @@ static dg_score exp_inFranicustom(dg_ctx *c, const double *u, int len, int *inli
 
 /* sym + LAF consistency of a candidate, shared shape of exp_ranF.c:1383-1411 / :1526-1556 / :1654-1682.
  * Returns 0 if the candidate must be rejected. */
+static int g_legacy_sym = 0;      /* exp_ransacFcustom's symmetric check: all points instead of the inliers (exp_ranF.c:943-953) */
 static int f_checks(const double *u, const double *u_1, const double *u_2, int len, const double *f, const int *inliers,
                     dg_score *S, const dg_score *maxS, int doSymCheck, double SymCheck_th, int DO_LAF_CHECK,
                     double th_laf_check, fdsidx_fn FDS1idx, double *d_check, double *err_laf)
 {
     int j, p1_inliers;
-    if (doSymCheck) {
+    if (doSymCheck && g_legacy_sym) {
+        FDsSym(u, f, d_check, len);
+        S->Is = 0;
+        for (j = 0; j < len; j++) if (d_check[j] <= SymCheck_th) S->Is++;
+        if (S->Is < maxS->Is) return 0;
+    } else if (doSymCheck) {
         FDsSymidx(u, f, d_check, len, inliers, S->I);
         S->Is = 0;
         for (j = 0; j < (int)S->I; j++) if (d_check[inliers[j]] <= SymCheck_th) S->Is++;
@@ -733,9 +739,9 @@ static int f_checks(const double *u, const double *u_1, const double *u_2, int l
 static int exp_ransacFcustomLAF(dg_ctx *c, const double *u, const double *u_1, const double *u_2, int len, double th,
                                 double laf_coef, double conf, int max_sam, double *F, unsigned char *inl,
                                 int do_lo, unsigned inlLimit, exfds_fn EXFDS1, fds_fn FDS1, fdsidx_fn FDS1idx,
-                                double SymCheck_th, int enable_degen_check, unsigned seed0, int final_flags, int *stats)
+                                double SymCheck_th_in, int enable_degen_check, unsigned seed0, int final_flags, int *stats)
 {
-    const int final_laf_filter = final_flags & 1, legacy = (final_flags >> 1) & 1;   /* bit 1: legacy sample-budget rule (no LAF, no symmetric check) */
+    const int final_laf_filter = final_flags & 1, legacy = (final_flags >> 1) & 1;   /* bit 1: the legacy drivers exp_ransacF / exp_ransacFcustom */
     unsigned seed; int *pool, no_sam, new_sam; double u7[42], H[9], FBest[9];
     double *f1, *f2, poly[4], roots[3], f[9], *err, *d, *d_check, *errs[5];
     int nsol, i = 0, j, *inliers, new_max = 0, do_iterate; unsigned I;
@@ -743,10 +749,13 @@ static int exp_ransacFcustomLAF(dg_ctx *c, const double *u, const double *u_1, c
     int *samidx, samidxBest[7]; double *errorsBest;
     int degen_cnt = 0, iter_cnt = 0, iterID = 0; unsigned non_degen_samples_count = 0;
     double jj, *HDsv = (double *)malloc(len * sizeof(double));
+    /* the legacy drivers' symmetric check has its own constant, CHECK_COEF * th (exp_ranF.c:19, :837) */
+    const double SymCheck_th = (legacy && SymCheck_th_in > 0) ? 16.0 * th : SymCheck_th_in;
     int Ihmax = 0; const int doSymCheck = SymCheck_th > 0; const int DO_LAF_CHECK = laf_coef > 0;
     const double th_laf_check = laf_coef * th; double *err_laf;
     double A[81], sol[81]; int nullspace_buff[18], nullsize, best_sample = 0;
 
+    g_legacy_sym = legacy;
     dg_srand(&c->rng, seed0);                               /* srand(time(NULL)), :1277 */
     c->ht_n = 0;                                            /* htInit, :1290 */
     pool = (int *)malloc(len * sizeof(int));
@@ -925,7 +934,12 @@ static int exp_ransacFcustomLAF(dg_ctx *c, const double *u, const double *u_1, c
 
     d = errs[3];
     for (j = 0; j < len; j++) inl[j] = (d[j] <= th) ? 1 : 0;
-    if (doSymCheck) {
+    if (doSymCheck && legacy) {
+        /* exp_ranF.c:1196-1203: on all points, and on `f` — whatever model the driver computed last — not on F */
+        S = inlidxs(d, len, th, inliers);
+        FDsSym(u, f, d_check, len);
+        for (j = 0; j < len; j++) if (d_check[j] > SymCheck_th) inl[j] = 0;
+    } else if (doSymCheck) {
         S = inlidxs(d, len, th, inliers);
         FDsSymidx(u, F, d_check, len, inliers, S.I);
         for (j = 0; j < (int)S.I; j++)
@@ -940,6 +954,7 @@ static int exp_ransacFcustomLAF(dg_ctx *c, const double *u, const double *u_1, c
     }
 
     free(d_check); free(err_laf); free(pool); free(err); free(errorsBest); free(inliers); free(HDsv);
+    g_legacy_sym = 0;
     if (stats) {
         stats[DG_ST_SAMPLES] = no_sam; stats[DG_ST_LO_RUNS] = iter_cnt; stats[DG_ST_REJECTED] = 0;
         stats[DG_ST_I] = (int)maxS.I; stats[DG_ST_MODELS] = (int)(c->n_fds + c->n_exfds);

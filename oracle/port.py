@@ -49,7 +49,7 @@ def ip(a):
 
 def find_fundamental(pts1, pts2, px_th=0.5, conf=0.9999, max_iters=100000, error_type=0, sym_check=True,
                      laf_coef=0.0, degen=True, seed=1, final_laf_filter=False, legacy=False):
-    """legacy=True: the sample-budget rule of exp_ransacF / exp_ransacFcustom (exp_ranF.c:242, :811; needs sym_check=False, laf_coef=0)"""
+    """legacy=True: the sample-budget rule of exp_ransacF / exp_ransacFcustom (exp_ranF.c:242, :811; laf_coef=0), incl. exp_ransacFcustom's own symmetric check when sym_check is set"""
     l = lib()
     a = np.ascontiguousarray(pts1, dtype=np.float64); b = np.ascontiguousarray(pts2, dtype=np.float64)
     n, dim = a.shape

@@ -10,7 +10,7 @@ HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def fixtures(kind):
-    return sorted(f for f in glob.glob(os.path.join(HERE, f"{kind}_*.npz")))
+    return sorted(f for f in glob.glob(os.path.join(HERE, f"{kind}_*.npz")))        # "L" = L_*.npz only, "LS" = LS_*.npz
 
 
 def load(path):

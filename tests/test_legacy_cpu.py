@@ -8,6 +8,7 @@ import pytest
 from tests import golden_util as gu
 
 L_FIX = gu.fixtures("L")
+LS_FIX = gu.fixtures("LS")
 
 
 @pytest.mark.parametrize("path", L_FIX, ids=[p.split("/")[-1][:-4] for p in L_FIX])
@@ -15,6 +16,16 @@ def test_port_legacy_matches_reference_goldens(oracle_port, path):
     g = gu.load(path); kw = g["call"]
     F, m, st = oracle_port.find_fundamental(g["p1"], g["p2"], kw.get("px_th", 0.5), kw.get("conf", 0.9999), kw.get("max_iters", 100000),
                                             kw.get("error_type", 0), False, 0.0, True, seed=g["seed"], legacy=True)
+    assert (st["samples"], st["lo_runs"], st["I"]) == (g["samples"], g["lo_runs"], g["I"])
+    assert np.array_equal(m, g["mask"]) and gu.rel(F, g["model"]) <= 1e-6
+
+
+@pytest.mark.parametrize("path", LS_FIX, ids=[p.split("/")[-1][:-4] for p in LS_FIX])
+def test_port_legacy_symmetric_check_matches_reference_goldens(oracle_port, path):
+    """exp_ransacFcustom with doSymCheck: all points, CHECK_COEF * th, and the final mask filtered on whatever model the
+    driver computed last (exp_ranF.c:943-953, :1196-1203) — restated in the oracle only"""
+    g = gu.load(path); kw = g["call"]
+    F, m, st = oracle_port.find_fundamental(g["p1"], g["p2"], 0.5, 0.9999, 100000, kw.get("error_type", 0), True, 0.0, True, seed=g["seed"], legacy=True)
     assert (st["samples"], st["lo_runs"], st["I"]) == (g["samples"], g["lo_runs"], g["I"])
     assert np.array_equal(m, g["mask"]) and gu.rel(F, g["model"]) <= 1e-6
 
@@ -39,6 +50,7 @@ def test_port_legacy_matches_reference_live(oracle_port, oracle_ref):
     for seed in range(24):
         p1, p2, _, _ = syn.two_view_fundamental(300 + 100 * (seed % 6), 0.4, 0.1, seed=100 + seed, plane_fraction=[0.0, 0.0, 0.6, 0.9][seed % 4])
         et = seed % 2
-        F0, m0, s0 = oracle_ref.find_fundamental_legacy(0, p1, p2, 0.5, 0.9999, 20000, et, False, seed=seed + 1)
-        F1, m1, s1 = oracle_port.find_fundamental(p1, p2, 0.5, 0.9999, 20000, et, False, 0.0, True, seed=seed + 1, legacy=True)
-        assert np.array_equal(m0, m1) and gu.rel(F0, F1) <= 1e-6 and (s0["samples"], s0["lo_runs"]) == (s1["samples"], s1["lo_runs"]), seed
+        for sym in (False, True):
+            F0, m0, s0 = oracle_ref.find_fundamental_legacy(0, p1, p2, 0.5, 0.9999, 20000, et, sym, seed=seed + 1)
+            F1, m1, s1 = oracle_port.find_fundamental(p1, p2, 0.5, 0.9999, 20000, et, sym, 0.0, True, seed=seed + 1, legacy=True)
+            assert np.array_equal(m0, m1) and gu.rel(F0, F1) <= 1e-6 and (s0["samples"], s0["lo_runs"]) == (s1["samples"], s1["lo_runs"]), (seed, sym)
