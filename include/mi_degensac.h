@@ -67,11 +67,14 @@ extern "C" {
  *   bit  4    sampler           1 = always use the sequential pool-swap stage
  *   bits 8-15 helper workgroups per pair of the cooperative large-n mode (fundamental matrix, placement HBM):
  *             0 = automatic (15 helpers when n >= 8192 and the batch leaves the device mostly idle), 255 = off
- *   bits 16-23 setting long pairs aside (fundamental matrix, batches larger than the resident grid): a pair still
- *             running after this many samples (units of 256) while unstarted pairs remain is written back to its
- *             workspace and resumed once every pair has been started, so that the batch ends one long pair after the
- *             last pair was STARTED instead of one long pair after the last long pair was started.
- *             0 = automatic (max_iters / 12, at least 4096 samples), 255 = off
+ *   bits 5-7  with bits 16-23: a pair set aside with at least (threshold << this) samples left counts as "long" and is
+ *             resumed before the others; 0 = automatic (threshold x 8)
+ *   bits 16-23 setting pairs aside (fundamental matrix, batches larger than the resident grid): a pair still running
+ *             after this many samples (units of 256) while unstarted pairs remain is written back to its workspace and
+ *             queued; free workgroups take unstarted pairs first, then the queued pairs with many samples left, then
+ *             the rest.  The first samples of every pair become a short discovery round after which the pairs with the
+ *             most work left restart first, so the batch ends at about (sum of pair times) / (resident workgroups)
+ *             instead of one long pair after the last pair was started.  0 = automatic (1024 samples), 255 = off
  *   bits 24-31 cap on the number of resident workgroups (0 = none; for tests of the queueing paths on small batches) */
 #define MI_DEGENSAC_TUNE_VARIANT(v)   ((uint32_t)(v) & 3u)
 #define MI_DEGENSAC_TUNE_PLACEMENT(p) (((uint32_t)(p) & 3u) << 2)
@@ -107,7 +110,7 @@ enum {
     MI_ST_FULL_PASSES = 8, MI_ST_EX_PASSES = 9, MI_ST_H_PASSES = 10, MI_ST_AUX_PASSES = 11,
     MI_ST_TICKS_BEST = 12,  /* 100 MHz device wall-clock ticks from the pair's start to that commit */
     MI_ST_TICKS_TOTAL = 13, /* ... to the pair's end                                                */
-    MI_ST_THREADS = 14,     /* workgroup size of the kernel variant that ran (512 / 256)            */
+    MI_ST_THREADS = 14,     /* workgroup size of the kernel variant that ran (512 / 256 / 128)      */
     MI_ST_PLACEMENT = 15    /* bits 0-7: 0 = points + pool in HBM, 1 = both in LDS, 2 = pool in LDS; bit 8: the pair was set aside once */
 };
 

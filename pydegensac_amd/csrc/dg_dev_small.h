@@ -115,38 +115,6 @@ __device__ __forceinline__ void dg_lartg_fast(double f, double g, double *c, dou
     *s = f < 0. ? -sq : sq;
 }
 
-/* dlartg without branches on the critical path: the scalar recurrence of dsteqr pays every compare -> exec-mask ->
- * branch round trip in full (one wave, nothing to overlap with), so the two zero cases are selected at the end instead
- * of branched on at the start (their lanes compute on garbage that is thrown away), and the out-of-range case — never
- * seen in practice — is one wave-wide ballot that sends the whole wave through the plain routine.  Same values as
- * dg_lartg bit for bit (checked by tools/gpu_micro.py on 1.28 M random pairs, and by the eigen-solver parity test). */
-__device__ __forceinline__ void dg_lartg_bf(double f, double g, double *c, double *s, double *r)
-{
-    const double f1 = fabs(f), g1 = fabs(g);
-    const bool gz = g == 0., fz = f == 0.;
-    const bool ok = f1 > 1e-140 && f1 < 1e140 && g1 > 1e-140 && g1 < 1e140;
-    if (__ballot(!ok && !gz && !fz) != 0ull) { dg_lartg(f, g, c, s, r); return; }
-    const double x = f*f + g*g;
-    double y = __builtin_amdgcn_rsq(x);
-    double sg = x * y, sh = y * 0.5;
-    double sr = __builtin_fma(-sh, sg, 0.5);
-    sg = __builtin_fma(sg, sr, sg); sh = __builtin_fma(sh, sr, sh);
-    double sd = __builtin_fma(-sg, sg, x); sg = __builtin_fma(sd, sh, sg);
-    sd = __builtin_fma(-sg, sg, x);        sg = __builtin_fma(sd, sh, sg);
-    const double d = sg;
-    double ry = __builtin_amdgcn_rcp(d);
-    double re = __builtin_fma(-d, ry, 1.0); ry = __builtin_fma(ry, re, ry);
-    re = __builtin_fma(-d, ry, 1.0);        ry = __builtin_fma(ry, re, ry);
-    double q0 = f1 * ry, rr = __builtin_fma(-d, q0, f1);
-    double cq = __builtin_fma(rr, ry, q0);
-    q0 = g * ry; rr = __builtin_fma(-d, q0, g);
-    const double sq = __builtin_fma(rr, ry, q0);
-    double rq = dg_sign(d, f), ss = f < 0. ? -sq : sq;
-    cq = fz ? 0. : cq; ss = fz ? dg_sign(1., g) : ss; rq = fz ? g1 : rq;
-    cq = gz ? 1. : cq; ss = gz ? 0. : ss;             rq = gz ? f : rq;      /* dlartg tests g == 0 first */
-    *c = cq; *s = ss; *r = rq;
-}
-
 DG_FN void dg_laev2(double a, double b, double c, double *rt1, double *rt2, double *cs1, double *sn1)
 {
     double sm = a + c, df = a - c, adf = fabs(df), tb = b + b, ab = fabs(tb);
@@ -741,34 +709,6 @@ DG_FN void dg_pinvJ(double a, double b, double c, double d, double e, double *pJ
     pJ[7] = c * (a2 + b2 + c2);
     N = a * pJ[0] + b * pJ[1] + c * pJ[2];
     for (i = 0; i < 8; i++) pJ[i] /= N;
-}
-
-/* ------------------------------------------------------------------------------------------------
- * degensac/hash.c:4-47  Hsieh SuperFastHash over the bytes of the int inlier list
- * ---------------------------------------------------------------------------------------------- */
-DG_FN uint32_t dg_superfasthash(const unsigned char *data, int len)
-{
-    uint32_t hash = (uint32_t)len, tmp; int rem;
-#define DG_GET16(d) ((((uint32_t)((d)[1])) << 8) + (uint32_t)((d)[0]))
-    if (len <= 0 || data == 0) return 0;
-    rem = len & 3; len >>= 2;
-    for (; len > 0; len--) {
-        hash += DG_GET16(data);
-        tmp = (DG_GET16(data + 2) << 11) ^ hash;
-        hash = (hash << 16) ^ tmp;
-        data += 4;
-        hash += hash >> 11;
-    }
-    switch (rem) {   /* never taken: the list is ints (len % 4 == 0) */
-    case 3: hash += DG_GET16(data); hash ^= hash << 16; hash ^= ((uint32_t)(int32_t)(signed char)data[2]) << 18; hash += hash >> 11; break;
-    case 2: hash += DG_GET16(data); hash ^= hash << 11; hash += hash >> 17; break;
-    case 1: hash += (uint32_t)(int32_t)(signed char)*data; hash ^= hash << 10; hash += hash >> 1;
-    }
-#undef DG_GET16
-    hash ^= hash << 3;  hash += hash >> 5;
-    hash ^= hash << 4;  hash += hash >> 17;
-    hash ^= hash << 25; hash += hash >> 6;
-    return hash;
 }
 
 /* degensac/rtools.c:202-225 */

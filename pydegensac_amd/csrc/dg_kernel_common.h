@@ -99,17 +99,23 @@ struct dg_args {
     const int *order;                /* optional processing order (ticket t -> pair order[t]); null = identity              */
     int coop_k;                      /* helper workgroups per owner (0 = every workgroup owns pairs)            */
     dg_coop_cb *coop;                /* [owner slots] control blocks (coop_k > 0)                              */
-    /* Setting long pairs aside (F driver, batches larger than the resident grid).  A pair that is still running after
-     * park_sam samples while unstarted pairs remain is written back to its workspace (the LDS image goes to wl.off_park)
-     * and queued; its workgroup continues with a spare workspace and the next ticket, and the queued pairs are resumed —
-     * by whichever workgroup runs out of tickets first — once every pair has been started.  The batch then ends one
-     * long pair after the last pair was STARTED, instead of one long pair after the last long pair was started.
+    /* Setting pairs aside (F driver, batches larger than the resident grid).  Which pairs run long is only known while
+     * they run, and a batch ends one long pair after the last long pair was started.  So every pair that is still running
+     * after park_sam samples while unstarted pairs remain is written back to its workspace (the LDS image goes to
+     * wl.off_park) and queued by what it has left: max_sam - no_sam >= park_long -> queue 1, else queue 0; its workgroup
+     * continues with a spare workspace.  A free workgroup takes, in this order: the next unstarted pair, queue 1, queue 0.
+     * The first park_sam samples of every pair are thus a cheap discovery round, after which the pairs with the most work
+     * left are (re)started first (longest-processing-time-first on discovered information); the batch ends at about
+     * (sum of pair times) / (resident workgroups) instead of one long pair after the last start.
      * Results do not depend on it (the image is the complete state between two chunks). */
     int park_sam;                    /* 0 = off */
     int n_res, n_ws;                 /* workspaces in `ws`: n_res = one per resident workgroup, then the spares up to n_ws */
     int dyn_bytes;                   /* dynamic LDS per workgroup                                              */
-    int *park_ctl;                   /* [0] spares handed out, [32] queue entries claimed, [64] queue entries taken (one 128-byte line each) */
-    long long *park_q;               /* [n_ws - grid] entries: pair << 32 | workspace, -1 until published        */
+    int *park_ctl;                   /* [0] spares handed out; queue q (0 = few samples left, 1 = many): [32 + 64 q] entries claimed,
+                                        [64 + 64 q] entries taken (one 128-byte line each) */
+    long long *park_q;               /* [2][park_cap] entries: pair << 32 | workspace, -1 until published        */
+    int park_cap;                    /* entries per queue                                                       */
+    int park_long;                   /* a pair set aside with at least this many samples left goes to queue 1    */
     int pool_seq;                    /* 1 = always use the sequential pool-swap stage (LDS exchange-order self-check failed, or forced) */
     int variant_threads, mode;       /* reported in the stats block */
     int *trace;                      /* debug: [0] = count, then (tag, I, J lo, J hi) records; null = off */

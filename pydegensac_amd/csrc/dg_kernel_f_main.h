@@ -668,8 +668,8 @@ __device__ __forceinline__ unsigned dg_sample_chunk(unsigned seed, int cn, int n
  * workgroup barrier, then the flag (the queue entry) with a relaxed agent-scope atomic; the taker polls the entry with
  * its whole first wave behind a scalar branch, then acquires. */
 #define DG_PARK_SPARE   0
-#define DG_PARK_CLAIMED 32
-#define DG_PARK_HEAD    64
+#define DG_PARK_CLAIMED 32                   /* queue q: claimed count at DG_PARK_CLAIMED + 64 q, taken count at DG_PARK_HEAD + 64 q */
+#define DG_PARK_HEAD    64                   /* (one 128-byte line each; q = 0: pairs with few samples left, q = 1: many) */
 #define DG_PARK_DYN_OFF ((sizeof(dg_f_shared) + 255) & ~(size_t)255)   /* the dynamic LDS follows the dg_f_shared image */
 
 /* copies between LDS and the workspace, 16 bytes per thread and step (both sides 16-byte aligned) */
@@ -682,29 +682,32 @@ __device__ __forceinline__ void dg_copy16(void *dst, const void *src, size_t byt
     for (size_t i = done + tid; i < bytes; i += DG_T) ((unsigned char *)dst)[i] = ((const unsigned char *)src)[i];
 }
 
-/* the next queued pair for a workgroup that found no ticket: pair << 32 | workspace, or -1 when the queue is empty.
- * Entries are taken with compare-and-swap, never past the claimed count: a workgroup that sets a pair aside later
- * finds its own entry when its tickets run out, so no entry is left behind. */
-__device__ __forceinline__ long long dg_park_take(const dg_args &A, long long *bc /* LDS */)
+/* the next pair of queue `q` (pair << 32 | workspace), or -1 when that queue is empty.
+ * Entries are taken with compare-and-swap, never past the claimed count: a workgroup that sets a pair aside goes round
+ * its loop again (long queue, tickets, short queue), so it finds its own entry if nobody else has taken it, and no entry
+ * is left behind. */
+__device__ __forceinline__ long long dg_park_take(const dg_args &A, long long *bc /* LDS */, const int q)
 {
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
+        int *const p_head = A.park_ctl + DG_PARK_HEAD + 64 * q, *const p_cl = A.park_ctl + DG_PARK_CLAIMED + 64 * q;
+        const long long *const pq = A.park_q + (size_t)q * A.park_cap;
         int h;
         for (;;) {
-            h = __builtin_amdgcn_readfirstlane(__hip_atomic_load(A.park_ctl + DG_PARK_HEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            const int cl = __builtin_amdgcn_readfirstlane(__hip_atomic_load(A.park_ctl + DG_PARK_CLAIMED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            h = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const int cl = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p_cl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (h >= cl) { h = -1; break; }
             int ok = 0;
             if (threadIdx.x == 0) {
                 int expect = h;
-                ok = __hip_atomic_compare_exchange_strong(A.park_ctl + DG_PARK_HEAD, &expect, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+                ok = __hip_atomic_compare_exchange_strong(p_head, &expect, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
             }
             if (__builtin_amdgcn_readfirstlane(ok)) break;
         }
         long long e = -1;
         if (h >= 0) {
             for (;;) {
-                const long long v = __hip_atomic_load(A.park_q + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const long long v = __hip_atomic_load(pq + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
                 e = ((long long)hi << 32) | (unsigned)lo;
                 if (e >= 0) break;
@@ -865,13 +868,15 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                 dg_copy16(pk, S, sizeof(dg_f_shared), tid);
                 dg_copy16(pk + DG_PARK_DYN_OFF, dyn_smem, (size_t)A.dyn_bytes, tid);
                 __syncthreads();
+                /* queue 1 = many samples left (resumed first: the pairs that will run longest must start early), queue 0 = few */
+                const int q = (max_sam - no_sam >= A.park_long) ? 1 : 0;
                 if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
                     int idx = 0;
-                    if (tid == 0) idx = __hip_atomic_fetch_add(A.park_ctl + DG_PARK_CLAIMED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid == 0) idx = __hip_atomic_fetch_add(A.park_ctl + DG_PARK_CLAIMED + 64 * q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     idx = __builtin_amdgcn_readfirstlane(idx);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (tid == 0) __hip_atomic_store(A.park_q + idx, ((long long)pair << 32) | (long long)(unsigned)wsid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid == 0) __hip_atomic_store(A.park_q + (size_t)q * A.park_cap + idx, ((long long)pair << 32) | (long long)(unsigned)wsid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 return nw;
             }
@@ -1404,18 +1409,23 @@ __global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_fundamental_kernel(dg_a
     }
     int wsid = slot;
     for (;;) {
-        const int pair = dg_next_pair(As, &next_pair);
-        if (pair >= 0) {
-            const int spare = dg_f_pair<T, LDSPTS>(As, &Sh, dyn_smem, pair, slot, wsid, 0, coop_gen);
-            if (spare >= 0) wsid = spare;            /* the pair was set aside with its workspace */
-            continue;
+        /* 1. pairs that have not been started (with pairs being set aside after park_sam samples this is the discovery
+         *    round: it is short, and at its end every pair with a lot of work left is known);
+         * 2. the pairs that were set aside with many samples left: they run longest, so they restart first;
+         * 3. the pairs that were set aside with few samples left fill the end of the batch.
+         * (The queues can look empty one after the other while another workgroup queues a pair in between: that workgroup
+         * takes it itself on its next round.) */
+        int resume = 0;
+        int pair = dg_next_pair(As, &next_pair);
+        if (pair < 0 && As.park_sam > 0) {
+            long long e = dg_park_take(As, &next_parked, 1);
+            if (e < 0) e = dg_park_take(As, &next_parked, 0);
+            if (e < 0) e = dg_park_take(As, &next_parked, 1);
+            if (e >= 0) { pair = (int)(e >> 32); wsid = (int)(e & 0xffffffffll); resume = 1; }   /* the image lives in the pair's own workspace */
         }
-        /* every pair has been started: continue the ones that were set aside */
-        if (As.park_sam <= 0) break;
-        const long long e = dg_park_take(As, &next_parked);
-        if (e < 0) break;
-        wsid = (int)(e & 0xffffffffll);
-        dg_f_pair<T, LDSPTS>(As, &Sh, dyn_smem, (int)(e >> 32), slot, wsid, 1, coop_gen);
+        if (pair < 0) break;
+        const int spare = dg_f_pair<T, LDSPTS>(As, &Sh, dyn_smem, pair, slot, wsid, resume, coop_gen);
+        if (spare >= 0) wsid = spare;                /* the pair was set aside with its workspace */
     }
     if (LDSPTS == 0 && As.coop_k > 0 && threadIdx.x == 0)          /* retire the slot: its helpers leave */
         __hip_atomic_store(&As.coop[slot].gen, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -10,12 +10,19 @@ hipError_t DG_VCAT(dg_variant_, DG_T, _init)(const unsigned C[8][32], const unsi
     if ((e = hipMemcpyToSymbol(HIP_SYMBOL(dg_rng_Ct), Ct, sizeof(unsigned) * 32 * 8)) != hipSuccess) return e;
     if ((e = hipMemcpyToSymbol(HIP_SYMBOL(dg_rng_G), G, sizeof(unsigned) * 32)) != hipSuccess) return e;
     hipFuncAttributes fa;
-    const void *kf[2] = {(const void *)dg_find_fundamental_kernel<DG_T, DG_MODE_LDS>, (const void *)dg_find_fundamental_kernel<DG_T, DG_MODE_POOL_LDS>};
-    const void *kh[2] = {(const void *)dg_find_homography_kernel<DG_T, DG_MODE_LDS>, (const void *)dg_find_homography_kernel<DG_T, DG_MODE_POOL_LDS>};
+    const void *kf[3] = {(const void *)dg_find_fundamental_kernel<DG_T, DG_MODE_LDS>, (const void *)dg_find_fundamental_kernel<DG_T, DG_MODE_POOL_LDS>,
+                         (const void *)dg_find_fundamental_kernel<DG_T, DG_MODE_HBM>};
+    const void *kh[3] = {(const void *)dg_find_homography_kernel<DG_T, DG_MODE_LDS>, (const void *)dg_find_homography_kernel<DG_T, DG_MODE_POOL_LDS>,
+                         (const void *)dg_find_homography_kernel<DG_T, DG_MODE_HBM>};
     for (int h = 0; h < 2; h++) {
         const void **k = h ? kh : kf;
-        if ((e = hipFuncGetAttributes(&fa, k[0])) != hipSuccess) return e;
-        static_lds[h] = (int)fa.sharedSizeBytes;
+        /* static LDS of the largest of the three placement instantiations: it sizes the residency clamp and the image of a
+         * pair that is set aside (which must hold the whole dg_f_shared) */
+        static_lds[h] = (int)sizeof(dg_f_shared);
+        for (int m = 0; m < 3; m++) {
+            if ((e = hipFuncGetAttributes(&fa, k[m])) != hipSuccess) return e;
+            if ((int)fa.sharedSizeBytes > static_lds[h]) static_lds[h] = (int)fa.sharedSizeBytes;
+        }
         for (int m = 0; m < 2; m++)
             if ((e = hipFuncSetAttribute(k[m], hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - static_lds[h] - 256)) != hipSuccess) return e;
     }

@@ -1,7 +1,7 @@
 """Where do the waves of co-resident workgroups sit?  Launches a grid shaped like the batch kernel's (workgroups of
 `threads`, `dyn_lds` bytes of LDS so that two fit a CU) and prints, per CU, the SIMD of every wave of its workgroups."""
 import os as _os
-_os.environ.setdefault("MI_DEGENSAC_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "pydegensac_amd", "libmi_degensac_dev.so"))
+_os.environ.setdefault("MI_DEGENSAC_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "libmi_degensac_dev.so"))
 import sys, os, ctypes as C, numpy as np, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pydegensac_amd import _lib

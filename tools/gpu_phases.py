@@ -1,6 +1,6 @@
 import os as _os
 # development exports live in libmi_degensac_dev.so (make -C pydegensac_amd/csrc dev), never in the product library
-_os.environ.setdefault("MI_DEGENSAC_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "pydegensac_amd", "libmi_degensac_dev.so"))
+_os.environ.setdefault("MI_DEGENSAC_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "libmi_degensac_dev.so"))
 import sys, numpy as np, ctypes as C, torch, time
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pydegensac_amd import synthetic as syn, _lib, parallel

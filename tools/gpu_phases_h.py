@@ -2,7 +2,7 @@
 solve / score||sample / commit / LO, and inside the LO: passes, long-list least squares + eigen-solve, inlier-set hash,
 small fits, consistency checks.  usage: gpu_phases_h.py [pairs]"""
 import os as _os
-_os.environ.setdefault("MI_DEGENSAC_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "pydegensac_amd", "libmi_degensac_dev.so"))
+_os.environ.setdefault("MI_DEGENSAC_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "libmi_degensac_dev.so"))
 import sys, numpy as np, ctypes as C, torch, time
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pydegensac_amd import synthetic as syn, _lib, parallel

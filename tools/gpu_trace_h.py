@@ -1,7 +1,7 @@
 """First divergence between the GPU's and the oracle's H-driver checkpoint traces for one fuzz case."""
 import os as _os
 # development exports live in libmi_degensac_dev.so (make -C pydegensac_amd/csrc dev), never in the product library
-_os.environ.setdefault("MI_DEGENSAC_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "pydegensac_amd", "libmi_degensac_dev.so"))
+_os.environ.setdefault("MI_DEGENSAC_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "libmi_degensac_dev.so"))
 
 import sys, os, numpy as np, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
