@@ -160,8 +160,8 @@ __device__ __forceinline__ dg_pass_res dg_f_pass(CTX &c, const double *Fm /* LDS
 #pragma unroll
     for (int i = 0; i < 9; i++) F[i] = Fm[i];
     const dg_pt *P = c.P;
-    /* ordered MSAC terms: the per-wave solver scratch is idle during a workgroup pass (LDS); HBM staging area otherwise */
-    cfg.jbuf = (size_t)cfg.n * sizeof(double) <= DG_JBUF_LDS_BYTES ? (double *)c.S->ww : (double *)c.stage;
+    /* ordered MSAC terms: the per-wave solver scratch is idle during a workgroup pass (LDS); what does not fit goes to the HBM staging area */
+    cfg.jbuf = (double *)c.stage; cfg.jl = (double *)c.S->ww; cfg.jl_cap = (int)(DG_JBUF_LDS_BYTES / sizeof(double));
     return dg_pass(&c.S->red, cfg, [&](int pid, int) { return dg_Ferr(kind, F, dg_ldpt<LDSPTS>(P, pid)); }, c.tid);
 }
 template <int LDSPTS>
@@ -171,13 +171,13 @@ __device__ __forceinline__ dg_pass_res dg_h_pass(CTX &c, const double *Hm /* LDS
 #pragma unroll
     for (int i = 0; i < 9; i++) H[i] = Hm[i];
     const dg_pt *P = c.P;
-    /* ordered MSAC terms: the per-wave solver scratch is idle during a workgroup pass (LDS); HBM staging area otherwise */
-    cfg.jbuf = (size_t)cfg.n * sizeof(double) <= DG_JBUF_LDS_BYTES ? (double *)c.S->ww : (double *)c.stage;
+    /* ordered MSAC terms: the per-wave solver scratch is idle during a workgroup pass (LDS); what does not fit goes to the HBM staging area */
+    cfg.jbuf = (double *)c.stage; cfg.jl = (double *)c.S->ww; cfg.jl_cap = (int)(DG_JBUF_LDS_BYTES / sizeof(double));
     return dg_pass(&c.S->red, cfg, [&](int pid, int) { dg_pt p = dg_ldpt<LDSPTS>(P, pid); return dg_HDs(H, p.x1, p.y1, p.x2, p.y2); }, c.tid);
 }
 __device__ __forceinline__ dg_pass_cfg dg_cfg0(int n)
 {
-    dg_pass_cfg c; c.n = n; c.src = 0; c.wantJ = 0; c.thJ = 0; c.jbuf = 0; c.wantC = 0; c.thC = 0; c.list = 0; c.thL = 0; c.listStrict = 0; c.list2 = 0; c.thL2 = 0; c.flags = 0; c.thF = 0;
+    dg_pass_cfg c; c.n = n; c.src = 0; c.wantJ = 0; c.thJ = 0; c.jbuf = 0; c.jl = 0; c.jl_cap = 0; c.wantC = 0; c.thC = 0; c.list = 0; c.thL = 0; c.listStrict = 0; c.list2 = 0; c.thL2 = 0; c.flags = 0; c.thF = 0;
     return c;
 }
 

@@ -59,8 +59,8 @@ __device__ __forceinline__ dg_pass_res dg_hm_pass(CTX &c, int kind, const double
 #pragma unroll
     for (int i = 0; i < 9; i++) { H[i] = Hm[i]; Hinv[i] = kind ? S->lsq.Z8[i] : 0; H1[i] = kind ? S->lsq.Z8[9+i] : 0; }
     const dg_pt *P = c.P;
-    /* ordered MSAC terms: the per-wave solver scratch is idle during a workgroup pass (LDS); HBM staging area otherwise */
-    cfg.jbuf = (size_t)cfg.n * sizeof(double) <= DG_JBUF_LDS_BYTES ? (double *)c.S->ww : (double *)c.stage;
+    /* ordered MSAC terms: the per-wave solver scratch is idle during a workgroup pass (LDS); what does not fit goes to the HBM staging area */
+    cfg.jbuf = (double *)c.stage; cfg.jl = (double *)c.S->ww; cfg.jl_cap = (int)(DG_JBUF_LDS_BYTES / sizeof(double));
     return dg_pass(&S->red, cfg, [&](int pid, int) { return dg_Herr(kind, H, Hinv, H1, dg_ldpt<LDSPTS>(P, pid)); }, c.tid);
 }
 

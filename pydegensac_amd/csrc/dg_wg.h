@@ -82,15 +82,51 @@ __device__ __forceinline__ double dg_wave_sum_d(double v) { return dg_tile_sum(v
 /* MSAC gain J of one model = the reference's sequential fp64 sum of truncQuad terms in point order (rtools.c:160-171,
  * 228-236).  Terms that are exactly zero do not change a running sum, so every scoring path stores the nonzero terms in
  * point order and one thread adds them one after the other: bit-identical to the reference for identical residuals,
- * whatever the kernel variant or path.  Eight independent loads are kept in flight; the adds stay strictly ordered. */
-__device__ __forceinline__ double dg_seq_sum(const double *t, int cnt)
+ * whatever the kernel variant or path.  The adds are one dependent chain (~2.2 ns per term on one lane); what can be
+ * taken off it is the memory latency: the loads run 16 terms ahead of the adds (address-space-qualified: ds_read /
+ * global_load, not flat), so a batch's latency is covered by the previous batch's adds.  Own register allocation: the
+ * callers are inlined into the drivers dozens of times. */
+template <int AS>
+__device__ __noinline__ double dg_seq_sum_from(const double *t_, int cnt, double J)
 {
-    double J = 0.0; int k = 0;
+    const __attribute__((address_space(AS))) double *t = (const __attribute__((address_space(AS))) double *)t_;
+    int k = 0;
+    /* DG_SEQ_AHEAD terms per batch, two batches in flight: at most 32 loads outstanding, well inside the 6-bit vmcnt
+     * (64 outstanding global loads returned wrong sums on gfx950: the counter saturates at 63) */
+#define DG_SEQ_AHEAD 16
+    if (cnt >= 2 * DG_SEQ_AHEAD) {
+        double a[DG_SEQ_AHEAD];
+#pragma unroll
+        for (int i = 0; i < DG_SEQ_AHEAD; i++) a[i] = t[i];
+        for (; k + 2 * DG_SEQ_AHEAD <= cnt; k += DG_SEQ_AHEAD) {
+            double b[DG_SEQ_AHEAD];
+#pragma unroll
+            for (int i = 0; i < DG_SEQ_AHEAD; i++) b[i] = t[k + DG_SEQ_AHEAD + i];
+#pragma unroll
+            for (int i = 0; i < DG_SEQ_AHEAD; i++) J += a[i];
+#pragma unroll
+            for (int i = 0; i < DG_SEQ_AHEAD; i++) a[i] = b[i];
+        }
+#pragma unroll
+        for (int i = 0; i < DG_SEQ_AHEAD; i++) J += a[i];
+        k += DG_SEQ_AHEAD;
+    }
+#undef DG_SEQ_AHEAD
     for (; k + 8 <= cnt; k += 8) {
         const double v0 = t[k], v1 = t[k+1], v2 = t[k+2], v3 = t[k+3], v4 = t[k+4], v5 = t[k+5], v6 = t[k+6], v7 = t[k+7];
         J += v0; J += v1; J += v2; J += v3; J += v4; J += v5; J += v6; J += v7;
     }
     for (; k < cnt; k++) J += t[k];
+    return J;
+}
+/* terms in global memory (HBM workspace) */
+__device__ __forceinline__ double dg_seq_sum(const double *t, int cnt) { return dg_seq_sum_from<1>(t, cnt, 0.0); }
+/* the first min(cnt, cap) terms in LDS (jl), the rest in global memory (jg[0..cnt - cap)) */
+__device__ __forceinline__ double dg_seq_sum_split(const double *jl, int cap, const double *jg, int cnt)
+{
+    const int nl = cnt < cap ? cnt : cap;
+    double J = dg_seq_sum_from<3>(jl, nl, 0.0);
+    if (cnt > nl) J = dg_seq_sum_from<1>(jg, cnt - nl, J);
     return J;
 }
 
@@ -152,7 +188,8 @@ struct dg_pass_cfg {
     int         n;
     const int  *src;        /* optional indirection */
     /* (I, J): I = #(d <= thJ), J = sum truncQuad(d, thJ)  (rtools.c:160-171, 228-236) */
-    int         wantJ;  double thJ;  double *jbuf;   /* jbuf: >= n doubles of scratch (HBM) for the ordered nonzero MSAC terms */
+    int         wantJ;  double thJ;  double *jbuf;   /* jbuf: >= n doubles of scratch (HBM) for the ordered nonzero MSAC terms ... */
+    double     *jl;     int jl_cap;                  /* ... behind the first jl_cap of them, which go to this LDS buffer (0 = none)   */
     /* second counter: #(d <= thC) */
     int         wantC;  double thC;
     /* ordered list of ids with d <= thL  (inlidxs' index list) */
@@ -216,7 +253,11 @@ __device__ __forceinline__ dg_pass_res dg_pass(dg_red *r, const dg_pass_cfg &c, 
                     out.nL += a; nJ += b; out.nL2 += a2;
                 }
                 if (in[u]) c.list[lbase + (unsigned)__popcll(bL[u] & ((1ull << lane) - 1ull))] = pid[u];
-                if (nz[u]) c.jbuf[jbase + (unsigned)__popcll(bJ[u] & ((1ull << lane) - 1ull))] = term[u];
+                if (nz[u]) {
+                    const unsigned jx = jbase + (unsigned)__popcll(bJ[u] & ((1ull << lane) - 1ull));
+                    if (jx < (unsigned)c.jl_cap) ((__attribute__((address_space(3))) double *)c.jl)[jx] = term[u];
+                    else ((__attribute__((address_space(1))) double *)c.jbuf)[jx - (unsigned)c.jl_cap] = term[u];
+                }
                 if (in2[u]) c.list2[l2base + (unsigned)__popcll(bL2[u] & ((1ull << lane) - 1ull))] = pid[u];
             }
             par ^= 1;
@@ -228,7 +269,7 @@ __device__ __forceinline__ dg_pass_res dg_pass(dg_red *r, const dg_pass_cfg &c, 
     cI = dg_wave_sum_u(cI); cC = dg_wave_sum_u(cC); cF = dg_wave_sum_u(cF);
     __syncthreads();
     if (lane == 0) { r->u[0][wave][0] = cI; r->u[0][wave][1] = cC; r->u[0][wave][3] = cF; }
-    if (tid == 0 && c.wantJ) r->bc[0] = dg_seq_sum(c.jbuf, (int)nJ);
+    if (tid == 0 && c.wantJ) r->bc[0] = dg_seq_sum_split(c.jl, c.jl_cap, c.jbuf, (int)nJ);
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < DG_NW; w++) { out.I += r->u[0][w][0]; out.C += r->u[0][w][1]; out.nF += r->u[0][w][3]; }

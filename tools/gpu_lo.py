@@ -1,10 +1,10 @@
 import os as _os
 # development exports live in libmi_degensac_dev.so (make -C pydegensac_amd/csrc dev), never in the product library
-_os.environ.setdefault("MI_DEGENSAC_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "libmi_degensac_dev.so"))
+_os.environ.setdefault("MI_DEGENSAC_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "libmi_degensac_loprof.so"))
 import sys, numpy as np, ctypes as C, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pydegensac_amd import synthetic as syn, _lib, parallel
-L=_lib.lib(); P=256; N=2000
+L=_lib.lib(); P=int(sys.argv[1]) if len(sys.argv)>1 else 256; N=2000   # MI_DEGENSAC_TUNING=2 forces the 256-thread variant
 a=np.empty((P*N,2)); b=np.empty((P*N,2))
 for i in range(P):
     p1,p2,_,_=syn.two_view_fundamental(N,0.4,0.1,seed=i); a[i*N:(i+1)*N]=p1; b[i*N:(i+1)*N]=p2
