@@ -50,7 +50,7 @@ struct dg_ws_layout {
     size_t off_models;    /* chunk models: [3*DG_CHUNK][9] doubles + tags                          */
     size_t off_pts;       /* dg_pt[n_max] when the points do not fit LDS                          */
     size_t off_pool;      /* int[n_max]   ditto                                                   */
-    size_t off_stage;     /* dg_pt[n_max] staging of long least-squares lists                     */
+    size_t off_stage;     /* dg_pt[2 * n_max]: staging of long least-squares lists + their per-coordinate arrays */
     size_t off_wave;      /* per-wave buffers of the wave-parallel sections: int[NW][n_max] + dg_pt[NW][n_max] */
     size_t off_res;       /* per-model results of a chunk: double J[768], unsigned I[768], int rf[256][5] */
     size_t off_mslot;     /* cooperative mode: the chunk's compact model index -> slot table, unsigned short[3*DG_CHUNK] */

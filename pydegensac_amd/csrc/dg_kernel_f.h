@@ -216,7 +216,7 @@ __device__ __forceinline__ void dg_u2f_list(CTX &c, const int *list, int len, co
         __syncthreads();
     } else {
         const dg_pt *P = c.P;
-        dg_u2f_big(&S->red, &S->lsq, [&](int i) { return dg_ldpt<LDSPTS>(P, i); }, list, len, c.tid, Fout, c.stage, c.n_max,
+        dg_u2f_big(&S->red, &S->lsq, [&](int i) { return dg_ldpt<LDSPTS>(P, i); }, list, len, c.tid, Fout, c.stage, 2 * c.n_max,
                    DG_LSQ_LTAB(S));
     }
 }
@@ -434,7 +434,7 @@ __device__ __noinline__ unsigned dg_u2Fit_wave(dg_wave_ws *w, const dg_pt *P, in
         } else {
             for (int j = lane; j < (int)cnt; j += 64) stage[j] = dg_ldpt<LDSPTS>(P, list[j]);
             DG_WSYNC();
-            if (2 * stage_cap >= 3 * (int)cnt) dg_lsq_seq_par(w, stage, (int)cnt, lane, 64, 0, w->A1, w->A2, [] { DG_WSYNC(); });
+            if (stage_cap >= 2 * (int)cnt) dg_lsq_seq_par(w, stage, (int)cnt, lane, 64, 0, w->A1, w->A2, [] { DG_WSYNC(); });
             else dg_lsq_seq_core(w, stage, (int)cnt, lane, 0, w->A1, w->A2);
             DG_WSYNC();
             dg_eig_sym_wave(w->V, w->D, lane, &w->ews);

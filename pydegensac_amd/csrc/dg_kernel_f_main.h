@@ -528,7 +528,7 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
                     cI += (act && d <= th) ? 1u : 0u;
                     const bool nz = !(term == 0.0);
                     const unsigned long long bJ = __ballot(nz);
-                    if (nz) jbuf[cnt + (unsigned)__popcll(bJ & ((1ull << lane) - 1ull))] = term;
+                    if (nz) ((__attribute__((address_space(1))) double *)jbuf)[cnt + (unsigned)__popcll(bJ & ((1ull << lane) - 1ull))] = term;
                     cnt += (unsigned)__popcll(bJ);
                 }
             }

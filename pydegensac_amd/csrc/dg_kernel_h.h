@@ -40,7 +40,7 @@ __device__ __forceinline__ void dg_u2h_list(CTX &c, const int *list, int len, do
         __syncthreads();
     } else {
         const dg_pt *P = c.P;
-        dg_u2h_big(&S->red, &S->lsq, [&](int i) { return dg_ldpt<LDSPTS>(P, i); }, list, len, c.tid, Hout, c.stage, c.n_max,
+        dg_u2h_big(&S->red, &S->lsq, [&](int i) { return dg_ldpt<LDSPTS>(P, i); }, list, len, c.tid, Hout, c.stage, 2 * c.n_max,
                    DG_LSQ_LTAB(S));
     }
 }
@@ -453,7 +453,7 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
                             cI += (act && d <= th) ? 1u : 0u;
                             const bool nz = !(term == 0.0);
                             const unsigned long long bJ = __ballot(nz);
-                            if (nz) jbuf[cnt + (unsigned)__popcll(bJ & ((1ull << lane) - 1ull))] = term;
+                            if (nz) ((__attribute__((address_space(1))) double *)jbuf)[cnt + (unsigned)__popcll(bJ & ((1ull << lane) - 1ull))] = term;
                             cnt += (unsigned)__popcll(bJ);
                         }
                     }

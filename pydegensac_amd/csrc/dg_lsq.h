@@ -250,22 +250,28 @@ __device__ __forceinline__ void dg_lsq_seq_core(SC *s, const dg_pt *stage, int l
 /* The same sums with the per-point work taken out of the serial loops.  `nthr` threads (a whole workgroup, or one
  * wave) compute in parallel, per listed point, the two centroid distances and then the Hartley-normalised
  * coordinates (identical operations to the serial form, so identical bits); the sequential, reference-order
- * accumulations that remain are plain adds (distances) or two to four multiplies and an add (normal matrix) per
- * term.  Needs 16 B of scratch per point behind the staged points: stage must hold 3/2 * len entries.
+ * accumulations that remain are plain adds (coordinates, distances) or two to four multiplies and an add (normal
+ * matrix) per term.  The plain sums run over CONTIGUOUS arrays (one per coordinate / per image, written by the parallel
+ * phases behind the staged points) through dg_seq_sum_from, whose loads run ahead of the add chain: these sums used to
+ * pay one cache round trip per four or eight terms, which made them the larger part of a long-list fit.
+ * Needs 32 B of scratch per point behind the staged points: stage must hold 2 * len entries.
  * `sync` separates the phases (__syncthreads for a workgroup, a wave barrier for one wave); tid < 64 is the wave that
  * runs the serial parts. */
 template <class SC, class Sync>
 __device__ __forceinline__ void dg_lsq_seq_par(SC *s, dg_pt *stage, int len, int tid, int nthr, int rows2, double *A1o, double *A2o, Sync sync,
                                                double *ltab = (double *)0 /* optional LDS scratch, 640 doubles, used by wave 0 only */)
 {
-    double *aux = (double *)(stage + len);
+    /* [4][len] coordinates, then [2][len] centroid distances; stored and loaded as global memory (not flat) */
+    __attribute__((address_space(1))) double *aux = (__attribute__((address_space(1))) double *)(double *)(stage + len);
     const int lane = tid & 63; const bool w0 = tid < 64;
+    for (int j = tid; j < len; j += nthr) {                       /* one array per coordinate */
+        const dg_pt p = stage[j];
+        aux[j] = p.x1; aux[len + j] = p.y1; aux[2*len + j] = p.x2; aux[3*len + j] = p.y2;
+    }
+    sync();
     if (w0) {                                                     /* centroids: lane l in 0..3 sums coordinate l, in list order */
         double acc = 0;
-        const double *sp = (const double *)stage + (lane & 3);
-        int j = 0;
-        for (; j + 4 <= len; j += 4) { double v0 = sp[4*j], v1 = sp[4*j+4], v2 = sp[4*j+8], v3 = sp[4*j+12]; acc += v0; acc += v1; acc += v2; acc += v3; }
-        for (; j < len; j++) acc += sp[4*j];
+        if (lane < 4) acc = dg_seq_sum_from<1>((const double *)(aux + (size_t)lane * len), len, 0.0);
         if (len > 0) acc /= len;
         if (lane < 4) s->D[lane] = acc;
     }
@@ -273,19 +279,13 @@ __device__ __forceinline__ void dg_lsq_seq_par(SC *s, dg_pt *stage, int len, int
     const double m1x = s->D[0], m1y = s->D[1], m2x = s->D[2], m2y = s->D[3];
     for (int j = tid; j < len; j += nthr) {                       /* distances to the centroids, one point per thread */
         const dg_pt p = stage[j];
-        double a = p.x1 - m1x, b = p.y1 - m1y; aux[2*j] = sqrt(a*a + b*b);
-        a = p.x2 - m2x; b = p.y2 - m2y; aux[2*j+1] = sqrt(a*a + b*b);
+        double a = p.x1 - m1x, b = p.y1 - m1y; aux[j] = sqrt(a*a + b*b);
+        a = p.x2 - m2x; b = p.y2 - m2y; aux[len + j] = sqrt(a*a + b*b);
     }
     sync();
     if (w0) {                                                     /* mean distances: lane 0 image 1, lane 1 image 2 */
         double dsum = 0;
-        const double *sp = aux + (lane & 1);
-        int j = 0;
-        for (; j + 8 <= len; j += 8) {
-            double v0 = sp[2*j], v1 = sp[2*j+2], v2 = sp[2*j+4], v3 = sp[2*j+6], v4 = sp[2*j+8], v5 = sp[2*j+10], v6 = sp[2*j+12], v7 = sp[2*j+14];
-            dsum += v0; dsum += v1; dsum += v2; dsum += v3; dsum += v4; dsum += v5; dsum += v6; dsum += v7;
-        }
-        for (; j < len; j++) dsum += sp[2*j];
+        if (lane < 2) dsum = dg_seq_sum_from<1>((const double *)(aux + (size_t)lane * len), len, 0.0);
         double A1[3], A2[3];
         A1[0] = __shfl(dsum, 0, 64); A2[0] = __shfl(dsum, 1, 64);
         if (A1[0] != 0) A1[0] = len * sqrt(2.0) / A1[0];
@@ -399,7 +399,7 @@ __device__ __forceinline__ void dg_lsq_seq(dg_lsq_scratch *s, PtFn pt, const int
     __syncthreads();
     for (int j = tid; j < len; j += DG_T) stage[j] = pt(list[j]);
     __syncthreads();
-    if (2 * stage_cap >= 3 * len) dg_lsq_seq_par(s, stage, len, tid, DG_T, rows2, A1o, A2o, [] { __syncthreads(); }, ltab);
+    if (stage_cap >= 2 * len) dg_lsq_seq_par(s, stage, len, tid, DG_T, rows2, A1o, A2o, [] { __syncthreads(); }, ltab);
     else if (tid < 64) dg_lsq_seq_core(s, stage, len, tid, rows2, A1o, A2o);
     __syncthreads();
 }
