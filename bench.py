@@ -36,6 +36,9 @@ CONFIGS = {
                prm=dict(px_th=0.5, conf=0.9999, max_iters=100000, error_type=0, sym=True, laf=0.0, degen=True)),
     "c3": dict(which="H", n_corr=5000, dim=6, pairs=1024,
                prm=dict(px_th=2.0, conf=0.999, max_iters=50000, error_type=0, sym=True, laf=3.0, degen=True)),
+    # --config c5: the stress case of BASELINE configs[4]: 50000 correspondences, 10 % inliers, max_iters 200000, one pair
+    "c5": dict(which="F", n_corr=50000, dim=2, pairs=1, inlier_ratio=0.1,
+               prm=dict(px_th=0.5, conf=0.9999, max_iters=200000, error_type=0, sym=True, laf=0.0, degen=True)),
 }
 CFG = CONFIGS["c2"]
 N_CORR = CFG["n_corr"]
@@ -52,7 +55,7 @@ def make_pair(pid):
     """synthetic correspondences of global pair id `pid` (SURVEY 8d generators)"""
     from pydegensac_amd import synthetic
     if CFG["which"] == "F":
-        return synthetic.two_view_fundamental(N_CORR, 0.4, 0.1, seed=pid)[:2]
+        return synthetic.two_view_fundamental(N_CORR, CFG.get("inlier_ratio", 0.4), 0.1, seed=pid)[:2]
     return synthetic.homography_pairs(N_CORR, 0.4, 0.5, seed=pid, laf=True)[:2]
 
 
@@ -65,7 +68,7 @@ def cpu_call(mod, p1, p2, seed, **kw):
                                seed=seed, **kw)
 
 
-def cpu_baseline(budget_s=20.0, max_pairs=1024):
+def cpu_baseline(budget_s=20.0, max_pairs=1024, skip_first=True):
     """The reference CPU path timed on this box's host cores (1 thread): oracle/_ref (the unmodified
     reference build, kind 'reference') when it loads, else the restatement (kind 'port')."""
     from pydegensac_amd import synthetic, parallel
@@ -89,13 +92,13 @@ def cpu_baseline(budget_s=20.0, max_pairs=1024):
         else:
             _, _, st = cpu_call(port, p1, p2, seed)
         dt = time.perf_counter() - t
-        if p == 0:
+        if p == 0 and skip_first:
             continue                                   # first call warms LAPACK / page cache
         models += st["models"]; samples += st["samples"]; t_total += dt; n_done += 1
         if t_total > budget_s:
             break
     return {"value": models / t_total, "unit": "models/s", "cores": 1, "kind": kind,
-            "sample": f"{n_done} pairs of the workload (pair ids 1..{n_done}, same generator/seeds as the GPU batch), "
+            "sample": f"{n_done} pairs of the workload (pair ids {1 if skip_first else 0}..{n_done - (0 if skip_first else 1)}, same generator/seeds as the GPU batch), "
                       f"{t_total:.1f} s, {samples / t_total:.0f} samples/s, {t_total / n_done * 1e3:.1f} ms/pair"}
 
 
@@ -177,7 +180,15 @@ def parity_check(which, cfg_pairs, n_check, lo, models, masks, stats):
     from pydegensac_amd import parallel
     port.lib()
     P = models.shape[0]
-    pick = sorted(set(int(x) for x in np.linspace(0, P - 1, n_check)))
+    pick = set(int(x) for x in np.linspace(0, P - 1, n_check))
+    # pairs that were set aside and resumed (stats word 15, bit 8) must be among the checked ones: at least four, spread over the batch
+    aside = np.flatnonzero((stats[:, 15] >> 8) & 1)
+    n_aside_checked = 0
+    if len(aside):
+        extra = [int(aside[i]) for i in np.linspace(0, len(aside) - 1, min(4, len(aside))).astype(int)]
+        pick.update(extra)
+    pick = sorted(pick)
+    n_aside_checked = int(sum(int((stats[p, 15] >> 8) & 1) for p in pick))
     for p in pick:
         p1, p2 = make_pair(lo + p)
         Mo, mo, so = cpu_call(port, p1, p2, parallel.pair_seed(lo + p))
@@ -190,7 +201,7 @@ def parity_check(which, cfg_pairs, n_check, lo, models, masks, stats):
         na, nb = np.linalg.norm(a), np.linalg.norm(b)
         if (na == 0) != (nb == 0) or (nb and np.linalg.norm(a / na - b / nb) > 1e-6):
             raise SystemExit(f"parity check failed: pair {lo + p} model differs")
-    return len(pick)
+    return len(pick), n_aside_checked
 
 
 def single_call_ms(reps=7):
@@ -210,35 +221,13 @@ def single_call_ms(reps=7):
             "note": "host-pointer API, PCIe staging included, 1 pair = 1 workgroup; never used as `value`"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
-    ap.add_argument("--pairs-per-gpu", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--parity-pairs", type=int, default=16, help="pairs of the timed batch checked against the oracle afterwards")
-    args = ap.parse_args()
-    set_config(args.config)
-    if args.pairs_per_gpu <= 0:
-        args.pairs_per_gpu = PAIRS_PER_GPU
-
+def measure(pairs_per_gpu, steps, warmup, parity_pairs, world, rank, local_rank, dev, always_collective=False):
+    """K timed steps of the hot path for the CURRENT config (set_config) on this rank's shard of `pairs_per_gpu * world`
+    pairs.  Returns a dict of raw results (rank-local stats, gathered stats, times); the caller formats the JSON line."""
     import torch
     import torch.distributed as dist
-    from pydegensac_amd import synthetic, parallel, _lib
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    P = args.pairs_per_gpu
+    from pydegensac_amd import parallel, _lib
+    P = pairs_per_gpu
     total_pairs = P * world
     lo, hi = parallel.shard_range(total_pairs, rank, world)
     # synthetic inputs of this rank's pairs (data seed = global pair id), staged to HBM once
@@ -269,19 +258,19 @@ def main():
         _lib.check(rc)
         if timed_events:
             timed_events[1].record(stream)
-        return parallel.gather_results(d_F, d_st, d_mask, N_CORR, total_pairs)
+        return parallel.gather_results(d_F, d_st, d_mask, N_CORR, total_pairs, always_collective=always_collective)
 
     def barrier():
-        if world > 1:
+        if world > 1 or (always_collective and dist.is_initialized()):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     barrier()
     kernel_ms = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         g = step(e); kernel_ms.append(e)
     barrier()
@@ -291,54 +280,124 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
     gm, gs, gmask = g
     st = gs.cpu().numpy()
-    models_step = int(st[:, 4].sum()); samples_step = int(st[:, 0].sum())
     kms = float(np.mean([a_.elapsed_time(b_) for a_, b_ in kernel_ms]))       # this rank's kernel, HIP events on its stream
     local_st = d_st.cpu().numpy()
     local_models = int(local_st[:, 4].sum())
     alg_bytes = local_models * 32.0 * N_CORR                                   # 32*N bytes per model scored
-    achieved = alg_bytes / (kms * 1e-3) / 1e9
     # spot check of THIS rank's timed batch against the CPU oracle (outside the timed region)
-    n_checked = 0
-    if args.parity_pairs > 0:
-        n_checked = parity_check(CFG["which"], P, args.parity_pairs, lo, d_F.cpu().numpy().reshape(P, 9),
-                                 d_mask.cpu().numpy().reshape(P, N_CORR), local_st)
+    n_checked = 0; n_aside_checked = 0
+    if parity_pairs > 0:
+        n_checked, n_aside_checked = parity_check(CFG["which"], P, parity_pairs, lo, d_F.cpu().numpy().reshape(P, 9),
+                                                  d_mask.cpu().numpy().reshape(P, N_CORR), local_st)
+    return dict(dt=dt, st=st, local_st=local_st, kms=kms, alg_bytes=alg_bytes, gmask=gmask, total_pairs=total_pairs, P=P,
+                n_checked=n_checked, n_aside_checked=n_aside_checked, homography=homography,
+                kernel=L.mi_degensac_kernel_name(int(homography)).decode())
+
+
+def secondary_line(name, pairs, steps, warmup, parity_pairs, cpu_budget_s, dev):
+    """One of the other BASELINE configs, measured the same way on one GPU and reduced to a few numbers (driver-visible: the
+    `secondary` object of the bench line).  Never raises: a failure is reported in place of the numbers."""
+    old = [k for k, v in CONFIGS.items() if v is CFG][0]
+    try:
+        set_config(name)
+        r = measure(pairs, steps, warmup, parity_pairs, 1, 0, dev.index or 0, dev)
+        models = int(r["st"][:, 4].sum())
+        ach = r["alg_bytes"] / (r["kms"] * 1e-3) / 1e9
+        out = {"workload": f"{name.upper()} x {pairs}", "ms_per_step": r["dt"] / steps * 1e3, "kernel_ms": r["kms"], "kernel": r["kernel"],
+               "models_per_s": models * steps / r["dt"], "pairs_per_s": pairs * steps / r["dt"], "models_per_pair": models / pairs,
+               "samples_per_pair": float(r["st"][:, 0].mean()), "threads": int(r["local_st"][0, 14]), "placement": int(r["local_st"][0, 15]) & 255,
+               "roofline_frac": ach / HBM_PEAK_GBS, "achieved_GBs": ach, "parity_checked": r["n_checked"]}
+        if cpu_budget_s > 0:
+            cb = cpu_baseline(budget_s=cpu_budget_s, max_pairs=max(2, min(pairs, 256)), skip_first=pairs > 1)
+            out["cpu_baseline"] = cb
+            out["gpu_over_cpu"] = out["models_per_s"] / cb["value"] if cb.get("value") else None
+        return out
+    except BaseException as e:                                     # incl. SystemExit from a failed parity check
+        return {"workload": name, "error": str(e)[:300]}
+    finally:
+        set_config(old)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--pairs-per-gpu", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short C2 x 512 / C3 / C5 measurements of the `secondary` object")
+    ap.add_argument("--parity-pairs", type=int, default=16, help="pairs of the timed batch checked against the oracle afterwards")
+    ap.add_argument("--dist-always", action="store_true",
+                    help="initialise the RCCL process group and run the result all-gather even with one rank (tests the N > 1 code path on one GPU)")
+    args = ap.parse_args()
+    set_config(args.config)
+    if args.pairs_per_gpu <= 0:
+        args.pairs_per_gpu = PAIRS_PER_GPU
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_dist = world > 1 or (args.dist_always and "MASTER_ADDR" in os.environ)
+    if use_dist:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    P = args.pairs_per_gpu
+    r = measure(P, args.steps, args.warmup, args.parity_pairs, world, rank, local_rank, dev, always_collective=use_dist)
+    dt, st, local_st, kms, alg_bytes, gmask, total_pairs = r["dt"], r["st"], r["local_st"], r["kms"], r["alg_bytes"], r["gmask"], r["total_pairs"]
+    homography = r["homography"]
+    models_step = int(st[:, 4].sum()); samples_step = int(st[:, 0].sum())
+    achieved = alg_bytes / (kms * 1e-3) / 1e9
 
     if rank == 0:
         inl = gmask.sum(dim=1).cpu().numpy()
         ticks = st[:, 13].astype(np.float64) / 100e6                           # 100 MHz device wall clock
         tbest = st[:, 12].astype(np.float64) / 100e6
+        wl = {"c2": (f"C2 x {P} pairs per GPU (C4 is a batch of 4096 such pairs): findFundamentalMatrix, "
+                     f"{N_CORR} correspondences, 40% inliers, sigma 0.1 px, px_th 0.5, conf 0.9999, max_iters 100000, "
+                     "sampson error, symmetric check on, degeneracy check on"),
+              "c3": (f"C3 x {P} pairs per GPU: findHomography, {N_CORR} correspondences with LAFs, 40% inliers, sigma 0.5 px, "
+                     "px_th 2, conf 0.999, max_iters 50000, sampson error, laf_consistensy_coef 3, symmetric check on, LO on"),
+              "c5": (f"C5 x {P} pairs per GPU: findFundamentalMatrix, {N_CORR} correspondences, 10% inliers, sigma 0.1 px, px_th 0.5, "
+                     "conf 0.9999, max_iters 200000, sampson error, symmetric check on, degeneracy check on")}[args.config]
         out = {
-            "metric": ("models/sec, findFundamentalMatrix @2000 corrs (LO-RANSAC + DEGENSAC, batched pairs)" if not homography else
-                       "models/sec, findHomography @5000 corrs with LAFs (LO-RANSAC, LAF + symmetric checks, batched pairs)"),
+            "metric": ("models/sec, findFundamentalMatrix @2000 corrs (LO-RANSAC + DEGENSAC, batched pairs)" if args.config == "c2" else
+                       "models/sec, findHomography @5000 corrs with LAFs (LO-RANSAC, LAF + symmetric checks, batched pairs)" if homography else
+                       "models/sec, findFundamentalMatrix @50000 corrs (LO-RANSAC + DEGENSAC)"),
             "value": models_step * args.steps / dt,
             "unit": "models/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"C2 x {P} pairs per GPU (C4 is a batch of 4096 such pairs): findFundamentalMatrix, "
-                                    f"{N_CORR} correspondences, 40% inliers, sigma 0.1 px, px_th 0.5, conf 0.9999, max_iters 100000, "
-                                    "sampson error, symmetric check on, degeneracy check on") if not homography else
-                                   (f"C3 x {P} pairs per GPU: findHomography, {N_CORR} correspondences with LAFs, 40% inliers, sigma 0.5 px, "
-                                    "px_th 2, conf 0.999, max_iters 50000, sampson error, laf_consistensy_coef 3, symmetric check on, LO on"),
+            "config": {"workload": wl,
                        "pairs_total": total_pairs, "pairs_per_gpu": P, "n_corr": N_CORR,
-                       "parallelism": f"pair-sharded x{world}, RCCL all-gather of per-pair results"},
+                       "parallelism": f"pair-sharded x{world}, RCCL all-gather of per-pair results",
+                       "collective": "nccl (RCCL) all_gather_into_tensor" if use_dist else "none (one rank)"},
             "samples_per_s": samples_step * args.steps / dt,
             "pairs_per_s": total_pairs * args.steps / dt,
             "models_per_pair": models_step / total_pairs,
             "mean_inliers": float(inl.mean()),
-            "time_to_best_ms": {"mean": float(tbest.mean() * 1e3), "p50": float(np.median(tbest) * 1e3), "max": float(tbest.max() * 1e3)},
+            "time_to_best_ms": {"mean": float(tbest.mean() * 1e3), "p50": float(np.median(tbest) * 1e3), "max": float(tbest.max() * 1e3),
+                                "note": "from a pair's start to the commit of its returned model, on the device clock; includes the time a pair waits while it is set aside"},
             "pair_latency_ms": {"mean": float(ticks.mean() * 1e3), "p50": float(np.median(ticks) * 1e3), "max": float(ticks.max() * 1e3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.config, P),
-                         "kernel": L.mi_degensac_kernel_name(int(homography)).decode(), "kernel_ms": kms,
+                         "kernel": r["kernel"], "kernel_ms": kms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "achieved = algorithmic bytes (models scored x 32 B x N, SURVEY 8d) / kernel time; the point set is "
                                  "LDS/L2-resident, so `traffic` (HBM bytes per launch from the committed PMC passes, profiles/) is far "
                                  "below it: inputs once, then model tables, lists and scratch"},
-            "parity_checked": n_checked,
+            "parity_checked": r["n_checked"], "parity_checked_set_aside": r["n_aside_checked"],
             "kernel_variant": {"threads": int(local_st[0, 14]), "placement": int(local_st[0, 15]) & 255},
-            "pairs_set_aside": int((local_st[:, 15] >> 8).sum()),        # long pairs written back and resumed after the last start
+            "pairs_set_aside": int((local_st[:, 15] >> 8).sum()),        # pairs written back after the discovery round and resumed by priority (DESIGN.md 3)
         }
         if world == 1:
             out["single_call_ms"] = single_call_ms()
@@ -348,8 +407,16 @@ def main():
             allc = cpu_baseline_all_cores(args.config)
             if allc is not None:
                 out["cpu_baseline_all_cores"] = allc
+        if world == 1 and not args.no_secondary and args.config == "c2":
+            # the other BASELINE configurations, short runs inside the same driver-timed process (about a minute together)
+            sec = {}
+            if P != 512:
+                sec["c2_512_pairs"] = secondary_line("c2", 512, 3, 1, 4, 0.0, dev)           # C4's own share of one GPU (8-GPU run of 4096 pairs)
+            sec["c3"] = secondary_line("c3", 1024, 3, 1, 4, 0.0 if args.no_cpu_baseline else 4.0, dev)
+            sec["c5"] = secondary_line("c5", 1, 2, 1, 1, 0.0 if args.no_cpu_baseline else 1.0, dev)
+            out["secondary"] = sec
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

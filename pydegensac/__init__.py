@@ -6,6 +6,6 @@ against the reference — e.g. examples/simple-example.py:18-37 — runs unchang
 """
 from pydegensac_amd import (findHomography, findFundamentalMatrix, convert_cv2_kpts_to_xyA,   # noqa: F401
                             findHomography_, findFundamentalMatrix_)
-from pydegensac_amd import api as utils                                                        # noqa: F401
+from . import utils, pydegensac                                                               # noqa: F401  (real submodules, as in the reference)
 
 __version__ = "0.1.2+mi355x"            # the reference's version (src/pydegensac/__init__.py:1) + local tag

@@ -26,7 +26,7 @@ def pair_seeds(lo, hi, base_seed=1):
     return np.array([pair_seed(p, base_seed) for p in range(lo, hi)], dtype=np.uint32)
 
 
-def gather_results(models, stats, masks, n_per_pair, n_pairs_total, group=None):
+def gather_results(models, stats, masks, n_per_pair, n_pairs_total, group=None, always_collective=False):
     """All-gather the per-pair results of every rank (torch tensors on the rank's device).
 
     models [P_r, 9] float64, stats [P_r, 16] int32, masks [sum of the rank's pair sizes] uint8.
@@ -35,6 +35,7 @@ def gather_results(models, stats, masks, n_per_pair, n_pairs_total, group=None):
     maximum for the collective).  Returns (models [P,9], stats [P,16], masks) in global pair order, where masks is
     [P, n] for equal sizes and a flat [sum of all sizes] uint8 tensor for a ragged batch (pair p at
     offsets[p]:offsets[p+1] with offsets = cumsum of the sizes).
+    always_collective: run the all-gather even in a one-rank group (exercises the RCCL path on a single GPU).
     """
     import torch
     import torch.distributed as dist
@@ -43,14 +44,14 @@ def gather_results(models, stats, masks, n_per_pair, n_pairs_total, group=None):
     counts = np.asarray(n_per_pair, dtype=np.int64).ravel() if ragged else np.full(n_pairs_total, int(n_per_pair), np.int64)
     if len(counts) != n_pairs_total:
         raise ValueError("need one size per pair")
-    if world == 1:
+    if world == 1 and not (always_collective and dist.is_initialized()):
         return models, stats, (masks if ragged else masks.view(-1, int(n_per_pair)))
     dev = models.device
     rng = [shard_range(n_pairs_total, r, world) for r in range(world)]
     mbytes = [int(counts[lo:hi].sum()) for lo, hi in rng]
     rec = [(hi - lo) * 136 + mb for (lo, hi), mb in zip(rng, mbytes)]      # 72 B model + 64 B stats per pair, then the masks
     cap = max(rec)
-    rank = dist.get_rank(group)
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
     p_r = models.shape[0]
     if p_r != rng[rank][1] - rng[rank][0] or masks.numel() != mbytes[rank]:
         raise ValueError("this rank's tensors do not match its shard of the batch")

@@ -103,6 +103,9 @@ def knn_match_tensors(desc1, desc2):
     else:
         raise ValueError("float32 descriptors (L2) or uint8 descriptors with dim % 4 == 0 (Hamming)")
     a = desc1.contiguous(); b = desc2.contiguous(); dev = a.device
+    # the kernel reads descriptor rows as 32-bit words: a contiguous view into a packed buffer may start at any byte
+    if a.data_ptr() % 4: a = a.clone()
+    if b.data_ptr() % 4: b = b.clone()
     n1, n2, dim = a.shape[0], b.shape[0], a.shape[1]
     idx = torch.full((n1, 2), -1, dtype=torch.int32, device=dev)
     dist = torch.full((n1, 2), float("inf"), dtype=torch.float32, device=dev)

@@ -59,3 +59,22 @@ def test_error_codes():
         pd.findHomographyBatch([p1[:3]], [p2[:3]], seeds=[1])                  # n < 4 (bindings.cpp:35)
     with pytest.raises(_lib.MiDegensacError):
         pd.findFundamentalMatrix(p1, p2, seed=1, device=63)                    # no such device: no CPU fallback
+
+
+def test_bench_under_torchrun_with_the_rccl_process_group():
+    """bench.py as the driver launches it for N > 1 (python -m torch.distributed.run, backend "nccl" = RCCL), with one rank
+    on this box's one GPU and --dist-always: process-group init on the device, the barrier, all_gather_into_tensor of the
+    packed per-pair results on device tensors and the rank-0 JSON line all execute on hardware.  (No multi-GPU box is
+    available to this suite; the world-size-2 logic runs under gloo in tests/test_host_cpu.py.)"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--pairs-per-gpu", "96", "--no-cpu-baseline", "--no-secondary", "--parity-pairs", "4", "--dist-always"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["parity_checked"] >= 4
+    assert j["config"]["collective"].startswith("nccl")

@@ -1,7 +1,7 @@
 """GPU: the per-LO residual dump (include/mi_degensac.h MI_DEGENSAC_RESIDS_M) against the dump the UNMODIFIED
 reference fills and frees (oracle/_ref, captured by ref_shim.c).  Row 0 of the first run (a minimal-sample model) is
 bit-exact; the other rows are residuals of least-squares models (also row 0 of a run started from the DEGENSAC branch), which agree with the reference's to the last bits of its LAPACK
-build's dsyev (models within 1e-9), so they are compared to 2e-5 relative; rows the reference memsets keep
+build's dsyev (models within 1e-9), so they are compared to 3e-6 / sqrt(residual) relative, at most 2e-5 (see _check); rows the reference memsets keep
 its byte pattern; asking for the dump changes nothing else."""
 import numpy as np
 import pytest
@@ -23,7 +23,16 @@ def _check(res, ref, lo_runs, n):
             if (row == 0 and r == 0) or not np.isfinite(b).all():
                 assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (r, row)
             else:
-                assert np.allclose(a, b, rtol=2e-5, atol=1e-9 * max(1.0, float(np.abs(b).max()))), (r, row, np.abs(a - b).max())
+                # Least-squares models agree with the reference's to the last bits of its LAPACK build (<= 1e-9 relative,
+                # DESIGN.md 6).  A residual is d = r^2 / den, and the model's 1e-9 moves r by a fixed absolute amount (r is a
+                # sum of terms ~1e3 .. 1e6 times a well-fitting r), so the relative change of d falls like 1 / sqrt(d):
+                # tolerance 3e-6 / sqrt(d) relative, capped at 2e-5 for residuals far below one squared pixel (3e-7 at
+                # d = 100, 3e-8 at d = 1e4).  A row taken from the wrong buffer (another iterate of the same LO) differs by
+                # 1e-3 .. 1 relative on most points and fails.
+                rt = np.minimum(2e-5, 3e-6 / np.sqrt(np.maximum(np.abs(b), 1e-300)))
+                err = np.abs(a - b)
+                bad = err > rt * np.abs(b) + 1e-12
+                assert not bad.any(), (r, row, int(bad.sum()), float((err / np.maximum(np.abs(b), 1e-300))[bad].max()), float(np.abs(b)[bad].min()))
     assert np.isnan(res[runs:]).all()
     return int(written.sum())
 

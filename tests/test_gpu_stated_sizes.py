@@ -83,7 +83,13 @@ def test_throughput_variant_batch_of_1100_against_oracle(oracle_port):
     F, m = pd.findFundamentalMatrixBatch(A, B, seeds=seeds)
     st = pd.last_stats()
     assert all(s_["threads"] == 256 for s_ in st)
-    pick = np.random.default_rng(11).choice(P, 64, replace=False)
+    pick = [int(x) for x in np.random.default_rng(11).choice(P, 64, replace=False)]
+    # the batch queues behind the resident grid, so pairs are set aside after the discovery round and resumed by priority:
+    # both kinds must be among the checked pairs (pairs that finish inside the discovery round are never set aside)
+    aside = [p for p in range(P) if st[p]["set_aside"]]
+    assert len(aside) >= 8, len(aside)
+    pick = sorted(set(pick + aside[:: max(1, len(aside) // 8)][:8]))
+    assert sum(st[p]["set_aside"] for p in pick) >= 8 and any(not st[p]["set_aside"] for p in pick)
     for p in pick:
         Fo, mo, so = oracle_port.find_fundamental(A[p], B[p], 0.5, 0.9999, 100000, seed=int(seeds[p]))
         assert (st[p]["samples"], st[p]["lo_runs"], st[p]["degen"]) == (so["samples"], so["lo_runs"], so["degen"]), p

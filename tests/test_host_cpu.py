@@ -182,3 +182,16 @@ def test_batch_api_validates_every_pair():
         pd.findHomographyBatch([np.zeros((20, 3))], [np.zeros((20, 3))], seeds=[1])
     with pytest.raises(ValueError):
         pd.findFundamentalMatrixBatch([a, a], [b, b], seeds=[1])                  # one seed per pair
+
+
+def test_alias_package_has_the_reference_submodules():
+    """the reference ships `pydegensac/utils.py` and the extension module `pydegensac.pydegensac` (src/pydegensac/__init__.py:1-4):
+    both import paths must work on the alias package"""
+    import importlib
+    u = importlib.import_module("pydegensac.utils")
+    ext = importlib.import_module("pydegensac.pydegensac")
+    from pydegensac.utils import convert_and_check, findHomography, findFundamentalMatrix, convert_cv2_kpts_to_xyA   # noqa: F401
+    import pydegensac_amd as pd
+    assert u.findHomography is pd.findHomography and ext.findFundamentalMatrix_ is pd.findFundamentalMatrix_
+    a = convert_and_check(np.arange(12).reshape(6, 2))
+    assert a.dtype == np.float64 and a.shape == (6, 2)
