@@ -2,6 +2,7 @@
 #ifndef DG_KERNEL_F_MAIN_H
 #define DG_KERNEL_F_MAIN_H
 #include "dg_kernel_f.h"
+#include "dg_score_tiles.h"
 
 /* Wave 0 (all 64 lanes): hash of an id list in global memory (hash.c:4-47 over the ints' bytes).  The list is
  * fetched 64 ids per load (one per lane) and the serial state chain runs on the scalar unit over readlane'd
@@ -394,133 +395,99 @@ __device__ __noinline__ void dg_sample_pool_seq(int cn, int n, int *pool, int (*
 }
 
 /* ---------------------------------------------------------------------------------------------- */
-/* Scoring phase of one wave: its groups of four consecutive models of the chunk (dg_group_owner), own register
- * allocation.  A model matters only if its MSAC gain beats tau = min(maxS.J, maxSs.J) strictly, and
- * J <= #points with residual < 9/4 th.  So models are first screened FOUR AT A TIME with a division-free count of a
- * superset of those points (one load of a correspondence serves four models: a quarter of the LDS / L2 traffic and of
- * the load latency per model); only survivors are scored exactly, the others get J = 0 (never an event in the commit,
- * so decisions are unchanged).  With tau < 4 nearly every model survives and the screen is skipped. */
-/* which wave scores group g (4 consecutive models).  With >= 6 waves the scoring waves 2.. share the groups round-robin
- * and the two sampler waves do not score (their stages are the critical path).  With 4 waves, wave 1 (seed chain
- * 33 us + draws 16 us per chunk: the longest stage) does not score, wave 0 (pool swaps, 45 us) takes 1 of every 16
- * groups (~7 us each), waves 2 and 3 eight and seven.  With 2 waves (128-thread workgroups: four resident pairs per CU) both waves score,
- * alternating groups, after their sampler stage. */
-__device__ __forceinline__ int dg_group_owner(int g)
-{
-#if DG_NW >= 6
-    return 2 + g % (DG_NW - 2);
-#elif DG_NW >= 4
-    return (int)((0x2032323232323232ull >> (4 * (g & 15))) & 15ull);   /* g & 15 = 0..15 -> 2,3,2,3,...,2,3,0,2 */
-#else
-    return g & 1;                                                      /* two waves: both score once their sampler stage is done */
-#endif
-}
-
-/* |epipolar residual| of (x1, y1, x2, y2) under the fp32 model f_ with 4 nested FMAs (level-1 screen) */
-#define DG_R32(f_) fabsf(__builtin_fmaf(x1, __builtin_fmaf((f_)[0], x2, __builtin_fmaf((f_)[3], y2, (f_)[6])), \
-                         __builtin_fmaf(y1, __builtin_fmaf((f_)[1], x2, __builtin_fmaf((f_)[4], y2, (f_)[7])), \
-                                        __builtin_fmaf((f_)[2], x2, __builtin_fmaf((f_)[5], y2, (f_)[8])))))
-
-/* Level-1 screen of one model (see dg_score_chunk_F): fp32 copy of the coefficients and the threshold on |r32| below
- * which a point may still be inside the 9/4 th band; +inf (everything passes) when the bound is not a normal fp32 number */
-__device__ __forceinline__ float dg_l1_setup(int kind, const double *f, const double *ext, double t94b, float *Ff)
-{
-    const double X1 = ext[0], Y1 = ext[1], X2 = ext[2], Y2 = ext[3];
-    const double u1 = fabs(f[0]) * X2 + fabs(f[3]) * Y2 + fabs(f[6]), u2 = fabs(f[1]) * X2 + fabs(f[4]) * Y2 + fabs(f[7]);
-    const double u3 = fabs(f[0]) * X1 + fabs(f[1]) * Y1 + fabs(f[2]), u4 = fabs(f[3]) * X1 + fabs(f[4]) * Y1 + fabs(f[5]);
-    const double uw = fabs(f[2]) * X2 + fabs(f[5]) * Y2 + fabs(f[8]);
-    const double am = u1*u1 + u2*u2, bm = u3*u3 + u4*u4;
-    const double lim = t94b * (1.0 + 1e-9) * (kind == DG_K_FDS ? am + bm : fmin(am, bm));
-    const double M = X1 * u1 + Y1 * u2 + uw;
-    const double tg = sqrt(lim) + M * (32.0 / 16777216.0);
-#pragma unroll
-    for (int j = 0; j < 9; j++) Ff[j] = (float)f[j];
-    /* unusable bound (overflow / underflow / NaN): make the level pass everything for this model */
-    return (tg > 1e-30 && tg < 1e30 && M < 1e30) ? (float)tg * (1.0f + 1.1920929e-7f) : __builtin_inff();
-}
-
+/* Scoring phase of one wave (own register allocation).  The chunk's models are dealt round-robin to the NS scoring
+ * waves (wave ws takes mi = ws, ws + NS, ...); lane j of the wave owns the wave's j-th model of the current batch of up
+ * to 64.  Screens (dg_score_tiles.h): level 1 when tau >= 64, level 2 when tau >= 4, each tile-major over the whole
+ * point set with the models' coefficients in this wave's LDS table `tab`; models whose count does not exceed tau get
+ * J = 0 (never an event in the commit, so decisions are unchanged); the survivors are scored exactly, one wave per
+ * model: I, and J as the reference's sequential sum (dg_seq_sum): the wave stores the nonzero terms in point order, lane 0
+ * adds them one after the other. */
 template <int LDSPTS>
 __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const double *gmodels, const unsigned short *mslot,
-                                             int Mtot, int wave, int kind, double th, double tauJ, const double *ext /* LDS[4] */,
+                                             int Mtot, int ws, int NS, int kind, double th, double tauJ, const double *ext /* LDS[4] */,
+                                             char *tab /* LDS, this wave's */, int tab_bytes,
                                              double *jbuf /* this wave's scratch, >= n doubles */, unsigned *res_I, double *res_J, int lane)
 {
+    /* workgroup-uniform arguments arrive in vector registers (separate function): make the loop control scalar again */
+    n = __builtin_amdgcn_readfirstlane(n); Mtot = __builtin_amdgcn_readfirstlane(Mtot); ws = __builtin_amdgcn_readfirstlane(ws);
+    NS = __builtin_amdgcn_readfirstlane(NS); kind = __builtin_amdgcn_readfirstlane(kind); tab_bytes = __builtin_amdgcn_readfirstlane(tab_bytes);
     const double t94 = th * 9 / 4, t94b = t94 * (1.0 + 1e-6);
     const bool use_bound = th != 0 && kind != DG_K_EXFSYM && tauJ >= 4.0;
-    for (int grp = 0; 4 * grp < Mtot; grp++) {
-        if (dg_group_owner(grp) != wave) continue;
-        const int m0 = 4 * grp;
-        int mi[4], ng = 0; double F[4][9];
+    const bool use_l1 = use_bound && tauJ >= 64.0;
+    const int nm = Mtot > ws ? (Mtot - ws + NS - 1) / NS : 0;
+    int B1 = tab_bytes / (DG_L1_ENTRY_FLOATS * (int)sizeof(float)), B2 = tab_bytes / (DG_L2_ENTRY_DOUBLES * (int)sizeof(double));
+    B1 = B1 > 64 ? 64 : B1; B2 = B2 > 64 ? 64 : B2;
+    float *tab_f = (float *)tab; double *tab_d = (double *)tab;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int j0 = 0; j0 < nm; j0 += 64) {
+        const int nb = nm - j0 < 64 ? nm - j0 : 64;
+        const bool have = lane < nb;
+        const int mi = ws + (j0 + lane) * NS;                       /* this lane's model (have) */
+        double F[9];
+        {
+            const double *gp = gmodels + (size_t)mslot[have ? mi : ws] * 9;
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const int idx = m0 + g;
-            mi[g] = idx < Mtot ? idx : m0;                       /* pad the last group with its first model */
-            if (idx < Mtot) ng = g + 1;
-            const double *gp = gmodels + (size_t)mslot[mi[g]] * 9;
-#pragma unroll
-            for (int j = 0; j < 9; j++) F[g][j] = gp[j];
+            for (int j = 0; j < 9; j++) F[j] = gp[j];
         }
-        unsigned surv = (1u << ng) - 1u;
-        if (use_bound && tauJ >= 64.0) {
-            /* level 1: only the epipolar residual r.  The Sampson denominator is at most Dmax = sum of the squared
-             * bounds |F00| X + |F10| Y + |F20| ... over the pair's coordinate extents, so {d < t} is inside
-             * {r^2 < t Dmax}; for the symmetric metric d = r^2 (a + b) / (a b) >= r^2 / min(a, b).  Random models have a
-             * few percent of the points even inside this looser band, far below tau. */
-            /* The residual is evaluated in SINGLE precision (half the issue cost of fp64 on this part) against a
-             * threshold widened by a rigorous rounding bound: with u = 2^-24, inputs rounded to fp32 and 4 nested FMAs,
-             * |r32 - r| <= 8 u M,  M = X1 u1 + Y1 u2 + (|F02| X2 + |F12| Y2 + |F22|) >= sum of |terms|;  32 u M is used.
-             * So every point with r^2 < t Dmax has |r32| < sqrt(t Dmax) + 32 u M.  Models whose bound is not a normal
-             * fp32 number skip this level. */
-            float thr[4], Ff[4][9];
+        unsigned long long surv = __ballot(have);
+        if (use_l1) {
+            unsigned C1 = 0;
+            for (int s0 = 0; s0 < nb; s0 += B1) {
+                const int sb = nb - s0 < B1 ? nb - s0 : B1;
+                const bool in = lane >= s0 && lane < s0 + sb;
+                if (in) {
+                    float Ff[9]; const float thr = dg_l1_setup(kind, F, ext, t94b, Ff);
+                    float *e = tab_f + (lane - s0) * DG_L1_ENTRY_FLOATS;
 #pragma unroll
-            for (int g = 0; g < 4; g++) thr[g] = dg_l1_setup(kind, F[g], ext, t94b, Ff[g]);
-            unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-            for (int p0 = lane; p0 < n; p0 += 64 * DG_PU) {
-                dg_pt qq[DG_PU];
-#pragma unroll
-                for (int u = 0; u < DG_PU; u++) { const int p = p0 + 64 * u; qq[u] = dg_ldpt<LDSPTS>(P, p < n ? p : p0); }
-#pragma unroll
-                for (int u = 0; u < DG_PU; u++) {
-                    const unsigned on = p0 + 64 * u < n ? 1u : 0u;
-                    const float x1 = (float)qq[u].x1, y1 = (float)qq[u].y1, x2 = (float)qq[u].x2, y2 = (float)qq[u].y2;
-                    c0 += !(DG_R32(Ff[0]) >= thr[0]) ? on : 0u; c1 += !(DG_R32(Ff[1]) >= thr[1]) ? on : 0u;
-                    c2 += !(DG_R32(Ff[2]) >= thr[2]) ? on : 0u; c3 += !(DG_R32(Ff[3]) >= thr[3]) ? on : 0u;
+                    for (int j = 0; j < 9; j++) e[j] = Ff[j];
+                    e[9] = thr; e[10] = 0.f; e[11] = 0.f;
                 }
+                DG_WSYNC();
+                const unsigned cq = dg_l1_tile_counts<LDSPTS>(P, 0, n, tab_f, sb, lane);      /* lane r < sb: model s0 + r */
+                const unsigned cs = (unsigned)__shfl((int)cq, (lane - s0) & 63, 64);
+                if (in) C1 = cs;
+                DG_WSYNC();
             }
-            const unsigned C1[4] = {dg_wave_sum_u(c0), dg_wave_sum_u(c1), dg_wave_sum_u(c2), dg_wave_sum_u(c3)};
-#pragma unroll
-            for (int g = 0; g < 4; g++)
-                if (g < ng && !((double)C1[g] > tauJ)) { surv &= ~(1u << g); if (lane == 0) { res_I[mi[g]] = 0; res_J[mi[g]] = 0; } }
+            const bool keep = have && ((double)C1 > tauJ);
+            if (have && !keep) { res_I[mi] = 0; res_J[mi] = 0; }
+            surv = __ballot(keep);
         }
         if (use_bound && surv) {
-            unsigned cb0 = 0, cb1 = 0, cb2 = 0, cb3 = 0;
-            for (int p0 = lane; p0 < n; p0 += 64 * DG_PU) {
-                dg_pt qq[DG_PU];
+            const bool mine = (surv >> lane) & 1ull;
+            const int myrank = __popcll(surv & lt_mask), ns = __popcll(surv);
+            unsigned C2 = 0;
+            for (int s0 = 0; s0 < ns; s0 += B2) {
+                const int sb = ns - s0 < B2 ? ns - s0 : B2;
+                const bool in = mine && myrank >= s0 && myrank < s0 + sb;
+                if (in) {
+                    double *e = tab_d + (myrank - s0) * DG_L2_ENTRY_DOUBLES;
 #pragma unroll
-                for (int u = 0; u < DG_PU; u++) { const int p = p0 + 64 * u; qq[u] = dg_ldpt<LDSPTS>(P, p < n ? p : p0); }
-#pragma unroll
-                for (int u = 0; u < DG_PU; u++) {
-                    const unsigned on = p0 + 64 * u < n ? 1u : 0u;
-                    cb0 += dg_Fbound(kind, F[0], qq[u], t94b) & on; cb1 += dg_Fbound(kind, F[1], qq[u], t94b) & on;
-                    cb2 += dg_Fbound(kind, F[2], qq[u], t94b) & on; cb3 += dg_Fbound(kind, F[3], qq[u], t94b) & on;
+                    for (int j = 0; j < 9; j++) e[j] = F[j];
+                    e[9] = 0.;
                 }
+                DG_WSYNC();
+                const unsigned cq = dg_l2_tile_counts<LDSPTS>(P, 0, n, tab_d, sb, kind, t94b, lane);   /* lane r < sb: survivor s0 + r */
+                const unsigned cs = (unsigned)__shfl((int)cq, (myrank - s0) & 63, 64);
+                if (in) C2 = cs;
+                DG_WSYNC();
             }
-            const unsigned CB[4] = {dg_wave_sum_u(cb0), dg_wave_sum_u(cb1), dg_wave_sum_u(cb2), dg_wave_sum_u(cb3)};
-#pragma unroll
-            for (int g = 0; g < 4; g++)
-                if (((surv >> g) & 1u) && !((double)CB[g] > tauJ)) { surv &= ~(1u << g); if (lane == 0) { res_I[mi[g]] = 0; res_J[mi[g]] = 0; } }
+            const bool keep = mine && ((double)C2 > tauJ);
+            if (mine && !keep) { res_I[mi] = 0; res_J[mi] = 0; }
+            surv = __ballot(keep);
         }
+        for (unsigned long long m = surv; m; m &= m - 1ull) {
+            const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+            const int mie = ws + (j0 + l) * NS;
+            double Fe[9];
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            if (!((surv >> g) & 1u)) continue;
-            /* exact score: I, and J as the reference's sequential sum (dg_seq_sum): the wave stores the nonzero terms in
-             * point order, lane 0 adds them one after the other */
+            for (int j = 0; j < 9; j++) Fe[j] = dg_readlane_d(F[j], l);
             unsigned cI = 0, cnt = 0;
             for (int base = 0; base < n; base += 64 * DG_PU) {
                 dg_pt qq[DG_PU]; double dd[DG_PU];
 #pragma unroll
                 for (int u = 0; u < DG_PU; u++) { const int p = base + 64 * u + lane; qq[u] = dg_ldpt<LDSPTS>(P, p < n ? p : 0); }
 #pragma unroll
-                for (int u = 0; u < DG_PU; u++) dd[u] = dg_Ferr(kind, F[g], qq[u]);
+                for (int u = 0; u < DG_PU; u++) dd[u] = dg_Ferr(kind, Fe, qq[u]);
 #pragma unroll
                 for (int u = 0; u < DG_PU; u++) {
                     const bool act = base + 64 * u + lane < n; const double d = dd[u];
@@ -528,16 +495,16 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
                     cI += (act && d <= th) ? 1u : 0u;
                     const bool nz = !(term == 0.0);
                     const unsigned long long bJ = __ballot(nz);
-                    if (nz) ((__attribute__((address_space(1))) double *)jbuf)[cnt + (unsigned)__popcll(bJ & ((1ull << lane) - 1ull))] = term;
+                    if (nz) ((__attribute__((address_space(1))) double *)jbuf)[cnt + (unsigned)__popcll(bJ & lt_mask)] = term;
                     cnt += (unsigned)__popcll(bJ);
                 }
             }
             DG_WSYNC();
             double J = 0.0; if (lane == 0) J = dg_seq_sum(jbuf, (int)cnt);
             J = __shfl(J, 0, 64);
-            unsigned I = dg_wave_sum_u(cI);
+            const unsigned I = dg_wave_sum_u(cI);
             DG_WSYNC();
-            if (lane == 0) { res_I[mi[g]] = I; res_J[mi[g]] = J; }
+            if (lane == 0) { res_I[mie] = I; res_J[mie] = J; }
         }
     }
 }
@@ -644,12 +611,124 @@ __device__ __noinline__ void dg_sample_pool_par(int cn, int n, int *vp_generic, 
     DG_DEVT(if (dbg && lane == 0) { long long ts3 = DG_CLK(); dbg[6] += ts3 - ts2; });
 }
 
+/* Sampler stage 2 for a pool in the HBM workspace (placement HBM: n too large for LDS, or many small workgroups per CU).
+ * The sequential form above pays one memory round trip per SAMPLE (each swap reads a drawn slot and writes it back; only
+ * the tail slots live in registers).  Here the samples are taken in GROUPS of G = LANES / NDRAW, lane = (sample, draw):
+ * when no sample of the group is alias-flagged and no two lanes of the group hold the same drawn position, the swaps of
+ * the group touch pairwise distinct slots besides the tail slots, which form NDRAW independent chains
+ *     id(k, i) = pool[s(k, i)]        pool[s(k, i)] <- tail_i before sample k = id(k - 1, i)        tail_i <- id(k, i)
+ * so the group is ONE gather, lane shuffles and ONE scatter: one round trip per G samples.  A group with a collision
+ * (LANES is chosen so that LANES^2 / 2n is at most ~0.1; found with two small LDS hash tables) or an alias-flagged sample is run by the sequential form
+ * (dg_sample_pool_seq_range), whose result is the reference's by construction.  Same pool contents and drawn ids either way. */
+#define DG_AS1(T) __attribute__((address_space(1))) T
+#define DG_AS3(T) __attribute__((address_space(3))) T
+/* draws and the alias mask live in LDS, the pool in global memory: qualified pointers, so that the accesses are ds_ /
+ * global_ instructions and not flat ones (a flat access to LDS waits on both memory counters) */
+template <int NDRAW>
+__device__ __forceinline__ int dg_sample_pool_seq_range(int k_lo, int k_hi, int n, DG_AS1(int) *vp, DG_AS3(int) *draws /* [.][8] */,
+                                                        const DG_AS3(unsigned long long) *almask, int t, int lane)
+{
+    const bool act = lane < NDRAW;
+    for (int k = k_lo; k < k_hi; k++) {
+        if ((almask[k >> 6] >> (k & 63)) & 1ull) {
+            /* order-dependent sample: replay it sequentially on lane 0 */
+            if (act) vp[n - 1 - lane] = t;
+            __threadfence_block();
+            DG_WSYNC();
+            if (lane == 0) {
+                for (int i = 0; i < NDRAW; i++) { int si = draws[8 * k + i], j = n - 1 - i, q = vp[si]; vp[si] = vp[j]; vp[j] = q; draws[8 * k + i] = q; }
+            }
+            __threadfence_block();
+            DG_WSYNC();
+            if (act) t = vp[n - 1 - lane];
+        } else if (act) {
+            const int s0 = draws[8 * k + lane];
+            const int r0 = vp[s0];
+            vp[s0] = t; t = r0; draws[8 * k + lane] = r0;
+        }
+        __threadfence_block();
+    }
+    return t;
+}
+
+#define DG_PGT (DG_JBUF_LDS_BYTES >= 8192 ? 1024 : 512)   /* slots per collision table; the two tables live in the pool stage's LDS scratch */
+static_assert(2 * DG_PGT * sizeof(int) <= DG_JBUF_LDS_BYTES, "collision tables do not fit the pool-stage scratch");
+template <int NDRAW>
+__device__ __noinline__ void dg_sample_pool_grp(int cn, int n, int *vp_, int (*draws_)[8], const unsigned long long *almask_, int *pscratch /* LDS, 2 * DG_PGT ints */,
+                                                int lane, long long *dbg)
+{
+    long long ts2 = DG_CLK();
+    __builtin_amdgcn_s_setprio(3);
+    DG_AS3(unsigned) *tab = (DG_AS3(unsigned) *)(unsigned *)pscratch;
+    for (int q = lane; q < 2 * DG_PGT; q += 64) tab[q] = 0u;
+    DG_WSYNC();
+    DG_AS1(int) *vp = (DG_AS1(int) *)vp_;
+    DG_AS3(int) *draws = (DG_AS3(int) *)(int *)draws_;
+    const DG_AS3(unsigned long long) *almask_in = (const DG_AS3(unsigned long long) *)almask_;
+    cn = __builtin_amdgcn_readfirstlane(cn); n = __builtin_amdgcn_readfirstlane(n);
+    /* lanes per group: 64, 32 or 16, the largest with LANES^2 <= n / 5 (collision probability ~ LANES^2 / 2n <= 0.1) */
+    const int LANES = (long long)64 * 64 * 5 <= n ? 64 : ((long long)32 * 32 * 5 <= n ? 32 : 16);
+    const int G = LANES / NDRAW;
+    int t = lane < NDRAW ? vp[n - 1 - lane] : 0;                 /* tail slot i lives in lane i */
+    const int j = lane / NDRAW, i = lane - j * NDRAW;
+    for (int k0 = 0; k0 < cn; k0 += G) {
+        const int g = cn - k0 < G ? cn - k0 : G;
+        const bool active = j < g;
+        /* any alias-flagged sample in [k0, k0 + g)?  (g <= 16 flag bits starting at bit k0: at most two words of the mask) */
+        bool al;
+        {
+            const int w = k0 >> 6, b = k0 & 63;
+            unsigned long long win = almask_in[w] >> b;
+            if (b && (w + 1) * 64 < cn) win |= almask_in[w + 1] << (64 - b);
+            al = (win & ((1ull << g) - 1ull)) != 0ull;
+        }
+        const int s = active ? draws[8 * (k0 + j) + i] : -1 - lane;
+        const int r = active ? vp[s] : 0;                         /* one gather for the whole group (used when nothing collides) */
+        /* Do two lanes hold the same position?  Two LDS tables of DG_PGT slots, each slot = max over the lanes that hash to
+         * it of (position << 6 | lane) (LDS atomic max).  A lane that finds its own position in its slot knows the answer
+         * exactly (a duplicate iff the lane part is not its own: the lower lane of a duplicate pair always sees the higher
+         * one); a lane whose slot shows a larger foreign position in both tables cannot tell and reports a collision
+         * (conservative: the group then takes the sequential form; ~1 group in 50).  The slots are cleared afterwards. */
+        bool coll = false;
+        if (!al) {
+            const unsigned key = ((unsigned)s << 6) | (unsigned)lane;
+            const unsigned h1 = (unsigned)s % DG_PGT, h2 = ((unsigned)s * 40503u >> 7) % DG_PGT;
+            if (active) { __hip_atomic_fetch_max(tab + h1, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_max(tab + DG_PGT + h2, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            DG_WSYNC();
+            if (active) {
+                const unsigned e1 = tab[h1], e2 = tab[DG_PGT + h2];
+                if ((e1 >> 6) == (unsigned)s) coll = (e1 & 63u) != (unsigned)lane;
+                else if ((e2 >> 6) == (unsigned)s) coll = (e2 & 63u) != (unsigned)lane;
+                else coll = true;
+            }
+            DG_WSYNC();
+            if (active) { tab[h1] = 0u; tab[DG_PGT + h2] = 0u; }
+            DG_WSYNC();
+        }
+        if (al || __ballot(active && coll) != 0ull) {
+            t = dg_sample_pool_seq_range<NDRAW>(k0, k0 + g, n, vp, draws, almask_in, t, lane);
+            continue;
+        }
+        const int prev = __shfl(r, lane >= NDRAW ? lane - NDRAW : 0, 64), carry = __shfl(t, i, 64);
+        if (active) { vp[s] = j == 0 ? carry : prev; draws[8 * (k0 + j) + i] = r; }      /* one scatter */
+        const int tn = __shfl(r, (g - 1) * NDRAW + (lane < NDRAW ? lane : 0), 64);
+        if (lane < NDRAW) t = tn;
+        __threadfence_block();
+    }
+    if (lane < NDRAW) vp[n - 1 - lane] = t;
+    __threadfence_block();
+    DG_WSYNC();
+    __builtin_amdgcn_s_setprio(0);
+    DG_DEVT(if (dbg && lane == 0) { long long ts3 = DG_CLK(); dbg[6] += ts3 - ts2; });
+}
+
 /* stage 2 dispatch: the parallel form needs the pool in LDS with 16-bit ids and 2*cn*NDRAW ints of LDS scratch */
 template <int NDRAW, int LDSPTS>
 __device__ __forceinline__ void dg_sample_pool(int cn, int n, int *pool, int (*draws)[8], const unsigned long long *almask, int *pscratch /* LDS or 0 */,
                                                int lane, long long *dbg = 0)
 {
     if (LDSPTS != 0 && pscratch && n < 65536) dg_sample_pool_par<NDRAW>(cn, n, pool, draws, pscratch, lane, dbg);
+    else if (LDSPTS == 0 && pscratch) dg_sample_pool_grp<NDRAW>(cn, n, pool, draws, almask, pscratch, lane, dbg);
     else dg_sample_pool_seq<NDRAW, LDSPTS>(cn, n, pool, draws, almask, lane, dbg);
 }
 
@@ -943,10 +1022,18 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             } else if (wave == 1) {
                 if (cn2 > 0) { unsigned sd = dg_sample_draws<7>(seed, cn2, n, S->seeds3[nx2], S->draws3[nx2], S->alm3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }
             }
-            /* cooperative mode: the helpers score every group (a whole workgroup per group); the owner's waves only sample */
-            if (!(LDSPTS == 0 && coopK > 0) && (wave >= 2 || DG_NW < 6))
-                dg_score_chunk_F<LDSPTS>(P, n, c.gmodels, S->mslot, Mtot, wave, mk_full, th,
-                                         A.hist_out ? 0.0 : (maxS.J < maxSs.J ? maxS.J : maxSs.J), S->ext, (double *)(c.wstage + (size_t)wave * c.n_max), c.res_I, c.res_J, lane);
+            /* cooperative mode: the helpers score every group (a whole workgroup per group); the owner's waves only sample.
+             * Otherwise: waves 2.. score while waves 0 and 1 run their sampler stages (the critical path); with two
+             * waves both score once their stage is done.  Each scoring wave's table of model coefficients lives in its
+             * share of the least-squares scratch, which is idle during the main loop. */
+            {
+                const int NS = DG_NW >= 4 ? DG_NW - 2 : DG_NW, wsi = DG_NW >= 4 ? wave - 2 : wave;
+                const int capw = (int)((sizeof(dg_lsq_scratch) / NS) & ~(size_t)15);
+                if (!(LDSPTS == 0 && coopK > 0) && wsi >= 0)
+                    dg_score_chunk_F<LDSPTS>(P, n, c.gmodels, S->mslot, Mtot, wsi, NS, mk_full, th,
+                                             A.hist_out ? 0.0 : (maxS.J < maxSs.J ? maxS.J : maxSs.J), S->ext, (char *)&S->lsq + (size_t)wsi * capw, capw,
+                                             (double *)(c.wstage + (size_t)wave * c.n_max), c.res_I, c.res_J, lane);
+            }
         }
         c.n_fds += Mtot;   /* provisional: models past the termination point are subtracted below */
         if (LDSPTS == 0 && coopK > 0) {
