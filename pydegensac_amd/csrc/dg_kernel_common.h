@@ -53,27 +53,40 @@ struct dg_ws_layout {
     size_t off_stage;     /* dg_pt[2 * n_max]: staging of long least-squares lists + their per-coordinate arrays */
     size_t off_wave;      /* per-wave buffers of the wave-parallel sections: int[NW][n_max] + dg_pt[NW][n_max] */
     size_t off_res;       /* per-model results of a chunk: double J[768], unsigned I[768], int rf[256][5] */
-    size_t off_mslot;     /* cooperative mode: the chunk's compact model index -> slot table, unsigned short[3*DG_CHUNK] */
+    size_t off_mslot;     /* cooperative mode: the chunk's compact model index -> slot table, unsigned short[3*DG_CHUNK]; then the per-model
+                             screening counters unsigned[3*DG_CHUNK] and the survivor list unsigned short[3*DG_CHUNK] */
     size_t off_park;      /* parked-pair image: dg_f_shared + the dynamic LDS of the workgroup that set the pair aside (F driver) */
     size_t off_hjbuf;     /* cooperative mode: ordered MSAC terms of each helper workgroup, double[coop_k][n_max]        */
     int    n_max;
 };
 
 /* Cooperative large-n mode (placement HBM, fundamental matrix): every pair owner has coop_k helper workgroups that
- * score groups of the current chunk's models against the point set in the owner's HBM workspace.  One control block
- * per owner slot (zeroed by the host per launch): the owner publishes a chunk with an agent-scope release and a new
- * `gen`, helpers acquire, score their groups, release and count themselves in `done` (MI355X_MICROARCH.md, inter-workgroup
- * visibility: plain payload, lane-0 agent release / acquire, relaxed agent flag). */
+ * share the scoring of the current chunk's models against the point set in the owner's HBM workspace.  One control block
+ * per owner slot (zeroed by the host per launch).  The owner publishes a STAGE (plain parameter stores, one agent-scope
+ * release, then a new `gen`): stage 1 = tile-major screening counts (unit = a slice of the point set, every wave of the
+ * claiming workgroup runs its share of the models over it and adds its counts to the per-model device counters), stage 2
+ * = exact scoring of the survivors (unit = one model, scored by the whole claiming workgroup).  Units are CLAIMED from a
+ * generation-tagged counter with compare-and-swap, by the helpers and — once its sampler stages are done — by the owner
+ * itself, so a helper that is not resident (another launch holds its CU) simply never claims anything: nobody waits for
+ * a workgroup that has not been dispatched, and the grid does not have to be co-resident.  `tau_bits` is the pair's
+ * best-score bound (min of the two running best MSAC gains, as ordered bits of a non-negative double): only the owner
+ * raises it (atomic max; it never falls while a pair runs), every claiming workgroup reads it per unit, and a model whose
+ * screening count does not exceed it is dropped without exact scoring.  (MI355X_MICROARCH.md, inter-workgroup visibility:
+ * plain payload, lane-0 agent release / acquire, relaxed agent-scope flags on their own 128-byte line.) */
 struct dg_coop_cb {
-    /* line 0: the two flags, touched ONLY with agent-scope atomics (a plain access would leave a copy of the line in the
+    /* line 0: flags, touched ONLY with agent-scope atomics (a plain access would leave a copy of the line in the
      * toucher's XCD L2, which later polls would hit: per-XCD L2s are not coherent with each other) */
-    int gen;              /* chunk generation, -1 = no more work for this slot's helpers */
-    int done;             /* helpers that finished generation `gen` */
-    int fpad[30];
-    /* line 1: the chunk's parameters, plain stores before the owner's release, plain loads after the helpers' acquire */
-    int Mtot, n, kind, err;
-    double th, tau, ext[4];
-    double ppad[8];
+    int gen;              /* stage generation, -1 = no more work for this slot's helpers */
+    int done;             /* units of generation `gen` that are finished */
+    int next;             /* (gen & 0xfffff) << 12 | next unclaimed unit of that generation */
+    int fpad0;
+    unsigned long long tau_bits;   /* device-wide monotone best-score bound of the running pair */
+    int fpad[26];
+    /* line 1: the stage's parameters, plain stores before the owner's release, plain loads after a successful claim (the
+     * stage cannot end before every claimed unit is done, so they are stable while a claimer reads them) */
+    int stage, n_units, Mtot, n, kind, slice, use_l1, err;
+    double th, ext[4];
+    double ppad[7];
 };
 static_assert(sizeof(dg_coop_cb) == 256, "control block = two 128-byte lines");
 

@@ -800,6 +800,201 @@ __device__ __forceinline__ long long dg_park_take(const dg_args &A, long long *b
     return *bc;
 }
 
+/* ---- cooperative large-n mode (dg_coop_cb, dg_kernel_common.h) -----------------------------------------------------
+ * Views of the owner's workspace that every claiming workgroup (the owner itself or one of its helpers) needs. */
+struct dg_coop_ws {
+    const dg_pt *P; const double *gmodels; const unsigned short *gms;
+    unsigned *cnt; unsigned short *surv; unsigned *res_I; double *res_J;
+};
+__device__ __forceinline__ dg_coop_ws dg_coop_views(const dg_args &A, int slot)
+{
+    char *ws = A.ws + (size_t)slot * A.wl.stride;
+    dg_coop_ws v;
+    v.P = (const dg_pt *)(ws + A.wl.off_pts);
+    v.gmodels = (const double *)(ws + A.wl.off_models);
+    v.gms = (const unsigned short *)(ws + A.wl.off_mslot);
+    v.cnt = (unsigned *)(ws + A.wl.off_mslot + (size_t)3 * DG_CHUNK * sizeof(unsigned short));
+    v.surv = (unsigned short *)(v.cnt + 3 * DG_CHUNK);
+    v.res_J = (double *)(ws + A.wl.off_res); v.res_I = (unsigned *)(v.res_J + 3 * DG_CHUNK);
+    return v;
+}
+#define DG_COOP_GEN_MASK 0xfffff
+
+/* Owner, whole workgroup: publish a stage of `n_units` units (<= 4095).  Parameters first (plain), the claim counter and
+ * the unit count with agent-scope atomics, one release, then the generation. */
+__device__ __forceinline__ void dg_coop_publish(dg_coop_cb *cb, int &coop_gen, int stage, int n_units, int Mtot, int n, int kind, int slice, int use_l1,
+                                                double th, const double *ext /* LDS */, double tau)
+{
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
+        if (threadIdx.x == 0) {
+            cb->stage = stage; cb->n_units = n_units; cb->Mtot = Mtot; cb->n = n; cb->kind = kind; cb->slice = slice; cb->use_l1 = use_l1; cb->th = th;
+            for (int i = 0; i < 4; i++) cb->ext[i] = ext[i];
+            /* the device-wide best-score bound only rises while a pair runs (atomic max on the ordered bits of a double >= 0) */
+            __hip_atomic_fetch_max(&cb->tau_bits, (unsigned long long)__double_as_longlong(tau < 0 ? 0.0 : tau), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&cb->done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&cb->next, (int)((((unsigned)(coop_gen + 1) & DG_COOP_GEN_MASK) << 12) | (unsigned)n_units), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) __hip_atomic_store(&cb->gen, coop_gen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    coop_gen++;
+    __syncthreads();
+}
+
+/* Whole workgroup: claim a unit of generation G.  Returns its index, or -1 when that stage has no unclaimed unit left
+ * (or is already over).  The first wave does the compare-and-swap behind a scalar branch and broadcasts through LDS. */
+__device__ __forceinline__ int dg_coop_claim(dg_coop_cb *cb, int G, int *bc /* LDS */)
+{
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
+        int res = -1;
+        for (;;) {
+            const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&cb->next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const unsigned d = (((unsigned)v >> 12) - (unsigned)G) & DG_COOP_GEN_MASK;
+            if (d == 0) {
+                const int rem = v & 0xfff;
+                if (rem == 0) break;
+                int ok = 0;
+                if (threadIdx.x == 0) { int e = v; ok = __hip_atomic_compare_exchange_strong(&cb->next, &e, v - 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0; }
+                if (__builtin_amdgcn_readfirstlane(ok)) { res = rem - 1; break; }
+            } else if (d < (DG_COOP_GEN_MASK + 1) / 2) break;             /* a newer stage is up: this one is over */
+            else __builtin_amdgcn_s_sleep(1);                            /* the counter still carries an older tag: not visible yet */
+        }
+        *bc = res;                                                       /* every lane stores the same value */
+    }
+    __syncthreads();
+    return *bc;
+}
+
+/* Whole workgroup: one unit is finished (its results are in global memory) */
+__device__ __forceinline__ void dg_coop_unit_done(dg_coop_cb *cb)
+{
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(&cb->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+/* Stage 1, one unit = the point slice [lo, hi): every wave of the workgroup takes the models w, w + DG_NW, ... in batches
+ * that fit its LDS table, counts them tile-major over the slice (level 1 when the owner asked for it and tau >= 64, else
+ * level 2) and adds the counts to the per-model device counters.  A model whose device counter already exceeds the
+ * device-wide bound needs no more counting (it will be scored exactly whatever this slice adds). */
+template <int T>
+__device__ __forceinline__ void dg_coop_unit_screen(dg_f_shared *S, const dg_coop_ws &v, const dg_coop_cb *cb, int lo, int hi, double tau, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const int Mtot = cb->Mtot, kind = cb->kind;
+    const double th = cb->th, t94b = th * 9 / 4 * (1.0 + 1e-6);
+    const bool l1 = cb->use_l1 && tau >= 64.0;
+    const int capw = (int)((sizeof(dg_lsq_scratch) / DG_NW) & ~(size_t)15);
+    char *tab = (char *)&S->lsq + (size_t)wave * capw;
+    int B = l1 ? capw / (DG_L1_ENTRY_FLOATS * (int)sizeof(float)) : capw / (DG_L2_ENTRY_DOUBLES * (int)sizeof(double));
+    B = B > 64 ? 64 : B;
+    const int nm = Mtot > wave ? (Mtot - wave + DG_NW - 1) / DG_NW : 0;
+    for (int j0 = 0; j0 < nm; j0 += B) {
+        const int nb = nm - j0 < B ? nm - j0 : B;
+        const bool have = lane < nb;
+        const int mi = wave + (j0 + lane) * DG_NW;
+        bool need = have;
+        if (have) need = !((double)__hip_atomic_load(v.cnt + mi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > tau);
+        /* all lanes write an entry (the tile loop runs over nb entries); models that need no counting get a zero model */
+        double F[9];
+        {
+            const double *gp = v.gmodels + (size_t)v.gms[have ? mi : wave] * 9;
+#pragma unroll
+            for (int q = 0; q < 9; q++) F[q] = gp[q];
+        }
+        if (have) {
+            if (l1) {
+                float Ff[9]; const float thr = dg_l1_setup(kind, F, S->ext, t94b, Ff);
+                float *e = (float *)tab + lane * DG_L1_ENTRY_FLOATS;
+#pragma unroll
+                for (int q = 0; q < 9; q++) e[q] = Ff[q];
+                e[9] = thr; e[10] = 0.f; e[11] = 0.f;
+            } else {
+                double *e = (double *)tab + lane * DG_L2_ENTRY_DOUBLES;
+#pragma unroll
+                for (int q = 0; q < 9; q++) e[q] = F[q];
+                e[9] = 0.;
+            }
+        }
+        DG_WSYNC();
+        unsigned cq = 0;
+        if (__ballot(need) != 0ull)
+            cq = l1 ? dg_l1_tile_counts<0>(v.P, lo, hi, (const float *)tab, nb, lane) : dg_l2_tile_counts<0>(v.P, lo, hi, (const double *)tab, nb, kind, t94b, lane);
+        if (have && need && cq) __hip_atomic_fetch_add(v.cnt + mi, cq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        DG_WSYNC();
+    }
+}
+
+/* Stage 2, one unit = one model, scored exactly by the whole workgroup: I and the reference-order J through dg_pass */
+template <int T>
+__device__ __forceinline__ void dg_coop_unit_exact(dg_f_shared *S, const dg_coop_ws &v, const dg_coop_cb *cb, int mi, double *jbuf, int tid)
+{
+    const int n = cb->n, kind = cb->kind; const double th = cb->th;
+    double F[9];
+    const double *gp = v.gmodels + (size_t)v.gms[mi] * 9;
+#pragma unroll
+    for (int q = 0; q < 9; q++) F[q] = gp[q];
+    dg_pass_cfg cfg = dg_cfg0(n); cfg.wantJ = 1; cfg.thJ = th; cfg.jbuf = jbuf;
+    const dg_pt *P = v.P;
+    dg_pass_res r = dg_pass(&S->red, cfg, [&](int pid, int) { return dg_Ferr(kind, F, dg_ldpt<0>(P, pid)); }, tid);
+    if (tid == 0) { v.res_I[mi] = r.I; v.res_J[mi] = r.J; }
+}
+
+/* Whole workgroup (owner or helper): work on generation G until it has no unclaimed unit left */
+template <int T>
+__device__ __forceinline__ void dg_coop_work(dg_f_shared *S, const dg_coop_ws &v, dg_coop_cb *cb, int G, double *jbuf, int *bc /* LDS */, int tid)
+{
+    for (;;) {
+        const int u = dg_coop_claim(cb, G, bc);
+        if (u < 0) break;
+        /* the stage cannot end before this unit is done: its parameters are stable now */
+        const int stage = cb->stage, n = cb->n, slice = cb->slice;
+        if (tid < 4) S->ext[tid] = cb->ext[tid];
+        __syncthreads();
+        if (stage == 1) {
+            const double tau = __longlong_as_double((long long)__hip_atomic_load(&cb->tau_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const int lo = u * slice, hi = lo + slice < n ? lo + slice : n;
+            dg_coop_unit_screen<T>(S, v, cb, lo, hi, tau, tid);
+        } else {
+            dg_coop_unit_exact<T>(S, v, cb, (int)v.surv[u], jbuf, tid);
+        }
+        dg_coop_unit_done(cb);
+    }
+}
+
+/* helper h (1..coop_k) of owner slot `slot`: follows the owner's stage generations until the owner retires the slot */
+template <int T>
+__device__ __forceinline__ void dg_f_helper(const dg_args &A, dg_f_shared *S, const int slot, const int h, int *bc /* LDS */)
+{
+    const int tid = threadIdx.x;
+    const dg_coop_ws v = dg_coop_views(A, slot);
+    double *jbuf = (double *)(A.ws + (size_t)slot * A.wl.stride + A.wl.off_hjbuf) + (size_t)h * A.wl.n_max;
+    dg_coop_cb *cb = A.coop + slot;
+    const bool wave0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;      /* scalar: a spin loop under a per-lane `if` inside a loop with
+                                                                              workgroup barriers lets the compiler split the wave around them */
+    int last = 0;
+    for (;;) {
+        if (wave0) {
+            int g;
+            while ((g = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&cb->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) == last) __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            *bc = g;                                                         /* every lane stores the same value */
+        }
+        __syncthreads();
+        const int g = *bc;
+        __syncthreads();
+        if (g < 0) break;
+        last = g;
+        dg_coop_work<T>(S, v, cb, g, jbuf, bc, tid);
+    }
+}
+
 /* the whole driver for ONE pair, run by one workgroup on workspace `wsid` (a resident workgroup starts on the workspace
  * of its own index).  resume != 0: `wsid` holds the image of a pair that was set aside, continue it.
  * Returns -1 when the pair is finished, else the pair was set aside and the return value is the spare workspace the
@@ -885,6 +1080,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     finKind = mk_full; accepted = 0;
     perm[0] = 0; perm[1] = 1; perm[2] = 2; perm[3] = 3; p4 = 3; e4kind = mk_full; track = 1;
     done = 0;
+    /* a new pair on this slot: its best-score bound starts from zero (no stage of this pair has been published yet) */
+    if (coopK > 0 && tid == 0) __hip_atomic_store(&cb->tau_bits, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     /* srand(seed0); seed = rand() */
     if (tid == 0) { dg_srand(&S->rng, A.seeds[pair]); S->itmp[31] = dg_rand(&S->rng); }
@@ -992,22 +1189,24 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             __syncthreads();
         }
         const int Mtot = __builtin_amdgcn_readfirstlane((int)S->moff[DG_CHUNK]);
+        /* cooperative mode: the chunk's models are scored by whoever claims the units: the helpers of this slot at once,
+         * this workgroup after its sampler stages (dg_coop_cb) */
+        const double tau_c = A.hist_out ? 0.0 : (maxS.J < maxSs.J ? maxS.J : maxSs.J);
+        const bool coop_screen = th != 0 && tau_c >= 4.0;
+        int coop_units = 0;
         if (LDSPTS == 0 && coopK > 0) {
-            /* publish the chunk to the helpers: model table (already in the workspace), slot table, parameters */
+            const dg_coop_ws cv = dg_coop_views(A, slot);
             unsigned short *gms = (unsigned short *)(ws + A.wl.off_mslot);
-            for (int i = tid; i < Mtot; i += DG_T) gms[i] = S->mslot[i];
-            __syncthreads();
-            if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
-                if (tid == 0) {
-                    cb->Mtot = Mtot; cb->n = n; cb->kind = mk_full; cb->th = th; cb->tau = A.hist_out ? 0.0 : (maxS.J < maxSs.J ? maxS.J : maxSs.J);
-                    for (int i = 0; i < 4; i++) cb->ext[i] = S->ext[i];
-                    __hip_atomic_store(&cb->done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (tid == 0) __hip_atomic_store(&cb->gen, coop_gen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            coop_gen++;
+            for (int i = tid; i < Mtot; i += DG_T) { gms[i] = S->mslot[i]; cv.cnt[i] = 0u; if (!coop_screen) cv.surv[i] = (unsigned short)i; }
+            /* stage 1: screening counts over slices of the point set (about three slices per claiming workgroup, at least
+             * four tiles each); without a bound to beat, straight to stage 2 with every model */
+            int slice = (n + 3 * (coopK + 1) - 1) / (3 * (coopK + 1)); if (slice < 64 * DG_PU * 4) slice = 64 * DG_PU * 4;
+            slice = (slice + 64 * DG_PU - 1) / (64 * DG_PU) * (64 * DG_PU);
+            coop_units = coop_screen ? (n + slice - 1) / slice : Mtot;
+            /* level 2 only: the cooperative mode is for large point sets with few inliers, where random models have far
+             * more points inside the looser level-1 band than the bound to beat (C5: thousands against a few hundred), so
+             * level 1 would pass nearly every model on to exact scoring */
+            if (coop_units > 0) dg_coop_publish(cb, coop_gen, coop_screen ? 1 : 2, coop_units, Mtot, n, mk_full, slice, 0, th, S->ext, tau_c);
         }
 
         DG_PH(1);
@@ -1036,13 +1235,40 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             }
         }
         c.n_fds += Mtot;   /* provisional: models past the termination point are subtracted below */
-        if (LDSPTS == 0 && coopK > 0) {
-            /* wait for the helpers' groups of this chunk (their results are in c.res_I / c.res_J).  The WHOLE first wave
-             * polls, behind a scalar branch: a spin loop under a per-lane `if` would let the compiler re-order the lanes of
-             * that wave around the barriers of the enclosing loop (a wave then arrives at s_barrier twice) */
-            if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
-                while (__hip_atomic_load(&cb->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < coopK) __builtin_amdgcn_s_sleep(4);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (LDSPTS == 0 && coopK > 0 && coop_units > 0) {
+            /* the sampler stages of this workgroup are done: claim units like a helper, then wait for the units others
+             * claimed (each claimed unit belongs to a running workgroup, so the wait ends).  The WHOLE first wave polls,
+             * behind a scalar branch: a spin loop under a per-lane `if` would let the compiler re-order the lanes of that wave
+             * around the barriers of the enclosing loop (a wave then arrives at s_barrier twice). */
+            const dg_coop_ws cv = dg_coop_views(A, slot);
+            double *jb0 = (double *)(ws + A.wl.off_hjbuf);
+            int units = coop_units;
+            for (int st = coop_screen ? 1 : 2; st <= 2; st++) {
+                __syncthreads();
+                dg_coop_work<T>(S, cv, cb, coop_gen, jb0, &S->itmp[28], tid);
+                if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
+                    while (__hip_atomic_load(&cb->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < units) __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                if (st == 2) break;
+                /* survivors of the screen, in model order; the others get J = 0 (never an event in the commit) */
+                unsigned ns = 0;
+                for (int base = 0; base < Mtot; base += DG_T) {
+                    const int mi = base + tid; const bool have = mi < Mtot;
+                    const bool keep = have && ((double)__hip_atomic_load(cv.cnt + (have ? mi : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > tau_c);
+                    if (have && !keep) { c.res_I[mi] = 0; c.res_J[mi] = 0; }
+                    const unsigned long long bk = __ballot(keep);
+                    if (lane == 0) S->wave_cnt[wave] = (unsigned)__popcll(bk);
+                    __syncthreads();
+                    unsigned off = ns;
+                    for (int w = 0; w < DG_NW; w++) { if (w < wave) off += S->wave_cnt[w]; ns += S->wave_cnt[w]; }
+                    if (keep) cv.surv[off + (unsigned)__popcll(bk & ((1ull << lane) - 1ull))] = (unsigned short)mi;
+                    __syncthreads();
+                }
+                units = (int)ns;
+                if (units == 0) break;
+                dg_coop_publish(cb, coop_gen, 2, units, Mtot, n, mk_full, 0, 0, th, S->ext, tau_c);
             }
         }
         __syncthreads();
@@ -1346,121 +1572,6 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     return -1;
 }
 
-/* ---- cooperative large-n mode: a helper workgroup ---------------------------------------------------------
- * One group of four models scored by a WHOLE workgroup on the owner's HBM-resident point set: the two screening levels
- * of dg_score_chunk_F with the points split over all threads (counts are sums, so the split is free), then every
- * survivor through dg_pass, which yields I and the reference-order J exactly as the owner's own passes do. */
-template <int T>
-__device__ __forceinline__ void dg_score_group_wg(dg_f_shared *S, const dg_pt *P, int n, const double *gmodels, const unsigned short *gms,
-                                                  int Mtot, int grp, int kind, double th, double tauJ, const double *ext, double *jbuf,
-                                                  unsigned *res_I, double *res_J, int tid)
-{
-    const double t94 = th * 9 / 4, t94b = t94 * (1.0 + 1e-6);
-    const bool use_bound = th != 0 && kind != DG_K_EXFSYM && tauJ >= 4.0;
-    const int m0 = 4 * grp;
-    int mi[4], ng = 0; double F[4][9];
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        const int idx = m0 + g;
-        mi[g] = idx < Mtot ? idx : m0;
-        if (idx < Mtot) ng = g + 1;
-        const double *gp = gmodels + (size_t)gms[mi[g]] * 9;
-#pragma unroll
-        for (int j = 0; j < 9; j++) F[g][j] = gp[j];
-    }
-    unsigned surv = (1u << ng) - 1u;
-    if (use_bound && tauJ >= 64.0) {
-        float thr[4], Ff[4][9];
-#pragma unroll
-        for (int g = 0; g < 4; g++) thr[g] = dg_l1_setup(kind, F[g], ext, t94b, Ff[g]);
-        unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-        for (int p0 = tid; p0 < n; p0 += T * DG_PU) {
-            dg_pt qq[DG_PU];
-#pragma unroll
-            for (int u = 0; u < DG_PU; u++) { const int p = p0 + T * u; qq[u] = dg_ldpt<0>(P, p < n ? p : p0); }
-#pragma unroll
-            for (int u = 0; u < DG_PU; u++) {
-                const unsigned on = p0 + T * u < n ? 1u : 0u;
-                const float x1 = (float)qq[u].x1, y1 = (float)qq[u].y1, x2 = (float)qq[u].x2, y2 = (float)qq[u].y2;
-                c0 += !(DG_R32(Ff[0]) >= thr[0]) ? on : 0u; c1 += !(DG_R32(Ff[1]) >= thr[1]) ? on : 0u;
-                c2 += !(DG_R32(Ff[2]) >= thr[2]) ? on : 0u; c3 += !(DG_R32(Ff[3]) >= thr[3]) ? on : 0u;
-            }
-        }
-        const unsigned C1[4] = {dg_block_sum_u(&S->red, c0, tid), dg_block_sum_u(&S->red, c1, tid), dg_block_sum_u(&S->red, c2, tid), dg_block_sum_u(&S->red, c3, tid)};
-#pragma unroll
-        for (int g = 0; g < 4; g++) if (g < ng && !((double)C1[g] > tauJ)) surv &= ~(1u << g);
-    }
-    if (use_bound && surv) {
-        unsigned cb0 = 0, cb1 = 0, cb2 = 0, cb3 = 0;
-        for (int p0 = tid; p0 < n; p0 += T * DG_PU) {
-            dg_pt qq[DG_PU];
-#pragma unroll
-            for (int u = 0; u < DG_PU; u++) { const int p = p0 + T * u; qq[u] = dg_ldpt<0>(P, p < n ? p : p0); }
-#pragma unroll
-            for (int u = 0; u < DG_PU; u++) {
-                const unsigned on = p0 + T * u < n ? 1u : 0u;
-                cb0 += dg_Fbound(kind, F[0], qq[u], t94b) & on; cb1 += dg_Fbound(kind, F[1], qq[u], t94b) & on;
-                cb2 += dg_Fbound(kind, F[2], qq[u], t94b) & on; cb3 += dg_Fbound(kind, F[3], qq[u], t94b) & on;
-            }
-        }
-        const unsigned CB[4] = {dg_block_sum_u(&S->red, cb0, tid), dg_block_sum_u(&S->red, cb1, tid), dg_block_sum_u(&S->red, cb2, tid), dg_block_sum_u(&S->red, cb3, tid)};
-#pragma unroll
-        for (int g = 0; g < 4; g++) if (((surv >> g) & 1u) && !((double)CB[g] > tauJ)) surv &= ~(1u << g);
-    }
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        if (g >= ng) continue;
-        unsigned I = 0; double J = 0;
-        if ((surv >> g) & 1u) {
-            dg_pass_cfg cfg = dg_cfg0(n); cfg.wantJ = 1; cfg.thJ = th; cfg.jbuf = jbuf;
-            const double *Fg = F[g];
-            dg_pass_res r = dg_pass(&S->red, cfg, [&](int pid, int) { return dg_Ferr(kind, Fg, dg_ldpt<0>(P, pid)); }, tid);
-            I = r.I; J = r.J;
-        }
-        if (tid == 0) { res_I[mi[g]] = I; res_J[mi[g]] = J; }
-    }
-}
-
-/* helper h (1..coop_k) of owner slot `slot`: follows the owner's chunk generations until the owner retires the slot */
-template <int T>
-__device__ __forceinline__ void dg_f_helper(const dg_args &A, dg_f_shared *S, const int slot, const int h)
-{
-    const int tid = threadIdx.x;
-    char *ws = A.ws + (size_t)slot * A.wl.stride;
-    const dg_pt *P = (const dg_pt *)(ws + A.wl.off_pts);
-    const double *gmodels = (const double *)(ws + A.wl.off_models);
-    const unsigned short *gms = (const unsigned short *)(ws + A.wl.off_mslot);
-    double *res_J = (double *)(ws + A.wl.off_res); unsigned *res_I = (unsigned *)(res_J + 3 * DG_CHUNK);
-    double *jbuf = (double *)(ws + A.wl.off_hjbuf) + (size_t)(h - 1) * A.wl.n_max;
-    dg_coop_cb *cb = A.coop + slot;
-    const bool wave0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;      /* scalar: see the owner's wait */
-    int last = 0;
-    for (;;) {
-        if (wave0) {
-            int g;
-            while ((g = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&cb->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) == last) __builtin_amdgcn_s_sleep(4);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            S->itmp[0] = g;                                                  /* every lane stores the same value */
-        }
-        __syncthreads();
-        const int g = S->itmp[0];
-        __syncthreads();
-        if (g < 0) break;
-        last = g;
-        const int Mtot = cb->Mtot, n = cb->n, kind = cb->kind; const double th = cb->th, tau = cb->tau;
-        if (tid < 4) S->ext[tid] = cb->ext[tid];
-        __syncthreads();
-        for (int grp = h - 1; 4 * grp < Mtot; grp += A.coop_k)
-            dg_score_group_wg<T>(S, P, n, gmodels, gms, Mtot, grp, kind, th, tau, S->ext, jbuf, res_I, res_J, tid);
-        __syncthreads();
-        if (wave0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (tid == 0) __hip_atomic_fetch_add(&cb->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
 /* Persistent workgroups: the grid is at most the number of workgroups the device keeps resident, every workgroup owns
  * one scratch slot and pulls pairs from a device-wide ticket counter until the batch is exhausted (optionally in a
  * caller-given order, e.g. expected-cost descending). */
@@ -1492,7 +1603,7 @@ __global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_fundamental_kernel(dg_a
         /* cooperative large-n mode: block b = owner of slot b / (k+1) when b % (k+1) == 0, else one of its helpers */
         slot = (int)blockIdx.x / (As.coop_k + 1);
         const int h = (int)blockIdx.x % (As.coop_k + 1);
-        if (h != 0) { dg_f_helper<T>(As, &Sh, slot, h); return; }
+        if (h != 0) { dg_f_helper<T>(As, &Sh, slot, h, &next_pair); return; }
     }
     int wsid = slot;
     for (;;) {
