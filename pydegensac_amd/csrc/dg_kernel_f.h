@@ -37,6 +37,20 @@ struct dg_lo_ahead { dg_rng before, after; int pos[32], val[32]; double F[9]; };
 /* LDS scratch of the long-list least squares (640 doubles): the per-wave solver scratch, idle while a workgroup fit runs */
 #define DG_LSQ_LTAB(S) (sizeof((S)->ww) + sizeof((S)->wpad) >= 640 * sizeof(double) ? (double *)(S)->ww : (double *)0)
 
+/* The pair's workspace views (workgroup-uniform pointers).  They live in LDS (dg_f_shared::K) and are read where they
+ * are used, instead of travelling through the whole driver in every lane's vector registers. */
+struct dg_f_cshared {
+    int *L[10];              /* global int lists: 0 inliers, 1 intbuff, 2 intbuff_best (LO); 3 inliersH, 4 intbuffH (innerH);
+                                5 idxN, 6 idxH, 7 idxV, 8 ptr (rFtH); 9 inlI (u2Fit) */
+    unsigned char *Fl[5];    /* global flag vectors: 0 hinl, 1 nhinl, 2 vN, 3 v (innerFH), 4 inl (innerFH result) */
+    double *gmodels;         /* [3*DG_CHUNK][9] chunk models */
+    dg_pt *stage;            /* [2 * n_max] gathered correspondences of a long least-squares list + its per-coordinate arrays */
+    unsigned *res_I; double *res_J;   /* [3*DG_CHUNK] per-model (I, J) of the current chunk */
+    int (*rf)[5];            /* [DG_CHUNK] rFtH batch: candidate point ids (2), swap log (2), count */
+    int *wlist; dg_pt *wstage;        /* per-wave buffers [DG_NW][n_max] of the wave-parallel innerFH / u2Fit */
+    int n_max;
+};
+
 struct dg_f_shared {
     dg_red red;
     dg_lsq_scratch lsq;
@@ -74,28 +88,22 @@ struct dg_f_shared {
     int      itmp[32];
     double   dtmp[32];
     dg_f_drv park;
+    dg_f_cshared K;                      /* the pair's workspace views (dg_f_ctx::K) */
 };
 
+/* ------------------------------------------------------------------------------------------------ */
 /* ------------------------------------------------------------------------------------------------ */
 template <int LDSPTS>
 struct dg_f_ctx {
     dg_f_shared *S;
+    const __attribute__((address_space(3))) dg_f_cshared *K;    /* = &S->K */
     const dg_pt *P;          /* correspondences (LDS or global) */
     int *pool;               /* sampler permutation pool (LDS or global) */
     int n, tid;
     const dg_args *A;
     long long off;           /* first row of this pair in the input arrays */
-    int *L[10];              /* global int lists: 0 inliers, 1 intbuff, 2 intbuff_best (LO); 3 inliersH, 4 intbuffH (innerH);
-                                5 idxN, 6 idxH, 7 idxV, 8 ptr (rFtH); 9 inlI (u2Fit) */
-    unsigned char *Fl[5];    /* global flag vectors: 0 hinl, 1 nhinl, 2 vN, 3 v (innerFH), 4 inl (innerFH result) */
     dg_ht ht;
-    double *gmodels;         /* [3*DG_CHUNK][9] chunk models */
-    dg_pt *stage;            /* [n] gathered correspondences of a long least-squares list */
-    unsigned *res_I; double *res_J;   /* [3*DG_CHUNK] per-model (I, J) of the current chunk */
-    int (*rf)[5];            /* [DG_CHUNK] rFtH batch: candidate point ids (2), swap log (2), count */
     unsigned *seeds; int (*draws)[8]; /* the chunk buffers of the chunk being committed */
-    int *wlist; dg_pt *wstage;        /* per-wave buffers [DG_NW][n_max] of the wave-parallel innerFH / u2Fit */
-    int n_max;
     /* counters */
     int n_fds, n_exfds, n_hds, n_aux;
     double *rrun;            /* diagnostics: the 62 x n residual rows of the current LO run, or null */
@@ -116,6 +124,17 @@ struct dg_f_ctx {
 #define DG_JBUF_LDS_BYTES (offsetof(dg_f_shared, wpad) + sizeof(((dg_f_shared *)0)->wpad) - offsetof(dg_f_shared, ww))
 static_assert(offsetof(dg_f_shared, wpad) == offsetof(dg_f_shared, ww) + sizeof(((dg_f_shared *)0)->ww), "ww and wpad must be contiguous");
 static_assert(DG_JBUF_LDS_BYTES >= 2 * DG_CHUNK * 7 * sizeof(int), "pool-stage scratch does not fit");
+
+/* thread 0 fills the pair's workspace views (dg_f_shared::K); the caller's next workgroup barrier publishes them */
+__device__ __forceinline__ void dg_fill_views(dg_f_cshared *K, char *ws, const dg_ws_layout &wl)
+{
+    for (int i = 0; i < 10; i++) K->L[i] = (int *)(ws + wl.off_lists) + (size_t)i * wl.n_max;
+    for (int i = 0; i < 5; i++) K->Fl[i] = (unsigned char *)(ws + wl.off_flags) + (size_t)i * wl.n_max;
+    K->gmodels = (double *)(ws + wl.off_models);
+    K->stage = (dg_pt *)(ws + wl.off_stage);
+    K->res_J = (double *)(ws + wl.off_res); K->res_I = (unsigned *)(K->res_J + 3 * DG_CHUNK); K->rf = (int (*)[5])(K->res_I + 3 * DG_CHUNK);
+    K->n_max = wl.n_max; K->wlist = (int *)(ws + wl.off_wave); K->wstage = (dg_pt *)(ws + wl.off_wave + (size_t)DG_NW * wl.n_max * sizeof(int));
+}
 
 #define CTX dg_f_ctx<LDSPTS>
 #define DG_RESIDS_M 62           /* rtools.h:15: 2 + RAN_REP * (1 + ILSQ_ITERS + 1) residual vectors per LO run */
@@ -161,7 +180,7 @@ __device__ __forceinline__ dg_pass_res dg_f_pass(CTX &c, const double *Fm /* LDS
     for (int i = 0; i < 9; i++) F[i] = Fm[i];
     const dg_pt *P = c.P;
     /* ordered MSAC terms: the per-wave solver scratch is idle during a workgroup pass (LDS); what does not fit goes to the HBM staging area */
-    cfg.jbuf = (double *)c.stage; cfg.jl = (double *)c.S->ww; cfg.jl_cap = (int)(DG_JBUF_LDS_BYTES / sizeof(double));
+    cfg.jbuf = (double *)c.K->stage; cfg.jl = (double *)c.S->ww; cfg.jl_cap = (int)(DG_JBUF_LDS_BYTES / sizeof(double));
     return dg_pass(&c.S->red, cfg, [&](int pid, int) { return dg_Ferr(kind, F, dg_ldpt<LDSPTS>(P, pid)); }, c.tid);
 }
 template <int LDSPTS>
@@ -172,7 +191,7 @@ __device__ __forceinline__ dg_pass_res dg_h_pass(CTX &c, const double *Hm /* LDS
     for (int i = 0; i < 9; i++) H[i] = Hm[i];
     const dg_pt *P = c.P;
     /* ordered MSAC terms: the per-wave solver scratch is idle during a workgroup pass (LDS); what does not fit goes to the HBM staging area */
-    cfg.jbuf = (double *)c.stage; cfg.jl = (double *)c.S->ww; cfg.jl_cap = (int)(DG_JBUF_LDS_BYTES / sizeof(double));
+    cfg.jbuf = (double *)c.K->stage; cfg.jl = (double *)c.S->ww; cfg.jl_cap = (int)(DG_JBUF_LDS_BYTES / sizeof(double));
     return dg_pass(&c.S->red, cfg, [&](int pid, int) { dg_pt p = dg_ldpt<LDSPTS>(P, pid); return dg_HDs(H, p.x1, p.y1, p.x2, p.y2); }, c.tid);
 }
 __device__ __forceinline__ dg_pass_cfg dg_cfg0(int n)
@@ -216,7 +235,7 @@ __device__ __forceinline__ void dg_u2f_list(CTX &c, const int *list, int len, co
         __syncthreads();
     } else {
         const dg_pt *P = c.P;
-        dg_u2f_big(&S->red, &S->lsq, [&](int i) { return dg_ldpt<LDSPTS>(P, i); }, list, len, c.tid, Fout, c.stage, 2 * c.n_max,
+        dg_u2f_big(&S->red, &S->lsq, [&](int i) { return dg_ldpt<LDSPTS>(P, i); }, list, len, c.tid, Fout, c.K->stage, 2 * c.K->n_max,
                    DG_LSQ_LTAB(S));
     }
 }
@@ -288,7 +307,7 @@ template <int LDSPTS>
 __device__ __noinline__ unsigned dg_innerH(CTX &c, double *H /* LDS, in/out */, double th, unsigned inlLimit, unsigned char *inl_flags)
 {
     dg_f_shared *S = c.S; const int n = c.n, tid = c.tid;
-    int *inliers = c.L[3], *intbuff = c.L[4];
+    int *inliers = c.K->L[3], *intbuff = c.K->L[4];
     double *h = S->Hx, *hbest = S->ftmp;            /* hbest = model in errs[0]-chain; H itself is the running best */
     /* d = HDs(H); S = inlidxs(d, th, inliers) */
     dg_pass_cfg cfg = dg_cfg0(n); cfg.list = inliers; cfg.thL = th;
@@ -528,7 +547,7 @@ __device__ __noinline__ void dg_innerFH(CTX &c, const int *idxH, unsigned lenH, 
         if (lane < 9) S->fhF2[rep][lane] = S->fhF[rep][lane];
         DG_WSYNC();
         double thf;
-        unsigned cnt = dg_u2Fit_wave<LDSPTS>(&S->ww[wave], P, n, S->fhF2[rep], th, th*3, 4, c.wlist + (size_t)wave * c.n_max, c.wstage + (size_t)wave * c.n_max, c.n_max, lane, &thf, &aux_local);
+        unsigned cnt = dg_u2Fit_wave<LDSPTS>(&S->ww[wave], P, n, S->fhF2[rep], th, th*3, 4, c.K->wlist + (size_t)wave * c.K->n_max, c.K->wstage + (size_t)wave * c.K->n_max, c.K->n_max, lane, &thf, &aux_local);
         if (lane == 0) { S->fhCnt2[rep] = (int)cnt; S->fhTh[rep] = thf; S->itmp[8 + wave] = aux_local; }
         DG_WSYNC();
     }
@@ -586,8 +605,8 @@ template <int LDSPTS>
 __device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, double th, const double *H /* LDS */, double *F /* LDS out */)
 {
     dg_f_shared *S = c.S; const int n = c.n, tid = c.tid, lane = tid & 63, wave = tid >> 6;
-    unsigned char *nhinl = c.Fl[1], *vN = c.Fl[2], *inl = c.Fl[4];
-    int *idxN = c.L[5], *idxH = c.L[6], *idxV = c.L[7];
+    unsigned char *nhinl = c.K->Fl[1], *vN = c.K->Fl[2], *inl = c.K->Fl[4];
+    int *idxN = c.K->L[5], *idxH = c.K->L[6], *idxV = c.K->L[7];
     const unsigned MAX_SAM = 10000; const double conf = .999;
     double Hr[9]; for (int i = 0; i < 9; i++) Hr[i] = H[i];
     const dg_pt *P = c.P;
@@ -603,8 +622,8 @@ __device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, doub
     }
     if (nhinlCount < 4 || hinlCount < 6) return 0;
     /* ptr[] lives in the sampler pool's LDS for the duration (the pool is parked in global memory) */
-    int *ptr = LDSPTS != 0 ? c.pool : c.L[8];
-    if (LDSPTS != 0) { for (int j = tid; j < n; j += DG_T) c.L[8][j] = c.pool[j]; __syncthreads(); }
+    int *ptr = LDSPTS != 0 ? c.pool : c.K->L[8];
+    if (LDSPTS != 0) { for (int j = tid; j < n; j += DG_T) c.K->L[8][j] = c.pool[j]; __syncthreads(); }
     for (int j = tid; j < (int)nhinlCount; j += DG_T) ptr[j] = j;
     __syncthreads();
     unsigned max_i = 3, m_i = 4, max_sam = MAX_SAM;
@@ -619,9 +638,9 @@ __device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, doub
                 for (unsigned pos = 0; pos < 2; ++pos) {
                     unsigned idx = pos + 1 + (unsigned)dg_rand(&S->rng) % (nhinlCount - pos - 1);
                     int aux = ptr[pos]; ptr[pos] = ptr[idx]; ptr[idx] = aux;
-                    c.rf[b][2 + pos] = (int)idx;
+                    c.K->rf[b][2 + pos] = (int)idx;
                 }
-                c.rf[b][0] = idxN[ptr[0]]; c.rf[b][1] = idxN[ptr[1]];
+                c.K->rf[b][0] = idxN[ptr[0]]; c.K->rf[b][1] = idxN[ptr[1]];
             }
         }
         __syncthreads();
@@ -629,7 +648,7 @@ __device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, doub
         /* one wave per candidate: #off-plane points with Sampson error < 2 th */
         for (int b = wave; b < B; b += DG_NW) {
             double aFt[9];
-            dg_rFtH_aFt<LDSPTS>(Hr, dg_ldpt<LDSPTS>(P, c.rf[b][0]), dg_ldpt<LDSPTS>(P, c.rf[b][1]), aFt);
+            dg_rFtH_aFt<LDSPTS>(Hr, dg_ldpt<LDSPTS>(P, c.K->rf[b][0]), dg_ldpt<LDSPTS>(P, c.K->rf[b][1]), aFt);
             unsigned cnt = 0;
             for (int j0 = lane; j0 < (int)nhinlCount; j0 += 64 * DG_PU) {     /* ids, then points, of DG_PU tiles in flight together */
                 int id[DG_PU]; dg_pt q[DG_PU];
@@ -641,12 +660,12 @@ __device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, doub
                 for (int u = 0; u < DG_PU; u++) cnt += (j0 + 64 * u < (int)nhinlCount && dg_FDs(aFt, q[u].x1, q[u].y1, q[u].x2, q[u].y2) < th*2) ? 1u : 0u;
             }
             cnt = dg_wave_sum_u(cnt);
-            if (lane == 0) c.rf[b][4] = (int)cnt;
+            if (lane == 0) c.K->rf[b][4] = (int)cnt;
         }
         __syncthreads();
         long long tg2 = DG_CLK(); DG_DEVT(if (tid == 0) S->dbg[2] += tg2 - tg1);
         /* first candidate beating m_i */
-        bool hit = tid < B && (unsigned)c.rf[tid][4] > m_i;
+        bool hit = tid < B && (unsigned)c.K->rf[tid][4] > m_i;
         unsigned long long bal = __ballot(hit);
         __syncthreads();
         if (lane == 0) S->wave_cnt[wave] = bal ? (unsigned)(wave * 64 + __ffsll((long long)bal) - 1) : 0xffffffffu;
@@ -658,7 +677,7 @@ __device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, doub
         __syncthreads();
         if (tid == 0) {
             for (int b = B - 1; b > (int)bE; b--)
-                for (int pos = 1; pos >= 0; --pos) { int idx = c.rf[b][2 + pos]; int aux = ptr[pos]; ptr[pos] = ptr[idx]; ptr[idx] = aux; }
+                for (int pos = 1; pos >= 0; --pos) { int idx = c.K->rf[b][2 + pos]; int aux = ptr[pos]; ptr[pos] = ptr[idx]; ptr[idx] = aux; }
             S->rng = S->rng_save;
             for (int q = 0; q < 2 * ((int)bE + 1); q++) dg_rand(&S->rng);
         }
@@ -666,7 +685,7 @@ __device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, doub
         no_sam += bE + 1; c.n_aux += (int)bE + 1;
         {
             double aFt[9];
-            dg_rFtH_aFt<LDSPTS>(Hr, dg_ldpt<LDSPTS>(P, c.rf[bE][0]), dg_ldpt<LDSPTS>(P, c.rf[bE][1]), aFt);
+            dg_rFtH_aFt<LDSPTS>(Hr, dg_ldpt<LDSPTS>(P, c.K->rf[bE][0]), dg_ldpt<LDSPTS>(P, c.K->rf[bE][1]), aFt);
             /* v = Ds < 2 th ; uV = uN(:, v) */
             dg_pass_cfg cfg = dg_cfg0((int)nhinlCount); cfg.src = idxN; cfg.flags = vN; cfg.thF = th*2;
             dg_pass(&S->red, cfg, [&](int pid, int) { dg_pt p = dg_ldpt<LDSPTS>(P, pid); return dg_FDs(aFt, p.x1, p.y1, p.x2, p.y2); }, tid);
@@ -693,7 +712,7 @@ __device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, doub
         DG_DEVT(if (tid == 0) S->dbg[3] += DG_CLK() - tg2);
     }
     __syncthreads();
-    if (LDSPTS != 0) { for (int j = tid; j < n; j += DG_T) c.pool[j] = c.L[8][j]; __syncthreads(); }
+    if (LDSPTS != 0) { for (int j = tid; j < n; j += DG_T) c.pool[j] = c.K->L[8][j]; __syncthreads(); }
     return max_i;
 }
 

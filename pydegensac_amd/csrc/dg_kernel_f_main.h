@@ -81,7 +81,7 @@ __device__ __forceinline__ dg_score dg_iterF(CTX &c, int *inliers, double th, do
     DG_LT(2);
     for (int it = 0; it < DG_ILSQ_ITERS; it++) {
         /* the same residuals also give the list at ths*MWM that the re-fit uses when this model does not improve */
-        int *alt = c.L[9];
+        int *alt = c.K->L[9];
         dg_pass_cfg c1 = dg_cfg0(n); c1.wantJ = 1; c1.thJ = th; c1.list = inliers; c1.thL = th; c1.list2 = alt; c1.thL2 = ths * DG_MWM;
         dg_pass_res r1 = dg_f_pass(c, fl, mk_ex, c1); c.n_exfds++;
         dg_dump_resid(c, rrow + it, fl, mk_ex);
@@ -166,7 +166,7 @@ __device__ __noinline__ dg_score dg_inFrani(CTX &c, int ninl, double th, double 
                                                int mk_full, int mk_ex, int *kindBest)
 {
     dg_f_shared *S = c.S; const int tid = c.tid;
-    int *inliers = c.L[0], *intbuff = c.L[1], *intbuff_best = c.L[2];
+    int *inliers = c.K->L[0], *intbuff = c.K->L[1], *intbuff_best = c.K->L[2];
     dg_score maxS = {0, 0, 0, 0};
     *kindBest = mk_full;
     if (ninl < 16) {
@@ -1013,15 +1013,12 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
 
     char *ws = A.ws + (size_t)wsid * A.wl.stride;
     CTX c;
-    c.S = S; c.n = n; c.tid = tid; c.A = &A; c.off = off;
-    for (int i = 0; i < 10; i++) c.L[i] = (int *)(ws + A.wl.off_lists) + (size_t)i * A.wl.n_max;
-    for (int i = 0; i < 5; i++) c.Fl[i] = (unsigned char *)(ws + A.wl.off_flags) + (size_t)i * A.wl.n_max;
+    c.S = S; c.K = (const __attribute__((address_space(3))) dg_f_cshared *)&S->K; c.n = n; c.tid = tid; c.A = &A; c.off = off;
+    __syncthreads();                                       /* nobody still reads the previous pair's views */
+    if (tid == 0) dg_fill_views(&S->K, ws, A.wl);
+    __syncthreads();
     c.ht.heads = (int *)(ws + A.wl.off_ht); c.ht.count = c.ht.heads + 64; c.ht.ent = c.ht.heads + 80;
-    c.gmodels = (double *)(ws + A.wl.off_models);
-    c.stage = (dg_pt *)(ws + A.wl.off_stage);
-    c.res_J = (double *)(ws + A.wl.off_res); c.res_I = (unsigned *)(c.res_J + 3 * DG_CHUNK); c.rf = (int (*)[5])(c.res_I + 3 * DG_CHUNK);
     c.seeds = S->seeds3[0]; c.draws = S->draws3[0];
-    c.n_max = A.wl.n_max; c.wlist = (int *)(ws + A.wl.off_wave); c.wstage = (dg_pt *)(ws + A.wl.off_wave + (size_t)DG_NW * A.wl.n_max * sizeof(int));
     c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0; c.rrun = 0;
     dg_pt *Pw; int *pool;
     /* LDSPTS: 1 = point set and sampler pool in LDS, 2 = pool in LDS / points in the HBM workspace (L2), 0 = both in HBM */
@@ -1115,6 +1112,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     dg_copy16(S, pk, sizeof(dg_f_shared), tid);
     dg_copy16(dyn_smem, pk + DG_PARK_DYN_OFF, (size_t)A.dyn_bytes, tid);
     __syncthreads();
+    if (tid == 0) dg_fill_views(&S->K, ws, A.wl);         /* the image carries the views of the same workspace; written again all the same */
     D = S->park;
     c.n_fds = D.n_fds; c.n_exfds = D.n_exfds; c.n_hds = D.n_hds; c.n_aux = D.n_aux;
     DG_DEVT(if (tid == 0) S->tq = DG_CLK());
@@ -1164,7 +1162,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         /* ================= solve: one 7-point problem per lane ================= */
         int nvalid = 0, nullbad = 0; unsigned rixp = 0;
         if (tid < chunk) {
-            int r_ = dg_solve7_lane(P, c.draws[tid], c.gmodels + (size_t)tid * 27, &rixp, (double *)&S->ww[wave]);
+            int r_ = dg_solve7_lane(P, c.draws[tid], c.K->gmodels + (size_t)tid * 27, &rixp, (double *)&S->ww[wave]);
             if (r_ < 0) nullbad = 1; else nvalid = r_;
         }
         /* ordered slots: exclusive scan of nvalid over the lanes of the chunk */
@@ -1229,9 +1227,9 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                 const int NS = DG_NW >= 4 ? DG_NW - 2 : DG_NW, wsi = DG_NW >= 4 ? wave - 2 : wave;
                 const int capw = (int)((sizeof(dg_lsq_scratch) / NS) & ~(size_t)15);
                 if (!(LDSPTS == 0 && coopK > 0) && wsi >= 0)
-                    dg_score_chunk_F<LDSPTS>(P, n, c.gmodels, S->mslot, Mtot, wsi, NS, mk_full, th,
+                    dg_score_chunk_F<LDSPTS>(P, n, c.K->gmodels, S->mslot, Mtot, wsi, NS, mk_full, th,
                                              A.hist_out ? 0.0 : (maxS.J < maxSs.J ? maxS.J : maxSs.J), S->ext, (char *)&S->lsq + (size_t)wsi * capw, capw,
-                                             (double *)(c.wstage + (size_t)wave * c.n_max), c.res_I, c.res_J, lane);
+                                             (double *)(c.K->wstage + (size_t)wave * c.K->n_max), c.K->res_I, c.K->res_J, lane);
             }
         }
         c.n_fds += Mtot;   /* provisional: models past the termination point are subtracted below */
@@ -1257,7 +1255,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                 for (int base = 0; base < Mtot; base += DG_T) {
                     const int mi = base + tid; const bool have = mi < Mtot;
                     const bool keep = have && ((double)__hip_atomic_load(cv.cnt + (have ? mi : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > tau_c);
-                    if (have && !keep) { c.res_I[mi] = 0; c.res_J[mi] = 0; }
+                    if (have && !keep) { c.K->res_I[mi] = 0; c.K->res_J[mi] = 0; }
                     const unsigned long long bk = __ballot(keep);
                     if (lane == 0) S->wave_cnt[wave] = (unsigned)__popcll(bk);
                     __syncthreads();
@@ -1285,7 +1283,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                 const double tau = maxS.J < maxSs.J ? maxS.J : maxSs.J;
                 bool ev = false;
                 if (tid >= k && tid < chunk && S->nv[tid] != 255)
-                    for (int r = 0; r < S->nv[tid]; r++) ev = ev || (tau < c.res_J[S->moff[tid] + r]);
+                    for (int r = 0; r < S->nv[tid]; r++) ev = ev || (tau < c.K->res_J[S->moff[tid] + r]);
                 unsigned long long bal = __ballot(ev);
                 __syncthreads();
                 if (lane == 0) S->wave_cnt[wave] = bal ? (unsigned)(wave * 64 + __ffsll((long long)bal) - 1) : 0xffffffffu;
@@ -1303,24 +1301,24 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             int new_max = 0, do_iterate = 0, rng_ready = 0, brk = 0;
             for (int r = 0; r < nvk && !brk; r++) {
                 const int mi = S->moff[k] + r, ri = S->ridx[k][r];
-                dg_score Sc = {c.res_I[mi], c.res_J[mi], 0, 0};
+                dg_score Sc = {c.K->res_I[mi], c.K->res_J[mi], 0, 0};
                 const int phys = perm[ri];
                 const bool ev1 = maxS.J < Sc.J, ev2 = maxSs.J < Sc.J;
                 if (!(ev1 || ev2)) {
-                    if (track && phys == p4) { __syncthreads(); if (tid < 9) e4F[tid] = c.gmodels[(size_t)S->mslot[mi]*9 + tid]; e4kind = mk_full; __syncthreads(); }
+                    if (track && phys == p4) { __syncthreads(); if (tid < 9) e4F[tid] = c.K->gmodels[(size_t)S->mslot[mi]*9 + tid]; e4kind = mk_full; __syncthreads(); }
                     continue;
                 }
                 __syncthreads();
-                if (tid < 9) S->f[tid] = c.gmodels[(size_t)S->mslot[mi]*9 + tid];
+                if (tid < 9) S->f[tid] = c.K->gmodels[(size_t)S->mslot[mi]*9 + tid];
                 __syncthreads();
                 if (track && phys == p4) { if (tid < 9) e4F[tid] = S->f[tid]; e4kind = mk_full; __syncthreads(); }
                 if (ev1) {
                     int pass = 1;
                     if (doSym || doLaf) {
                         /* `inliers` = exact th-list of this model */
-                        dg_pass_cfg cl = dg_cfg0(n); cl.list = c.L[0]; cl.thL = th;
+                        dg_pass_cfg cl = dg_cfg0(n); cl.list = c.K->L[0]; cl.thL = th;
                         dg_pass_res rl = dg_f_pass(c, S->f, mk_full, cl);
-                        pass = dg_f_checks(c, S->f, c.L[0], (int)rl.nL, Sc, maxS, mk_full);
+                        pass = dg_f_checks(c, S->f, c.K->L[0], (int)rl.nL, Sc, maxS, mk_full);
                     }
                     if (!pass) continue;
                     { int t = perm[ri]; perm[ri] = perm[3]; perm[3] = t; }
@@ -1352,14 +1350,14 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                             __syncthreads();
                             rng_ready = 1;
                         }
-                        dg_pass_cfg ch = dg_cfg0(n); ch.flags = c.Fl[1]; ch.thF = th*3;
+                        dg_pass_cfg ch = dg_cfg0(n); ch.flags = c.K->Fl[1]; ch.thF = th*3;
                         dg_pass_res rh = dg_h_pass(c, S->H, ch); c.n_hds++;
                         unsigned I = rh.nF;
                         if (I < 8) { brk = 1; c.n_fds -= (nvk - 1 - r); if (A.hist_out) { __syncthreads(); if (tid == 0) S->nv[k] = (unsigned char)(r + 1); __syncthreads(); } break; }   /* exp_ranF.c:1437-1439: later roots are never scored */
-                        { long long ti0 = DG_CLK(); I = dg_innerH(c, S->H, 16*th, 10, c.Fl[0]); DG_DEVT(if (tid == 0) S->dbg[0] += DG_CLK() - ti0); (void)ti0; }
+                        { long long ti0 = DG_CLK(); I = dg_innerH(c, S->H, 16*th, 10, c.K->Fl[0]); DG_DEVT(if (tid == 0) S->dbg[0] += DG_CLK() - ti0); (void)ti0; }
                         if ((int)I > Ihmax) Ihmax = (int)I;
                         if (I > 6) {
-                            I = dg_rFtH(c, c.Fl[0], th, S->H, S->f);
+                            I = dg_rFtH(c, c.K->Fl[0], th, S->H, S->f);
                             int dphys;
                             if (I > maxS.I) {
                                 maxS.I = I;
@@ -1403,18 +1401,18 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                 dg_resid_begin(c, iter_cnt - 1); __syncthreads();
                 dg_dump_resid(c, 0, e4F, e4kind);                              /* errs[4], exp_ranF.c:1503-1504 */
                 /* LSQ before LO: S = inlidxs(errs[4], TC*th*MWM); u2f; FDS1; inlidxs(th)  (:1506-1511) */
-                dg_pass_cfg ca = dg_cfg0(n); ca.list = c.L[0]; ca.thL = DG_TC * th * DG_MWM;
+                dg_pass_cfg ca = dg_cfg0(n); ca.list = c.K->L[0]; ca.thL = DG_TC * th * DG_MWM;
                 dg_pass_res ra = dg_f_pass(c, e4F, e4kind, ca);
                 DG_TRACE(c, 1, ra.nL, no_sam);
-                dg_u2f_list(c, c.L[0], (int)ra.nL, 0, 0, S->f);
-                dg_pass_cfg cb = dg_cfg0(n); cb.wantJ = 1; cb.thJ = th; cb.list = c.L[0]; cb.thL = th;
+                dg_u2f_list(c, c.K->L[0], (int)ra.nL, 0, 0, S->f);
+                dg_pass_cfg cb = dg_cfg0(n); cb.wantJ = 1; cb.thJ = th; cb.list = c.K->L[0]; cb.thL = th;
                 dg_pass_res rb = dg_f_pass(c, S->f, mk_full, cb); c.n_fds++;
                 dg_dump_resid(c, 1, S->f, mk_full);                            /* d after the LSQ, :1511 */
                 DG_TRACE(c, 2, rb.nL, rb.J);
                 int kb;
                 dg_score Sl = dg_inFrani(c, (int)rb.nL, th, S->Hx /* LO result model */, &iterID, mk_full, mk_ex, &kb);
                 if (maxS.J < Sl.J) {
-                    if (dg_f_checks(c, S->Hx, c.L[0], (int)Sl.I, Sl, maxS, mk_full)) {
+                    if (dg_f_checks(c, S->Hx, c.K->L[0], (int)Sl.I, Sl, maxS, mk_full)) {
                         maxS = Sl;
                         __syncthreads();
                         if (tid < 9) S->F[tid] = S->Hx[tid];
@@ -1441,7 +1439,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             const int reached = no_sam - chunk_base;
             if (tid < reached && tid < chunk && S->nv[tid] != 255) {
                 unsigned best = 0;
-                for (int r = 0; r < S->nv[tid]; r++) { const unsigned I_ = c.res_I[S->moff[tid] + r]; best = I_ > best ? I_ : best; }
+                for (int r = 0; r < S->nv[tid]; r++) { const unsigned I_ = c.K->res_I[S->moff[tid] + r]; best = I_ > best ? I_ : best; }
                 atomicAdd(&hist[2 + best], 1);
             }
         }
@@ -1477,17 +1475,17 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         }
         __syncthreads();
         if (degenerate) {
-            dg_pass_cfg ch = dg_cfg0(n); ch.flags = c.Fl[1]; ch.thF = th*3;
+            dg_pass_cfg ch = dg_cfg0(n); ch.flags = c.K->Fl[1]; ch.thF = th*3;
             dg_pass_res rh = dg_h_pass(c, S->H, ch); c.n_hds++;
             unsigned I = rh.nF;
-            if (I >= 8) I = dg_innerH(c, S->H, 16*th, 10, c.Fl[0]);
-            else { for (int j = tid; j < n; j += DG_T) c.Fl[0][j] = 0; __syncthreads(); }
+            if (I >= 8) I = dg_innerH(c, S->H, 16*th, 10, c.K->Fl[0]);
+            else { for (int j = tid; j < n; j += DG_T) c.K->Fl[0][j] = 0; __syncthreads(); }
             if ((int)I > Ihmax) Ihmax = (int)I;
             if (I > 6) {
                 __syncthreads();
                 if (tid < 9) S->f[tid] = S->FBest[tid];
                 __syncthreads();
-                I = dg_rFtH(c, c.Fl[0], th, S->H, S->f);
+                I = dg_rFtH(c, c.K->Fl[0], th, S->H, S->f);
                 int nm = 0;
                 if (I > maxS.I) {
                     maxS.I = I;
@@ -1506,16 +1504,16 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             dg_resid_begin(c, iter_cnt - 1); __syncthreads();
             /* row 0 (errs[4], exp_ranF.c:1634) stays NaN here: which sample's residuals that physical buffer holds after the
              * loop is not tracked past sample 50 */
-            dg_pass_cfg ca = dg_cfg0(n); ca.list = c.L[0]; ca.thL = DG_TC * th * DG_MWM;
+            dg_pass_cfg ca = dg_cfg0(n); ca.list = c.K->L[0]; ca.thL = DG_TC * th * DG_MWM;
             dg_pass_res ra = dg_f_pass(c, S->FBest, mk_full, ca);
-            dg_u2f_list(c, c.L[0], (int)ra.nL, 0, 0, S->f);
-            dg_pass_cfg cb = dg_cfg0(n); cb.list = c.L[0]; cb.thL = th;
+            dg_u2f_list(c, c.K->L[0], (int)ra.nL, 0, 0, S->f);
+            dg_pass_cfg cb = dg_cfg0(n); cb.list = c.K->L[0]; cb.thL = th;
             dg_pass_res rb = dg_f_pass(c, S->f, mk_full, cb); c.n_fds++;
             dg_dump_resid(c, 1, S->f, mk_full);
             int kb;
             dg_score Sl = dg_inFrani(c, (int)rb.nL, th, S->Hx, &iterID, mk_full, mk_ex, &kb);
             if (maxS.J < Sl.J) {
-                if (dg_f_checks(c, S->Hx, c.L[0], (int)Sl.I, Sl, maxS, mk_full)) {
+                if (dg_f_checks(c, S->Hx, c.K->L[0], (int)Sl.I, Sl, maxS, mk_full)) {
                     maxS = Sl;
                     __syncthreads();
                     if (tid < 9) S->F[tid] = S->Hx[tid];
@@ -1537,9 +1535,9 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         for (int j = tid; j < n; j += DG_T) mask[j] = dg_Ferr(finKind, F, dg_ldpt<LDSPTS>(P, j)) <= th ? 1 : 0;
         __syncthreads();
         if (doSym || (doLaf && pr.final_laf_filter)) {
-            dg_pass_cfg cl = dg_cfg0(n); cl.list = c.L[0]; cl.thL = th;
+            dg_pass_cfg cl = dg_cfg0(n); cl.list = c.K->L[0]; cl.thL = th;
             dg_pass_res rl = dg_f_pass(c, S->F, finKind, cl);
-            const int cnt = (int)rl.nL; const int *lst = c.L[0];
+            const int cnt = (int)rl.nL; const int *lst = c.K->L[0];
             /* clears list POSITION j, not lst[j]: exp_ranF.c:1719-1721 */
             if (doSym)
                 for (int j = tid; j < cnt; j += DG_T) if (dg_Ferr(DG_K_FSYM, F, dg_ldpt<LDSPTS>(P, lst[j])) > pr.sym_th) mask[j] = 0;

@@ -40,7 +40,7 @@ __device__ __forceinline__ void dg_u2h_list(CTX &c, const int *list, int len, do
         __syncthreads();
     } else {
         const dg_pt *P = c.P;
-        dg_u2h_big(&S->red, &S->lsq, [&](int i) { return dg_ldpt<LDSPTS>(P, i); }, list, len, c.tid, Hout, c.stage, 2 * c.n_max,
+        dg_u2h_big(&S->red, &S->lsq, [&](int i) { return dg_ldpt<LDSPTS>(P, i); }, list, len, c.tid, Hout, c.K->stage, 2 * c.K->n_max,
                    DG_LSQ_LTAB(S));
     }
 }
@@ -60,7 +60,7 @@ __device__ __forceinline__ dg_pass_res dg_hm_pass(CTX &c, int kind, const double
     for (int i = 0; i < 9; i++) { H[i] = Hm[i]; Hinv[i] = kind ? S->lsq.Z8[i] : 0; H1[i] = kind ? S->lsq.Z8[9+i] : 0; }
     const dg_pt *P = c.P;
     /* ordered MSAC terms: the per-wave solver scratch is idle during a workgroup pass (LDS); what does not fit goes to the HBM staging area */
-    cfg.jbuf = (double *)c.stage; cfg.jl = (double *)c.S->ww; cfg.jl_cap = (int)(DG_JBUF_LDS_BYTES / sizeof(double));
+    cfg.jbuf = (double *)c.K->stage; cfg.jl = (double *)c.S->ww; cfg.jl_cap = (int)(DG_JBUF_LDS_BYTES / sizeof(double));
     return dg_pass(&S->red, cfg, [&](int pid, int) { return dg_Herr(kind, H, Hinv, H1, dg_ldpt<LDSPTS>(P, pid)); }, c.tid);
 }
 
@@ -201,7 +201,7 @@ template <int LDSPTS>
 __device__ __forceinline__ dg_score dg_inHranic(CTX &c, int kind, int ninl, double th, double *Hout, int *iterID, unsigned inlLimit, dg_hbufs &B)
 {
     dg_f_shared *S = c.S; const int tid = c.tid;
-    int *inliers = c.L[0], *intbuff = c.L[1];
+    int *inliers = c.K->L[0], *intbuff = c.K->L[1];
     dg_score maxS = {0, 0, 0, 0};
     if (ninl < 8) {
         if (c.rrun) {                                                    /* exp_ranH.c:429: memset(.., 0xFF, ..) */
@@ -248,14 +248,14 @@ __device__ __noinline__ int dg_h_lo(CTX &c, int kind, const double *e4, double t
     dg_resid_begin(c, lo_run); __syncthreads();
     DG_DEVT(if (tid == 0) S->dbg[7] = DG_CLK());
     dg_dump_resid(c, 0, e4, 10 + kind);                                   /* errs[4], exp_ranH.c:679 / :794 */
-    dg_pass_cfg ca = dg_cfg0(n); ca.list = c.L[0]; ca.thL = DG_TC * th * DG_MWM;
+    dg_pass_cfg ca = dg_cfg0(n); ca.list = c.K->L[0]; ca.thL = DG_TC * th * DG_MWM;
     dg_pass_res ra = dg_hm_pass(c, kind, e4, ca);
     DG_HT(0);
     DG_TRACE(c, 1, ra.nL, no_sam);
-    dg_u2h_list(c, c.L[0], (int)ra.nL, S->f);
+    dg_u2h_list(c, c.K->L[0], (int)ra.nL, S->f);
     DG_HT(1);
     DG_BUFSET(S, B0, S->f);
-    dg_pass_cfg cb = dg_cfg0(n); cb.wantJ = 1; cb.thJ = th; cb.list = c.L[0]; cb.thL = th;
+    dg_pass_cfg cb = dg_cfg0(n); cb.wantJ = 1; cb.thJ = th; cb.list = c.K->L[0]; cb.thL = th;
     dg_pass_res rb = dg_hm_pass(c, kind, S->f, cb); c.n_hds++;
     DG_HT(0);
     dg_dump_resid(c, 1, S->f, 10 + kind);                                 /* d after the LSQ, exp_ranH.c:694 / :810 */
@@ -271,10 +271,10 @@ __device__ __noinline__ int dg_h_lo(CTX &c, int kind, const double *e4, double t
     const dg_params &pr = c.A->prm;
     if (pr.sym_th > 0 || pr.laf_coef > 0) {
         /* Scheck = inlidxs(d, th): `d` is the physical buffer that was errs[0] before the LO (exp_ranH.c:708) */
-        dg_pass_cfg cl = dg_cfg0(n); cl.wantJ = 1; cl.thJ = th; cl.list = c.L[2]; cl.thL = th;
+        dg_pass_cfg cl = dg_cfg0(n); cl.wantJ = 1; cl.thJ = th; cl.list = c.K->L[2]; cl.thL = th;
         dg_pass_res rl = dg_hm_pass(c, kind, S->bufF[B0], cl);
         DG_TRACE(c, 4, rl.nL, rl.J);
-        const int ok_ = dg_h_checks(c, kind, S->Hx, c.L[2], (int)rl.nL, Sl, maxS, p1_inliers, 0);
+        const int ok_ = dg_h_checks(c, kind, S->Hx, c.K->L[2], (int)rl.nL, Sl, maxS, p1_inliers, 0);
         DG_HT(4);
         if (!ok_) return 0;
     }
@@ -333,15 +333,12 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
 
     char *ws = A.ws + (size_t)slot * A.wl.stride;
     CTX c;
-    c.S = S; c.n = n; c.tid = tid; c.A = &A; c.off = off;
-    for (int i = 0; i < 10; i++) c.L[i] = (int *)(ws + A.wl.off_lists) + (size_t)i * A.wl.n_max;
-    for (int i = 0; i < 5; i++) c.Fl[i] = (unsigned char *)(ws + A.wl.off_flags) + (size_t)i * A.wl.n_max;
+    c.S = S; c.K = (const __attribute__((address_space(3))) dg_f_cshared *)&S->K; c.n = n; c.tid = tid; c.A = &A; c.off = off;
+    __syncthreads();                                       /* nobody still reads the previous pair's views */
+    if (tid == 0) dg_fill_views(&S->K, ws, A.wl);
+    __syncthreads();
     c.ht.heads = (int *)(ws + A.wl.off_ht); c.ht.count = c.ht.heads + 64; c.ht.ent = c.ht.heads + 80;
-    c.gmodels = (double *)(ws + A.wl.off_models);
-    c.stage = (dg_pt *)(ws + A.wl.off_stage);
-    c.res_J = (double *)(ws + A.wl.off_res); c.res_I = (unsigned *)(c.res_J + 3 * DG_CHUNK); c.rf = (int (*)[5])(c.res_I + 3 * DG_CHUNK);
     c.seeds = S->seeds3[0]; c.draws = S->draws3[0];
-    c.n_max = A.wl.n_max; c.wlist = (int *)(ws + A.wl.off_wave); c.wstage = (dg_pt *)(ws + A.wl.off_wave + (size_t)DG_NW * A.wl.n_max * sizeof(int));
     c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0; c.rrun = 0;
     dg_pt *Pw; int *pool;
     /* LDSPTS: 1 = point set and sampler pool in LDS, 2 = pool in LDS / points in the HBM workspace (L2), 0 = both in HBM */
@@ -406,7 +403,7 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
             if (tid < chunk) {
                 S->nv[tid] = (unsigned char)valid;
                 if (valid) {
-                    double *g = c.gmodels + (size_t)excl * 18;
+                    double *g = c.K->gmodels + (size_t)excl * 18;
 #pragma unroll
                     for (int j = 0; j < 9; j++) { g[j] = hm[j]; g[9+j] = kind ? H1m[j] : 0.0; }
                 }
@@ -433,13 +430,13 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
                 for (int mi = wave - DG_SW0; mi < Mtot; mi += DG_NW - DG_SW0) {
 
                     double H[9], Hinv[9], H1[9];
-                    const double *g = c.gmodels + (size_t)mi * 18;
+                    const double *g = c.K->gmodels + (size_t)mi * 18;
 #pragma unroll
                     for (int j = 0; j < 9; j++) { H[j] = g[j]; H1[j] = g[9+j]; }
                     Hinv[0] = H[0]; Hinv[1] = H[3]; Hinv[2] = H[6]; Hinv[3] = H[1]; Hinv[4] = H[4]; Hinv[5] = H[7]; Hinv[6] = H[2]; Hinv[7] = H[5]; Hinv[8] = H[8];
                     /* I, and J as the reference's sequential sum (dg_seq_sum) over the nonzero terms in point order */
                     unsigned cI = 0, cnt = 0; const double t94 = th * 9 / 4;
-                    double *jbuf = (double *)(c.wstage + (size_t)wave * c.n_max);
+                    double *jbuf = (double *)(c.K->wstage + (size_t)wave * c.K->n_max);
                     for (int base = 0; base < n; base += 64 * DG_PU) {
                         dg_pt qq[DG_PU]; double dd[DG_PU];
 #pragma unroll
@@ -462,7 +459,7 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
                     J = __shfl(J, 0, 64);
                     unsigned I = dg_wave_sum_u(cI);
                     DG_WSYNC();
-                    if (lane == 0) { c.res_I[mi] = I; c.res_J[mi] = J; }
+                    if (lane == 0) { c.K->res_I[mi] = I; c.K->res_J[mi] = J; }
                 }
             }
         }
@@ -480,7 +477,7 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
                  * has run yet) any scored sample, which fires the first LO (exp_ranH.c:639-640) */
                 const double tau = maxS.J < maxSs.J ? maxS.J : maxSs.J;
                 const bool first_lo = iter_cnt == 0 && maxSs.I > 4;
-                bool ev = tid >= k && tid < chunk && S->nv[tid] && (first_lo || tau < c.res_J[S->moff[tid]]);
+                bool ev = tid >= k && tid < chunk && S->nv[tid] && (first_lo || tau < c.K->res_J[S->moff[tid]]);
                 unsigned long long bal = __ballot(ev);
                 __syncthreads();
                 if (lane == 0) S->wave_cnt[wave] = bal ? (unsigned)(wave * 64 + __ffsll((long long)bal) - 1) : 0xffffffffu;
@@ -496,20 +493,20 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
             no_sam++;
             if (!S->nv[k]) { no_rej++; continue; }
             const int mi = S->moff[k];
-            dg_score Sc = {c.res_I[mi], c.res_J[mi], 0, 0};
+            dg_score Sc = {c.K->res_I[mi], c.K->res_J[mi], 0, 0};
             int new_max = 0, do_iterate = 0;
             const bool ev1 = maxS.J < Sc.J;
             if (ev1 || maxSs.J < Sc.J) {
                 __syncthreads();
-                if (tid < 9) S->f[tid] = c.gmodels[(size_t)mi*18 + tid];
+                if (tid < 9) S->f[tid] = c.K->gmodels[(size_t)mi*18 + tid];
                 __syncthreads();
             }
             if (ev1) {
                 int pass = 1;
                 if (pr.sym_th > 0 || pr.laf_coef > 0) {
-                    dg_pass_cfg cl = dg_cfg0(n); cl.list = c.L[2]; cl.thL = th;
+                    dg_pass_cfg cl = dg_cfg0(n); cl.list = c.K->L[2]; cl.thL = th;
                     dg_pass_res rl = dg_hm_pass(c, kind, S->f, cl);
-                    pass = dg_h_checks(c, kind, S->f, c.L[2], (int)rl.nL, Sc, maxS, &p1_inliers, 1);
+                    pass = dg_h_checks(c, kind, S->f, c.K->L[2], (int)rl.nL, Sc, maxS, &p1_inliers, 1);
                 }
                 if (!pass) continue;
                 maxS = Sc; new_max = 1; accepted = 1; best_sample = no_sam; t_best = wall_clock64();
