@@ -257,6 +257,12 @@ int mi_degensac_solve7(const double *pts1, const double *pts2, int n, int dim,
  * degensac/lapwrap.c:67-96), one problem per wave: in 81, out 9 eigenvalues (smallest first, the rest as the QL/QR
  * iteration left them) + 81 (column-major vectors, column 0 = the one of the smallest eigenvalue), flag = info. */
 int mi_degensac_mat3(int op, const double *in, int count, int device, double *out, int32_t *flag);
+/* the screening counts of the scoring phase (dg_score_tiles.h) for given fundamental-matrix models over a point set:
+ * c1[m] = level-1 count (single precision, loosest denominator, rounding-widened threshold), c2[m] = level-2 count
+ * (double precision, the point's own denominator, threshold x (1 + 1e-6)); both must be >= the number of points whose
+ * exact residual is < 9/4 th (kind 0 = Sampson, 1 = symmetric epipolar).  Models in batches of 64 per wave, as in the kernels. */
+int mi_degensac_screen_counts(const double *pts1, const double *pts2, int n, int dim, const double *models, int n_models,
+                              int kind, double th, int device, uint32_t *c1, uint32_t *c2);
 
 /* ---- misc -------------------------------------------------------------------------------------- */
 int         mi_degensac_device_count(void);

@@ -117,6 +117,8 @@ def lib():
         l.mi_degensac_match_last_error.restype = C.c_char_p
         l.mi_degensac_mat3.restype = C.c_int
         l.mi_degensac_mat3.argtypes = [C.c_int, dp, C.c_int, C.c_int, dp, ip]
+        l.mi_degensac_screen_counts.restype = C.c_int
+        l.mi_degensac_screen_counts.argtypes = [dp, dp, C.c_int, C.c_int, dp, C.c_int, C.c_int, C.c_double, C.c_int, up, up]
         l.mi_degensac_last_error.restype = C.c_char_p
         l.mi_degensac_version.restype = C.c_char_p
         l.mi_degensac_kernel_name.restype = C.c_char_p

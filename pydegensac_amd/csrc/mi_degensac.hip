@@ -72,6 +72,52 @@ extern "C" int mi_degensac_score_models(const double *pts1, const double *pts2, 
     return 0;
 }
 
+/* ---- unit level: screening counts ------------------------------------------- */
+__global__ void dg_screen_counts_kernel(const dg_pt *P, int n, const double *models, int n_models, int kind, double th,
+                                        double e0, double e1, double e2, double e3, unsigned *c1, unsigned *c2)
+{
+    __shared__ __attribute__((aligned(16))) float tab1[64 * DG_L1_ENTRY_FLOATS];
+    __shared__ __attribute__((aligned(16))) double tab2[64 * DG_L2_ENTRY_DOUBLES];
+    const int lane = threadIdx.x, m = blockIdx.x * 64 + lane;
+    const int nb = n_models - blockIdx.x * 64 < 64 ? n_models - blockIdx.x * 64 : 64;
+    const double t94b = th * 9 / 4 * (1.0 + 1e-6), ext[4] = {e0, e1, e2, e3};
+    if (lane < nb) {
+        double F[9]; float Ff[9];
+        for (int j = 0; j < 9; j++) F[j] = models[(size_t)m * 9 + j];
+        const float thr = dg_l1_setup(kind, F, ext, t94b, Ff);
+        for (int j = 0; j < 9; j++) { tab1[lane * DG_L1_ENTRY_FLOATS + j] = Ff[j]; tab2[lane * DG_L2_ENTRY_DOUBLES + j] = F[j]; }
+        tab1[lane * DG_L1_ENTRY_FLOATS + 9] = thr; tab1[lane * DG_L1_ENTRY_FLOATS + 10] = 0.f; tab1[lane * DG_L1_ENTRY_FLOATS + 11] = 0.f;
+        tab2[lane * DG_L2_ENTRY_DOUBLES + 9] = 0.;
+    }
+    DG_WSYNC();
+    const unsigned a = dg_l1_tile_counts<0>(P, 0, n, tab1, nb, lane);
+    const unsigned b = dg_l2_tile_counts<0>(P, 0, n, tab2, nb, kind, t94b, lane);
+    if (lane < nb) { c1[m] = a; c2[m] = b; }
+}
+
+extern "C" int mi_degensac_screen_counts(const double *pts1, const double *pts2, int n, int dim, const double *models, int n_models,
+        int kind, double th, int device, uint32_t *c1, uint32_t *c2)
+{
+    DG_UNIT_ENTER(device);
+    if (!(kind == 0 || kind == 1) || n <= 0 || n_models <= 0 || (dim != 2 && dim != 6)) { set_err("bad argument"); return MI_DEGENSAC_EINVAL; }
+    std::vector<dg_pt> hp((size_t)n);
+    double ext[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n; i++) {
+        dg_pt q; q.x1 = pts1[(size_t)i * dim]; q.y1 = pts1[(size_t)i * dim + 1]; q.x2 = pts2[(size_t)i * dim]; q.y2 = pts2[(size_t)i * dim + 1];
+        hp[i] = q;
+        ext[0] = fmax(ext[0], fabs(q.x1)); ext[1] = fmax(ext[1], fabs(q.y1)); ext[2] = fmax(ext[2], fabs(q.x2)); ext[3] = fmax(ext[3], fabs(q.y2));
+    }
+    DevBuf<dg_pt> dp; DevBuf<double> dm; DevBuf<uint32_t> d1, d2;
+    if (dp.alloc(n) || dm.alloc((size_t)n_models * 9) || d1.alloc(n_models) || d2.alloc(n_models)) { set_err("device allocation failed"); return MI_DEGENSAC_ENOMEM; }
+    HIPCHK(hipMemcpy(dp.p, hp.data(), (size_t)n * sizeof(dg_pt), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dm.p, models, (size_t)n_models * 72, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(dg_screen_counts_kernel, dim3((n_models + 63) / 64), dim3(64), 0, 0, dp.p, n, dm.p, n_models, kind, th, ext[0], ext[1], ext[2], ext[3], d1.p, d2.p);
+    HIPCHK(hipGetLastError()); HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(c1, d1.p, (size_t)n_models * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(c2, d2.p, (size_t)n_models * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 __global__ void dg_sample_stream_kernel(unsigned seed0, int n, int ssz, int iters, int seq_pool, int *pool_g, int *out)
 {
     /* the main kernels' sampler (dg_sample_chunk), chunk by chunk, run by one wave: with the pool in LDS (n <= 4096:

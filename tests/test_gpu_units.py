@@ -237,3 +237,34 @@ def test_wave_eigensolver_equals_oracle_dsyev():
         if not ok:
             bad.append(t)
     assert not bad, (len(bad), bad[:10], flag[bad[:10]])
+
+
+def test_screening_counts_are_supersets_of_the_exact_band():
+    """Level 1 (fp32, loosest denominator) and level 2 (fp64, own denominator) of the scoring phase's screens must never
+    count fewer points than lie inside the 9/4 th band of the exact residuals, for random models, for models fitted to the
+    data (many points ON the band edge region), and for adversarial ones: tiny and huge scales, large coordinates."""
+    import ctypes as C
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    p1, p2, lab, Fgt = syn.two_view_fundamental(3000, 0.5, 0.3, seed=8)
+    big1 = p1 * 37.0 + 5000.0; big2 = p2 * 37.0 - 9000.0                   # large coordinates: the fp32 bound must widen with them
+    models = [rng.normal(size=9) for _ in range(300)]
+    models += [Fgt.ravel() * s for s in (1.0, 1e-12, 1e12, -3.0)]
+    models += [Fgt.ravel() + rng.normal(scale=10.0 ** -k, size=9) * np.abs(Fgt).max() for k in range(1, 9) for _ in range(12)]
+    models += [rng.normal(size=9) * 10.0 ** rng.integers(-30, 30) for _ in range(100)]
+    M = np.ascontiguousarray(np.array(models, dtype=np.float64)); nm = M.shape[0]
+    for (a, b) in ((p1, p2), (big1, big2)):
+        a = np.ascontiguousarray(a); b = np.ascontiguousarray(b); n = a.shape[0]
+        for kind in (0, 1):
+            for th in (0.25, 4.0):
+                c1 = np.zeros(nm, np.uint32); c2 = np.zeros(nm, np.uint32)
+                _lib.check(L.mi_degensac_screen_counts(_lib.dptr(a), _lib.dptr(b), n, 2, _lib.dptr(M), nm, kind, C.c_double(th), 0,
+                                                       c1.ctypes.data_as(C.POINTER(C.c_uint32)), c2.ctypes.data_as(C.POINTER(C.c_uint32))))
+                I = np.zeros(nm, np.uint32); J = np.zeros(nm); R = np.zeros((nm, n))
+                _lib.check(L.mi_degensac_score_models(_lib.dptr(a), _lib.dptr(b), n, 2, _lib.dptr(M), nm, kind, C.c_double(th), 0,
+                                                      I.ctypes.data_as(C.POINTER(C.c_uint32)), _lib.dptr(J), _lib.dptr(R)))
+                exact = (R < th * 9 / 4).sum(axis=1)                            # the band of the MSAC gain, on the kernel's own residuals
+                assert (c2 >= exact).all(), (kind, th, int(np.argmax(exact.astype(np.int64) - c2)))
+                assert (c1 >= exact).all(), (kind, th, int(np.argmax(exact.astype(np.int64) - c1)))
+                assert (exact > 0).any() and (c1[:300] < n).any()                 # the test has teeth: bands are hit, level 1 rejects
+
