@@ -11,7 +11,7 @@
  * images' worth of descriptors, and is LDS-tiled instead: a workgroup owns 64 queries, streams the train set through
  * LDS 64 rows at a time (both tiles stored dimension-major, so a wave reads consecutive words / one broadcast word),
  * every thread keeps a 4 x 4 block of running sums in registers and its own running top-2 per query; the 16 threads
- * sharing a query merge their candidates at the end. */
+ * sharing a query merge their candidates at the end.  The train set is additionally split over blockIdx.y (see mt_knn2_kernel). */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -34,9 +34,14 @@ __device__ __forceinline__ void mt_push(mt_best &b, float d, int i)
 }
 
 /* NORM: 0 = L2 over float words, 1 = Hamming over 32-bit words of packed bytes.  q, t: [n, words] row-major. */
+/* Launch shape: grid = (ceil(n1 / 64), train splits).  Two images' worth of descriptors give only a few dozen query
+ * tiles (1 500 queries = 24), so the train set is split over blockIdx.y until the grid covers the CUs about twice; a split
+ * writes its top-2 per query (squared distances) to part[split][query] and mt_merge_kernel merges the splits with the same
+ * (distance, index) order, so the result does not depend on the split count.  With one split the kernel writes the final
+ * answer itself. */
 template <int NORM>
-__global__ __launch_bounds__(256) void mt_knn2_kernel(const uint32_t *q, int n1, const uint32_t *t, int n2, int words,
-                                                      int32_t *idx /* [n1,2] */, float *dist /* [n1,2] */)
+__global__ __launch_bounds__(256) void mt_knn2_kernel(const uint32_t *q, int n1, const uint32_t *t, int n2, int words, int t_chunk /* train rows per split, multiple of 64 */,
+                                                      int32_t *idx /* [n1,2] */, float *dist /* [n1,2] */, mt_best *part /* [splits][n1] or null */)
 {
     __shared__ uint32_t qs[MT_DC][MT_Q + 1], ts[MT_DC][MT_T + 1];
     __shared__ mt_best merge[MT_Q][16];
@@ -45,7 +50,8 @@ __global__ __launch_bounds__(256) void mt_knn2_kernel(const uint32_t *q, int n1,
     mt_best best[4];
 #pragma unroll
     for (int a = 0; a < 4; a++) { best[a].d0 = best[a].d1 = __builtin_inff(); best[a].i0 = best[a].i1 = -1; }
-    for (int t0 = 0; t0 < n2; t0 += MT_T) {
+    const int t_lo = (int)blockIdx.y * t_chunk, t_hi = t_lo + t_chunk < n2 ? t_lo + t_chunk : n2;
+    for (int t0 = t_lo; t0 < t_hi; t0 += MT_T) {
         float acc[4][4]; unsigned hacc[4][4];
 #pragma unroll
         for (int a = 0; a < 4; a++)
@@ -56,7 +62,7 @@ __global__ __launch_bounds__(256) void mt_knn2_kernel(const uint32_t *q, int n1,
             /* stage both tiles dimension-major: thread r loads row (r / 4), a quarter of the chunk's words, coalesced per row */
             for (int e = tid; e < MT_Q * MT_DC; e += 256) {
                 const int r = e / MT_DC, w = e - r * MT_DC;
-                const bool okq = q0 + r < n1 && w0 + w < words, okt = t0 + r < n2 && w0 + w < words;
+                const bool okq = q0 + r < n1 && w0 + w < words, okt = t0 + r < t_hi && w0 + w < words;
                 qs[w][r] = okq ? q[(size_t)(q0 + r) * words + w0 + w] : 0u;
                 ts[w][r] = okt ? t[(size_t)(t0 + r) * words + w0 + w] : 0u;
             }
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(256) void mt_knn2_kernel(const uint32_t *q, int n1,
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                 const int ti = t0 + tx + 16 * b;
-                if (ti < n2) mt_push(best[a], NORM == 0 ? acc[a][b] : (float)hacc[a][b], ti);
+                if (ti < t_hi) mt_push(best[a], NORM == 0 ? acc[a][b] : (float)hacc[a][b], ti);
             }
     }
     /* the 16 threads of a query row merge their candidates (lane order does not matter: mt_push orders by (d, i)) */
@@ -92,10 +98,22 @@ __global__ __launch_bounds__(256) void mt_knn2_kernel(const uint32_t *q, int n1,
     if (tid < MT_Q && q0 + tid < n1) {
         mt_best m = merge[tid][0];
         for (int k = 1; k < 16; k++) { const mt_best c = merge[tid][k]; if (c.i0 >= 0) mt_push(m, c.d0, c.i0); if (c.i1 >= 0) mt_push(m, c.d1, c.i1); }
+        if (part) { part[(size_t)blockIdx.y * n1 + q0 + tid] = m; return; }
         const size_t o = (size_t)(q0 + tid) * 2;
         idx[o] = m.i0; idx[o + 1] = m.i1;
         dist[o] = NORM == 0 ? sqrtf(m.d0) : m.d0; dist[o + 1] = NORM == 0 ? sqrtf(m.d1) : m.d1;
     }
+}
+
+/* merge the per-split top-2 of every query (any order gives the same result: mt_push orders by (distance, index)) */
+__global__ void mt_merge_kernel(const mt_best *part, int splits, int n1, int l2, int32_t *idx, float *dist)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n1) return;
+    mt_best m = part[i];
+    for (int s = 1; s < splits; s++) { const mt_best c = part[(size_t)s * n1 + i]; if (c.i0 >= 0) mt_push(m, c.d0, c.i0); if (c.i1 >= 0) mt_push(m, c.d1, c.i1); }
+    idx[2 * i] = m.i0; idx[2 * i + 1] = m.i1;
+    dist[2 * i] = l2 ? sqrtf(m.d0) : m.d0; dist[2 * i + 1] = l2 ? sqrtf(m.d1) : m.d1;
 }
 
 /* keep[i] = second-nearest-neighbour ratio test (strict, as the example's `m.distance < ratio * n.distance`; a query with
@@ -154,10 +172,24 @@ extern "C" int mi_degensac_match_knn2_dev(int norm, const void *d_desc1, int n1,
     if (words < 0) { snprintf(mt_err, sizeof mt_err, "Hamming descriptors must be padded to a multiple of 4 bytes"); return MI_DEGENSAC_EINVAL; }
     MtDevGuard g; int rc = g.enter(device); if (rc) return rc;
     if (n1 == 0) return 0;
-    const dim3 grid((n1 + MT_Q - 1) / MT_Q), block(256);
-    if (norm == MI_DEGENSAC_NORM_L2) hipLaunchKernelGGL(mt_knn2_kernel<0>, grid, block, 0, (hipStream_t)stream, (const uint32_t *)d_desc1, n1, (const uint32_t *)d_desc2, n2, words, d_idx, d_dist);
-    else                             hipLaunchKernelGGL(mt_knn2_kernel<1>, grid, block, 0, (hipStream_t)stream, (const uint32_t *)d_desc1, n1, (const uint32_t *)d_desc2, n2, words, d_idx, d_dist);
-    MTCHK(hipGetLastError());
+    /* train splits: enough workgroups to cover the device about twice, never less than one 64-row tile per split */
+    const int qtiles = (n1 + MT_Q - 1) / MT_Q, ttiles = n2 > 0 ? (n2 + MT_T - 1) / MT_T : 1;
+    int cus = 256; { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) cus = pr.multiProcessorCount; else (void)hipGetLastError(); }
+    int splits = (2 * cus + qtiles - 1) / qtiles; if (splits > ttiles) splits = ttiles; if (splits < 1) splits = 1; if (splits > 256) splits = 256;
+    const int t_chunk = ((ttiles + splits - 1) / splits) * MT_T;
+    splits = n2 > 0 ? (n2 + t_chunk - 1) / t_chunk : 1;
+    mt_best *part = nullptr;
+    if (splits > 1) MTCHK(hipMallocAsync((void **)&part, (size_t)splits * n1 * sizeof(mt_best), (hipStream_t)stream));
+    const dim3 grid(qtiles, splits), block(256);
+    if (norm == MI_DEGENSAC_NORM_L2) hipLaunchKernelGGL(mt_knn2_kernel<0>, grid, block, 0, (hipStream_t)stream, (const uint32_t *)d_desc1, n1, (const uint32_t *)d_desc2, n2, words, n2 > 0 ? t_chunk : MT_T, d_idx, d_dist, part);
+    else                             hipLaunchKernelGGL(mt_knn2_kernel<1>, grid, block, 0, (hipStream_t)stream, (const uint32_t *)d_desc1, n1, (const uint32_t *)d_desc2, n2, words, n2 > 0 ? t_chunk : MT_T, d_idx, d_dist, part);
+    hipError_t le = hipGetLastError();
+    if (le == hipSuccess && part) {
+        hipLaunchKernelGGL(mt_merge_kernel, dim3((n1 + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, splits, n1, norm == MI_DEGENSAC_NORM_L2 ? 1 : 0, d_idx, d_dist);
+        le = hipGetLastError();
+    }
+    if (part) (void)hipFreeAsync(part, (hipStream_t)stream);
+    MTCHK(le);
     return 0;
 }
 
