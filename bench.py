@@ -158,10 +158,10 @@ def source_id():
 def pmc_traffic(cfg_name, pairs_per_gpu):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/README.md):
     2 x FETCH_SIZE + WRITE_SIZE KiB (MI355X_MICROARCH.md: FETCH_SIZE under-reports coalesced reads 2x on gfx950).
-    Counters cannot be read from inside the process, so the figure comes from profiles/r2_pmc_<config>.json, which
+    Counters cannot be read from inside the process, so the figure comes from profiles/r3_pmc_<config>.json, which
     tools/pmc_summary.py writes next to the rocprofv3 CSVs together with the hash of the kernel sources it was measured
     on and the batch size; any mismatch with this build / this batch gives null instead of a stale number."""
-    path = os.path.join(ROOT, "profiles", f"r2_pmc_{cfg_name}.json")
+    path = os.path.join(ROOT, "profiles", f"r3_pmc_{cfg_name}.json")
     if not os.path.exists(path):
         return None
     try:
