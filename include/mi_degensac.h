@@ -67,7 +67,9 @@ extern "C" {
  *   bit  4    sampler           1 = always use the sequential pool-swap stage
  *   bits 8-15 helper workgroups per pair of the cooperative large-n mode (fundamental matrix, placement HBM):
  *             0 = automatic (15 helpers when n >= 8192 and the batch leaves the device mostly idle), 255 = off
- *   bits 5-7  with bits 16-23: a pair set aside with at least (threshold << this) samples left counts as "long" and is
+ *   bit  5    with helper workgroups (bits 8-15): distribute every pass over the whole point set over the claiming
+ *             workgroups, not only those over >= 8192 points (tests)
+ *   bits 5-7  with bits 16-23 (no helpers): a pair set aside with at least (threshold << this) samples left counts as "long" and is
  *             resumed before the others; 0 = automatic (threshold x 8)
  *   bits 16-23 setting pairs aside (fundamental matrix, batches larger than the resident grid): a pair still running
  *             after this many samples (units of 256) while unstarted pairs remain is written back to its workspace and

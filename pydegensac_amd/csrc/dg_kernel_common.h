@@ -56,7 +56,9 @@ struct dg_ws_layout {
     size_t off_mslot;     /* cooperative mode: the chunk's compact model index -> slot table, unsigned short[3*DG_CHUNK]; then the per-model
                              screening counters unsigned[3*DG_CHUNK] and the survivor list unsigned short[3*DG_CHUNK] */
     size_t off_park;      /* parked-pair image: dg_f_shared + the dynamic LDS of the workgroup that set the pair aside (F driver) */
-    size_t off_hjbuf;     /* cooperative mode: ordered MSAC terms of each helper workgroup, double[coop_k][n_max]        */
+    size_t off_hjbuf;     /* cooperative mode: ordered MSAC terms of each claiming workgroup, double[coop_k + 1][n_max]   */
+    size_t off_job;       /* cooperative mode: the job of a distributed pass (dg_coop_job), its per-slice records and the slice-local
+                             staging of its outputs: int[n_max] x 2 (lists), double[n_max] (MSAC terms)                       */
     int    n_max;
 };
 
@@ -90,6 +92,19 @@ struct dg_coop_cb {
 };
 static_assert(sizeof(dg_coop_cb) == 256, "control block = two 128-byte lines");
 
+/* Stage 3 of the cooperative mode: ONE pass of the local optimisation over the whole point set (residuals of model F under
+ * metric `kind`, inlier count, MSAC terms, up to two ordered inlier lists), distributed over point slices.  A unit = one
+ * slice: the claiming workgroup runs the ordinary workgroup pass on it and leaves the slice's lists and nonzero MSAC terms
+ * in slice-local staging (at the slice's own offset) and its counts in rec[unit]; the owner concatenates the lists in slice
+ * order (= point order) and adds the terms one after the other in that order: the same lists and the same J as one
+ * workgroup would produce. */
+struct dg_coop_job {
+    double F[9], thJ, thL, thL2;
+    int kind, wantJ, listStrict, has_list, has_list2, slice, n, pad;
+};
+struct dg_coop_rec { unsigned I, nL, nL2, nJ; };
+#define DG_COOP_MAX_SLICES 64
+
 struct dg_args {
     const double *pts1, *pts2;       /* [total, dim] */
     const long long *offsets;        /* [n_pairs + 1] */
@@ -111,6 +126,7 @@ struct dg_args {
     int *ticket;                     /* device counter, zeroed per launch: persistent workgroups pull the next pair from it */
     const int *order;                /* optional processing order (ticket t -> pair order[t]); null = identity              */
     int coop_k;                      /* helper workgroups per owner (0 = every workgroup owns pairs)            */
+    int coop_pass_min;               /* cooperative mode: passes over at least this many points are distributed (stage 3) */
     dg_coop_cb *coop;                /* [owner slots] control blocks (coop_k > 0)                              */
     /* Setting pairs aside (F driver, batches larger than the resident grid).  Which pairs run long is only known while
      * they run, and a batch ends one long pair after the last long pair was started.  So every pair that is still running

@@ -107,6 +107,7 @@ struct dg_f_ctx {
     /* counters */
     int n_fds, n_exfds, n_hds, n_aux;
     double *rrun;            /* diagnostics: the 62 x n residual rows of the current LO run, or null */
+    dg_coop_cb *cb; int *coop_gen; int coop_slot;   /* cooperative large-n mode: this owner's control block (null = off) */
 
     __device__ __forceinline__ dg_pt pt(int i) const { return P[i]; }
     /* LAF point sets u_1 (which=1: +a12,+a22) and u_2 (which=2: +a11,+a21): bindings.cpp:337-409 */
@@ -173,8 +174,13 @@ __device__ __forceinline__ void dg_resid_begin(CTX &c, int run /* 0-based */)
 
 /* a full scoring pass of model F (kind) with optional list/flags; counts as FDS1/EXFDS1/aux */
 template <int LDSPTS>
+__device__ __noinline__ dg_pass_res dg_coop_pass(CTX &c, const double *Fm /* LDS */, int kind, const dg_pass_cfg &cfg);
+
+template <int LDSPTS>
 __device__ __forceinline__ dg_pass_res dg_f_pass(CTX &c, const double *Fm /* LDS */, int kind, dg_pass_cfg cfg)
 {
+    /* cooperative large-n mode: passes over the whole point set are distributed over the claiming workgroups */
+    if (LDSPTS == 0 && c.cb && !cfg.src && !cfg.flags && !cfg.wantC && cfg.n >= c.A->coop_pass_min) return dg_coop_pass<LDSPTS>(c, Fm, kind, cfg);
     double F[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) F[i] = Fm[i];
@@ -196,7 +202,7 @@ __device__ __forceinline__ dg_pass_res dg_h_pass(CTX &c, const double *Hm /* LDS
 }
 __device__ __forceinline__ dg_pass_cfg dg_cfg0(int n)
 {
-    dg_pass_cfg c; c.n = n; c.src = 0; c.wantJ = 0; c.thJ = 0; c.jbuf = 0; c.jl = 0; c.jl_cap = 0; c.wantC = 0; c.thC = 0; c.list = 0; c.thL = 0; c.listStrict = 0; c.list2 = 0; c.thL2 = 0; c.flags = 0; c.thF = 0;
+    dg_pass_cfg c; c.n = n; c.src = 0; c.p0 = 0; c.wantJ = 0; c.thJ = 0; c.jbuf = 0; c.jl = 0; c.jl_cap = 0; c.wantC = 0; c.thC = 0; c.list = 0; c.thL = 0; c.listStrict = 0; c.list2 = 0; c.thL2 = 0; c.flags = 0; c.thF = 0;
     return c;
 }
 

@@ -805,6 +805,7 @@ __device__ __forceinline__ long long dg_park_take(const dg_args &A, long long *b
 struct dg_coop_ws {
     const dg_pt *P; const double *gmodels; const unsigned short *gms;
     unsigned *cnt; unsigned short *surv; unsigned *res_I; double *res_J;
+    dg_coop_job *job; dg_coop_rec *rec; int *stg_list, *stg_list2; double *stg_j;
 };
 __device__ __forceinline__ dg_coop_ws dg_coop_views(const dg_args &A, int slot)
 {
@@ -816,6 +817,10 @@ __device__ __forceinline__ dg_coop_ws dg_coop_views(const dg_args &A, int slot)
     v.cnt = (unsigned *)(ws + A.wl.off_mslot + (size_t)3 * DG_CHUNK * sizeof(unsigned short));
     v.surv = (unsigned short *)(v.cnt + 3 * DG_CHUNK);
     v.res_J = (double *)(ws + A.wl.off_res); v.res_I = (unsigned *)(v.res_J + 3 * DG_CHUNK);
+    v.job = (dg_coop_job *)(ws + A.wl.off_job);
+    v.rec = (dg_coop_rec *)(ws + A.wl.off_job + ((sizeof(dg_coop_job) + 255) & ~(size_t)255));
+    v.stg_list = (int *)((char *)v.rec + ((DG_COOP_MAX_SLICES * sizeof(dg_coop_rec) + 255) & ~(size_t)255));
+    v.stg_list2 = v.stg_list + A.wl.n_max; v.stg_j = (double *)(v.stg_list2 + A.wl.n_max);
     return v;
 }
 #define DG_COOP_GEN_MASK 0xfffff
@@ -946,6 +951,25 @@ __device__ __forceinline__ void dg_coop_unit_exact(dg_f_shared *S, const dg_coop
     if (tid == 0) { v.res_I[mi] = r.I; v.res_J[mi] = r.J; }
 }
 
+/* Stage 3, one unit = slice u of a distributed pass (dg_coop_job): the ordinary workgroup pass on the slice, outputs in
+ * slice-local staging, counts in rec[u] */
+template <int T>
+__device__ __forceinline__ void dg_coop_unit_pass(dg_f_shared *S, const dg_coop_ws &v, int u, int tid)
+{
+    const dg_coop_job *jb = v.job;
+    const int n = jb->n, slice = jb->slice, lo = u * slice, hi = lo + slice < n ? lo + slice : n, kind = jb->kind;
+    double F[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++) F[q] = jb->F[q];
+    dg_pass_cfg cfg = dg_cfg0(hi - lo); cfg.p0 = lo;
+    if (jb->wantJ) { cfg.wantJ = 2; cfg.thJ = jb->thJ; cfg.jbuf = v.stg_j + lo; }
+    if (jb->has_list) { cfg.list = v.stg_list + lo; cfg.thL = jb->thL; cfg.listStrict = jb->listStrict; }
+    if (jb->has_list2) { cfg.list2 = v.stg_list2 + lo; cfg.thL2 = jb->thL2; }
+    const dg_pt *P = v.P;
+    const dg_pass_res r = dg_pass(&S->red, cfg, [&](int pid, int) { return dg_Ferr(kind, F, dg_ldpt<0>(P, pid)); }, tid);
+    if (tid == 0) { dg_coop_rec rc; rc.I = r.I; rc.nL = r.nL; rc.nL2 = r.nL2; rc.nJ = r.nJ; v.rec[u] = rc; }
+}
+
 /* Whole workgroup (owner or helper): work on generation G until it has no unclaimed unit left */
 template <int T>
 __device__ __forceinline__ void dg_coop_work(dg_f_shared *S, const dg_coop_ws &v, dg_coop_cb *cb, int G, double *jbuf, int *bc /* LDS */, int tid)
@@ -961,8 +985,10 @@ __device__ __forceinline__ void dg_coop_work(dg_f_shared *S, const dg_coop_ws &v
             const double tau = __longlong_as_double((long long)__hip_atomic_load(&cb->tau_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             const int lo = u * slice, hi = lo + slice < n ? lo + slice : n;
             dg_coop_unit_screen<T>(S, v, cb, lo, hi, tau, tid);
-        } else {
+        } else if (stage == 2) {
             dg_coop_unit_exact<T>(S, v, cb, (int)v.surv[u], jbuf, tid);
+        } else {
+            dg_coop_unit_pass<T>(S, v, u, tid);
         }
         dg_coop_unit_done(cb);
     }
@@ -995,6 +1021,54 @@ __device__ __forceinline__ void dg_f_helper(const dg_args &A, dg_f_shared *S, co
     }
 }
 
+/* Owner, whole workgroup: one pass over the whole point set, distributed (stage 3).  Same result as dg_pass on all points:
+ * the lists are the slices' lists in slice order, J the sequential sum of the slices' terms in slice order. */
+template <int LDSPTS>
+__device__ __noinline__ dg_pass_res dg_coop_pass(CTX &c, const double *Fm /* LDS */, int kind, const dg_pass_cfg &cfg)
+{
+    dg_f_shared *S = c.S; const dg_args &A = *c.A; dg_coop_cb *cb = c.cb;
+    const int tid = c.tid, lane = tid & 63, wave = tid >> 6, n = cfg.n;
+    const dg_coop_ws v = dg_coop_views(A, c.coop_slot);
+    int slice = (n + A.coop_k) / (A.coop_k + 1);                               /* one slice per claiming workgroup ... */
+    slice = (slice + DG_T * DG_PU - 1) / (DG_T * DG_PU) * (DG_T * DG_PU);      /* ... in whole steps of the workgroup pass */
+    if ((n + slice - 1) / slice > DG_COOP_MAX_SLICES) slice = (n + DG_COOP_MAX_SLICES - 1) / DG_COOP_MAX_SLICES;
+    const int n_units = (n + slice - 1) / slice;
+    __syncthreads();
+    if (tid == 0) {
+        dg_coop_job *jb = v.job;
+        for (int q = 0; q < 9; q++) jb->F[q] = Fm[q];
+        jb->thJ = cfg.thJ; jb->thL = cfg.thL; jb->thL2 = cfg.thL2; jb->kind = kind; jb->wantJ = cfg.wantJ ? 1 : 0; jb->listStrict = cfg.listStrict;
+        jb->has_list = cfg.list ? 1 : 0; jb->has_list2 = cfg.list2 ? 1 : 0; jb->slice = slice; jb->n = n; jb->pad = 0;
+    }
+    dg_coop_publish(cb, *c.coop_gen, 3, n_units, 0, n, kind, slice, 0, cfg.thJ, S->ext, 0.0);
+    dg_coop_work<DG_T>(S, v, cb, *c.coop_gen, (double *)(A.ws + (size_t)c.coop_slot * A.wl.stride + A.wl.off_hjbuf), &S->itmp[28], tid);
+    if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
+        while (__hip_atomic_load(&cb->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_units) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    dg_pass_res out; out.I = 0; out.J = 0; out.C = 0; out.nL = 0; out.nF = 0; out.nL2 = 0; out.nJ = 0;
+    /* concatenate: wave w copies the slices w, w + DG_NW, ...; the last wave's first lane meanwhile adds the terms in order */
+    for (int u = 0; u < n_units; u++) {
+        const dg_coop_rec rc = v.rec[u];
+        if (u % DG_NW == wave) {
+            const int lo = u * slice;
+            if (cfg.list)  for (int k = lane; k < (int)rc.nL; k += 64)  cfg.list[out.nL + k] = v.stg_list[lo + k];
+            if (cfg.list2) for (int k = lane; k < (int)rc.nL2; k += 64) cfg.list2[out.nL2 + k] = v.stg_list2[lo + k];
+        }
+        out.I += rc.I; out.nL += rc.nL; out.nL2 += rc.nL2; out.nJ += rc.nJ;
+    }
+    if (cfg.wantJ && tid == DG_T - 64) {
+        double J = 0.0;
+        for (int u = 0; u < n_units; u++) J = dg_seq_sum_from<1>(v.stg_j + (size_t)u * slice, (int)v.rec[u].nJ, J);
+        S->red.bc[0] = J;
+    }
+    __syncthreads();
+    if (cfg.wantJ) out.J = S->red.bc[0];
+    __syncthreads();
+    return out;
+}
+
 /* the whole driver for ONE pair, run by one workgroup on workspace `wsid` (a resident workgroup starts on the workspace
  * of its own index).  resume != 0: `wsid` holds the image of a pair that was set aside, continue it.
  * Returns -1 when the pair is finished, else the pair was set aside and the return value is the spare workspace the
@@ -1020,6 +1094,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     c.ht.heads = (int *)(ws + A.wl.off_ht); c.ht.count = c.ht.heads + 64; c.ht.ent = c.ht.heads + 80;
     c.seeds = S->seeds3[0]; c.draws = S->draws3[0];
     c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0; c.rrun = 0;
+    c.cb = cb; c.coop_gen = &coop_gen; c.coop_slot = slot;
     dg_pt *Pw; int *pool;
     /* LDSPTS: 1 = point set and sampler pool in LDS, 2 = pool in LDS / points in the HBM workspace (L2), 0 = both in HBM */
     if (LDSPTS == 1) { Pw = (dg_pt *)dyn_smem; pool = (int *)(dyn_smem + (size_t)n * sizeof(dg_pt)); }

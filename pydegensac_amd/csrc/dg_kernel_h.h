@@ -340,6 +340,7 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
     c.ht.heads = (int *)(ws + A.wl.off_ht); c.ht.count = c.ht.heads + 64; c.ht.ent = c.ht.heads + 80;
     c.seeds = S->seeds3[0]; c.draws = S->draws3[0];
     c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0; c.rrun = 0;
+    c.cb = (dg_coop_cb *)0; c.coop_gen = (int *)0; c.coop_slot = 0;
     dg_pt *Pw; int *pool;
     /* LDSPTS: 1 = point set and sampler pool in LDS, 2 = pool in LDS / points in the HBM workspace (L2), 0 = both in HBM */
     if (LDSPTS == 1) { Pw = (dg_pt *)dyn_smem; pool = (int *)(dyn_smem + (size_t)n * sizeof(dg_pt)); }

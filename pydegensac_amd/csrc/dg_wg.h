@@ -187,8 +187,10 @@ __device__ __forceinline__ double dg_block_sum_d(dg_red *r, double v, int tid)
 struct dg_pass_cfg {
     int         n;
     const int  *src;        /* optional indirection */
+    int         p0;         /* without src: item j is point p0 + j (a slice of the point set) */
     /* (I, J): I = #(d <= thJ), J = sum truncQuad(d, thJ)  (rtools.c:160-171, 228-236) */
-    int         wantJ;  double thJ;  double *jbuf;   /* jbuf: >= n doubles of scratch (HBM) for the ordered nonzero MSAC terms ... */
+    int         wantJ;  double thJ;  double *jbuf;   /* jbuf: >= n doubles of scratch (HBM) for the ordered nonzero MSAC terms ...;
+                                                        wantJ == 2: only store the terms and count them (res.nJ), the caller sums */
     double     *jl;     int jl_cap;                  /* ... behind the first jl_cap of them, which go to this LDS buffer (0 = none)   */
     /* second counter: #(d <= thC) */
     int         wantC;  double thC;
@@ -199,13 +201,13 @@ struct dg_pass_cfg {
     /* flags[item position] = d < thF (strict, DegUtils.c style) and their count */
     unsigned char *flags; double thF;
 };
-struct dg_pass_res { unsigned I; double J; unsigned C; unsigned nL; unsigned nF; unsigned nL2; };
+struct dg_pass_res { unsigned I; double J; unsigned C; unsigned nL; unsigned nF; unsigned nL2; unsigned nJ; };
 
 template <class Err>
 __device__ __forceinline__ dg_pass_res dg_pass(dg_red *r, const dg_pass_cfg &c, Err err, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
-    dg_pass_res out; out.I = 0; out.J = 0; out.C = 0; out.nL = 0; out.nF = 0; out.nL2 = 0;
+    dg_pass_res out; out.I = 0; out.J = 0; out.C = 0; out.nL = 0; out.nF = 0; out.nL2 = 0; out.nJ = 0;
     const double t94 = c.thJ * 9 / 4;
     unsigned cI = 0, cC = 0, cF = 0, nJ = 0;
     int par = 0;
@@ -216,7 +218,7 @@ __device__ __forceinline__ dg_pass_res dg_pass(dg_red *r, const dg_pass_cfg &c, 
 #pragma unroll
         for (int u = 0; u < DG_PU; u++) { jj[u] = base + u * DG_T + tid; act[u] = jj[u] < c.n; }
 #pragma unroll
-        for (int u = 0; u < DG_PU; u++) pid[u] = act[u] ? (c.src ? c.src[jj[u]] : jj[u]) : 0;
+        for (int u = 0; u < DG_PU; u++) pid[u] = act[u] ? (c.src ? c.src[jj[u]] : c.p0 + jj[u]) : 0;
 #pragma unroll
         for (int u = 0; u < DG_PU; u++) d[u] = act[u] ? err(pid[u], jj[u]) : 0.0;
         double term[DG_PU]; bool nz[DG_PU], in[DG_PU], in2[DG_PU];
@@ -269,11 +271,12 @@ __device__ __forceinline__ dg_pass_res dg_pass(dg_red *r, const dg_pass_cfg &c, 
     cI = dg_wave_sum_u(cI); cC = dg_wave_sum_u(cC); cF = dg_wave_sum_u(cF);
     __syncthreads();
     if (lane == 0) { r->u[0][wave][0] = cI; r->u[0][wave][1] = cC; r->u[0][wave][3] = cF; }
-    if (tid == 0 && c.wantJ) r->bc[0] = dg_seq_sum_split(c.jl, c.jl_cap, c.jbuf, (int)nJ);
+    if (tid == 0 && c.wantJ == 1) r->bc[0] = dg_seq_sum_split(c.jl, c.jl_cap, c.jbuf, (int)nJ);
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < DG_NW; w++) { out.I += r->u[0][w][0]; out.C += r->u[0][w][1]; out.nF += r->u[0][w][3]; }
-    if (c.wantJ) out.J = r->bc[0];
+    if (c.wantJ == 1) out.J = r->bc[0];
+    out.nJ = nJ;
     __syncthreads();
     return out;
 }

@@ -65,9 +65,9 @@ def test_cooperative_helpers_match_the_oracle(oracle_port):
     per owner): every run, pair by pair, against the CPU oracle (counters, masks, models), not against another GPU run"""
     A, B = _f_batch(); A = A * 3; B = B * 3; seeds = list(range(1, 13))
     for variant in (512, 256):
-        for helpers in (255, 1, 3, 7):
-            F, m = pd.findFundamentalMatrixBatch(A, B, max_iters=20000, seeds=seeds, tuning=tune(variant, 0) | (helpers << 8))
-            _check_against_oracle(oracle_port, A, B, seeds, F, m, pd.last_stats(), (variant, helpers))
+        for helpers, dist in ((255, 0), (1, 0), (3, 1), (7, 0), (7, 1)):    # dist: the LO's full passes distributed too (tuning bit 5)
+            F, m = pd.findFundamentalMatrixBatch(A, B, max_iters=20000, seeds=seeds, tuning=tune(variant, 0) | (helpers << 8) | (dist << 5))
+            _check_against_oracle(oracle_port, A, B, seeds, F, m, pd.last_stats(), (variant, helpers, dist))
 
 
 def test_setting_pairs_aside_matches_the_oracle(oracle_port):
