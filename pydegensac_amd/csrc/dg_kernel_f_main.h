@@ -302,8 +302,7 @@ __device__ __noinline__ int dg_solve7_lane(const dg_pt *P, const int *ids, doubl
 /* Sampler stage 1 (one wave): the seed chain of a chunk and the raw draws of every sample.
  * Returns the seed that follows the chunk; almask[] (LDS) receives the per-sample alias flags. */
 template <int NDRAW>
-__device__ __noinline__ unsigned dg_sample_draws(unsigned seed, int cn, int n, unsigned *seeds, int (*draws)[8],
-                                                 unsigned long long *almask, int lane, long long *dbg = 0)
+__device__ __noinline__ unsigned dg_sample_chain(unsigned seed, int cn, unsigned *seeds, int lane, long long *dbg = 0)
 {
     long long ts0 = DG_CLK();
     __builtin_amdgcn_s_setprio(3);                        /* the serial waves must not queue behind the scoring waves */
@@ -317,29 +316,42 @@ __device__ __noinline__ unsigned dg_sample_draws(unsigned seed, int cn, int n, u
         sd = dg_wave_sum_u(ck * rj) >> 1;
     }
     DG_WSYNC();
-    long long ts1 = DG_CLK();
-    /* draws of every sample (lane = sample) + per-sample alias flag: two draws on the same position, or a draw
-     * inside the tail block, make the swaps of that sample order-dependent -> replayed sequentially in stage 2 */
-#pragma unroll
-    for (int rd = 0; rd < DG_CHUNK / 64; rd++) {
-        const int k = rd * 64 + lane;
-        bool al = false;
-        if (k < cn) {
-            unsigned o[8]; int dr[NDRAW];
-            dg_rng_outputs(seeds[k], o);
-#pragma unroll
-            for (int i = 0; i < NDRAW; i++) { dr[i] = (int)(o[i] % (unsigned)(n - i)); draws[k][i] = dr[i]; al = al || dr[i] >= n - NDRAW; }
-#pragma unroll
-            for (int i = 0; i < NDRAW; i++)
-#pragma unroll
-                for (int j = i + 1; j < NDRAW; j++) al = al || dr[i] == dr[j];
-        }
-        unsigned long long b = __ballot(al);
-        if (lane == 0) almask[rd] = b;
-    }
-    DG_WSYNC();
     __builtin_amdgcn_s_setprio(0);
-    DG_DEVT(if (dbg && lane == 0) { long long ts2 = DG_CLK(); dbg[4] += ts1 - ts0; dbg[5] += ts2 - ts1; });
+    DG_DEVT(if (dbg && lane == 0) { dbg[4] += DG_CLK() - ts0; });
+    return sd;
+}
+/* Sampler stage 1b: the draws of the samples 64 rd .. 64 rd + 63 of a chunk whose seeds are known (lane = sample) + the
+ * per-sample alias flag: two draws on the same position, or a draw inside the tail block, make the swaps of that sample
+ * order-dependent -> replayed sequentially in stage 2.  The rounds of a chunk are independent: one wave each. */
+template <int NDRAW>
+__device__ __noinline__ void dg_sample_draws_round(int rd, int cn, int n, const unsigned *seeds, int (*draws)[8], unsigned long long *almask, int lane, long long *dbg = 0)
+{
+    long long ts1 = DG_CLK();
+    const int k = rd * 64 + lane;
+    bool al = false;
+    if (k < cn) {
+        unsigned o[8]; int dr[NDRAW];
+        dg_rng_outputs(seeds[k], o);
+#pragma unroll
+        for (int i = 0; i < NDRAW; i++) { dr[i] = (int)(o[i] % (unsigned)(n - i)); draws[k][i] = dr[i]; al = al || dr[i] >= n - NDRAW; }
+#pragma unroll
+        for (int i = 0; i < NDRAW; i++)
+#pragma unroll
+            for (int j = i + 1; j < NDRAW; j++) al = al || dr[i] == dr[j];
+    }
+    unsigned long long b = __ballot(al);
+    if (lane == 0) almask[rd] = b;
+    DG_WSYNC();
+    DG_DEVT(if (dbg && lane == 0 && rd == 0) { dbg[5] += DG_CLK() - ts1; });
+}
+/* Sampler stage 1 on ONE wave (prologue of the kernels, unit-test kernel): the seed chain of a chunk, then its draws.
+ * Returns the seed that follows the chunk; almask[] (LDS) receives the per-sample alias flags. */
+template <int NDRAW>
+__device__ __forceinline__ unsigned dg_sample_draws(unsigned seed, int cn, int n, unsigned *seeds, int (*draws)[8],
+                                                  unsigned long long *almask, int lane, long long *dbg = 0)
+{
+    const unsigned sd = dg_sample_chain<NDRAW>(seed, cn, seeds, lane, dbg);
+    for (int rd = 0; rd < DG_CHUNK / 64; rd++) dg_sample_draws_round<NDRAW>(rd, cn, n, seeds, draws, almask, lane, dbg);
     return sd;
 }
 
@@ -1292,7 +1304,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             if (wave == 0) {
                 if (chunk_s[nxt] > 0) dg_sample_pool<7, LDSPTS>(chunk_s[nxt], n, pool, S->draws3[nxt], S->alm3[nxt], pscr, lane, S->dbg);
             } else if (wave == 1) {
-                if (cn2 > 0) { unsigned sd = dg_sample_draws<7>(seed, cn2, n, S->seeds3[nx2], S->draws3[nx2], S->alm3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }
+                if (cn2 > 0) { unsigned sd = dg_sample_chain<7>(seed, cn2, S->seeds3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }   /* its draws: after the barrier, one wave per 64 samples */
             }
             /* cooperative mode: the helpers score every group (a whole workgroup per group); the owner's waves only sample.
              * Otherwise: waves 2.. score while waves 0 and 1 run their sampler stages (the critical path); with two
@@ -1346,6 +1358,11 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         }
         __syncthreads();
         if (cn2 > 0) seed = (unsigned)S->itmp[31];
+        /* the draws of chunk c+2 (its seeds are complete now): the rounds of 64 samples are independent, one wave each; nothing
+         * reads them before the pool stage of the next iteration, which sits behind the barriers of the commit */
+        if (cn2 > 0 && wave < DG_CHUNK / 64) {
+            for (int rd = wave; rd < DG_CHUNK / 64; rd += DG_NW) dg_sample_draws_round<7>(rd, cn2, n, S->seeds3[nx2], S->draws3[nx2], S->alm3[nx2], lane, S->dbg);
+        }
         DG_PH(2);
         /* ================= commit: replay exp_ranF.c:1334-1577 in order ================= */
         int k;

@@ -424,7 +424,7 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
             if (wave == 0) {
                 if (chunk_s[nxt] > 0) dg_sample_pool<4, LDSPTS>(chunk_s[nxt], n, pool, S->draws3[nxt], S->alm3[nxt], pscr, lane, S->dbg);
             } else if (wave == 1) {
-                if (cn2 > 0) { unsigned sd = dg_sample_draws<4>(seed, cn2, n, S->seeds3[nx2], S->draws3[nx2], S->alm3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }
+                if (cn2 > 0) { unsigned sd = dg_sample_chain<4>(seed, cn2, S->seeds3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }   /* its draws: after the barrier */
             }
             /* static round-robin over the scoring waves: waves 2.. when there are more than two, else both waves after their sampler stage */
             if (wave >= DG_SW0) {
@@ -467,6 +467,9 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
         c.n_hds += Mtot;
         __syncthreads();
         if (cn2 > 0) seed = (unsigned)S->itmp[31];
+        if (cn2 > 0 && wave < DG_CHUNK / 64) {               /* the draws of chunk c+2, one wave per 64 samples (see the F kernel) */
+            for (int rd = wave; rd < DG_CHUNK / 64; rd += DG_NW) dg_sample_draws_round<4>(rd, cn2, n, S->seeds3[nx2], S->draws3[nx2], S->alm3[nx2], lane, S->dbg);
+        }
         DG_PHH(1);
 
         /* ---- commit: replay exp_ranH.c:547-757 in order ---- */
