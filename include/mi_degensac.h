@@ -56,8 +56,10 @@ extern "C" {
                                                  and exp_ransacFcustom (:811) instead of exp_ransacFcustomLAF: the sample budget
                                                  follows EVERY new best model, also one found by the main loop or the DEGENSAC
                                                  branch between two local optimisations (:1085-1090 sits outside the LO block
-                                                 there).  Needs symmetric_error_check = 0 and no LAF check (their symmetric
-                                                 check is a different one and is not built); error_type 0 = exp_ransacF */
+                                                 there).  No LAF check.  symmetric_error_check = 1 gives exp_ransacFcustom's own
+                                                 symmetric check: over ALL points, against CHECK_COEF * th = 16 px_th^2, and in
+                                                 the final mask against the model the driver computed LAST, not the best one
+                                                 (exp_ranF.c:943-953, :1196-1203); error_type 0 without it = exp_ransacF */
 
 /* tuning word (0 = let the library decide; results never depend on it, only speed does):
  *   bits 0-1  kernel variant    1 = latency (512-thread workgroups)   2 = throughput (256-thread, 2 pairs per CU)

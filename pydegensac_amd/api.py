@@ -234,23 +234,25 @@ def findFundamentalMatrixBatch(pts1_list, pts2_list, px_th=0.5, conf=0.9999, max
                   max(0, laf_consistensy_coef), enable_degeneracy_check, seeds, device, tuning)
 
 
-def ransacF_legacy(pts1, pts2, px_th=0.5, conf=0.9999, max_iters=100000, error_type="sampson", seed=None, device=0, tuning=0):
+def ransacF_legacy(pts1, pts2, px_th=0.5, conf=0.9999, max_iters=100000, error_type="sampson", seed=None, device=0, tuning=0,
+                   symmetric_error_check=False):
     """The reference's older fundamental-matrix drivers, which its Python module no longer reaches: `exp_ransacF`
-    (exp_ranF.c:242; error_type "sampson") and `exp_ransacFcustom` without its symmetric check (exp_ranF.c:811; either
-    metric).  They differ from findFundamentalMatrix in one rule: the sample budget follows every new best model, also one
-    found between two local optimisations (MI_DEGENSAC_FLAG_LEGACY_F).  Returns (F [3,3], mask [n] bool)."""
+    (exp_ranF.c:242; error_type "sampson") and `exp_ransacFcustom` (exp_ranF.c:811; either metric; symmetric_error_check =
+    its own symmetric check: all points, 16 px_th^2, the final mask filtered with the model the driver computed last).  They
+    differ from findFundamentalMatrix in one rule: the sample budget follows every new best model, also one found between
+    two local optimisations (MI_DEGENSAC_FLAG_LEGACY_F).  Returns (F [3,3], mask [n] bool)."""
     et = _error_type(error_type_dict_fundamental, error_type)
-    return _call_single("F", convert_and_check(pts1), convert_and_check(pts2), px_th, conf, max_iters, et, False, 0.0, True,
+    return _call_single("F", convert_and_check(pts1), convert_and_check(pts2), px_th, conf, max_iters, et, bool(symmetric_error_check), 0.0, True,
                         _time_seed() if seed is None else seed, device, _lib.FLAG_LEGACY_F, tuning)
 
 
 def ransacF_legacy_batch(pts1_list, pts2_list, px_th=0.5, conf=0.9999, max_iters=100000, error_type="sampson", seeds=None,
-                         device=0, tuning=0):
+                         device=0, tuning=0, symmetric_error_check=False):
     """ransacF_legacy for independent pairs in one launch.  Returns (F [P,3,3], [mask_p])."""
     et = _error_type(error_type_dict_fundamental, error_type)
     if seeds is None:
         seeds = (_time_seed() + np.arange(len(pts1_list))) & 0xFFFFFFFF
-    return _batch("F", pts1_list, pts2_list, px_th, conf, max_iters, et, False, 0.0, True, seeds, device, tuning, _lib.FLAG_LEGACY_F)
+    return _batch("F", pts1_list, pts2_list, px_th, conf, max_iters, et, bool(symmetric_error_check), 0.0, True, seeds, device, tuning, _lib.FLAG_LEGACY_F)
 
 
 def findHomographyBatch(pts1_list, pts2_list, px_th=1.0, conf=0.999, max_iters=50000, laf_consistensy_coef=-1.0,

@@ -24,6 +24,7 @@ struct dg_f_drv {
     dg_score maxS, maxSs;
     int no_sam, max_sam, iter_cnt, degen_cnt, iterID, Ihmax; unsigned non_degen;
     int best_sample; long long t_best, t_start;
+    int flast_k, has_last;           /* legacy drivers' symmetric check: sample whose last model is in flast (0 = none); lastIds valid */
     int finKind, accepted, perm[4], p4, e4kind, track, done;
     unsigned seed; int cur, chunk_s[3], chunk_base;
     int n_fds, n_exfds, n_hds, n_aux;
@@ -86,6 +87,8 @@ struct dg_f_shared {
     double   ext[4], extw[DG_NW][4];     /* max |x1|, |y1|, |x2|, |y2| over the pair (screening bound), per-wave partials */
     int      samidxBest[7];
     int      itmp[32];
+    unsigned char nsolv[DG_CHUNK];       /* real roots of each sample's cubic (legacy drivers' symmetric check) */
+    double   flast[9]; int lastIds[8];    /* ... the model the reference's local `f` holds, the ids of the last sample that reached the cubic */
     double   dtmp[32];
     dg_f_drv park;
     dg_f_cshared K;                      /* the pair's workspace views (dg_f_ctx::K) */
@@ -253,7 +256,9 @@ __device__ __forceinline__ int dg_f_checks(CTX &c, const double *f, const int *l
 {
     const dg_params &pr = c.A->prm;
     if (pr.sym_th > 0) {
-        dg_pass_cfg cfg = dg_cfg0(cnt); cfg.src = list; cfg.wantC = 1; cfg.thC = pr.sym_th;
+        /* exp_ransacFcustom counts the symmetric-consistent points over ALL points (exp_ranF.c:943-953), the LAF driver over
+         * the candidate's inliers */
+        dg_pass_cfg cfg = pr.legacy ? dg_cfg0(c.n) : dg_cfg0(cnt); if (!pr.legacy) cfg.src = list; cfg.wantC = 1; cfg.thC = pr.sym_th;
         dg_pass_res r = dg_f_pass(c, f, DG_K_FSYM, cfg);
         S.Is = r.C;
         if (S.Is < maxS.Is) return 0;

@@ -291,8 +291,44 @@ __device__ __noinline__ int dg_solve7_lane(const dg_pt *P, const int *ids, doubl
         for (int j = 0; j < 9; j++) out[9*nvalid + j] = f[j];
         rx |= (unsigned)i << (2*nvalid); nvalid++;
     }
-    *rix = rx;
+    *rix = rx | ((unsigned)nsol << 8);       /* bits 8-9: the number of real roots */
     return nvalid;
+}
+
+/* The model the reference's driver holds in its local `f` after a sample whose roots were all computed: the LAST real root's
+ * model, valid or not (exp_ranF.c:1365-1368 forms it before the orientation test).  One lane, for the legacy drivers' final
+ * symmetric filter (exp_ranF.c:1196-1203).  Returns 0 when the null space is not two-dimensional. */
+__device__ __noinline__ int dg_solve7_lastroot(const dg_pt *P, const int *ids, double *f /* 9 */, double *wscr /* LDS, >= 81 doubles */)
+{
+    dg_pt sp[7];
+    double m[7][9];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        sp[i] = P[ids[i]];
+        double a[3] = {sp[i].x1, sp[i].y1, 1.0}, b[3] = {sp[i].x2, sp[i].y2, 1.0};
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int l = 0; l < 3; l++) m[i][3*k+l] = b[k] * a[l];
+    }
+    double f1[9], f2[9];
+    int ok = dg_gj7(m, f1, f2);
+    if (!ok) {
+        for (int i = 0; i < 7; i++) {
+            const double a[3] = {sp[i].x1, sp[i].y1, 1.0}, b[3] = {sp[i].x2, sp[i].y2, 1.0};
+            for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) wscr[9*i + 3*k + l] = b[k] * a[l];
+        }
+        if (dg_null9<7, 2>(wscr, wscr + 63) != 2) return 0;
+        for (int i = 0; i < 9; i++) { f1[i] = wscr[63 + i]; f2[i] = wscr[72 + i]; }
+    }
+    double poly[4], roots[3];
+    dg_slcm(f1, f2, poly);
+    const int nsol = dg_rroots3(poly, roots);
+    if (nsol < 1) return 0;
+    const double r = roots[nsol - 1];
+#pragma unroll
+    for (int j = 0; j < 9; j++) f[j] = f1[j] * r + f2[j] * (1 - r);
+    return 1;
 }
 
 /* One chunk of the reference's sample stream, executed by ONE wave (all 64 lanes): the seed chain
@@ -758,6 +794,8 @@ __device__ __forceinline__ unsigned dg_sample_chunk(unsigned seed, int cn, int n
  * Cross-workgroup hand-off as in the cooperative mode: plain payload, then ONE agent-scope release by wave 0 after the
  * workgroup barrier, then the flag (the queue entry) with a relaxed agent-scope atomic; the taker polls the entry with
  * its whole first wave behind a scalar branch, then acquires. */
+/* legacy drivers' symmetric check: remember that the reference's local `f` holds model M (LDS) after sample no_sam */
+#define DG_FLAST(M) do { if (legacy_sym) { __syncthreads(); if (tid < 9) S->flast[tid] = (M)[tid]; D.flast_k = no_sam; __syncthreads(); } } while (0)
 #define DG_PARK_SPARE   0
 #define DG_PARK_CLAIMED 32                   /* queue q: claimed count at DG_PARK_CLAIMED + 64 q, taken count at DG_PARK_HEAD + 64 q */
 #define DG_PARK_HEAD    64                   /* (one 128-byte line each; q = 0: pairs with few samples left, q = 1: many) */
@@ -1118,6 +1156,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     const int mk_full = pr.error_type == 1 ? DG_K_FSYM : DG_K_FDS;
     const int mk_ex   = pr.error_type == 1 ? DG_K_EXFSYM : DG_K_FDS;
     const int doSym = pr.sym_th > 0, doLaf = pr.laf_coef > 0;
+    const int legacy_sym = pr.legacy && doSym;         /* exp_ransacFcustom's symmetric check: its final filter needs the driver's last `f` */
 
     /* ---- driver state (workgroup-uniform, replicated in every lane) ---- */
     dg_f_drv D;
@@ -1164,6 +1203,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     finKind = mk_full; accepted = 0;
     perm[0] = 0; perm[1] = 1; perm[2] = 2; perm[3] = 3; p4 = 3; e4kind = mk_full; track = 1;
     done = 0;
+    D.flast_k = 0; D.has_last = 0;
     /* a new pair on this slot: its best-score bound starts from zero (no stage of this pair has been published yet) */
     if (coopK > 0 && tid == 0) __hip_atomic_store(&cb->tau_bits, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
@@ -1265,6 +1305,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             if (tid < chunk) {
                 S->moff[tid] = (unsigned short)excl;
                 S->nv[tid] = nullbad ? 255 : (unsigned char)nvalid;
+                S->nsolv[tid] = (unsigned char)((rixp >> 8) & 3u);
                 for (int r = 0; r < nvalid; r++) {
                     S->ridx[tid][r] = (unsigned char)((rixp >> (2*r)) & 3u);
                     S->mslot[excl + r] = (unsigned short)(tid * 3 + r);      /* compact model index -> fixed slot */
@@ -1445,11 +1486,12 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                         dg_pass_cfg ch = dg_cfg0(n); ch.flags = c.K->Fl[1]; ch.thF = th*3;
                         dg_pass_res rh = dg_h_pass(c, S->H, ch); c.n_hds++;
                         unsigned I = rh.nF;
-                        if (I < 8) { brk = 1; c.n_fds -= (nvk - 1 - r); if (A.hist_out) { __syncthreads(); if (tid == 0) S->nv[k] = (unsigned char)(r + 1); __syncthreads(); } break; }   /* exp_ranF.c:1437-1439: later roots are never scored */
+                        if (I < 8) { DG_FLAST(S->f); brk = 1; c.n_fds -= (nvk - 1 - r); if (A.hist_out) { __syncthreads(); if (tid == 0) S->nv[k] = (unsigned char)(r + 1); __syncthreads(); } break; }   /* exp_ranF.c:1437-1439: later roots are never scored */
                         { long long ti0 = DG_CLK(); I = dg_innerH(c, S->H, 16*th, 10, c.K->Fl[0]); DG_DEVT(if (tid == 0) S->dbg[0] += DG_CLK() - ti0); (void)ti0; }
                         if ((int)I > Ihmax) Ihmax = (int)I;
                         if (I > 6) {
                             I = dg_rFtH(c, c.K->Fl[0], th, S->H, S->f);
+                            if (ri == (int)S->nsolv[k] - 1) DG_FLAST(S->f);      /* no later root overwrites f (exp_ranF.c:1365-1368) */
                             int dphys;
                             if (I > maxS.I) {
                                 maxS.I = I;
@@ -1502,7 +1544,9 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                 dg_dump_resid(c, 1, S->f, mk_full);                            /* d after the LSQ, :1511 */
                 DG_TRACE(c, 2, rb.nL, rb.J);
                 int kb;
+                DG_FLAST(S->f);                                                /* u2f wrote f, :1506-1511 */
                 dg_score Sl = dg_inFrani(c, (int)rb.nL, th, S->Hx /* LO result model */, &iterID, mk_full, mk_ex, &kb);
+                if (Sl.J > 0) DG_FLAST(S->Hx);                                 /* exp_inFranicustom copies its best model into f (:793) */
                 if (maxS.J < Sl.J) {
                     if (dg_f_checks(c, S->Hx, c.K->L[0], (int)Sl.I, Sl, maxS, mk_full)) {
                         maxS = Sl;
@@ -1538,6 +1582,19 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         if (k < chunk) { c.n_fds -= (Mtot - (int)S->moff[k]); done = 1; }
         else if (no_sam >= max_sam) done = 1;
         __syncthreads();
+        if (legacy_sym && !done) {
+            /* the chunk was processed to its end: keep the ids of its last sample that reached the cubic (the final filter
+             * may need that sample's last root when the run ends inside samples of a later chunk that never get there) */
+            const bool cand = tid < chunk && S->nv[tid] != 255;
+            const unsigned long long bal = __ballot(cand);
+            if (lane == 0) S->wave_cnt[wave] = bal ? (unsigned)(wave * 64 + 63 - __clzll((long long)bal)) : 0xffffffffu;
+            __syncthreads();
+            int kf = -1;
+            for (int w = 0; w < DG_NW; w++) if (S->wave_cnt[w] != 0xffffffffu) kf = (int)S->wave_cnt[w];
+            __syncthreads();
+            if (kf >= 0) { if (tid < 7) S->lastIds[tid] = c.draws[kf][tid]; D.has_last = 1; }
+            __syncthreads();
+        }
         if (!done) cur = nxt;
     }
 
@@ -1578,6 +1635,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                 if (tid < 9) S->f[tid] = S->FBest[tid];
                 __syncthreads();
                 I = dg_rFtH(c, c.K->Fl[0], th, S->H, S->f);
+                DG_FLAST(S->f);
                 int nm = 0;
                 if (I > maxS.I) {
                     maxS.I = I;
@@ -1603,7 +1661,9 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             dg_pass_res rb = dg_f_pass(c, S->f, mk_full, cb); c.n_fds++;
             dg_dump_resid(c, 1, S->f, mk_full);
             int kb;
+            DG_FLAST(S->f);
             dg_score Sl = dg_inFrani(c, (int)rb.nL, th, S->Hx, &iterID, mk_full, mk_ex, &kb);
+            if (Sl.J > 0) DG_FLAST(S->Hx);
             if (maxS.J < Sl.J) {
                 if (dg_f_checks(c, S->Hx, c.K->L[0], (int)Sl.I, Sl, maxS, mk_full)) {
                     maxS = Sl;
@@ -1626,7 +1686,31 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         for (int i = 0; i < 9; i++) F[i] = S->F[i];
         for (int j = tid; j < n; j += DG_T) mask[j] = dg_Ferr(finKind, F, dg_ldpt<LDSPTS>(P, j)) <= th ? 1 : 0;
         __syncthreads();
-        if (doSym || (doLaf && pr.final_laf_filter)) {
+        if (legacy_sym) {
+            /* exp_ranF.c:1196-1203: all points against the symmetric error of `f`, the model the driver computed LAST (not
+             * the best one F): the recorded event model of the last sample that reached the cubic, else that sample's last root */
+            const int li = no_sam - 1 - chunk_base;
+            const bool cand = tid <= li && tid < DG_CHUNK && S->nv[tid] != 255;
+            const unsigned long long bal = __ballot(cand);
+            if (lane == 0) S->wave_cnt[wave] = bal ? (unsigned)(wave * 64 + 63 - __clzll((long long)bal)) : 0xffffffffu;
+            __syncthreads();
+            int kf = -1;
+            for (int w = 0; w < DG_NW; w++) if (S->wave_cnt[w] != 0xffffffffu) kf = (int)S->wave_cnt[w];
+            __syncthreads();
+            int have = 0;
+            if (kf >= 0 && D.flast_k == chunk_base + kf + 1) have = 1;                  /* an event of that very sample wrote f last */
+            else if (kf >= 0 || D.has_last) {
+                if (tid == 0) { int ids[7]; for (int i = 0; i < 7; i++) ids[i] = kf >= 0 ? c.draws[kf][i] : S->lastIds[i];
+                                S->itmp[2] = dg_solve7_lastroot(P, ids, S->flast, (double *)&S->ww[0]); }
+                __syncthreads();
+                have = S->itmp[2];
+            }
+            __syncthreads();
+            if (have) {
+                double Fl[9]; for (int i = 0; i < 9; i++) Fl[i] = S->flast[i];
+                for (int j = tid; j < n; j += DG_T) if (dg_Ferr(DG_K_FSYM, Fl, dg_ldpt<LDSPTS>(P, j)) > pr.sym_th) mask[j] = 0;
+            }
+        } else if (doSym || (doLaf && pr.final_laf_filter)) {
             dg_pass_cfg cl = dg_cfg0(n); cl.list = c.K->L[0]; cl.thL = th;
             dg_pass_res rl = dg_f_pass(c, S->F, finKind, cl);
             const int cnt = (int)rl.nL; const int *lst = c.K->L[0];
