@@ -307,6 +307,8 @@ def secondary_line(name, pairs, steps, warmup, parity_pairs, cpu_budget_s, dev):
                "models_per_s": models * steps / r["dt"], "pairs_per_s": pairs * steps / r["dt"], "models_per_pair": models / pairs,
                "samples_per_pair": float(r["st"][:, 0].mean()), "threads": int(r["local_st"][0, 14]), "placement": int(r["local_st"][0, 15]) & 255,
                "roofline_frac": ach / HBM_PEAK_GBS, "achieved_GBs": ach, "parity_checked": r["n_checked"]}
+        if name == "c3":
+            out["single_call_ms"] = single_call_ms(reps=5)          # one C3 pair through the host-pointer API (the reference: ~10.5 ms on one core)
         if cpu_budget_s > 0:
             cb = cpu_baseline(budget_s=cpu_budget_s, max_pairs=max(2, min(pairs, 256)), skip_first=pairs > 1)
             out["cpu_baseline"] = cb

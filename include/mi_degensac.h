@@ -23,7 +23,12 @@
  *   - the entry points without a context argument use a context private to the calling thread;
  *   - the *_dev entry points are asynchronous on the caller's stream; the per-launch scratch is
  *     private to (device, stream), so launches on different streams never share memory, and the
- *     thread's current HIP device is left as it was found.
+ *     thread's current HIP device is left as it was found;
+ *   - enqueueing is serialised per DEVICE only (launches for different devices never wait for each other);
+ *   - launches may overlap on one device, also with other processes' work: no workgroup of these kernels ever waits for
+ *     a workgroup that may not have been dispatched.  (Cross-workgroup work — the cooperative mode for one very large
+ *     pair, pairs that are set aside and resumed — is handed over through queues and claim counters: whoever is
+ *     running takes the next unit, and a wait is only ever for a unit that a RUNNING workgroup has claimed.)
  */
 #ifndef MI_DEGENSAC_H
 #define MI_DEGENSAC_H

@@ -32,7 +32,10 @@ struct dg_f_drv {
 
 /* A 14-point sample of the local optimisation prepared ahead of time by an idle wave (dg_inFrani): the generator state
  * it assumes at the start of the repetition, the state after its draws, the list slots the draws would store, the model. */
-#define DG_LO_AHEAD (DG_NW - 1 < 5 ? DG_NW - 1 : 5)
+#ifndef DG_LO_AHEAD_MAX
+#define DG_LO_AHEAD_MAX 5
+#endif
+#define DG_LO_AHEAD (DG_NW - 1 < DG_LO_AHEAD_MAX ? DG_NW - 1 : DG_LO_AHEAD_MAX)
 struct dg_lo_ahead { dg_rng before, after; int pos[32], val[32]; double F[9]; };
 
 /* LDS scratch of the long-list least squares (640 doubles): the per-wave solver scratch, idle while a workgroup fit runs */

@@ -40,6 +40,9 @@ __device__ __forceinline__ unsigned dg_hash_list(const int *list, int count, boo
     return hash;
 }
 
+#ifndef DG_AHEAD_ON
+#define DG_AHEAD_ON 1
+#endif
 #ifdef DG_LO_PROF
 #define DG_LT(i) do { __syncthreads(); if (c.tid == 0) { long long t_ = wall_clock64(); c.S->lt[i] += t_ - c.S->ltq; c.S->ltq = t_; } } while (0)
 #else
@@ -212,7 +215,7 @@ __device__ __noinline__ dg_score dg_inFrani(CTX &c, int ninl, double th, double 
             __syncthreads();
             if (wave == 0) {
                 dg_u2f_small_w(&S->lsq, S->lsq.px, 0, ssiz, S->f, tid);
-            } else if (wave <= DG_LO_AHEAD && ssiz > 8 && i + 1 < DG_RAN_REP) {
+            } else if (DG_AHEAD_ON && wave <= DG_LO_AHEAD && ssiz > 8 && i + 1 < DG_RAN_REP) {
                 /* subsets assumed for this repetition's iterF, most frequent first */
                 const int sub = wave == 1 ? 2 : wave == 2 ? 3 : wave == 3 ? 4 : wave == 4 ? 1 : 5;
                 dg_lo_ahead *h = &S->ahead[wave - 1];
@@ -225,9 +228,12 @@ __device__ __noinline__ dg_score dg_inFrani(CTX &c, int ninl, double th, double 
                 DG_WSYNC();
                 dg_u2f_norm_w(w, w->px, (const double *)0, ssiz, h->F, lane);
             }
-            if (tid == 0) S->n_ahead = (ssiz > 8 && i + 1 < DG_RAN_REP) ? DG_LO_AHEAD : 0;
+            if (tid == 0) S->n_ahead = (DG_AHEAD_ON && ssiz > 8 && i + 1 < DG_RAN_REP) ? DG_LO_AHEAD : 0;
         } else if (tid == 0) S->n_ahead = 0;
         DG_LT(8);
+#ifdef DG_LO_PROF
+        if (c.tid == 0) { if (taken) c.S->lt[10]++; else c.S->lt[11]++; }
+#endif
         __syncthreads();
         int k0;
         ++*iterID;

@@ -19,7 +19,9 @@ prm=_lib.make_params(0.5,0.9999,100000,0,True,0.0,True)
 rc=L.mi_degensac_find_fundamental_batch_dev(d_a.data_ptr(),d_b.data_ptr(),d_off.data_ptr(),offs.ctypes.data_as(C.POINTER(C.c_int64)),P,2,C.byref(prm),d_seeds.data_ptr(),0,None,d_F.data_ptr(),d_mask.data_ptr(),d_st.data_ptr())
 torch.cuda.synchronize()
 ph=d_ph.cpu().numpy().astype(np.float64)/1e5; st=d_st.cpu().numpy()
-names=["other","init pass","first fit","EX pass","Ss pass","hash||fit","commit","final pass","u2f14"]
+names=["other","init pass","first fit","EX pass","Ss pass","hash||fit","commit","final pass","u2f14","-","reps taken from look-ahead (count x 1e5)","reps fitted (count x 1e5)"]
 lo=st[:,1].mean()
 print("lo_runs mean",lo,"ex_passes mean",st[:,9].mean())
-for i,nm in enumerate(names): print(f"{nm:12s} {ph[:,i].mean():8.3f} ms/pair   {ph[:,i].mean()/lo*1e3:8.1f} us/LO-run")
+for i,nm in enumerate(names):
+    if "count" in nm: print(f"{nm:46s} {ph[:,i].mean()*1e5/lo:6.2f} per LO run")
+    else: print(f"{nm:12s} {ph[:,i].mean():8.3f} ms/pair   {ph[:,i].mean()/lo*1e3:8.1f} us/LO-run")
