@@ -388,7 +388,7 @@ def main():
             "models_per_pair": models_step / total_pairs,
             "mean_inliers": float(inl.mean()),
             "time_to_best_ms": {"mean": float(tbest.mean() * 1e3), "p50": float(np.median(tbest) * 1e3), "max": float(tbest.max() * 1e3),
-                                "note": "from a pair's start to the commit of its returned model, on the device clock; includes the time a pair waits while it is set aside"},
+                                "note": "from a pair's start to the commit of its returned model, on the device clock, while the pair is being worked on (the time a pair waits in the set-aside queues of a batch is not counted)"},
             "pair_latency_ms": {"mean": float(ticks.mean() * 1e3), "p50": float(np.median(ticks) * 1e3), "max": float(ticks.max() * 1e3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.config, P),

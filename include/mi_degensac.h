@@ -117,7 +117,8 @@ enum {
     MI_ST_IH = 6,           /* F: largest H-inlier count seen (exp_ranF.c *Ih)                      */
     MI_ST_BEST_SAMPLE = 7,  /* sample number at which the returned model was committed              */
     MI_ST_FULL_PASSES = 8, MI_ST_EX_PASSES = 9, MI_ST_H_PASSES = 10, MI_ST_AUX_PASSES = 11,
-    MI_ST_TICKS_BEST = 12,  /* 100 MHz device wall-clock ticks from the pair's start to that commit */
+    MI_ST_TICKS_BEST = 12,  /* 100 MHz device wall-clock ticks from the pair's start to that commit; the time a pair waits
+                               while it is set aside (batches) is not counted: ticks = time it was being worked on */
     MI_ST_TICKS_TOTAL = 13, /* ... to the pair's end                                                */
     MI_ST_THREADS = 14,     /* workgroup size of the kernel variant that ran (512 / 256 / 128)      */
     MI_ST_PLACEMENT = 15    /* bits 0-7: 0 = points + pool in HBM, 1 = both in LDS, 2 = pool in LDS; bit 8: the pair was set aside once */

@@ -24,6 +24,7 @@ struct dg_f_drv {
     dg_score maxS, maxSs;
     int no_sam, max_sam, iter_cnt, degen_cnt, iterID, Ihmax; unsigned non_degen;
     int best_sample; long long t_best, t_start;
+    long long t_parked;              /* device clock when the pair was set aside (its waiting time is taken out of the reported times) */
     int flast_k, has_last;           /* legacy drivers' symmetric check: sample whose last model is in flast (0 = none); lastIds valid */
     int finKind, accepted, perm[4], p4, e4kind, track, done;
     unsigned seed; int cur, chunk_s[3], chunk_base;

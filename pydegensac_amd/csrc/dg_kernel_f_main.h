@@ -1247,6 +1247,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     __syncthreads();
     if (tid == 0) dg_fill_views(&S->K, ws, A.wl);         /* the image carries the views of the same workspace; written again all the same */
     D = S->park;
+    { const long long waited = wall_clock64() - D.t_parked; D.t_start += waited; D.t_best += waited; }   /* reported times = time the pair was being worked on */
     c.n_fds = D.n_fds; c.n_exfds = D.n_exfds; c.n_hds = D.n_hds; c.n_aux = D.n_aux;
     DG_DEVT(if (tid == 0) S->tq = DG_CLK());
     __syncthreads();
@@ -1268,7 +1269,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             const int nw = S->itmp[30];
             __syncthreads();
             if (nw >= 0) {
-                D.n_fds = c.n_fds; D.n_exfds = c.n_exfds; D.n_hds = c.n_hds; D.n_aux = c.n_aux;
+                D.n_fds = c.n_fds; D.n_exfds = c.n_exfds; D.n_hds = c.n_hds; D.n_aux = c.n_aux; D.t_parked = wall_clock64();
                 if (tid == 0) S->park = D;
                 __syncthreads();
                 char *pk = ws + A.wl.off_park;
