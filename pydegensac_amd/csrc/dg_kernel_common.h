@@ -59,7 +59,25 @@ struct dg_ws_layout {
     size_t off_hjbuf;     /* cooperative mode: ordered MSAC terms of each claiming workgroup, double[coop_k + 1][n_max]   */
     size_t off_job;       /* cooperative mode: the job of a distributed pass (dg_coop_job), its per-slice records and the slice-local
                              staging of its outputs: int[n_max] x 2 (lists), double[n_max] (MSAC terms)                       */
+    size_t off_hrep;      /* homography LO, one repetition per wave: dg_hrep_log[DG_RAN_REP], then per wave int[2][n_max] (id lists),
+                             double[n_max] (ordered MSAC terms), dg_pt[2 * n_max] (staging of its long least-squares lists) */
+    int    hrep;          /* 1 = that area exists */
     int    n_max;
+};
+
+/* What one repetition of exp_inHranicustom (exp_ranH.c:415-467) leaves behind when it is run on its own by one wave: every
+ * model whose residuals the reference would have put into an errs[] buffer, and every (hash, I, J) that decides something.
+ * The repetitions only depend on each other through the inlier-set hash table, the best-so-far score and the rotation of
+ * the errs[] buffers; dg_inHranic_waves replays those in repetition order from these records. */
+struct dg_hrep_it { double hl[9]; double J; unsigned hash; int I; };
+struct dg_hrep_log {
+    double h0[9]; double J0; int I0;       /* the sample's model and its score at th */
+    int nit;                               /* iterations of exp_iterHcustom that scored their model (0..4) */
+    int last_short;                        /* 1: the last of them left fewer than 4 ids for the next fit (exp_ranH.c:366) */
+    int has_fin;                           /* 1: the model after the last iteration was scored (exp_ranH.c:397-408) */
+    dg_hrep_it it[4];
+    double hf[9]; double Jf; int If;
+    int ids[12];                           /* the sample */
 };
 
 /* Cooperative large-n mode (placement HBM, fundamental matrix): every pair owner has coop_k helper workgroups that
@@ -145,6 +163,7 @@ struct dg_args {
     long long *park_q;               /* [2][park_cap] entries: pair << 32 | workspace, -1 until published        */
     int park_cap;                    /* entries per queue                                                       */
     int park_long;                   /* a pair set aside with at least this many samples left goes to queue 1    */
+    int lo_serial;                   /* homography: 1 = run the repetitions of a local optimisation one after the other on the whole workgroup */
     int pool_seq;                    /* 1 = always use the sequential pool-swap stage (LDS exchange-order self-check failed, or forced) */
     int variant_threads, mode;       /* reported in the stats block */
     int *trace;                      /* debug: [0] = count, then (tag, I, J lo, J hi) records; null = off */

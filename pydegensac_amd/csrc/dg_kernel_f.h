@@ -53,6 +53,7 @@ struct dg_f_cshared {
     unsigned *res_I; double *res_J;   /* [3*DG_CHUNK] per-model (I, J) of the current chunk */
     int (*rf)[5];            /* [DG_CHUNK] rFtH batch: candidate point ids (2), swap log (2), count */
     int *wlist; dg_pt *wstage;        /* per-wave buffers [DG_NW][n_max] of the wave-parallel innerFH / u2Fit */
+    char *hrep;              /* homography LO with one repetition per wave (dg_ws_layout::off_hrep), or null */
     int n_max;
 };
 
@@ -115,6 +116,7 @@ struct dg_f_ctx {
     int n_fds, n_exfds, n_hds, n_aux;
     double *rrun;            /* diagnostics: the 62 x n residual rows of the current LO run, or null */
     dg_coop_cb *cb; int *coop_gen; int coop_slot;   /* cooperative large-n mode: this owner's control block (null = off) */
+    double *hlt;             /* homography kernel: [DG_NW][DG_HLT] doubles of LDS, one block per wave (one-repetition-per-wave LO) */
 
     __device__ __forceinline__ dg_pt pt(int i) const { return P[i]; }
     /* LAF point sets u_1 (which=1: +a12,+a22) and u_2 (which=2: +a11,+a21): bindings.cpp:337-409 */
@@ -141,6 +143,7 @@ __device__ __forceinline__ void dg_fill_views(dg_f_cshared *K, char *ws, const d
     K->gmodels = (double *)(ws + wl.off_models);
     K->stage = (dg_pt *)(ws + wl.off_stage);
     K->res_J = (double *)(ws + wl.off_res); K->res_I = (unsigned *)(K->res_J + 3 * DG_CHUNK); K->rf = (int (*)[5])(K->res_I + 3 * DG_CHUNK);
+    K->hrep = wl.hrep ? ws + wl.off_hrep : (char *)0;
     K->n_max = wl.n_max; K->wlist = (int *)(ws + wl.off_wave); K->wstage = (dg_pt *)(ws + wl.off_wave + (size_t)DG_NW * wl.n_max * sizeof(int));
 }
 

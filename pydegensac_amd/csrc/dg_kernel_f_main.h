@@ -1149,7 +1149,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     __syncthreads();
     c.ht.heads = (int *)(ws + A.wl.off_ht); c.ht.count = c.ht.heads + 64; c.ht.ent = c.ht.heads + 80;
     c.seeds = S->seeds3[0]; c.draws = S->draws3[0];
-    c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0; c.rrun = 0;
+    c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0; c.rrun = 0; c.hlt = (double *)0;
     c.cb = cb; c.coop_gen = &coop_gen; c.coop_slot = slot;
     dg_pt *Pw; int *pool;
     /* LDSPTS: 1 = point set and sampler pool in LDS, 2 = pool in LDS / points in the HBM workspace (L2), 0 = both in HBM */

@@ -238,6 +238,384 @@ __device__ __forceinline__ dg_score dg_inHranic(CTX &c, int kind, int ninl, doub
     return maxS;
 }
 
+/* ---- the repetitions of exp_inHranicustom, one wave each (exp_ranH.c:415-467, :291-412) ---------------------------------
+ * A repetition = a 12-point fit, its score, then up to four rounds of (score the model, hash its inlier set, refit on the
+ * ids under the shrinking threshold) and a last score.  On one workgroup that is a string of workgroup-wide passes
+ * separated by stretches where one wave runs a reference-order sum or the 9 x 9 eigen-solve and the others wait.  But the
+ * repetitions barely depend on each other:
+ *   - the samples: randsubset permutes `inliers` in place and nothing else draws (inlLimit is never reached), so all ten
+ *     samples can be drawn up front;
+ *   - the inlier-set hash table (a repetition that meets a set an EARLIER repetition inserted stops and counts as empty),
+ *     the best-so-far comparison and the rotation of the errs[] buffers: all three are decided by a handful of numbers
+ *     per repetition.
+ * So every wave runs whole repetitions on its own (its own id lists, MSAC terms and staging area in the workspace, its own
+ * solver scratch in LDS, wave barriers only) and records those numbers (dg_hrep_log); thread 0 then replays the hash
+ * table, the comparisons and the buffer rotation in repetition order.  Same arithmetic per repetition, same decisions in
+ * the same order; a repetition the reference would have cut short is simply computed further than needed. */
+#define DG_HLT 640                /* doubles of LDS per wave: the long-list fit's table (dg_lsq_seq_par), the 12-point fit's design matrix */
+struct dg_hrep_sc { double *Z, *V, *D, *A1, *A2; dg_eig_ws &ews; };     /* scratch view with the member names the solvers use */
+__device__ __forceinline__ size_t dg_hrep_logs_bytes() { return ((size_t)DG_RAN_REP * sizeof(dg_hrep_log) + 255) & ~(size_t)255; }
+__device__ __forceinline__ size_t dg_hrep_wave_bytes(int n_max) { return ((size_t)n_max * (2 * sizeof(int) + sizeof(double) + 2 * sizeof(dg_pt)) + 255) & ~(size_t)255; }
+
+#define DG_AS1(T) __attribute__((address_space(1))) T
+#define DG_AS3(T) __attribute__((address_space(3))) T
+/* acc += t[STRIDE * k], k = 0..cnt-1, in that order (LDS): eight loads, then their eight adds */
+template <int STRIDE>
+__device__ __forceinline__ double dg_chain_lds(const DG_AS3(double) *t, int cnt, double acc)
+{
+    int k = 0;
+    for (; k + 8 <= cnt; k += 8) {
+        const double v0 = t[STRIDE*k], v1 = t[STRIDE*(k+1)], v2 = t[STRIDE*(k+2)], v3 = t[STRIDE*(k+3)];
+        const double v4 = t[STRIDE*(k+4)], v5 = t[STRIDE*(k+5)], v6 = t[STRIDE*(k+6)], v7 = t[STRIDE*(k+7)];
+        acc += v0; acc += v1; acc += v2; acc += v3; acc += v4; acc += v5; acc += v6; acc += v7;
+    }
+    for (; k < cnt; k++) acc += t[STRIDE*k];
+    return acc;
+}
+
+/* The sums of dg_lsq_seq_par (normu, utools.c:7-51, and cov_mat, utools.c:170-184, in the reference's order per output
+ * number) by ONE wave without a memory round trip per point: the list is taken 256 ids at a time, the next 256 being
+ * loaded while the current ones are worked on; each group of points goes through this wave's LDS block and the lanes
+ * that own an output number add its terms from there in list order.  Three sweeps: gather + centroids (the gathered
+ * points are kept contiguously in `stage` for the other two), distances to the centroids, Hartley-normalised
+ * design-matrix entries + the 45 normal-matrix sums.
+ * ROWS2: 0 = lin_fmN (one row per point), 1 = lin_hgN (two).  V (9 x 9, both triangles), A1o, A2o: LDS. */
+__device__ __forceinline__ void dg_stage_ld4(const DG_AS1(double) *stage, int base, int len, int lane, dg_pt *q)
+{
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int j = base + 64 * u + lane; q[u].x1 = q[u].y1 = q[u].x2 = q[u].y2 = 0.0;
+        if (j < len) { const DG_AS1(double) *o = stage + 4 * (size_t)j; q[u].x1 = o[0]; q[u].y1 = o[1]; q[u].x2 = o[2]; q[u].y2 = o[3]; }
+    }
+}
+template <int LDSPTS, int ROWS2>
+__device__ __forceinline__ void dg_lsq_wave_stream(const dg_pt *P, const int *list_, int len, dg_pt *stage_, double *lt_, double *V, double *A1o, double *A2o, int lane)
+{
+    const DG_AS1(int) *list = (const DG_AS1(int) *)list_;
+    DG_AS1(double) *stage = (DG_AS1(double) *)(double *)stage_;
+    DG_AS3(double) *t = (DG_AS3(double) *)lt_;
+    double acc = 0;
+    {
+        int idn[4]; dg_pt qn[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int j = 64 * u + lane; idn[u] = j < len ? list[j] : -1; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { qn[u].x1 = qn[u].y1 = qn[u].x2 = qn[u].y2 = 0.0; if (idn[u] >= 0) qn[u] = dg_ldpt<LDSPTS>(P, idn[u]); }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int j = 256 + 64 * u + lane; idn[u] = j < len ? list[j] : -1; }
+        for (int base = 0; base < len; base += 4 * 64) {
+            dg_pt q[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) q[u] = qn[u];
+            if (base + 256 < len) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) { qn[u].x1 = qn[u].y1 = qn[u].x2 = qn[u].y2 = 0.0; if (idn[u] >= 0) qn[u] = dg_ldpt<LDSPTS>(P, idn[u]); }
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int j = base + 512 + 64 * u + lane; idn[u] = j < len ? list[j] : -1; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (base + 64 * u + lane < len) { DG_AS1(double) *o = stage + 4 * (size_t)(base + 64 * u + lane); o[0] = q[u].x1; o[1] = q[u].y1; o[2] = q[u].x2; o[3] = q[u].y2; }
+#pragma unroll
+            for (int f = 0; f < 2; f++) {            /* 128 points per fill, one array per coordinate */
+                const int cnt = len - base - 128 * f < 128 ? len - base - 128 * f : 128;
+                if (cnt <= 0) break;
+                t[lane] = q[2*f].x1; t[128 + lane] = q[2*f].y1; t[256 + lane] = q[2*f].x2; t[384 + lane] = q[2*f].y2;
+                t[64 + lane] = q[2*f+1].x1; t[192 + lane] = q[2*f+1].y1; t[320 + lane] = q[2*f+1].x2; t[448 + lane] = q[2*f+1].y2;
+                DG_WSYNC();
+                if (lane < 4) acc = dg_seq_sum_from<3>(lt_ + 128 * lane, cnt, acc);
+                DG_WSYNC();
+            }
+        }
+    }
+    if (len > 0) acc /= len;
+    const double m1x = dg_readlane_d(acc, 0), m1y = dg_readlane_d(acc, 1), m2x = dg_readlane_d(acc, 2), m2y = dg_readlane_d(acc, 3);
+    double dsum = 0;
+    {
+        dg_pt qn[4];
+        dg_stage_ld4(stage, 0, len, lane, qn);
+        for (int base = 0; base < len; base += 4 * 64) {
+            dg_pt q[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) q[u] = qn[u];
+            if (base + 256 < len) dg_stage_ld4(stage, base + 256, len, lane, qn);
+            /* 256 points per fill: image 1 distances in t[0..256), image 2 in t[256..512) */
+            const int cnt = len - base < 256 ? len - base : 256;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                double a = q[u].x1 - m1x, b = q[u].y1 - m1y; t[64 * u + lane] = sqrt(a*a + b*b);
+                a = q[u].x2 - m2x; b = q[u].y2 - m2y; t[256 + 64 * u + lane] = sqrt(a*a + b*b);
+            }
+            DG_WSYNC();
+            if (lane < 2) dsum = dg_seq_sum_from<3>(lt_ + 256 * lane, cnt, dsum);
+            DG_WSYNC();
+        }
+    }
+    double A1[3], A2[3];
+    A1[0] = dg_readlane_d(dsum, 0); A2[0] = dg_readlane_d(dsum, 1);
+    if (A1[0] != 0) A1[0] = len * sqrt(2.0) / A1[0];
+    if (A2[0] != 0) A2[0] = len * sqrt(2.0) / A2[0];
+    A1[1] = m1x * -A1[0]; A1[2] = m1y * -A1[0];
+    A2[1] = m2x * -A2[0]; A2[2] = m2y * -A2[0];
+    if (lane == 0) { for (int i = 0; i < 3; i++) { A1o[i] = A1[i]; A2o[i] = A2[i]; } }
+    /* normal matrix: lane e < 45 owns entry (ie, je), je <= ie, in cov_mat's enumeration order; per 64-point tile the wave
+     * forms, one point per lane, the nine (lin_fmN: z[3k+l] = a_l b_k) or ten (lin_hgN: b_q, -a0 b_q, -a1 b_q and a
+     * structural zero) design-matrix entries of each point, and every accumulating lane reads its two (F) or four (H)
+     * factors per point from there: same factors, same multiplies, same adds in list order as dg_lsq_seq_par */
+    int ie = 0, je = 0;
+    { int e = 0; for (int i = 0; i < 9; i++) for (int q_ = 0; q_ <= i; q_++) { if (e == lane) { ie = i; je = q_; } e++; } }
+    const int ki = ie / 3, li = ie % 3, kj = je / 3, lj = je % 3;
+    const int x0 = !ROWS2 ? ie : (li == 0 ? ki : li == 1 ? 9 : 3 + ki), y0 = !ROWS2 ? je : (lj == 0 ? kj : lj == 1 ? 9 : 3 + kj);
+    const int x1 = li == 0 ? 9 : li == 1 ? ki : 6 + ki, y1 = lj == 0 ? 9 : lj == 1 ? kj : 6 + kj;
+    double val = 0;
+    {
+        dg_pt qn[4];
+        dg_stage_ld4(stage, 0, len, lane, qn);
+        for (int base = 0; base < len; base += 4 * 64) {
+            dg_pt q[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) q[u] = qn[u];
+            if (base + 256 < len) dg_stage_ld4(stage, base + 256, len, lane, qn);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int cnt = len - base - 64 * u < 64 ? len - base - 64 * u : 64;
+                if (cnt <= 0) break;
+                {
+                    const double nx1 = q[u].x1 * A1[0] + A1[1], ny1 = q[u].y1 * A1[0] + A1[2], nx2 = q[u].x2 * A2[0] + A2[1], ny2 = q[u].y2 * A2[0] + A2[2];
+                    DG_AS3(double) *w = t + 10 * lane;
+                    if (!ROWS2) {
+                        const double a[3] = {nx1, ny1, 1.0}, b[3] = {nx2, ny2, 1.0};
+#pragma unroll
+                        for (int k = 0; k < 3; k++)
+#pragma unroll
+                            for (int l = 0; l < 3; l++) w[3*k + l] = a[l] * b[k];
+                    } else {
+                        const double b[3] = {nx2, ny2, 1.0};
+#pragma unroll
+                        for (int k = 0; k < 3; k++) { w[k] = b[k]; w[3 + k] = -nx1 * b[k]; w[6 + k] = -ny1 * b[k]; }
+                    }
+                    w[9] = 0.0;
+                }
+                DG_WSYNC();
+                if (lane < 45) {
+                    int p = 0;
+                    if (!ROWS2) {
+                        for (; p + 8 <= cnt; p += 8) {
+                            const DG_AS3(double) *w = t + 10 * p;
+                            const double u0 = w[x0], v0 = w[y0], u1 = w[10 + x0], v1 = w[10 + y0], u2 = w[20 + x0], v2 = w[20 + y0], u3 = w[30 + x0], v3 = w[30 + y0];
+                            const double u4 = w[40 + x0], v4 = w[40 + y0], u5 = w[50 + x0], v5 = w[50 + y0], u6 = w[60 + x0], v6 = w[60 + y0], u7 = w[70 + x0], v7 = w[70 + y0];
+                            val += u0 * v0; val += u1 * v1; val += u2 * v2; val += u3 * v3; val += u4 * v4; val += u5 * v5; val += u6 * v6; val += u7 * v7;
+                        }
+                        for (; p < cnt; p++) { const DG_AS3(double) *w = t + 10 * p; val += w[x0] * w[y0]; }
+                    } else {
+                        for (; p + 4 <= cnt; p += 4) {
+                            const DG_AS3(double) *w = t + 10 * p;
+                            const double u0 = w[x0], v0 = w[y0], p0 = w[x1], q0 = w[y1], u1 = w[10 + x0], v1 = w[10 + y0], p1 = w[10 + x1], q1 = w[10 + y1];
+                            const double u2 = w[20 + x0], v2 = w[20 + y0], p2 = w[20 + x1], q2 = w[20 + y1], u3 = w[30 + x0], v3 = w[30 + y0], p3 = w[30 + x1], q3 = w[30 + y1];
+                            val += u0 * v0; val += p0 * q0; val += u1 * v1; val += p1 * q1; val += u2 * v2; val += p2 * q2; val += u3 * v3; val += p3 * q3;
+                        }
+                        for (; p < cnt; p++) { const DG_AS3(double) *w = t + 10 * p; val += w[x0] * w[y0]; val += w[x1] * w[y1]; }
+                    }
+                }
+                DG_WSYNC();
+            }
+        }
+    }
+    if (lane < 45) { V[9*ie + je] = val; V[ie + 9*je] = val; }
+}
+
+/* u2h on an id list of any length >= 4, by one wave (Htools.c:101-133) */
+template <int LDSPTS>
+__device__ __noinline__ void dg_u2h_wave(CTX &c, dg_wave_ws *w, double *lt, const int *list, int len, dg_pt *stage, double *Hout /* LDS */, int lane)
+{
+    const dg_pt *P = c.P;
+    dg_hrep_sc sc = {lt, w->V, w->D, w->A1, w->A2, w->ews};
+    DG_WSYNC();
+    if (len <= 12) {
+        if (lane < len) { const dg_pt q = dg_ldpt<LDSPTS>(P, list[lane]); w->px[4*lane] = q.x1; w->px[4*lane+1] = q.y1; w->px[4*lane+2] = q.x2; w->px[4*lane+3] = q.y2; }
+        DG_WSYNC();
+        if (len == 4) { if (lane == 0) dg_u2h_4pt_mv(lt, lt + 81, w->px, Hout); DG_WSYNC(); }
+        else if (len > 4) dg_u2h_norm_w(&sc, w->px, len, Hout, lane);
+    } else {
+        dg_lsq_wave_stream<LDSPTS, 1>(P, list, len, stage, lt, w->V, w->A1, w->A2, lane);
+        DG_WSYNC();
+        dg_eig_sym_wave(w->V, w->D, lane, &w->ews);
+        if (lane == 0) { for (int i = 0; i < 9; i++) Hout[i] = w->V[i]; dg_denormH(Hout, w->A1, w->A2); }
+        DG_WSYNC();
+    }
+}
+
+/* one wave's pass of model Hm over all n points: I = #(d <= thJ), J = the reference-order MSAC sum, the ordered id list
+ * at thL (la, when given) and a second one at thL2 (lb, when given): what dg_pass does for a workgroup.  The nonzero MSAC
+ * terms of a step (256 points) go through this wave's LDS block and are added, in point order, before the next step;
+ * the next step's points are loaded before that. */
+template <int LDSPTS>
+__device__ __noinline__ dg_pass_res dg_hm_wpass(const dg_pt *P, int n, int kind, const double *Hm /* LDS */, double *z18 /* LDS */, double thJ,
+                                                int *la_, double thL, int *lb_, double thL2, double *lt_, int lane)
+{
+    double H[9], Hinv[9], H1[9];
+    DG_WSYNC();
+    if (kind != 0) { if (lane == 0) dg_hsym_prepare(Hm, z18, z18 + 9); DG_WSYNC(); }
+#pragma unroll
+    for (int i = 0; i < 9; i++) { H[i] = Hm[i]; Hinv[i] = kind ? z18[i] : 0; H1[i] = kind ? z18[9+i] : 0; }
+    DG_AS3(double) *t = (DG_AS3(double) *)lt_;
+    DG_AS1(int) *la = (DG_AS1(int) *)la_, *lb = (DG_AS1(int) *)lb_;
+    dg_pass_res out; out.I = 0; out.J = 0; out.C = 0; out.nL = 0; out.nF = 0; out.nL2 = 0; out.nJ = 0;
+    const double t94 = thJ * 9 / 4;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned cI = 0, nJ = 0, nA = 0, nB = 0;
+    double J = 0;
+    dg_pt qn[DG_PU];
+#pragma unroll
+    for (int u = 0; u < DG_PU; u++) { qn[u].x1 = qn[u].y1 = qn[u].x2 = qn[u].y2 = 0.0; const int j = u * 64 + lane; if (j < n) qn[u] = dg_ldpt<LDSPTS>(P, j); }
+    for (int base = 0; base < n; base += DG_PU * 64) {
+        dg_pt q[DG_PU];
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) q[u] = qn[u];
+        if (LDSPTS != 1) {
+#pragma unroll
+            for (int u = 0; u < DG_PU; u++) { const int j = base + DG_PU * 64 + u * 64 + lane; if (j < n) qn[u] = dg_ldpt<LDSPTS>(P, j); }
+        }
+        unsigned sJ = 0;
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) {
+            const int j = base + u * 64 + lane; const bool act = j < n;
+            const double d = act ? dg_Herr(kind, H, Hinv, H1, q[u]) : 0.0;
+            double term = 0.0;
+            if (act && thJ != 0 && !(d >= t94)) term = 1 - (d / t94);
+            const bool nz = !(term == 0.0);
+            cI += (act && d <= thJ) ? 1u : 0u;
+            const bool inA = la_ && act && d <= thL, inB = lb_ && act && d <= thL2;
+            const unsigned long long mJ = __ballot(nz), mA = __ballot(inA), mB = __ballot(inB);
+            if (nz) t[sJ + (unsigned)__popcll(mJ & below)] = term;
+            if (inA) la[nA + (unsigned)__popcll(mA & below)] = j;
+            if (inB) lb[nB + (unsigned)__popcll(mB & below)] = j;
+            sJ += (unsigned)__popcll(mJ); nA += (unsigned)__popcll(mA); nB += (unsigned)__popcll(mB);
+        }
+        if (LDSPTS == 1) {
+#pragma unroll
+            for (int u = 0; u < DG_PU; u++) { const int j = base + DG_PU * 64 + u * 64 + lane; if (j < n) qn[u] = dg_ldpt<LDSPTS>(P, j); }
+        }
+        DG_WSYNC();
+        J = dg_seq_sum_from<3>((const double *)lt_, (int)sJ, J);
+        nJ += sJ;
+        DG_WSYNC();
+    }
+    out.I = dg_wave_sum_u(cI);
+    out.J = J;
+    out.nL = nA; out.nL2 = nB; out.nJ = nJ;
+    DG_WSYNC();
+    return out;
+}
+
+/* one repetition (sample lg->ids), by one wave; writes the rest of *lg */
+template <int LDSPTS>
+__device__ __noinline__ void dg_hrep_wave(CTX &c, int kind, dg_hrep_log *lg, int ssiz, double th, double *lt, char *wb, int lane, int wave)
+{
+    dg_f_shared *S = c.S; const int n = c.n, nm = c.K->n_max; const dg_pt *P = c.P;
+    dg_wave_ws *w = &S->ww[wave];
+    int *la = (int *)wb, *lb = la + nm; dg_pt *stage = (dg_pt *)((double *)(lb + nm) + nm);
+    double *h = w->H, *hl = w->F, *z18 = w->Z;
+#define DG_HW(i) DG_DEVT(do { if (wave == 0 && lane == 0) { long long t_ = DG_CLK(); S->dbg[i] += t_ - tw_; tw_ = t_; } } while (0))
+    long long tw_ = DG_CLK(); (void)tw_;
+    dg_u2h_wave<LDSPTS>(c, w, lt, lg->ids, ssiz, stage, h, lane);
+    DG_HW(3);
+    if (lane < 9) lg->h0[lane] = h[lane];
+    const dg_pass_res r0 = dg_hm_wpass<LDSPTS>(P, n, kind, h, z18, th, lb, th * DG_MWM, (int *)0, 0.0, lt, lane);
+    DG_HW(0);
+    if (lane == 0) { lg->I0 = (int)r0.I; lg->J0 = r0.J; lg->nit = 0; lg->last_short = 0; lg->has_fin = 0; }
+    if (r0.I < 4) return;
+    dg_u2h_wave<LDSPTS>(c, w, lt, lb, (int)r0.nL, stage, hl, lane);
+    DG_HW(1);
+    double ths = DG_TC * th; const double dth = (ths - th) / DG_ILSQ_ITERS;
+    for (int it = 0; it < DG_ILSQ_ITERS; it++) {
+        const dg_pass_res r1 = dg_hm_wpass<LDSPTS>(P, n, kind, hl, z18, th, la, th, lb, ths * DG_MWM, lt, lane);
+        DG_WSYNC();
+        DG_HW(0);
+        const unsigned hash = dg_hash_list(la, (int)r1.I, n < 65536);
+        DG_HW(2);
+        if (lane < 9) lg->it[it].hl[lane] = hl[lane];
+        if (lane == 0) { lg->it[it].J = r1.J; lg->it[it].hash = hash; lg->it[it].I = (int)r1.I; lg->nit = it + 1; }
+        /* a set some EARLIER local optimisation already inserted ends the repetition here at the latest, whatever the other
+         * repetitions of this one do (the table is not written before the replay) */
+        { int known = 0; if (lane == 0) known = dg_ht_contains(c.ht, hash, (int)r1.I, -1) != -1; if (__builtin_amdgcn_readfirstlane(known)) return; }
+        if (r1.nL2 < 4) { if (lane == 0) lg->last_short = 1; return; }
+        dg_u2h_wave<LDSPTS>(c, w, lt, lb, (int)r1.nL2, stage, hl, lane);
+        DG_HW(1);
+        ths -= dth;
+    }
+    const dg_pass_res rf = dg_hm_wpass<LDSPTS>(P, n, kind, hl, z18, th, (int *)0, 0.0, (int *)0, 0.0, lt, lane);
+    DG_HW(0);
+    if (lane < 9) lg->hf[lane] = hl[lane];
+    if (lane == 0) { lg->If = (int)rf.I; lg->Jf = rf.J; lg->has_fin = 1; }
+}
+
+/* exp_inHranicustom with the repetitions spread over the waves; ninl >= 8; same results as dg_inHranic */
+template <int LDSPTS>
+__device__ __forceinline__ dg_score dg_inHranic_waves(CTX &c, int kind, int ninl, double th, double *Hout, int *iterID, dg_hbufs &B)
+{
+    dg_f_shared *S = c.S; const int tid = c.tid, lane = tid & 63, wave = tid >> 6;
+    int *inliers = c.K->L[0];
+    dg_score maxS = {0, 0, 0, 0};
+    int ssiz = ninl / 2; if (ssiz > 12) ssiz = 12;
+    { int t = B.pe[2]; B.pe[2] = B.pe[0]; B.pe[0] = t; }
+    dg_hrep_log *logs = (dg_hrep_log *)c.K->hrep;
+    char *wb = c.K->hrep + dg_hrep_logs_bytes() + (size_t)wave * dg_hrep_wave_bytes(c.K->n_max);
+    __syncthreads();
+    if (tid < 64) {
+        for (int r = 0; r < DG_RAN_REP; r++) {
+            int id = 0;
+            dg_randsubset_wave(&S->rng, inliers, ninl, ssiz, lane, &id);
+            if (lane < ssiz) logs[r].ids[lane] = id;
+            DG_WSYNC();
+        }
+    }
+    __syncthreads();
+    for (int r = wave; r < DG_RAN_REP; r += DG_NW) dg_hrep_wave<LDSPTS>(c, kind, &logs[r], ssiz, th, c.hlt + (size_t)DG_HLT * wave, wb, lane, wave);
+    __syncthreads();
+    if (tid == 0) {
+        int pe0 = B.pe[0], pe1 = B.pe[1], pe2 = B.pe[2], nh = 0, id = *iterID;
+        unsigned mI = 0; double mJ = 0;
+        for (int r = 0; r < DG_RAN_REP; r++) {
+            const dg_hrep_log *g = &logs[r];
+            for (int i = 0; i < 9; i++) S->bufF[pe0][i] = g->h0[i];
+            ++id; nh++;
+            int pd = pe1; unsigned ScI = 0; double ScJ = 0; const double *hres = g->h0;
+            if (g->I0 >= 4) {
+                unsigned mlI = (unsigned)g->I0; double mlJ = g->J0; bool dead = false, done = false;
+                for (int it = 0; it < g->nit; it++) {
+                    const dg_hrep_it *q = &g->it[it];
+                    nh++;
+                    for (int i = 0; i < 9; i++) S->bufF[pd][i] = q->hl[i];
+                    const int ret = dg_ht_contains(c.ht, q->hash, q->I, id);
+                    if (ret == -1) dg_ht_insert(c.ht, q->hash, q->I, id);
+                    if (ret != -1 && ret != id) { dead = true; break; }
+                    if (mlJ < q->J) { mlI = (unsigned)q->I; mlJ = q->J; const int t = pe0; pe1 = t; pe0 = pd; pd = pe1; hres = q->hl; }
+                    if (it == g->nit - 1 && g->last_short) done = true;
+                }
+                if (!dead && !done) {
+                    nh++;
+                    for (int i = 0; i < 9; i++) S->bufF[pd][i] = g->hf[i];
+                    if (mlJ < g->Jf) { mlI = (unsigned)g->If; mlJ = g->Jf; pe1 = pe0; pe0 = pd; hres = g->hf; }
+                }
+                if (!dead) { ScI = mlI; ScJ = mlJ; }
+            }
+            if (mJ < ScJ) {
+                mI = ScI; mJ = ScJ;
+                { const int t = pe2; pe2 = pe0; pe0 = t; }
+                for (int i = 0; i < 9; i++) Hout[i] = hres[i];
+            }
+        }
+        { const int t = pe2; pe2 = pe0; pe0 = t; }
+        S->red.bi[0] = pe0; S->red.bi[1] = pe1; S->red.bi[2] = pe2; S->red.bi[3] = nh; S->red.bi[4] = (int)mI; S->red.bc[0] = mJ;
+    }
+    __syncthreads();
+    B.pe[0] = S->red.bi[0]; B.pe[1] = S->red.bi[1]; B.pe[2] = S->red.bi[2];
+    c.n_hds += S->red.bi[3]; *iterID += DG_RAN_REP;
+    maxS.I = (unsigned)S->red.bi[4]; maxS.J = S->red.bc[0];
+    __syncthreads();
+    return maxS;
+}
+
 /* one LO run of the driver (exp_ranH.c:678-747 / :795-861).  e4 = model behind errs[4].  Returns 1 if accepted. */
 template <int LDSPTS>
 __device__ __noinline__ int dg_h_lo(CTX &c, int kind, const double *e4, double th, dg_score &maxS, int *iterID, int *p1_inliers, int no_sam, int lo_run /* 0-based */)
@@ -264,7 +642,9 @@ __device__ __noinline__ int dg_h_lo(CTX &c, int kind, const double *e4, double t
     __syncthreads();
     if (tid < 9) S->Hx[tid] = S->f[tid];
     __syncthreads();
-    dg_score Sl = dg_inHranic(c, kind, (int)rb.nL, th, S->Hx, iterID, 1000000u, B);
+    /* one repetition per wave unless a diagnostic needs the reference's order of events (residual dump, trace) */
+    const bool waves = c.hlt && c.K->hrep && !c.rrun && !c.A->trace && !c.A->lo_serial && (int)rb.nL >= 8 && n <= 1000000;
+    dg_score Sl = waves ? dg_inHranic_waves(c, kind, (int)rb.nL, th, S->Hx, iterID, B) : dg_inHranic(c, kind, (int)rb.nL, th, S->Hx, iterID, 1000000u, B);
     DG_TRACE(c, 3, Sl.I, Sl.J);
     if (!(maxS.J < Sl.J)) return 0;
     if (dg_HcloseToSingular(S->Hx)) return 0;
@@ -321,7 +701,7 @@ __device__ __noinline__ int dg_solve4_lane(const dg_pt *P, const int *ids, int k
 
 /* ---------------------------------------------------------------------------------------------- */
 template <int T, int LDSPTS>
-__device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsigned char *dyn_smem, const int pair, const int slot)
+__device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsigned char *dyn_smem, double *hlt, const int pair, const int slot)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long off = A.offsets[pair];
@@ -339,7 +719,7 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
     __syncthreads();
     c.ht.heads = (int *)(ws + A.wl.off_ht); c.ht.count = c.ht.heads + 64; c.ht.ent = c.ht.heads + 80;
     c.seeds = S->seeds3[0]; c.draws = S->draws3[0];
-    c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0; c.rrun = 0;
+    c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0; c.rrun = 0; c.hlt = hlt;
     c.cb = (dg_coop_cb *)0; c.coop_gen = (int *)0; c.coop_slot = 0;
     dg_pt *Pw; int *pool;
     /* LDSPTS: 1 = point set and sampler pool in LDS, 2 = pool in LDS / points in the HBM workspace (L2), 0 = both in HBM */
@@ -601,6 +981,7 @@ __global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_homography_kernel(dg_ar
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
     __shared__ dg_f_shared Sh;
     __shared__ int next_pair;
+    __shared__ double Hlt[DG_NW][DG_HLT];       /* per-wave solver tables of the one-repetition-per-wave local optimisation */
     /* the device code reads the arguments through a pointer (dg_f_ctx::A, also inside non-inlined functions): give it an
      * LDS copy, so the by-value kernel argument's address is never taken (that would make the compiler keep a private
      * per-lane copy of the whole block in scratch memory and turn every uniform argument into a vector value) */
@@ -610,7 +991,7 @@ __global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_homography_kernel(dg_ar
     for (;;) {
         const int pair = dg_next_pair(As, &next_pair);
         if (pair < 0) break;
-        dg_h_pair<T, LDSPTS>(As, &Sh, dyn_smem, pair, (int)blockIdx.x);
+        dg_h_pair<T, LDSPTS>(As, &Sh, dyn_smem, &Hlt[0][0], pair, (int)blockIdx.x);
     }
 }
 

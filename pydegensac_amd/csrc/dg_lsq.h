@@ -49,10 +49,9 @@ __device__ __forceinline__ void dg_normu_small(const double *p, int len, double 
 /* Htools.c:101-114 u2h on exactly 4 gathered points (one lane): the 8 x 9 DLT system laid out as the reference
  * lays it out (entry (j, r) of the 9 x 8 array lin_hg fills, read back as a 9 x 9 array after an in-place 9 x 9
  * transpose; entries the reference never writes are zero here), then its null vector. */
-__device__ __noinline__ void dg_u2h_4pt(dg_lsq_scratch *s, const double *p, double *H)
+__device__ __noinline__ void dg_u2h_4pt_mv(double *M /* 81 */, double *V /* 81 */, const double *p, double *H)
 {
-    double *M = s->U9;
-    for (int i = 0; i < 81; i++) { M[i] = 0.; s->V[i] = 0.; }
+    for (int i = 0; i < 81; i++) { M[i] = 0.; V[i] = 0.; }
     for (int i = 0; i < 4; i++) {
         const double s0 = p[4*i], s1 = p[4*i+1], s3 = p[4*i+2], s4 = p[4*i+3];
         const double z0[9] = {s3, 0, -s0*s3, s4, 0, -s0*s4, 1.0, 0, -s0*1.0};
@@ -64,9 +63,10 @@ __device__ __noinline__ void dg_u2h_4pt(dg_lsq_scratch *s, const double *p, doub
         }
     }
     for (int i = 72; i < 81; i++) M[i] = 0.;
-    dg_null9<9, 1>(M, s->V);
-    for (int i = 0; i < 9; i++) H[i] = s->V[i];
+    dg_null9<9, 1>(M, V);
+    for (int i = 0; i < 9; i++) H[i] = V[i];
 }
+__device__ __forceinline__ void dg_u2h_4pt(dg_lsq_scratch *s, const double *p, double *H) { dg_u2h_4pt_mv(s->U9, s->V, p, H); }
 
 /* ---- wave-cooperative variants of the small solvers (all 64 lanes of wave 0 call these) ----------------
  * Same arithmetic as the reference's u2f / u2h (Ftools.c:350-458, Htools.c:101-133); the design-matrix rows, the 45 normal-matrix entries and

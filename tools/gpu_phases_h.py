@@ -26,6 +26,6 @@ for it in range(2):
     torch.cuda.synchronize(); dt = time.perf_counter() - t
 print("rc", rc, "batch ms", dt * 1e3)
 ph = d_ph.cpu().numpy().astype(np.float64) / 1e5; st = d_st.cpu().numpy()
-names = ["solve", "score||sample", "commit", "LO", "-", "-", "tail", "total", "LO passes", "LO lsq+eig (long lists)", "LO hash", "LO small fits", "LO checks", "-", "-", "(mark)"]
+names = ["solve", "score||sample", "commit", "LO", "-", "-", "tail", "total", "LO passes", "LO lsq+eig (long lists)", "LO hash", "LO small fits", "LO checks|gather", "lsq_par", "eig", "(mark)"]
 print("mean ms per pair:", {n: round(float(ph[:, i].mean()), 3) for i, n in enumerate(names) if n not in ("-", "(mark)")})
 print("samples mean", st[:, 0].mean(), "lo_runs mean", st[:, 1].mean(), "threads", st[0, 14], "placement", st[0, 15] & 255)
