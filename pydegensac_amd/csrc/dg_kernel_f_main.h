@@ -18,9 +18,11 @@ __device__ __forceinline__ unsigned dg_hash_list(const int *list, int count, boo
 #define DG_HSTEP16(v_) { unsigned v = (unsigned)(v_); \
         hash += v; hash = (hash << 16) ^ hash; hash += hash >> 11; }
     int k = 0;
+    /* the ids of four 64-id blocks are in flight while one block's chain runs (the list is in global memory) */
     int cur = (lane < count) ? list[lane] : 0;
+    int n1 = (64 + lane < count) ? list[64 + lane] : 0, n2 = (128 + lane < count) ? list[128 + lane] : 0, n3 = (192 + lane < count) ? list[192 + lane] : 0;
     for (; k + 64 <= count; k += 64) {
-        int nxt = (k + 64 + lane < count) ? list[k + 64 + lane] : 0;
+        const int n4 = (k + 256 + lane < count) ? list[k + 256 + lane] : 0;
         if (small_ids) {
 #pragma unroll
             for (int i = 0; i < 64; i++) DG_HSTEP16(__builtin_amdgcn_readlane(cur, i))
@@ -28,7 +30,7 @@ __device__ __forceinline__ unsigned dg_hash_list(const int *list, int count, boo
 #pragma unroll
             for (int i = 0; i < 64; i++) DG_HSTEP(__builtin_amdgcn_readlane(cur, i))
         }
-        cur = nxt;
+        cur = n1; n1 = n2; n2 = n3; n3 = n4;
     }
     const int rem = count - k;
     for (int i = 0; i < rem; i++) DG_HSTEP(__builtin_amdgcn_readlane(cur, i))

@@ -570,45 +570,51 @@ __device__ __forceinline__ dg_score dg_inHranic_waves(CTX &c, int kind, int ninl
         }
     }
     __syncthreads();
-    for (int r = wave; r < DG_RAN_REP; r += DG_NW) dg_hrep_wave<LDSPTS>(c, kind, &logs[r], ssiz, th, c.hlt + (size_t)DG_HLT * wave, wb, lane, wave);
-    __syncthreads();
-    if (tid == 0) {
-        int pe0 = B.pe[0], pe1 = B.pe[1], pe2 = B.pe[2], nh = 0, id = *iterID;
-        unsigned mI = 0; double mJ = 0;
-        for (int r = 0; r < DG_RAN_REP; r++) {
-            const dg_hrep_log *g = &logs[r];
-            for (int i = 0; i < 9; i++) S->bufF[pe0][i] = g->h0[i];
-            ++id; nh++;
-            int pd = pe1; unsigned ScI = 0; double ScJ = 0; const double *hres = g->h0;
-            if (g->I0 >= 4) {
-                unsigned mlI = (unsigned)g->I0; double mlJ = g->J0; bool dead = false, done = false;
-                for (int it = 0; it < g->nit; it++) {
-                    const dg_hrep_it *q = &g->it[it];
-                    nh++;
-                    for (int i = 0; i < 9; i++) S->bufF[pd][i] = q->hl[i];
-                    const int ret = dg_ht_contains(c.ht, q->hash, q->I, id);
-                    if (ret == -1) dg_ht_insert(c.ht, q->hash, q->I, id);
-                    if (ret != -1 && ret != id) { dead = true; break; }
-                    if (mlJ < q->J) { mlI = (unsigned)q->I; mlJ = q->J; const int t = pe0; pe1 = t; pe0 = pd; pd = pe1; hres = q->hl; }
-                    if (it == g->nit - 1 && g->last_short) done = true;
+    /* rounds of DG_NW repetitions; after each round thread 0 replays, in repetition order, what those repetitions decide
+     * (hash table, best-so-far, buffer rotation), so the next round's repetitions already meet the sets this round inserted */
+    int pe0 = B.pe[0], pe1 = B.pe[1], pe2 = B.pe[2], nh = 0, id = *iterID;       /* replay state (thread 0) */
+    unsigned mI = 0; double mJ = 0;
+    for (int r0 = 0; r0 < DG_RAN_REP; r0 += DG_NW) {
+        if (r0 + wave < DG_RAN_REP) dg_hrep_wave<LDSPTS>(c, kind, &logs[r0 + wave], ssiz, th, c.hlt + (size_t)DG_HLT * wave, wb, lane, wave);
+        __syncthreads();
+        if (tid == 0) {
+            for (int r = r0; r < r0 + DG_NW && r < DG_RAN_REP; r++) {
+                const dg_hrep_log *g = &logs[r];
+                for (int i = 0; i < 9; i++) S->bufF[pe0][i] = g->h0[i];
+                ++id; nh++;
+                int pd = pe1; unsigned ScI = 0; double ScJ = 0; const double *hres = g->h0;
+                if (g->I0 >= 4) {
+                    unsigned mlI = (unsigned)g->I0; double mlJ = g->J0; bool dead = false, done = false;
+                    for (int it = 0; it < g->nit; it++) {
+                        const dg_hrep_it *q = &g->it[it];
+                        nh++;
+                        for (int i = 0; i < 9; i++) S->bufF[pd][i] = q->hl[i];
+                        const int ret = dg_ht_contains(c.ht, q->hash, q->I, id);
+                        if (ret == -1) dg_ht_insert(c.ht, q->hash, q->I, id);
+                        if (ret != -1 && ret != id) { dead = true; break; }
+                        if (mlJ < q->J) { mlI = (unsigned)q->I; mlJ = q->J; const int t = pe0; pe1 = t; pe0 = pd; pd = pe1; hres = q->hl; }
+                        if (it == g->nit - 1 && g->last_short) done = true;
+                    }
+                    if (!dead && !done) {
+                        nh++;
+                        for (int i = 0; i < 9; i++) S->bufF[pd][i] = g->hf[i];
+                        if (mlJ < g->Jf) { mlI = (unsigned)g->If; mlJ = g->Jf; pe1 = pe0; pe0 = pd; hres = g->hf; }
+                    }
+                    if (!dead) { ScI = mlI; ScJ = mlJ; }
                 }
-                if (!dead && !done) {
-                    nh++;
-                    for (int i = 0; i < 9; i++) S->bufF[pd][i] = g->hf[i];
-                    if (mlJ < g->Jf) { mlI = (unsigned)g->If; mlJ = g->Jf; pe1 = pe0; pe0 = pd; hres = g->hf; }
+                if (mJ < ScJ) {
+                    mI = ScI; mJ = ScJ;
+                    { const int t = pe2; pe2 = pe0; pe0 = t; }
+                    for (int i = 0; i < 9; i++) Hout[i] = hres[i];
                 }
-                if (!dead) { ScI = mlI; ScJ = mlJ; }
             }
-            if (mJ < ScJ) {
-                mI = ScI; mJ = ScJ;
+            if (r0 + DG_NW >= DG_RAN_REP) {
                 { const int t = pe2; pe2 = pe0; pe0 = t; }
-                for (int i = 0; i < 9; i++) Hout[i] = hres[i];
+                S->red.bi[0] = pe0; S->red.bi[1] = pe1; S->red.bi[2] = pe2; S->red.bi[3] = nh; S->red.bi[4] = (int)mI; S->red.bc[0] = mJ;
             }
         }
-        { const int t = pe2; pe2 = pe0; pe0 = t; }
-        S->red.bi[0] = pe0; S->red.bi[1] = pe1; S->red.bi[2] = pe2; S->red.bi[3] = nh; S->red.bi[4] = (int)mI; S->red.bc[0] = mJ;
+        __syncthreads();
     }
-    __syncthreads();
     B.pe[0] = S->red.bi[0]; B.pe[1] = S->red.bi[1]; B.pe[2] = S->red.bi[2];
     c.n_hds += S->red.bi[3]; *iterID += DG_RAN_REP;
     maxS.I = (unsigned)S->red.bi[4]; maxS.J = S->red.bc[0];
