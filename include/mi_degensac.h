@@ -76,6 +76,8 @@ extern "C" {
  *             0 = automatic (15 helpers when n >= 8192 and the batch leaves the device mostly idle), 255 = off
  *   bit  5    with helper workgroups (bits 8-15): distribute every pass over the whole point set over the claiming
  *             workgroups, not only those over >= 8192 points (tests)
+ *   bit  5    homography: run the ten repetitions of every local optimisation one after the other on the whole workgroup
+ *             instead of one repetition per wave (tests; the residual dump of mi_degensac_find_homography_resids always does)
  *   bits 5-7  with bits 16-23 (no helpers): a pair set aside with at least (threshold << this) samples left counts as "long" and is
  *             resumed before the others; 0 = automatic (threshold x 8)
  *   bits 16-23 setting pairs aside (fundamental matrix, batches larger than the resident grid): a pair still running
@@ -88,6 +90,7 @@ extern "C" {
 #define MI_DEGENSAC_TUNE_VARIANT(v)   ((uint32_t)(v) & 3u)
 #define MI_DEGENSAC_TUNE_PLACEMENT(p) (((uint32_t)(p) & 3u) << 2)
 #define MI_DEGENSAC_TUNE_SEQ_POOL     (1u << 4)
+#define MI_DEGENSAC_TUNE_H_SERIAL_LO  (1u << 5)
 #define MI_DEGENSAC_TUNE_HELPERS(h)   (((uint32_t)(h) & 255u) << 8)
 #define MI_DEGENSAC_TUNE_SET_ASIDE(t)  (((uint32_t)(t) & 255u) << 16)
 #define MI_DEGENSAC_TUNE_GRID_CAP(g)   (((uint32_t)(g) & 255u) << 24)

@@ -15,6 +15,7 @@ FLAG_LEGACY_F = 2            # exp_ransacF / exp_ransacFcustom sample-budget rul
 TUNE_LATENCY, TUNE_THROUGHPUT, TUNE_THROUGHPUT4 = 1, 2, 3   # kernel variant: 512- / 256- / 128-thread workgroups
 TUNE_PLACE_HBM, TUNE_PLACE_LDS, TUNE_PLACE_POOL_LDS = 1 << 2, 2 << 2, 3 << 2
 TUNE_SEQ_POOL = 1 << 4
+TUNE_H_SERIAL_LO = 1 << 5   # homography: local-optimisation repetitions one after the other (default: one per wave)
 # bits 8-15: cooperative helper workgroups per pair (0 auto, 255 off); bits 16-23: samples after which a running pair is
 # set aside while unstarted pairs remain, in units of 256 (0 auto, 255 off); bits 24-31: cap on resident workgroups (tests)
 

@@ -104,6 +104,41 @@ def test_homography_variants_and_modes_agree():
                 assert all(np.array_equal(np.asarray(x), y) for x, y in zip(m, ref[1])), (variant, mode)
 
 
+def test_homography_lo_one_repetition_per_wave_equals_the_serial_order(oracle_port):
+    """The homography kernel runs the ten repetitions of a local optimisation on one wave each and replays the hash
+    table / best-so-far / errs[] rotation in repetition order.  Forcing the reference's serial order
+    (tuning bit 5) must give the same bits and counters for every workgroup size (2, 4, 8 waves = 5, 3, 2 rounds), with and
+    without the symmetric metrics, and the oracle must agree."""
+    A, B = [], []
+    for i, n in enumerate([5000, 700, 2500, 64, 20, 9]):
+        p1, p2, _, _ = syn.homography_pairs(n, 0.45, 0.5, seed=130 + i, laf=True); A.append(p1); B.append(p2)
+    seeds = [11, 12, 13, 14, 15, 16]
+    for err in ("sampson", "symm_max"):
+        ref = None
+        for variant in (512, 256, 128):
+            for serial in (0, _lib.TUNE_H_SERIAL_LO):
+                H, m = pd.findHomographyBatch(A, B, 1.5, 0.999, 20000, 3.0, err, True, seeds=seeds, tuning=VARIANT[variant] | serial)
+                st = pd.last_stats()
+                cur = (np.asarray(H).copy(), [np.asarray(x).copy() for x in m], [(s_["samples"], s_["lo_runs"], s_["models"], s_["I"]) for s_ in st])
+                if ref is None:
+                    ref = cur
+                else:
+                    assert np.array_equal(cur[0], ref[0]), (err, variant, serial)
+                    assert all(np.array_equal(x, y) for x, y in zip(cur[1], ref[1])), (err, variant, serial)
+                    assert cur[2] == ref[2], (err, variant, serial)
+        assert any(c[1] >= 2 for c in ref[2])                     # several local optimisations share one hash table
+        et = {"sampson": 0, "symm_max": 2}[err]
+        for p in (0, 1, 3, 5):
+            Ho, mo, so = oracle_port.find_homography(A[p], B[p], 1.5, 0.999, 20000, et, True, 3.0, seed=seeds[p])
+            assert (ref[2][p][0], ref[2][p][1]) == (so["samples"], so["lo_runs"]), (err, p)
+            assert np.array_equal(ref[1][p], mo.astype(bool)), (err, p)
+            if np.abs(np.asarray(Ho)).sum() == 0:
+                assert np.abs(ref[0][p]).sum() == 0, (err, p)
+                continue
+            Hu = np.linalg.inv(np.asarray(Ho).reshape(3, 3).T)         # utils.py:108
+            assert np.linalg.norm(ref[0][p] - Hu) <= 1e-6 * np.linalg.norm(Hu), (err, p)
+
+
 def test_sequential_pool_stage_fallback_matches_goldens():
     """The parallel pool-swap stage relies on the LDS exchange order that the library probes once per device
     (mi_degensac_pool_stage_parallel); when the probe fails every launch uses the sequential stage.  Forcing that
