@@ -1432,3 +1432,162 @@ int dg_oracle_find_homography(const double *x1, const double *x2, int n, int dim
     free(u); free(ua); free(ub); free(c.ht);
     return (int)S.I;
 }
+
+/* ------------------------------------------------------------------ ranH2el.c: RANSAC on ellipse-to-ellipse (LAF) correspondences
+ * (SURVEY.md 8f #4).  Minimal sample = 2 correspondences, model from the 14 x 15 system of Chum & Matas (ICPR 2012) through
+ * the reference's own Gauss-Jordan null space; scoring and the LO are those of ranH.c with a second, wider threshold.
+ * u10 per correspondence: x1 y1 a1 b1 c1 | x2 y2 a2 b2 c2 (LAF = [a 0; b c]); the model maps image 2 to image 1 like every
+ * homography of the reference's C layer (ranH2el.c:38-45 builds u6 = x1 y1 1 x2 y2 1 for HDs / u2h). */
+#define H2_TAU (18.0*18.0/7.0/7.0)                                 /* ranH2el.h:31 */
+static void getTransf(const double *u10, double *N, double *D)      /* ranH2el.c:209-230, column-wise */
+{
+    D[0] = u10[2]; D[1] = u10[3]; D[2] = 0; D[3] = 0; D[4] = u10[4]; D[5] = 0; D[6] = u10[0]; D[7] = u10[1]; D[8] = 1;
+    N[0] = 1 / u10[7];
+    N[1] = - u10[8] / u10[7] / u10[9];
+    N[2] = 0; N[3] = 0;
+    N[4] = 1 / u10[9];
+    N[5] = 0;
+    N[6] = - u10[5] / u10[7];
+    N[7] = (u10[8]*u10[5] - u10[7]*u10[6]) / u10[7] / u10[9];
+    N[8] = 1;
+}
+/* ranH2el.c:342-360 Zu and :382-399 Znd for len = 2: Z is 14 x 15 column-major (leading dimension 14) */
+static void Zu2(double *Z, const double *u)
+{
+    const int ld = 14; const double u1 = u[0], u2 = u[1], u4 = u[5], u5 = u[6];
+    Z[0 + 0*ld] = -1; Z[0 + 6*ld] = u1;
+    Z[1 + 1*ld] = -1; Z[1 + 7*ld] = u1;
+    Z[2 + 2*ld] = -1; Z[2 + 6*ld] = - u1 * u4; Z[2 + 7*ld] = - u1 * u5;
+    Z[3 + 3*ld] = -1; Z[3 + 6*ld] = u2;
+    Z[4 + 4*ld] = -1; Z[4 + 7*ld] = u2;
+    Z[5 + 5*ld] = -1; Z[5 + 6*ld] = - u2 * u4; Z[5 + 7*ld] = - u2 * u5;
+    Z[6 + 8*ld] = -1; Z[6 + 6*ld] = - u4; Z[6 + 7*ld] = - u5;
+}
+static void Znd2(double *Z, const double *A, const double *B)
+{
+    const int ld = 14;
+    /* ranH2el.h:9-27: _aK / _bK read A and B transposed */
+    const double a1 = A[0], a2 = A[3], a3 = A[6], a4 = A[1], a5 = A[4], a6 = A[7];
+    const double b1 = B[0], b2 = B[3], b3 = B[6], b4 = B[1], b5 = B[4], b6 = B[7];
+    Z[2 + 2*ld] = a3; Z[5 + 2*ld] = a6; Z[6 + 2*ld] = 1;
+    Z[0 + 0*ld] = a2*b1 - a1*b4; Z[1 + 0*ld] = a2*b2 - a1*b5; Z[2 + 0*ld] = a2*b3 - a1*b6;
+    Z[3 + 0*ld] = a5*b1 - a4*b4; Z[4 + 0*ld] = a5*b2 - a4*b5; Z[5 + 0*ld] = a5*b3 - a4*b6;
+    Z[0 + 1*ld] = a1*b1 + a2*b4; Z[1 + 1*ld] = a1*b2 + a2*b5; Z[2 + 1*ld] = a1*b3 + a2*b6;
+    Z[3 + 1*ld] = a4*b1 + a5*b4; Z[4 + 1*ld] = a4*b2 + a5*b5; Z[5 + 1*ld] = a4*b3 + a5*b6;
+}
+/* ranH2el.c:232-283 with do_norm = 0.  U (15 x 15) persists across calls like nothing in the reference does: there it is an
+ * uninitialised stack array of which nullspace() writes the first `nullsize` rows; h = its first 9 entries, which are
+ * written whenever nullsize >= 1.  With nullsize == 0 the reference copies stack garbage and then discards the sample
+ * (return value != 0), so zeroes serve. */
+static int A2toRH(const double *u10, const int *samidx, double *h)
+{
+    double Z[15*15], ZT[15*15], U[15*15], N1[9], D1[9], N2[9], D2[9], t; int i, j, nullsize, nb[30];
+    getTransf(u10 + 10*samidx[0], N1, D1);
+    getTransf(u10 + 10*samidx[1], N2, D2);
+    for (i = 0; i < 15*15; i++) { Z[i] = 0.0; U[i] = 0.0; }
+    Zu2(Z, u10 + 10*samidx[0]);
+    Zu2(Z + 7, u10 + 10*samidx[1]);
+    Znd2(Z + 2*7*9, D1, N1);
+    Znd2(Z + 2*7*9 + 2*7*3 + 7, D2, N2);
+    for (i = 0; i < 14; i++) for (j = 0; j < 15; j++) ZT[i*15 + j] = Z[j*14 + i];   /* mattr(ZT, Z, 15, 14) */
+    for (i = 14*15; i < 15*15; i++) ZT[i] = 0;
+    nullsize = dg_nullspace(ZT, U, 15, nb);
+    memcpy(h, U, 9 * sizeof(double));
+    t = h[1]; h[1] = h[3]; h[3] = t; t = h[2]; h[2] = h[6]; h[6] = t; t = h[5]; h[5] = h[7]; h[7] = t;   /* trnm(h, 3) */
+    return nullsize != 1;
+}
+static double det3(const double *A)                                  /* utools.c:196-202 */
+{
+    double r = (A[0]*A[4]*A[8] + A[2]*A[3]*A[7] + A[1]*A[5]*A[6]);
+    r -= (A[2]*A[4]*A[6] + A[0]*A[5]*A[7] + A[1]*A[3]*A[8]);
+    return r;
+}
+
+/* ranH2el.c:19-206.  inHraniEl (ranH2el.c:493-543) is ranH.c's inHrani plus a minimal-sample branch (ssiz < 4) that its
+ * loLimit = 8 never reaches, so inHrani above stands in for it.  seed0: the caller's srand() value; the driver itself only
+ * draws `seed = rand()` (ranH2el.c:71). */
+static dg_score ransacH2el(dg_ctx *c, const double *u10, int len, double th, double conf, int max_sam, double *H, unsigned char *inl,
+                           int do_lo, int inlLimit, unsigned seed0, int *stats)
+{
+    int *pool, no_sam, new_sam, *samidx, i, j, *inliers, new_max, do_iterate, iter_cnt = 0, rej_cnt = 0, lo;
+    double *u6, *err, *d, h[9], *errs[5], tol, v;
+    dg_score maxS = {0,0,0,0}, maxSs = {0,0,0,0}, S;
+    unsigned seed;
+    if (inlLimit == 0) inlLimit = 0x7fffffff;
+    u6 = (double *)malloc(6 * (size_t)len * sizeof(double));
+    for (i = 0; i < len; ++i) { u6[i*6+0] = u10[i*10+0]; u6[i*6+1] = u10[i*10+1]; u6[i*6+2] = 1; u6[i*6+3] = u10[i*10+5]; u6[i*6+4] = u10[i*10+6]; u6[i*6+5] = 1; }
+    pool = (int *)malloc(len * sizeof(int));
+    for (i = 0; i < len; i++) pool[i] = i;
+    samidx = pool + len - 2;
+    err = (double *)calloc((size_t)len * 4, sizeof(double));
+    for (i = 0; i < 4; i++) errs[i] = err + (size_t)i * len;
+    errs[4] = errs[3];
+    inliers = (int *)malloc(len * sizeof(int));
+    for (i = 0; i < 9; i++) h[i] = 0;
+    no_sam = 0;
+    dg_srand(&c->rng, seed0);
+    seed = (unsigned)dg_rand(&c->rng);
+    for (lo = 0; ; ) {
+        if (!lo) {
+            if (!(no_sam < max_sam)) { if (do_lo && !iter_cnt) lo = 2; else break; }   /* :163 "no LO's so far: make one now" */
+        }
+        if (!lo) {
+            no_sam++; new_max = 0; do_iterate = 0;
+            dg_srand(&c->rng, seed);
+            randsubset(c, pool, len, 2);
+            seed = (unsigned)dg_rand(&c->rng);
+            if (A2toRH(u10, samidx, h)) continue;
+            v = det3(h); tol = h[8]; tol = tol*tol*tol;
+            if (fabs(v/tol) < 10e-2) continue;
+            d = errs[0];
+            HDs(u6, h, d, len); c->n_hds++;
+            S = inlidxs(d, len, th, inliers);
+            if (scoreLess(maxS, S)) { maxS = S; errs[0] = errs[3]; errs[3] = d; memcpy(H, h, 9*sizeof(double)); new_max = 1; }
+            S = inlidxs(d, len, th*H2_TAU, inliers);
+            if (scoreLess(maxSs, S)) {
+                maxSs = S; do_iterate = no_sam > ITER_SAM;
+                if (!new_max) { errs[0] = errs[2]; errs[2] = d; }
+                errs[4] = d;
+            }
+            if (no_sam >= ITER_SAM && iter_cnt == 0 && maxSs.I > 4) do_iterate = 1;
+            if (do_iterate && do_lo) lo = 1;
+        }
+        if (lo) {                                                   /* :128-151 and :165-187, the same block twice */
+            iter_cnt++;
+            d = errs[0];
+            S = inlidxs(errs[4], len, TC*th*H2_TAU, inliers);
+            u2h(u6, inliers, S.I, h);                               /* fewer than 4 ids: h keeps the last sample's model */
+            HDs(u6, h, d, len); c->n_hds++;
+            S = inlidxs(d, len, th, inliers);
+            S = inHrani(c, u6, len, inliers, S.I, th, errs, h, (unsigned)inlLimit);
+            tol = h[8]; tol = tol*tol*tol;
+            if (scoreLess(maxS, S) && (fabs(det3(h)/tol) > 10e-2)) {
+                maxS = S; d = errs[0]; errs[0] = errs[3]; errs[3] = d; memcpy(H, h, 9*sizeof(double)); new_max = 1;
+            }
+            if (lo == 2) break;
+            lo = 0;
+        }
+        if (new_max) { new_sam = dg_nsamples(maxS.I + 1, len, 2, conf); if (new_sam < max_sam) max_sam = new_sam; }
+    }
+    if (inl) { d = errs[3]; for (j = 0; j < len; j++) inl[j] = d[j] <= th ? 1 : 0; }
+    if (stats) {
+        memset(stats, 0, sizeof(int) * DG_ST_COUNT);
+        stats[DG_ST_SAMPLES] = no_sam; stats[DG_ST_LO_RUNS] = iter_cnt; stats[DG_ST_REJECTED] = rej_cnt;
+        stats[DG_ST_I] = (int)maxS.I; stats[DG_ST_MODELS] = (int)c->n_hds;
+    }
+    free(pool); free(err); free(inliers); free(u6);
+    return maxS;
+}
+
+/* u10: [n, 10] row-major.  th is the threshold on the (squared) transfer error HDs returns, as ranH2el.h:35 takes it. */
+int dg_oracle_ransacH2el(const double *u10, int n, double th, double conf, int max_iters, int do_lo, int inl_limit, unsigned seed,
+                         double *H, unsigned char *mask, int *stats)
+{
+    dg_ctx c; dg_score S; int i;
+    if (n < 2) return -1;
+    memset(&c, 0, sizeof c);
+    for (i = 0; i < 9; i++) H[i] = 0;
+    S = ransacH2el(&c, u10, n, th, conf, max_iters, H, mask, do_lo, inl_limit, seed, stats);
+    free(c.ht);
+    return (int)S.I;
+}

@@ -31,6 +31,10 @@ int dg_oracle_find_homography(const double *x1, const double *x2, int n, int dim
                               int sym_check, double laf_coef, unsigned seed,
                               double *H, unsigned char *mask, int *stats);
 
+/* ranH2el.c:19 ransacH2el (2 ellipse-to-ellipse correspondences per sample); u10 = [n, 10], th on HDs' squared distance */
+int dg_oracle_ransacH2el(const double *u10, int n, double th, double conf, int max_iters, int do_lo, int inl_limit, unsigned seed,
+                         double *H, unsigned char *mask, int *stats);
+
 /* unit-level entry points used by the tests (thin wrappers over dg_small.h / dg_oracle.c) */
 void dg_oracle_rand_stream(unsigned seed, int count, int *out);
 int  dg_oracle_sample_stream(unsigned seed, int n, int sample_size, int iters, int *samidx_out, unsigned *seeds_out);

@@ -74,3 +74,14 @@ def find_homography(pts1, pts2, px_th=1.0, conf=0.999, max_iters=50000, error_ty
     stats = dict(samples=int(st[0]), lo_runs=int(st[1]), rejected=int(st[2]), I=int(st[3]), models=int(st[4]),
                  best_sample=int(st[7]))
     return H.reshape(3, 3), mask.astype(bool), stats
+
+
+def ransacH2el(u10, th=4.0, conf=0.99, max_iters=10000, do_lo=True, inl_limit=0, seed=1):
+    """Restatement of ranH2el.c:19 (2 ellipse-to-ellipse correspondences per sample).  u10: [n, 10] = x1 y1 a1 b1 c1 x2 y2 a2 b2 c2.
+    Returns the RAW internal H (column-wise, image 2 -> image 1), mask, stats."""
+    l = lib()
+    u = np.ascontiguousarray(u10, dtype=np.float64); n = u.shape[0]
+    H = np.zeros(9); mask = np.zeros(n, np.uint8); st = np.zeros(ST_COUNT, np.int32)
+    l.dg_oracle_ransacH2el(dp(u), n, C.c_double(th), C.c_double(conf), int(max_iters), int(bool(do_lo)), int(inl_limit), C.c_uint(seed),
+                           dp(H), mask.ctypes.data_as(C.POINTER(C.c_ubyte)), ip(st))
+    return H.reshape(3, 3), mask.astype(bool), dict(samples=int(st[0]), lo_runs=int(st[1]), I=int(st[3]), models=int(st[4]))

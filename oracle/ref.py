@@ -119,3 +119,13 @@ def find_fundamental_legacy(variant, pts1, pts2, px_th=0.5, conf=0.9999, max_ite
     l.ref_find_fundamental_legacy(int(variant), _dp(a), _dp(b), n, dim, px_th, conf, max_iters, error_type, int(sym_check), seed,
                                   _dp(F), mask.ctypes.data_as(C.POINTER(C.c_ubyte)), st)
     return F.reshape(3, 3), mask.astype(bool), dict(samples=st[0], lo_runs=st[1], Ih=st[2], I=st[3])
+
+
+def ransacH2el(u10, th=4.0, conf=0.99, max_iters=10000, do_lo=True, inl_limit=0, seed=1):
+    """The reference's ransacH2el (ranH2el.c:19), seeded through srand(seed).  Returns raw H, mask, stats."""
+    l = lib()
+    u = np.ascontiguousarray(u10, dtype=np.float64); n = u.shape[0]
+    H = np.zeros(9); mask = np.zeros(n, np.uint8); st = (C.c_int * 4)()
+    l.ref_ransacH2el(_dp(u), n, C.c_double(th), C.c_double(conf), int(max_iters), int(bool(do_lo)), int(inl_limit), C.c_uint(seed),
+                     _dp(H), mask.ctypes.data_as(C.POINTER(C.c_ubyte)), st)
+    return H.reshape(3, 3), mask.astype(bool), dict(samples=st[0], lo_runs=st[1], I=st[3])

@@ -202,3 +202,21 @@ int ref_find_fundamental_legacy(int variant, const double *x1, const double *x2,
     free(resids); free(data_out); free(u); free(ua); free(ub);
     return ret;
 }
+
+/* ---- ransacH2el (ranH2el.c:19): no binding in the reference's Python layer, called as its header declares
+ * it.  The driver draws `seed = rand()` from the process-wide generator without seeding it: srand(seed) here. */
+/* ranH2el.h:35 (its header does not compile on its own after Ftools.h: macro clashes) */
+Score ransacH2el(double *u10, int len, double th, double conf, int max_sam, double *H, unsigned char *inl, int *data_out, int do_lo, int inlLimit);
+int ref_ransacH2el(const double *u10, int n, double th, double conf, int max_iters, int do_lo, int inl_limit, unsigned seed,
+                   double *H, unsigned char *mask, int *stats)
+{
+    int data_out[3] = {0, 0, 0}, i; Score S;
+    double *u = (double *)malloc(sizeof(double) * 10 * (size_t)n);
+    memcpy(u, u10, sizeof(double) * 10 * (size_t)n);
+    for (i = 0; i < 9; i++) H[i] = 0;
+    srand(seed);
+    S = ransacH2el(u, n, th, conf, max_iters, H, mask, data_out, do_lo, inl_limit);
+    if (stats) { stats[0] = data_out[0]; stats[1] = data_out[1]; stats[2] = data_out[2]; stats[3] = (int)S.I; }
+    free(u);
+    return (int)S.I;
+}

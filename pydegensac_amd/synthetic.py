@@ -81,3 +81,34 @@ def homography_pairs(n=5000, inlier_ratio=0.4, sigma=0.5, seed=0, laf=False, H=N
         pts1 = np.concatenate([pts1, A1], 1); pts2 = np.concatenate([pts2, A2], 1)
     perm = rng.permutation(n)
     return np.ascontiguousarray(pts1[perm]), np.ascontiguousarray(pts2[perm]), lab[perm], H
+
+
+def ellipse_pairs(n=1000, inlier_ratio=0.3, sigma=1.0, seed=0, laf_noise=0.05, H=None, w=788.0, h=522.0):
+    """Generator for ransacH2el (ranH2el.c): u10 [n, 10] = x1 y1 a1 b1 c1 | x2 y2 a2 b2 c2, one lower-triangular local
+    affine frame [a 0; b c] per image.  The frame of image 2 is random, the one of image 1 is its image under the local
+    affine approximation of the ground-truth homography (which maps image 2 to image 1, like the reference's internal H),
+    perturbed by laf_noise and reduced to lower-triangular form by a rotation (an ellipse does not fix one).  Outliers
+    keep their frames and get a uniformly random position in image 1.  Returns (u10, inlier labels)."""
+    rng = np.random.default_rng(seed)
+    H = H_1_6 if H is None else H
+    x2 = np.stack([rng.uniform(0, w, n), rng.uniform(0, h, n)], 1)
+    a = rng.uniform(5, 30, n); b = rng.uniform(-10, 10, n); c = rng.uniform(5, 30, n)
+    q = np.concatenate([x2, np.ones((n, 1))], 1) @ H.T
+    wz = q[:, 2]
+    x1 = q[:, :2] / wz[:, None]
+    J = np.empty((n, 2, 2))
+    for r in range(2):
+        for k in range(2):
+            J[:, r, k] = (H[r, k] * wz - q[:, r] * H[2, k]) / (wz * wz)
+    A2 = np.zeros((n, 2, 2)); A2[:, 0, 0] = a; A2[:, 1, 0] = b; A2[:, 1, 1] = c
+    M = np.einsum('nij,njk->nik', J, A2) * (1.0 + laf_noise * rng.normal(size=(n, 2, 2)))
+    r0 = np.hypot(M[:, 0, 0], M[:, 0, 1])
+    Q = np.empty((n, 2, 2)); Q[:, 0, 0] = M[:, 0, 0] / r0; Q[:, 0, 1] = -M[:, 0, 1] / r0; Q[:, 1, 0] = M[:, 0, 1] / r0; Q[:, 1, 1] = M[:, 0, 0] / r0
+    L = np.einsum('nij,njk->nik', M, Q)
+    n_in = int(round(n * inlier_ratio))
+    lab = np.zeros(n, bool); lab[:n_in] = True
+    x1[:n_in] += rng.normal(0, sigma, (n_in, 2))
+    x1[n_in:] = np.stack([rng.uniform(0, w, n - n_in), rng.uniform(0, h, n - n_in)], 1)
+    u = np.stack([x1[:, 0], x1[:, 1], L[:, 0, 0], L[:, 1, 0], L[:, 1, 1], x2[:, 0], x2[:, 1], a, b, c], 1)
+    perm = rng.permutation(n)
+    return np.ascontiguousarray(u[perm]), lab[perm]

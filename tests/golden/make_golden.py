@@ -66,6 +66,16 @@ LEGACY_SYM_CASES = [
     ("LS_custom_sym_sampson", 0, dict(n=1500, inlier_ratio=0.4, sigma=0.5, seed=5, plane_fraction=0.6), dict(sym_check=True)),
     ("LS_custom_sym_symm_epipolar", 0, dict(n=800, inlier_ratio=0.4, sigma=0.5, seed=6), dict(sym_check=True, error_type=1)),
 ]
+# ransacH2el (ranH2el.c:19): 2 ellipse-to-ellipse correspondences per sample; fixtures E_*.npz, kind "E"
+ELLIPSE_CASES = [
+    ("E_n1000", dict(n=1000, inlier_ratio=0.3, sigma=1.0, seed=1001, laf_noise=0.05), dict(th=4.0, conf=0.99, max_iters=10000)),
+    ("E_n3000_low", dict(n=3000, inlier_ratio=0.1, sigma=1.0, seed=3001, laf_noise=0.05), dict(th=4.0, conf=0.99, max_iters=10000)),
+    ("E_n400_noisy", dict(n=400, inlier_ratio=0.15, sigma=1.5, seed=401, laf_noise=0.1), dict(th=4.0, conf=0.99, max_iters=10000)),
+    ("E_n5000", dict(n=5000, inlier_ratio=0.4, sigma=0.5, seed=5007, laf_noise=0.02), dict(th=4.0, conf=0.999, max_iters=10000)),
+    ("E_nolo", dict(n=800, inlier_ratio=0.2, sigma=1.0, seed=801, laf_noise=0.05), dict(th=4.0, conf=0.99, max_iters=3000, do_lo=False)),
+    ("E_limit25", dict(n=2000, inlier_ratio=0.12, sigma=1.0, seed=2001, laf_noise=0.05), dict(th=9.0, conf=0.99, max_iters=10000, inl_limit=25)),
+    ("E_all_outliers", dict(n=300, inlier_ratio=0.0, sigma=1.0, seed=301, laf_noise=0.05), dict(th=4.0, conf=0.99, max_iters=500)),
+]
 SEEDS = [1, 7]
 
 
@@ -101,6 +111,16 @@ def main():
             F, m, st = ref.find_fundamental_legacy(variant, p1, p2, seed=s, **kw)
             np.savez_compressed(os.path.join(HERE, f"{name}_s{s}.npz"), kind="L", variant=variant, gen=repr(g), call=repr(kw), seed=s,
                                 model=F, mask=np.packbits(m), n=len(m), samples=st["samples"], lo_runs=st["lo_runs"],
+                                full_passes=0, I=st["I"])
+            n_written += 1
+    for name, g, kw in ELLIPSE_CASES:
+        if not sel(name):
+            continue
+        u10, _ = syn.ellipse_pairs(**g)
+        for s in SEEDS:
+            H, m, st = ref.ransacH2el(u10, seed=s, **kw)
+            np.savez_compressed(os.path.join(HERE, f"{name}_s{s}.npz"), kind="E", gen=repr(g), call=repr(kw), seed=s,
+                                model=H, mask=np.packbits(m), n=len(m), samples=st["samples"], lo_runs=st["lo_runs"],
                                 full_passes=0, I=st["I"])
             n_written += 1
     print("wrote", n_written, "fixtures")

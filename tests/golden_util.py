@@ -19,6 +19,8 @@ def load(path):
     kind = str(z["kind"])
     if kind in ("F", "L"):
         p1, p2, _, _ = syn.two_view_fundamental(**g)
+    elif kind == "E":
+        p1, _ = syn.ellipse_pairs(**g); p2 = None          # p1 = u10 [n, 10]
     else:
         p1, p2, _, _ = syn.homography_pairs(**g)
     n = int(z["n"])

@@ -125,6 +125,29 @@ def test_port_matches_reference_random_sweep(oracle_port, oracle_ref):
     assert worst < 1e-5          # ill-conditioned (plane-dominated) final fits may differ beyond rounding, never grossly
 
 
+@pytest.mark.parametrize("path", gu.fixtures("E"), ids=lambda p: os.path.basename(p)[:-4])
+def test_port_matches_golden_ellipse_ransac(oracle_port, path):
+    """ransacH2el (ranH2el.c:19): the restatement against fixtures from the unmodified reference"""
+    g = gu.load(path)
+    H, m, st = oracle_port.ransacH2el(g["p1"], seed=g["seed"], **g["call"])
+    assert (st["samples"], st["lo_runs"], st["I"]) == (g["samples"], g["lo_runs"], g["I"])
+    assert np.array_equal(m, g["mask"])
+    assert gu.rel(H, g["model"]) < 1e-9
+
+
+def test_ellipse_ransac_port_matches_reference_live(oracle_port, oracle_ref):
+    """ransacH2el restated against the reference build on seeded problems: LO on / off, a finite inlLimit (random subsets
+    inside iterH), 60..3000 correspondences, 10-50 % inliers"""
+    for n, ir, sig, ln in [(1000, 0.3, 1.0, 0.05), (3000, 0.1, 1.0, 0.05), (400, 0.15, 1.5, 0.1), (60, 0.5, 1.0, 0.05)]:
+        for seed in (2, 5):
+            u, _ = syn.ellipse_pairs(n, ir, sig, seed + n, ln)
+            for lo, lim, mi, th in [(True, 0, 10000, 4.0), (False, 0, 3000, 4.0), (True, 25, 10000, 9.0)]:
+                Hr, mr, sr = oracle_ref.ransacH2el(u, th, 0.99, mi, lo, lim, seed)
+                Hp, mp, sp = oracle_port.ransacH2el(u, th, 0.99, mi, lo, lim, seed)
+                assert (sr["samples"], sr["lo_runs"], sr["I"]) == (sp["samples"], sp["lo_runs"], sp["I"]), (n, seed, lo, lim)
+                assert np.array_equal(mr, mp) and gu.rel(Hr, Hp) < 1e-9, (n, seed, lo, lim)
+
+
 def test_h_symmetric_metrics_match_reference(oracle_port, oracle_ref):
     """the four symmetric transfer errors of the restatement (HDS_full kinds 1..4) against the reference's own
     HDsSymMaxSq / HDsSymMax / HDsSymSumSq / HDsSymSum (Htools.c:202-370), bit for bit"""
