@@ -178,6 +178,27 @@ int mi_degensac_find_homography_batch_dev(const double *d_pts1, const double *d_
                                           int n_pairs, int dim, const mi_degensac_params *prm,
                                           const uint32_t *d_seeds, int device, void *stream,
                                           double *d_H, uint8_t *d_mask, int32_t *d_stats);
+/* ---- RANSAC on ellipse-to-ellipse correspondences: the reference's ransacH2el (degensac/ranH2el.h:35, ranH2el.c:19-206;
+ * no binding in the reference's Python layer — this is its C signature with the allocation-free device conventions of
+ * the entry points above).  u10: [total, 10] doubles, per correspondence x1 y1 a1 b1 c1 | x2 y2 a2 b2 c2 with the local
+ * affine frame [a 0; b c] of each image; a sample is TWO correspondences (14 x 15 system of Chum & Matas, ICPR 2012).
+ * H (9 doubles per pair, column-wise like the reference's internal H) maps image 2 to image 1; mask[j] = HDs residual of
+ * the returned model <= th (ranH2el.c:189-198).  stats as for the other drivers ([0] samples, [1] LO runs, [3] I). */
+typedef struct mi_degensac_h2el_params {
+    double   th;          /* threshold on the squared transfer error HDs returns (the reference's `th`)       */
+    double   conf;        /* confidence of the sample-count rule (nsamples with sample size 2)                  */
+    int32_t  max_iters;   /* max_sam                                                                            */
+    int32_t  do_lo;       /* bool: local optimisation (inHraniEl)                                               */
+    int32_t  inl_limit;   /* inlLimit: correspondences per least-squares fit inside the LO; 0 = all (>= 4 else)  */
+    int32_t  reserved;
+} mi_degensac_h2el_params;
+int mi_degensac_ransac_h2el_batch(const double *u10, const int64_t *offsets, int n_pairs,
+                                  const mi_degensac_h2el_params *prm, const uint32_t *seeds, int device,
+                                  double *H, uint8_t *mask, int32_t *stats);
+int mi_degensac_ransac_h2el_batch_dev(const double *d_u10, const int64_t *d_offsets, const int64_t *offsets_host, int n_pairs,
+                                      const mi_degensac_h2el_params *prm, const uint32_t *d_seeds, int device, void *stream,
+                                      double *d_H, uint8_t *d_mask, int32_t *d_stats);
+
 /* release the scratch cached for (device, stream) pairs whose work has completed (all of them when
  * `stream_or_null` is NULL, else only that stream's); call before destroying a stream */
 int mi_degensac_release_scratch(int device, void *stream_or_null);

@@ -26,6 +26,11 @@ class Params(C.Structure):
                 ("laf_consistensy_coef", C.c_double), ("flags", C.c_uint32), ("tuning", C.c_uint32)]
 
 
+class H2elParams(C.Structure):
+    _fields_ = [("th", C.c_double), ("conf", C.c_double), ("max_iters", C.c_int32), ("do_lo", C.c_int32),
+                ("inl_limit", C.c_int32), ("reserved", C.c_int32)]
+
+
 class MiDegensacError(RuntimeError):
     pass
 
@@ -74,6 +79,11 @@ def lib():
         for name in ("mi_degensac_find_fundamental_batch", "mi_degensac_find_homography_batch"):
             f = getattr(l, name); f.restype = C.c_int
             f.argtypes = [dp, dp, lp, C.c_int, C.c_int, pp, up, C.c_int, dp, bp, ip]
+        l.mi_degensac_ransac_h2el_batch.restype = C.c_int
+        l.mi_degensac_ransac_h2el_batch.argtypes = [dp, lp, C.c_int, C.POINTER(H2elParams), up, C.c_int, dp, bp, ip]
+        l.mi_degensac_ransac_h2el_batch_dev.restype = C.c_int
+        l.mi_degensac_ransac_h2el_batch_dev.argtypes = [C.c_void_p, C.c_void_p, lp, C.c_int, C.POINTER(H2elParams), C.c_void_p, C.c_int,
+                                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         for name in ("mi_degensac_find_fundamental_batch_dev", "mi_degensac_find_homography_batch_dev"):
             f = getattr(l, name); f.restype = C.c_int
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, lp, C.c_int, C.c_int, pp, C.c_void_p, C.c_int, C.c_void_p,

@@ -268,3 +268,40 @@ def findHomographyBatch(pts1_list, pts2_list, px_th=1.0, conf=0.999, max_iters=5
         if np.abs(H[i]).sum() != 0:
             out[i] = np.linalg.inv(H[i].T)
     return out, masks
+
+
+def ransacH2el_batch(u10_list, th=4.0, conf=0.99, max_iters=10000, do_lo=True, inl_limit=0, seeds=None, device=0):
+    """The reference's ransacH2el (degensac/ranH2el.c:19, ranH2el.h:35; it has no Python binding there): RANSAC on
+    ellipse-to-ellipse correspondences, two per sample.  u10: [n, 10] = x1 y1 a1 b1 c1 x2 y2 a2 b2 c2 with the local affine
+    frame [a 0; b c] of each image.  th is the threshold on the squared transfer error.  Returns (H [P, 3, 3] — the RAW
+    internal model, image 2 -> image 1, zeros when none —, list of masks); `last_stats()` has the counters."""
+    n_pairs = len(u10_list)
+    if n_pairs == 0:
+        raise ValueError("u10_list must hold at least one pair")
+    a = [np.ascontiguousarray(p, dtype=np.float64) for p in u10_list]
+    for i, x in enumerate(a):
+        if x.ndim != 2 or x.shape[1] != 10 or x.shape[0] < 2:
+            raise ValueError(f"pair {i}: u10 should be an array with dims [n,10], n >= 2")
+    if seeds is None:
+        seeds = (_time_seed() + np.arange(n_pairs)) & 0xFFFFFFFF
+    if len(seeds) != n_pairs:
+        raise ValueError("one seed per pair")
+    offs = np.zeros(n_pairs + 1, np.int64)
+    offs[1:] = np.cumsum([x.shape[0] for x in a])
+    U = np.ascontiguousarray(np.concatenate(a, 0))
+    prm = _lib.H2elParams(float(th), float(conf), int(max_iters), int(bool(do_lo)), int(inl_limit), 0)
+    model = np.zeros((n_pairs, 9)); mask = np.zeros(int(offs[-1]), np.uint8); st = np.zeros((n_pairs, 16), np.int32)
+    sd = np.ascontiguousarray(seeds, dtype=np.uint32)
+    rc = _lib.lib().mi_degensac_ransac_h2el_batch(_lib.dptr(U), offs.ctypes.data_as(C.POINTER(C.c_int64)), n_pairs, C.byref(prm),
+                                                  sd.ctypes.data_as(C.POINTER(C.c_uint32)), int(device), _lib.dptr(model),
+                                                  mask.ctypes.data_as(C.POINTER(C.c_uint8)), st.ctypes.data_as(C.POINTER(C.c_int32)))
+    _lib.check(rc)
+    _tls.stats = [_lib.stats_dict(s) for s in st]
+    return model.reshape(n_pairs, 3, 3), [mask[offs[i]:offs[i + 1]].astype(bool) for i in range(n_pairs)]
+
+
+def ransacH2el(u10, th=4.0, conf=0.99, max_iters=10000, do_lo=True, inl_limit=0, seed=None, device=0):
+    """One pair of ransacH2el_batch: returns (H [3, 3], mask [n])."""
+    H, m = ransacH2el_batch([u10], th, conf, max_iters, do_lo, inl_limit, None if seed is None else [seed], device)
+    _tls.stats = _tls.stats[0]
+    return H[0], m[0]

@@ -38,6 +38,7 @@ struct dg_params {
     int    error_type;
     int    degen;
     int    final_laf_filter;
+    int    h2_do_lo, h2_inl_limit;   /* ransacH2el (dg_kernel_h2el.h): do_lo and inlLimit of ranH2el.h:35 (0 = no limit) */
     int    legacy;        /* F: the sample-budget rule of exp_ransacF / exp_ransacFcustom (MI_DEGENSAC_FLAG_LEGACY_F) */
 };
 

@@ -11,6 +11,7 @@
 #define DG_T 512
 #include "dg_kernel_f_main.h"
 #include "dg_kernel_h.h"
+#include "dg_kernel_h2el.h"
 #include "dg_variant_impl.h"
 #include "mi_degensac_host.inc"
 
