@@ -1272,6 +1272,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             __syncthreads();
             if (nw >= 0) {
                 D.n_fds = c.n_fds; D.n_exfds = c.n_exfds; D.n_hds = c.n_hds; D.n_aux = c.n_aux; D.t_parked = wall_clock64();
+                /* development build (tools/gpu_tail.py): what is known about the pair when it is set aside */
+                DG_DEVT(if (A.phase_out && tid == 0) { long long *o_ = A.phase_out + ((size_t)A.n_pairs + 4096 + pair) * 16; o_[0] = max_sam - no_sam; o_[1] = iter_cnt; o_[2] = degen_cnt; o_[3] = D.t_parked - t_start; o_[4] = (long long)maxS.I; });
                 if (tid == 0) S->park = D;
                 __syncthreads();
                 char *pk = ws + A.wl.off_park;
@@ -1750,7 +1752,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     if (A.phase_out && tid == 0) { for (int i = 0; i < 16; i++) A.phase_out[(size_t)pair * 16 + i] = S->lt[i]; }
     if (0)
 #endif
-    DG_DEVT(if (A.phase_out && tid == 0) { S->ph[7] = DG_CLK() - t_start; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + i] = S->ph[i]; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + 8 + i] = S->dbg[i]; });
+    DG_DEVT(if (A.phase_out && tid == 0) { S->ph[7] = DG_CLK() - t_start; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + i] = S->ph[i]; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + 8 + i] = S->dbg[i]; A.phase_out[(size_t)pair * 16 + 15] = DG_CLK(); });
 #undef DG_PH
     return -1;
 }
@@ -1810,6 +1812,8 @@ __global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_fundamental_kernel(dg_a
     }
     if (LDSPTS == 0 && As.coop_k > 0 && threadIdx.x == 0)          /* retire the slot: its helpers leave */
         __hip_atomic_store(&As.coop[slot].gen, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    /* development build: when this workgroup ran out of work (tools/gpu_sched.py: the tail of a launch) */
+    DG_DEVT(if (As.phase_out && threadIdx.x == 0) As.phase_out[((size_t)As.n_pairs + blockIdx.x) * 16] = DG_CLK());
 
 }
 
