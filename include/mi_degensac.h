@@ -73,7 +73,7 @@ extern "C" {
  *             (a placement that does not fit the device's LDS is ignored)
  *   bit  4    sampler           1 = always use the sequential pool-swap stage
  *   bits 8-15 helper workgroups per pair of the cooperative large-n mode (fundamental matrix, placement HBM):
- *             0 = automatic (15 helpers when n >= 8192 and the batch leaves the device mostly idle), 255 = off
+ *             0 = automatic (23 helpers when n >= 8192 and the batch leaves the device mostly idle, 15 with less room), 255 = off
  *   bit  5    with helper workgroups (bits 8-15): distribute every pass over the whole point set over the claiming
  *             workgroups, not only those over >= 8192 points (tests)
  *   bit  5    homography: run the ten repetitions of every local optimisation one after the other on the whole workgroup
