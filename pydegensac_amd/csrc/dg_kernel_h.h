@@ -4,7 +4,9 @@
  *   - 4 draws per sample (next seed = 5th output), orientation / rank / near-singularity rejects
  *     happen in the per-lane solve, at most one model per sample;
  *   - five selectable error metrics (Htools.c) incl. the symmetric ones that need H^-1 per model;
- *   - LO re-fits on ALL band inliers (inlLimit = 1e6): workgroup-parallel normalised DLT.
+ *   - LO re-fits on ALL band inliers (inlLimit = 1e6): normalised DLT over long id lists;
+ *   - the ten repetitions of a local optimisation run one per WAVE and are replayed in repetition order
+ *     (dg_inHranic_waves below); the workgroup-wide serial order (dg_inHranic) remains for the residual dump.
  */
 #ifndef DG_KERNEL_H_H
 #define DG_KERNEL_H_H
