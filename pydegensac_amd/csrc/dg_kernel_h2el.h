@@ -4,8 +4,8 @@
  * thresholds (th and th * TAU), the local optimisation is ranH.c's inHrani / iterH on the point coordinates.
  *
  * The driver needs a few dozen to a few hundred samples (the sample size is 2), so there is nothing to speculate on: one
- * workgroup runs the reference's loop as it stands — thread 0 draws and solves (the 15 x 15 elimination lives in the
- * pair's workspace), the workgroup scores with the passes of the homography kernel (dg_h_pass), and the least squares
+ * workgroup runs the reference's loop as it stands — thread 0 draws, wave 0 solves (the 15 x 15 elimination in LDS, one
+ * element group per lane), the workgroup scores with the passes of the homography kernel (dg_h_pass), and the least squares
  * are the homography kernel's (dg_u2h_list).  What each errs[] buffer holds is tracked as "the model whose residuals it
  * contains" (S->bufF), like in the other drivers.
  *
@@ -17,38 +17,67 @@
 
 #define DG_H2_TAU (18.0*18.0/7.0/7.0)            /* ranH2el.h:31 */
 
-/* utools.c:97-167 nullspace(): Gauss-Jordan null space of an n x n row-major matrix, tol 1e-12; one thread; buffer 2n ints */
-__device__ __noinline__ int dg_nullspace_n(double *matrix, double *nullspace, int n, int *buffer)
+/* utools.c:97-167 nullspace(): Gauss-Jordan null space of an n x n row-major matrix (n <= 16), tol 1e-12, by ONE WAVE on a
+ * matrix in LDS.  Lane e handles the elements e, e + 64, ... of the matrix; within one pivot step the updates of different
+ * elements are independent of each other (each reads its row's entry of the pivot column, the pivot row and itself), so every
+ * element sees the reference's sequence of operations.  buffer: 2n ints (LDS).  All 64 lanes call it; returns the number of
+ * null vectors (rows of `nullspace`, n doubles each). */
+__device__ __noinline__ int dg_nullspace_wave(double *matrix, double *nullspace, int n, int *buffer, int lane)
 {
     int nonpivot = 0, npiv = 0, i = 0;
     const double tol = 1e-12;
     for (int j = 0; j < n; j++) {
-        double pivot = fabs(matrix[n*i + j]); int max = i;
-        for (int k = i + 1; k < n; k++) { const double t = fabs(matrix[n*k + j]); if (pivot < t) { pivot = t; max = k; } }
+        DG_WSYNC();
+        /* pivot search, the reference's order: first row of the largest magnitude from the diagonal down */
+        const double mine = lane < n ? fabs(matrix[n*lane + j]) : 0.0;
+        double pivot = dg_readlane_d(mine, i); int max = i;
+        for (int k = i + 1; k < n; k++) { const double t = dg_readlane_d(mine, k); if (pivot < t) { pivot = t; max = k; } }
         if (pivot < tol) {
-            buffer[nonpivot++] = j;
-            for (int k = i; k < n; k++) matrix[n*k + j] = 0;
+            if (lane == 0) buffer[nonpivot] = j;
+            nonpivot++;
+            if (lane >= i && lane < n) matrix[n*lane + j] = 0;
         } else {
-            buffer[n + npiv++] = j;
-            for (int k = j; k < n; k++) { const double t = matrix[i*n + k]; matrix[i*n + k] = matrix[max*n + k]; matrix[max*n + k] = t; }
-            pivot = matrix[i*n + j];
-            for (int k = j; k < n; k++) matrix[i*n + k] /= pivot;
-            for (int k = 0; k < i; k++) {
-                pivot = -matrix[k*n + j];
-                for (int l = j; l < n; l++) matrix[k*n + l] += pivot * matrix[i*n + l];
+            if (lane == 0) buffer[n + npiv] = j;
+            npiv++;
+            /* swap rows i <-> max (columns j..n-1), then divide the pivot row by the pivot element */
+            if (lane >= j && lane < n) {
+                const double a = matrix[i*n + lane], b = matrix[max*n + lane];
+                matrix[i*n + lane] = b; matrix[max*n + lane] = a;
             }
-            for (int k = i + 1; k < n; k++) {
-                pivot = matrix[k*n + j];
-                for (int l = j; l < n; l++) matrix[k*n + l] -= pivot * matrix[i*n + l];
+            DG_WSYNC();
+            const double pv = matrix[i*n + j];
+            DG_WSYNC();
+            if (lane >= j && lane < n) matrix[i*n + lane] /= pv;
+            DG_WSYNC();
+            /* subtract multiples of the pivot row from all the other rows: reads first, then the stores */
+            double f[4], r[4], v[4]; bool act[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int e = lane + 64 * u, k = e / n, l = e - k * n;
+                act[u] = e < n * n && k != i && l >= j;
+                f[u] = act[u] ? matrix[k*n + j] : 0.0; r[u] = act[u] ? matrix[i*n + l] : 0.0; v[u] = act[u] ? matrix[e] : 0.0;
+            }
+            DG_WSYNC();
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int e = lane + 64 * u, k = e / n;
+                if (act[u]) {
+                    if (k < i) { const double pm = -f[u]; matrix[e] = v[u] + pm * r[u]; }
+                    else matrix[e] = v[u] - f[u] * r[u];
+                }
             }
             i++;
         }
     }
-    for (int k = 0; k < nonpivot; k++) {
-        const int j = buffer[k];
-        for (int l = 0; l < n - nonpivot; l++) nullspace[k*n + buffer[n + l]] = -matrix[l*n + j];
-        for (int l = 0; l < nonpivot; l++) nullspace[k*n + buffer[l]] = (j == buffer[l]) ? 1 : 0;
+    DG_WSYNC();
+    if (lane == 0) {
+        for (int k = 0; k < nonpivot; k++) {
+            const int j = buffer[k];
+            for (int l = 0; l < n - nonpivot; l++) nullspace[k*n + buffer[n + l]] = -matrix[l*n + j];
+            for (int l = 0; l < nonpivot; l++) nullspace[k*n + buffer[l]] = (j == buffer[l]) ? 1 : 0;
+        }
     }
+    DG_WSYNC();
     return nonpivot;
 }
 
@@ -89,24 +118,31 @@ __device__ __forceinline__ void dg_h2_Znd(double *Z, const double *A, const doub
     Z[0 + 1*ld] = a1*b1 + a2*b4; Z[1 + 1*ld] = a1*b2 + a2*b5; Z[2 + 1*ld] = a1*b3 + a2*b6;
     Z[3 + 1*ld] = a4*b1 + a5*b4; Z[4 + 1*ld] = a4*b2 + a5*b5; Z[5 + 1*ld] = a4*b3 + a5*b6;
 }
-/* ranH2el.c:232-283 A2toRH without normalisation (do_norm = 0 there), one thread.  scr: >= 3 * 225 doubles + 30 ints of
- * global scratch.  Returns 1 when the null space is not one-dimensional (sample rejected). */
-__device__ __noinline__ int dg_h2_A2toRH(const double *ua, const double *ub, double *scr, double *h)
+/* ranH2el.c:232-283 A2toRH without normalisation (do_norm = 0 there), by one wave (all 64 lanes call it).  scr: 3 * 225 doubles +
+ * 30 ints of LDS.  Returns 1 when the null space is not one-dimensional (sample rejected); h (LDS) is written either way. */
+__device__ __noinline__ int dg_h2_A2toRH(const double *ua, const double *ub, double *scr, double *h, int lane)
 {
     double *Z = scr, *ZT = scr + 225, *U = scr + 450; int *nb = (int *)(scr + 675);
-    double N1[9], D1[9], N2[9], D2[9];
-    dg_h2_transf(ua, N1, D1);
-    dg_h2_transf(ub, N2, D2);
-    for (int i = 0; i < 225; i++) { Z[i] = 0.0; U[i] = 0.0; }
-    dg_h2_Zu(Z, ua);
-    dg_h2_Zu(Z + 7, ub);
-    dg_h2_Znd(Z + 2*7*9, D1, N1);
-    dg_h2_Znd(Z + 2*7*9 + 2*7*3 + 7, D2, N2);
-    for (int i = 0; i < 14; i++) for (int j = 0; j < 15; j++) ZT[i*15 + j] = Z[j*14 + i];        /* mattr(ZT, Z, 15, 14) */
-    for (int i = 14*15; i < 15*15; i++) ZT[i] = 0;
-    const int nullsize = dg_nullspace_n(ZT, U, 15, nb);
-    for (int i = 0; i < 9; i++) h[i] = U[i];
-    { double t = h[1]; h[1] = h[3]; h[3] = t; t = h[2]; h[2] = h[6]; h[6] = t; t = h[5]; h[5] = h[7]; h[7] = t; }   /* trnm(h, 3) */
+    for (int i = lane; i < 225; i += 64) { Z[i] = 0.0; U[i] = 0.0; }
+    DG_WSYNC();
+    if (lane == 0) {
+        double N1[9], D1[9], N2[9], D2[9];
+        dg_h2_transf(ua, N1, D1);
+        dg_h2_transf(ub, N2, D2);
+        dg_h2_Zu(Z, ua);
+        dg_h2_Zu(Z + 7, ub);
+        dg_h2_Znd(Z + 2*7*9, D1, N1);
+        dg_h2_Znd(Z + 2*7*9 + 2*7*3 + 7, D2, N2);
+    }
+    DG_WSYNC();
+    for (int e = lane; e < 225; e += 64) { const int i = e / 15, j = e - 15 * i; ZT[e] = i < 14 ? Z[j*14 + i] : 0.0; }   /* mattr(ZT, Z, 15, 14), last row zero */
+    DG_WSYNC();
+    const int nullsize = dg_nullspace_wave(ZT, U, 15, nb, lane);
+    if (lane == 0) {
+        for (int i = 0; i < 9; i++) h[i] = U[i];
+        double t = h[1]; h[1] = h[3]; h[3] = t; t = h[2]; h[2] = h[6]; h[6] = t; t = h[5]; h[5] = h[7]; h[7] = t;   /* trnm(h, 3) */
+    }
+    DG_WSYNC();
     return nullsize != 1;
 }
 
@@ -260,7 +296,8 @@ __device__ __forceinline__ void dg_h2_pair(const dg_args &A, dg_f_shared *S, con
     if (tid < 9) { S->F[tid] = 0; S->Hx[tid] = 0; }
     if (tid < 36) S->bufF[tid / 9][tid % 9] = 0;
     __syncthreads();
-    double *scr = c.K->gmodels;                                   /* 3 * 225 doubles + 30 ints of thread-0 scratch for the elimination */
+    double *scr = (double *)&S->lsq;                               /* 3 * 225 doubles + 30 ints of LDS for the elimination (the least-squares scratch is idle then) */
+    static_assert(sizeof(dg_lsq_scratch) >= 3 * 225 * sizeof(double) + 30 * sizeof(int), "elimination scratch does not fit");
     const unsigned inlLimit = pr.h2_inl_limit == 0 ? 0x7fffffffu : (unsigned)pr.h2_inl_limit;
     const int do_lo = pr.h2_do_lo;
     dg_score maxS = {0, 0, 0, 0}, maxSs = {0, 0, 0, 0};
@@ -273,12 +310,17 @@ __device__ __forceinline__ void dg_h2_pair(const dg_args &A, dg_f_shared *S, con
         no_sam++;
         int new_max = 0, do_iterate = 0;
         __syncthreads();
-        if (tid == 0) {
-            dg_srand(&S->rng, seed);
-            dg_randsubset(&S->rng, pool, n, 2);
-            S->itmp[31] = dg_rand(&S->rng);
+        if (tid < 64) {
+            if (tid == 0) {
+                dg_srand(&S->rng, seed);
+                dg_randsubset(&S->rng, pool, n, 2);
+                S->itmp[31] = dg_rand(&S->rng);
+                S->itmp[28] = pool[n - 2]; S->itmp[29] = pool[n - 1];
+            }
+            DG_WSYNC();
             /* the driver's `h` is S->Hx: A2toRH overwrites it even when it rejects the sample */
-            S->itmp[30] = dg_h2_A2toRH(u10 + (size_t)pool[n - 2] * 10, u10 + (size_t)pool[n - 1] * 10, scr, S->Hx);
+            const int rej = dg_h2_A2toRH(u10 + (size_t)S->itmp[28] * 10, u10 + (size_t)S->itmp[29] * 10, scr, S->Hx, tid);
+            if (tid == 0) S->itmp[30] = rej;
         }
         __syncthreads();
         seed = (unsigned)S->itmp[31];
