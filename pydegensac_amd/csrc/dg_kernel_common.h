@@ -61,7 +61,8 @@ struct dg_ws_layout {
     size_t off_job;       /* cooperative mode: the job of a distributed pass (dg_coop_job), its per-slice records and the slice-local
                              staging of its outputs: int[n_max] x 2 (lists), double[n_max] (MSAC terms)                       */
     size_t off_hrep;      /* homography LO, one repetition per wave: dg_hrep_log[DG_RAN_REP], then per wave int[2][n_max] (id lists),
-                             double[n_max] (ordered MSAC terms), dg_pt[2 * n_max] (staging of its long least-squares lists) */
+                             8 n_max bytes of slack (the MSAC terms go through LDS; keeps what follows 16-byte aligned for any n_max),
+                             dg_pt[2 * n_max] (the gathered points of its long least-squares lists; the second half is spare) */
     int    hrep;          /* 1 = that area exists */
     int    n_max;
 };
