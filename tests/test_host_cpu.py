@@ -195,3 +195,19 @@ def test_alias_package_has_the_reference_submodules():
     assert u.findHomography is pd.findHomography and ext.findFundamentalMatrix_ is pd.findFundamentalMatrix_
     a = convert_and_check(np.arange(12).reshape(6, 2))
     assert a.dtype == np.float64 and a.shape == (6, 2)
+
+
+def test_ellipse_ransac_validates_its_input_before_touching_the_device():
+    """ransacH2el (ranH2el.h:35): u10 must be [n, 10] with n >= 2, one seed per pair — checked on the host"""
+    import pydegensac_amd as pd
+    from pydegensac_amd import synthetic as syn
+    u, lab = syn.ellipse_pairs(40, 0.5, 1.0, 3, 0.05)
+    assert u.shape == (40, 10) and lab.sum() == 20
+    with pytest.raises(ValueError):
+        pd.ransacH2el(u[:, :6])
+    with pytest.raises(ValueError):
+        pd.ransacH2el(u[:1])
+    with pytest.raises(ValueError):
+        pd.ransacH2el_batch([])
+    with pytest.raises(ValueError):
+        pd.ransacH2el_batch([u, u], seeds=[1])
