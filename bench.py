@@ -320,6 +320,29 @@ def secondary_line(name, pairs, steps, warmup, parity_pairs, cpu_budget_s, dev):
         set_config(old)
 
 
+def h2el_line(pairs=64, n=5000, reps=3):
+    """SURVEY 8f #4's last driver, ransacH2el (ranH2el.c:19), on `pairs` synthetic ellipse-correspondence sets through the
+    host-pointer API (PCIe staging included); pair 0 checked against the CPU oracle.  Never raises."""
+    try:
+        import pydegensac_amd as pd
+        from pydegensac_amd import synthetic as syn
+        U = [syn.ellipse_pairs(n, 0.4, 1.0, 500 + i, 0.05)[0] for i in range(pairs)]
+        seeds = list(range(1, pairs + 1))
+        pd.ransacH2el_batch(U, 4.0, 0.99, 10000, True, 0, seeds=seeds)
+        best = 1e9
+        for _ in range(reps):
+            t = time.perf_counter(); H, m = pd.ransacH2el_batch(U, 4.0, 0.99, 10000, True, 0, seeds=seeds); best = min(best, time.perf_counter() - t)
+        st = pd.last_stats()
+        from oracle import port
+        Ho, mo, so = port.ransacH2el(U[0], 4.0, 0.99, 10000, True, 0, seeds[0])
+        if (st[0]["samples"], st[0]["lo_runs"], st[0]["I"]) != (so["samples"], so["lo_runs"], so["I"]) or not np.array_equal(np.asarray(m[0]), mo):
+            return {"workload": "ransacH2el", "error": "pair 0 differs from the oracle"}
+        return {"workload": f"ransacH2el x {pairs}, {n} ellipse correspondences (40 % inliers), host-pointer API", "ms_per_call": best * 1e3,
+                "pairs_per_s": pairs / best, "samples_per_pair": float(np.mean([s_["samples"] for s_ in st])), "parity_checked": 1}
+    except BaseException as e:
+        return {"workload": "ransacH2el", "error": str(e)[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -416,6 +439,7 @@ def main():
                 sec["c2_512_pairs"] = secondary_line("c2", 512, 3, 1, 4, 0.0, dev)           # C4's own share of one GPU (8-GPU run of 4096 pairs)
             sec["c3"] = secondary_line("c3", 1024, 3, 1, 4, 0.0 if args.no_cpu_baseline else 4.0, dev)
             sec["c5"] = secondary_line("c5", 1, 2, 1, 1, 0.0 if args.no_cpu_baseline else 1.0, dev)
+            sec["h2el"] = h2el_line()
             out["secondary"] = sec
         print(json.dumps(out))
     if use_dist:
