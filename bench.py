@@ -82,7 +82,7 @@ def cpu_baseline(budget_s=20.0, max_pairs=1024, skip_first=True):
     if kind == "port":
         from oracle import port
         port.lib()
-    models = 0; samples = 0; t_total = 0.0; n_done = 0
+    models = 0; samples = 0; t_total = 0.0; n_done = 0; tbest = []; ids = []
     for p in range(max_pairs):
         p1, p2 = make_pair(p)
         seed = parallel.pair_seed(p)
@@ -94,12 +94,21 @@ def cpu_baseline(budget_s=20.0, max_pairs=1024, skip_first=True):
         dt = time.perf_counter() - t
         if p == 0 and skip_first:
             continue                                   # first call warms LAPACK / page cache
-        models += st["models"]; samples += st["samples"]; t_total += dt; n_done += 1
+        models += st["models"]; samples += st["samples"]; t_total += dt; n_done += 1; ids.append(p)
+        if st.get("time_to_best_s", -1) >= 0:
+            tbest.append(st["time_to_best_s"] * 1e3)
         if t_total > budget_s:
             break
-    return {"value": models / t_total, "unit": "models/s", "cores": 1, "kind": kind,
-            "sample": f"{n_done} pairs of the workload (pair ids {1 if skip_first else 0}..{n_done - (0 if skip_first else 1)}, same generator/seeds as the GPU batch), "
-                      f"{t_total:.1f} s, {samples / t_total:.0f} samples/s, {t_total / n_done * 1e3:.1f} ms/pair"}
+    out = {"value": models / t_total, "unit": "models/s", "cores": 1, "kind": kind,
+           "sample": f"{n_done} pairs of the workload (pair ids {1 if skip_first else 0}..{n_done - (0 if skip_first else 1)}, same generator/seeds as the GPU batch), "
+                     f"{t_total:.1f} s, {samples / t_total:.0f} samples/s, {t_total / n_done * 1e3:.1f} ms/pair",
+           "pair_ids": [ids[0], ids[-1]]}
+    if tbest:
+        # the reference-side half of the metric's "time-to-best-inlier-set": from the driver's start to the end of the first
+        # scoring pass over the model it RETURNS (oracle/ref_shim.c logs every FDS1 / EXFDS1 / HDS1 pass with its model)
+        out["time_to_best_ms"] = {"mean": float(np.mean(tbest)), "p50": float(np.median(tbest)), "max": float(np.max(tbest)), "pairs": len(tbest),
+                                  "note": "wall clock of one host core, from the driver's start to the end of the first scoring pass over the returned model"}
+    return out
 
 
 def _cpu_worker(args):
@@ -158,10 +167,12 @@ def source_id():
 def pmc_traffic(cfg_name, pairs_per_gpu):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/README.md):
     2 x FETCH_SIZE + WRITE_SIZE KiB (MI355X_MICROARCH.md: FETCH_SIZE under-reports coalesced reads 2x on gfx950).
-    Counters cannot be read from inside the process, so the figure comes from profiles/r3_pmc_<config>.json, which
+    Counters cannot be read from inside the process, so the figure comes from profiles/r4_pmc_<config>.json, which
     tools/pmc_summary.py writes next to the rocprofv3 CSVs together with the hash of the kernel sources it was measured
     on and the batch size; any mismatch with this build / this batch gives null instead of a stale number."""
-    path = os.path.join(ROOT, "profiles", f"r3_pmc_{cfg_name}.json")
+    path = os.path.join(ROOT, "profiles", f"r4_pmc_{cfg_name}.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", f"r3_pmc_{cfg_name}.json")
     if not os.path.exists(path):
         return None
     try:
@@ -289,14 +300,15 @@ def measure(pairs_per_gpu, steps, warmup, parity_pairs, world, rank, local_rank,
     if parity_pairs > 0:
         n_checked, n_aside_checked = parity_check(CFG["which"], P, parity_pairs, lo, d_F.cpu().numpy().reshape(P, 9),
                                                   d_mask.cpu().numpy().reshape(P, N_CORR), local_st)
-    return dict(dt=dt, st=st, local_st=local_st, kms=kms, alg_bytes=alg_bytes, gmask=gmask, total_pairs=total_pairs, P=P,
+    return dict(dt=dt, st=st, local_st=local_st, kms=kms, alg_bytes=alg_bytes, gmask=gmask, gm=gm, total_pairs=total_pairs, P=P,
                 n_checked=n_checked, n_aside_checked=n_aside_checked, homography=homography,
                 kernel=L.mi_degensac_kernel_name(int(homography)).decode())
 
 
 def secondary_line(name, pairs, steps, warmup, parity_pairs, cpu_budget_s, dev):
     """One of the other BASELINE configs, measured the same way on one GPU and reduced to a few numbers (driver-visible: the
-    `secondary` object of the bench line).  Never raises: a failure is reported in place of the numbers."""
+    `secondary` object of the bench line).  An ordinary failure (e.g. out of memory) is reported in place of the numbers; a
+    parity mismatch (SystemExit from parity_check) is NOT swallowed: it ends the bench with a non-zero exit code."""
     old = [k for k, v in CONFIGS.items() if v is CFG][0]
     try:
         set_config(name)
@@ -314,15 +326,16 @@ def secondary_line(name, pairs, steps, warmup, parity_pairs, cpu_budget_s, dev):
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = out["models_per_s"] / cb["value"] if cb.get("value") else None
         return out
-    except BaseException as e:                                     # incl. SystemExit from a failed parity check
+    except Exception as e:        # a failed parity check is a SystemExit and ends the bench; so does KeyboardInterrupt
         return {"workload": name, "error": str(e)[:300]}
     finally:
         set_config(old)
 
 
-def h2el_line(pairs=64, n=5000, reps=3):
+def h2el_line(pairs=64, n=5000, reps=3, n_check=8):
     """SURVEY 8f #4's last driver, ransacH2el (ranH2el.c:19), on `pairs` synthetic ellipse-correspondence sets through the
-    host-pointer API (PCIe staging included); pair 0 checked against the CPU oracle.  Never raises."""
+    host-pointer API (PCIe staging included); `n_check` pairs spread over the batch are checked against the CPU oracle
+    (a mismatch ends the bench)."""
     try:
         import pydegensac_amd as pd
         from pydegensac_amd import synthetic as syn
@@ -334,12 +347,14 @@ def h2el_line(pairs=64, n=5000, reps=3):
             t = time.perf_counter(); H, m = pd.ransacH2el_batch(U, 4.0, 0.99, 10000, True, 0, seeds=seeds); best = min(best, time.perf_counter() - t)
         st = pd.last_stats()
         from oracle import port
-        Ho, mo, so = port.ransacH2el(U[0], 4.0, 0.99, 10000, True, 0, seeds[0])
-        if (st[0]["samples"], st[0]["lo_runs"], st[0]["I"]) != (so["samples"], so["lo_runs"], so["I"]) or not np.array_equal(np.asarray(m[0]), mo):
-            return {"workload": "ransacH2el", "error": "pair 0 differs from the oracle"}
+        pick = sorted(set(int(x) for x in np.linspace(0, pairs - 1, n_check)))
+        for q in pick:
+            Ho, mo, so = port.ransacH2el(U[q], 4.0, 0.99, 10000, True, 0, seeds[q])
+            if (st[q]["samples"], st[q]["lo_runs"], st[q]["I"]) != (so["samples"], so["lo_runs"], so["I"]) or not np.array_equal(np.asarray(m[q]), mo):
+                raise SystemExit(f"parity check failed: ransacH2el pair {q} differs from the oracle")
         return {"workload": f"ransacH2el x {pairs}, {n} ellipse correspondences (40 % inliers), host-pointer API", "ms_per_call": best * 1e3,
-                "pairs_per_s": pairs / best, "samples_per_pair": float(np.mean([s_["samples"] for s_ in st])), "parity_checked": 1}
-    except BaseException as e:
+                "pairs_per_s": pairs / best, "samples_per_pair": float(np.mean([s_["samples"] for s_ in st])), "parity_checked": len(pick)}
+    except Exception as e:
         return {"workload": "ransacH2el", "error": str(e)[:300]}
 
 
@@ -353,6 +368,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short C2 x 512 / C3 / C5 measurements of the `secondary` object")
     ap.add_argument("--parity-pairs", type=int, default=16, help="pairs of the timed batch checked against the oracle afterwards")
+    ap.add_argument("--dump-results", default="", help="rank 0 writes the gathered per-pair results of the last timed step to this .npz (tests)")
     ap.add_argument("--dist-always", action="store_true",
                     help="initialise the RCCL process group and run the result all-gather even with one rank (tests the N > 1 code path on one GPU)")
     args = ap.parse_args()
@@ -380,7 +396,18 @@ def main():
     homography = r["homography"]
     models_step = int(st[:, 4].sum()); samples_step = int(st[:, 0].sum())
     achieved = alg_bytes / (kms * 1e-3) / 1e9
+    # C4 as BASELINE.json words it: ONE batch of 4096 pairs over the N GPUs (strong scaling, 4096 / N pairs per GPU), measured
+    # by every rank next to the weak-scaling headline (4096 pairs PER GPU); at N = 1 it IS the headline
+    c4 = None
+    if args.config == "c2" and world > 1 and not args.no_secondary and 4096 % world == 0:
+        r4 = measure(4096 // world, 3, 1, 4, world, rank, local_rank, dev, always_collective=use_dist)
+        m4 = int(r4["st"][:, 4].sum())
+        c4 = {"workload": f"C4 literal: 4096 C2 pairs over {world} GPUs = {4096 // world} per GPU (strong scaling)", "n_gpus": world,
+              "pairs_per_gpu": 4096 // world, "ms_per_step": r4["dt"] / 3 * 1e3, "kernel_ms_rank0": r4["kms"], "models_per_s": m4 * 3 / r4["dt"],
+              "pairs_per_s": 4096 * 3 / r4["dt"], "parity_checked_rank0": r4["n_checked"]}
 
+    if rank == 0 and args.dump_results:
+        np.savez(args.dump_results, models=r["gm"].cpu().numpy(), stats=st, masks=gmask.cpu().numpy())
     if rank == 0:
         inl = gmask.sum(dim=1).cpu().numpy()
         ticks = st[:, 13].astype(np.float64) / 100e6                           # 100 MHz device wall clock
@@ -405,14 +432,16 @@ def main():
             "config": {"workload": wl,
                        "pairs_total": total_pairs, "pairs_per_gpu": P, "n_corr": N_CORR,
                        "parallelism": f"pair-sharded x{world}, RCCL all-gather of per-pair results",
-                       "collective": "nccl (RCCL) all_gather_into_tensor" if use_dist else "none (one rank)"},
+                       "collective": "nccl (RCCL) all_gather_into_tensor" if use_dist else "none (one rank)",
+                       "process_group": ({"backend": dist.get_backend(), "world_size": dist.get_world_size()} if use_dist else None)},
             "samples_per_s": samples_step * args.steps / dt,
             "pairs_per_s": total_pairs * args.steps / dt,
             "models_per_pair": models_step / total_pairs,
             "mean_inliers": float(inl.mean()),
             "time_to_best_ms": {"mean": float(tbest.mean() * 1e3), "p50": float(np.median(tbest) * 1e3), "max": float(tbest.max() * 1e3),
                                 "note": "from a pair's start to the commit of its returned model, on the device clock, while the pair is being worked on (the time a pair waits in the set-aside queues of a batch is not counted)"},
-            "pair_latency_ms": {"mean": float(ticks.mean() * 1e3), "p50": float(np.median(ticks) * 1e3), "max": float(ticks.max() * 1e3)},
+            "pair_latency_ms": {"mean": float(ticks.mean() * 1e3), "p50": float(np.median(ticks) * 1e3), "max": float(ticks.max() * 1e3),
+                                "note": "device clock, time the pair was being worked on; the time a pair waits in the set-aside queues of a batch is excluded (as in time_to_best_ms)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.config, P),
                          "kernel": r["kernel"], "kernel_ms": kms,
@@ -427,8 +456,12 @@ def main():
         if world == 1:
             out["single_call_ms"] = single_call_ms()
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cb = cpu_baseline()
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            if "time_to_best_ms" in cb and cb["pair_ids"][1] < P:
+                # the GPU figure on exactly the pairs the CPU leg ran (device clock, inside the timed 4096-pair batch)
+                a_, b_ = cb["pair_ids"]; g_ = tbest[a_:b_ + 1] * 1e3
+                cb["time_to_best_ms"]["gpu_same_pairs"] = {"mean": float(g_.mean()), "p50": float(np.median(g_)), "max": float(g_.max())}
             allc = cpu_baseline_all_cores(args.config)
             if allc is not None:
                 out["cpu_baseline_all_cores"] = allc
@@ -436,11 +469,15 @@ def main():
             # the other BASELINE configurations, short runs inside the same driver-timed process (about a minute together)
             sec = {}
             if P != 512:
-                sec["c2_512_pairs"] = secondary_line("c2", 512, 3, 1, 4, 0.0, dev)           # C4's own share of one GPU (8-GPU run of 4096 pairs)
-            sec["c3"] = secondary_line("c3", 1024, 3, 1, 4, 0.0 if args.no_cpu_baseline else 4.0, dev)
+                sec["c2_512_pairs"] = secondary_line("c2", 512, 3, 1, 8, 0.0, dev)           # C4's own share of one GPU (8-GPU run of 4096 pairs)
+            sec["c3"] = secondary_line("c3", 1024, 3, 1, 16, 0.0 if args.no_cpu_baseline else 4.0, dev)
             sec["c5"] = secondary_line("c5", 1, 2, 1, 1, 0.0 if args.no_cpu_baseline else 1.0, dev)
             sec["h2el"] = h2el_line()
+            sec["c4_literal"] = {"workload": "C4 literal at 1 GPU = the headline (4096 pairs on this GPU); with --gpus N every rank also measures 4096 / N pairs per GPU",
+                                 "n_gpus": 1, "pairs_per_gpu": P, "ms_per_step": out["ms_per_step"], "models_per_s": out["value"]} if P == 4096 else None
             out["secondary"] = sec
+        if c4 is not None:
+            out.setdefault("secondary", {})["c4_literal"] = c4
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

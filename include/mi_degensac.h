@@ -72,28 +72,34 @@ extern "C" {
  *   bits 2-3  placement         1 = points + sampler pool in HBM      2 = both in LDS      3 = pool in LDS
  *             (a placement that does not fit the device's LDS is ignored)
  *   bit  4    sampler           1 = always use the sequential pool-swap stage
+ *   bit  5    homography only: run the ten repetitions of every local optimisation one after the other on the whole
+ *             workgroup instead of one repetition per wave (tests; the residual dump of
+ *             mi_degensac_find_homography_resids always does).  EINVAL on a fundamental-matrix call
+ *   bit  6    fundamental matrix with helper workgroups only (bits 8-15 or automatic): distribute EVERY pass over the whole
+ *             point set over the claiming workgroups, not only those over >= 8192 points (tests).  EINVAL on a homography call
+ *   bit  7    reserved, must be 0
  *   bits 8-15 helper workgroups per pair of the cooperative large-n mode (fundamental matrix, placement HBM):
  *             0 = automatic (23 helpers when n >= 8192 and the batch leaves the device mostly idle, 15 with less room), 255 = off
- *   bit  5    with helper workgroups (bits 8-15): distribute every pass over the whole point set over the claiming
- *             workgroups, not only those over >= 8192 points (tests)
- *   bit  5    homography: run the ten repetitions of every local optimisation one after the other on the whole workgroup
- *             instead of one repetition per wave (tests; the residual dump of mi_degensac_find_homography_resids always does)
- *   bits 5-7  with bits 16-23 (no helpers): a pair set aside with at least (threshold << this) samples left counts as "long" and is
- *             resumed before the others; 0 = automatic (threshold x 8)
  *   bits 16-23 setting pairs aside (fundamental matrix, batches larger than the resident grid): a pair still running
  *             after this many samples (units of 256) while unstarted pairs remain is written back to its workspace and
  *             queued; free workgroups take unstarted pairs first, then the queued pairs with many samples left, then
  *             the rest.  The first samples of every pair become a short discovery round after which the pairs with the
  *             most work left restart first, so the batch ends at about (sum of pair times) / (resident workgroups)
  *             instead of one long pair after the last pair was started.  0 = automatic (1024 samples), 255 = off
- *   bits 24-31 cap on the number of resident workgroups (0 = none; for tests of the queueing paths on small batches) */
+ *   bits 24-28 cap on the number of resident workgroups (0 = none, 1..31; for tests of the queueing paths on small batches)
+ *   bits 29-31 with bits 16-23: a pair set aside with at least (threshold << this) samples left counts as "long" and is
+ *             resumed before the others; 0 = automatic (threshold x 8).  EINVAL on a homography call
+ * Every field has its own bits; a field that does not apply to the call (see above) is rejected with MI_DEGENSAC_EINVAL
+ * rather than silently reinterpreted. */
 #define MI_DEGENSAC_TUNE_VARIANT(v)   ((uint32_t)(v) & 3u)
 #define MI_DEGENSAC_TUNE_PLACEMENT(p) (((uint32_t)(p) & 3u) << 2)
 #define MI_DEGENSAC_TUNE_SEQ_POOL     (1u << 4)
 #define MI_DEGENSAC_TUNE_H_SERIAL_LO  (1u << 5)
+#define MI_DEGENSAC_TUNE_COOP_ALL_PASSES (1u << 6)
 #define MI_DEGENSAC_TUNE_HELPERS(h)   (((uint32_t)(h) & 255u) << 8)
 #define MI_DEGENSAC_TUNE_SET_ASIDE(t)  (((uint32_t)(t) & 255u) << 16)
-#define MI_DEGENSAC_TUNE_GRID_CAP(g)   (((uint32_t)(g) & 255u) << 24)
+#define MI_DEGENSAC_TUNE_GRID_CAP(g)   (((uint32_t)(g) & 31u) << 24)
+#define MI_DEGENSAC_TUNE_LONG_SHIFT(l) (((uint32_t)(l) & 7u) << 29)
 
 typedef struct mi_degensac_params {
     double   px_th;                    /* pixel threshold (utils.py:76,113)                         */

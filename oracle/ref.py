@@ -36,6 +36,8 @@ def lib(flavour=""):
         l.ref_capture_resids.restype = None
         l.ref_counters_reset.argtypes = [C.c_int]
         l.ref_counters_get.argtypes = [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
+        l.ref_time_to_best.argtypes = []
+        l.ref_time_to_best.restype = C.c_double
         l.ref_find_fundamental_legacy.argtypes = [C.c_int, dp, dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_uint,
                                                   dp, C.POINTER(C.c_ubyte), C.POINTER(C.c_int)]
         l.ref_find_fundamental_legacy.restype = C.c_int
@@ -64,7 +66,8 @@ def find_fundamental(pts1, pts2, px_th=0.5, conf=0.9999, max_iters=100000, error
     full = C.c_longlong(); ex = C.c_longlong(); sec = C.c_double()
     l.ref_counters_get(C.byref(full), C.byref(ex), C.byref(sec))
     stats = dict(samples=st[0], lo_runs=st[1], Ih=st[2], I=st[3], full_passes=full.value,
-                 ex_passes=ex.value, models=full.value + ex.value, pass_seconds=sec.value)
+                 ex_passes=ex.value, models=full.value + ex.value, pass_seconds=sec.value,
+                 time_to_best_s=l.ref_time_to_best())        # -1: not logged (count_models off) or the returned model was never scored
     return F.reshape(3, 3), mask.astype(bool), stats
 
 
@@ -84,7 +87,7 @@ def find_homography(pts1, pts2, px_th=1.0, conf=0.999, max_iters=50000, error_ty
     full = C.c_longlong(); ex = C.c_longlong(); sec = C.c_double()
     l.ref_counters_get(C.byref(full), C.byref(ex), C.byref(sec))
     stats = dict(samples=st[0], lo_runs=st[1], rejected=st[2], I=st[3], full_passes=full.value,
-                 models=full.value, pass_seconds=sec.value)
+                 models=full.value, pass_seconds=sec.value, time_to_best_s=l.ref_time_to_best())
     return H.reshape(3, 3), mask.astype(bool), stats
 
 

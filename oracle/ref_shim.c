@@ -11,7 +11,11 @@
  *     point sets, pick metric function pointers, threshold conventions), restated in C so that
  *     ctypes can call the reference without pybind11.
  *   - counting thunks for the injected metric pointers (FDS1/EXFDS1/HDS1): number of full
- *     N-point scoring passes ("models scored") and time spent in them.
+ *     N-point scoring passes ("models scored") and time spent in them; with
+ *     count_models they also log (time since the driver started, model) of every pass, so that
+ *     ref_time_to_best() can report when the model the driver RETURNS was first scored
+ *     (exp_ranF.c:1381-1421 / :1523-1569 commit a model right after that pass) — the
+ *     reference-side half of BASELINE.json's "time-to-best-inlier-set".
  */
 #include <stdlib.h>
 #include <string.h>
@@ -37,6 +41,25 @@ static double now_s(void) {
     return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
 
+/* pass log: when each scored model was seen (seconds since the driver call started) */
+typedef struct { double t; double m[9]; } pass_rec;
+static pass_rec *g_log = 0; static size_t g_log_n = 0, g_log_cap = 0; static int g_log_on = 0;
+static double g_t_start = 0, g_t_best = -1;
+static void log_pass(const double *m) {
+    if (!g_log_on) return;
+    if (g_log_n == g_log_cap) { g_log_cap = g_log_cap ? 2 * g_log_cap : 4096; g_log = (pass_rec *)realloc(g_log, g_log_cap * sizeof(pass_rec)); }
+    g_log[g_log_n].t = now_s() - g_t_start; memcpy(g_log[g_log_n].m, m, 72); g_log_n++;
+}
+static void log_begin(int on) { g_log_on = on; g_log_n = 0; g_t_best = -1; g_t_start = now_s(); }
+/* the first logged pass over exactly the returned model (bitwise); -1 when the driver returns a model it never scored */
+static void log_end(const double *model) {
+    size_t i;
+    g_t_best = -1;
+    for (i = 0; i < g_log_n && g_log_on; i++) if (!memcmp(g_log[i].m, model, 72)) { g_t_best = g_log[i].t; break; }
+    g_log_on = 0;
+}
+double ref_time_to_best(void) { return g_t_best; }
+
 static FDsPtr   g_FDS = 0;
 static exFDsPtr g_EXFDS = 0;
 static HDsPtr   g_HDS = 0;
@@ -45,19 +68,19 @@ static void thunk_FDS(const double *u, const double *F, double *p, int len) {
     double t0 = g_time_passes ? now_s() : 0;
     g_FDS(u, F, p, len);
     if (g_time_passes) g_pass_seconds += now_s() - t0;
-    g_full_passes++;
+    g_full_passes++; log_pass(F);
 }
 static void thunk_EXFDS(const double *u, const double *F, double *p, double *w, int len) {
     double t0 = g_time_passes ? now_s() : 0;
     g_EXFDS(u, F, p, w, len);
     if (g_time_passes) g_pass_seconds += now_s() - t0;
-    g_ex_passes++;
+    g_ex_passes++; log_pass(F);
 }
 static void thunk_HDS(const double *lin, const double *u, const double *H, double *p, int len) {
     double t0 = g_time_passes ? now_s() : 0;
     g_HDS(lin, u, H, p, len);
     if (g_time_passes) g_pass_seconds += now_s() - t0;
-    g_full_passes++;
+    g_full_passes++; log_pass(H);
 }
 
 void ref_counters_reset(int time_passes) {
@@ -125,8 +148,10 @@ int ref_find_fundamental(const double *x1, const double *x2, int n, int dim,
     for (i = 0; i < 9; i++) F[i] = 0;
 
     oracle_set_seed(seed);
+    log_begin(count_models);
     ret = exp_ransacFcustomLAF(u, ulaf1, ulaf2, n, th, laf_coef, conf, max_iters, F, mask, data_out,
                                1, 0, &resids, HinF, &I_H, EXFDS1, FDS1, FDSidx1, sym_th, degen);
+    log_end(F);
     if (stats) { stats[0] = data_out[0]; stats[1] = data_out[1]; stats[2] = I_H; stats[3] = ret; }
     capture_resids(resids, data_out[1], n);
     if (g_dataout_dst) { memcpy(g_dataout_dst, data_out, sizeof(int) * (size_t)g_dataout_len); g_dataout_dst = 0; }
@@ -163,8 +188,10 @@ int ref_find_homography(const double *x1, const double *x2, int n, int dim,
     for (i = 0; i < 9; i++) H[i] = 0;
 
     oracle_set_seed(seed);
+    log_begin(count_models);
     S = exp_ransacHcustomLAF(u, ulaf1, ulaf2, n, th, laf_coef, conf, max_iters, H, mask, 4, data_out,
                              1, 0, &resids, HDS1, HDSi1, HDSidx1, sym_th);
+    log_end(H);
     if (stats) { stats[0] = data_out[0]; stats[1] = data_out[1]; stats[2] = data_out[2]; stats[3] = (int)S.I; }
     capture_resids(resids, data_out[1], n);
     free(resids); free(data_out); free(u); free(ulaf1); free(ulaf2);

@@ -15,7 +15,14 @@ FLAG_LEGACY_F = 2            # exp_ransacF / exp_ransacFcustom sample-budget rul
 TUNE_LATENCY, TUNE_THROUGHPUT, TUNE_THROUGHPUT4 = 1, 2, 3   # kernel variant: 512- / 256- / 128-thread workgroups
 TUNE_PLACE_HBM, TUNE_PLACE_LDS, TUNE_PLACE_POOL_LDS = 1 << 2, 2 << 2, 3 << 2
 TUNE_SEQ_POOL = 1 << 4
-TUNE_H_SERIAL_LO = 1 << 5   # homography: local-optimisation repetitions one after the other (default: one per wave)
+TUNE_H_SERIAL_LO = 1 << 5   # homography only: local-optimisation repetitions one after the other (default: one per wave)
+TUNE_COOP_ALL_PASSES = 1 << 6   # fundamental matrix with helper workgroups: distribute every full pass (tests)
+
+
+def TUNE_HELPERS(h): return (int(h) & 255) << 8          # noqa: E704  helper workgroups per pair (255 = off)
+def TUNE_SET_ASIDE(t): return (int(t) & 255) << 16       # noqa: E704  set pairs aside after t * 256 samples (255 = off)
+def TUNE_GRID_CAP(g): return (int(g) & 31) << 24         # noqa: E704  cap on resident workgroups (tests)
+def TUNE_LONG_SHIFT(l): return (int(l) & 7) << 29        # noqa: E704,E741  "many samples left" = threshold << l
 # bits 8-15: cooperative helper workgroups per pair (0 auto, 255 off); bits 16-23: samples after which a running pair is
 # set aside while unstarted pairs remain, in units of 256 (0 auto, 255 off); bits 24-31: cap on resident workgroups (tests)
 

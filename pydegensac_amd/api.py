@@ -270,11 +270,14 @@ def findHomographyBatch(pts1_list, pts2_list, px_th=1.0, conf=0.999, max_iters=5
     return out, masks
 
 
-def ransacH2el_batch(u10_list, th=4.0, conf=0.99, max_iters=10000, do_lo=True, inl_limit=0, seeds=None, device=0):
+def ransacH2el_batch(u10_list, th=4.0, conf=0.99, max_iters=10000, do_lo=True, inl_limit=0, seeds=None, device=0, raw=False):
     """The reference's ransacH2el (degensac/ranH2el.c:19, ranH2el.h:35; it has no Python binding there): RANSAC on
     ellipse-to-ellipse correspondences, two per sample.  u10: [n, 10] = x1 y1 a1 b1 c1 x2 y2 a2 b2 c2 with the local affine
-    frame [a 0; b c] of each image.  th is the threshold on the squared transfer error.  Returns (H [P, 3, 3] — the RAW
-    internal model, image 2 -> image 1, zeros when none —, list of masks); `last_stats()` has the counters."""
+    frame [a 0; b c] of each image.  th is the threshold on the squared transfer error.  Returns (H [P, 3, 3], list of
+    masks); `last_stats()` has the counters.  H follows findHomography's convention: the conventional row-major matrix that
+    maps image 1 to image 2, H_out = inv(H_raw.T) (utils.py:108), zeros when no model was found (or when the raw model is
+    singular).  raw=True returns the driver's own array instead: the reference's internal model as the C-ABI documents it,
+    9 doubles stored column-wise that map image 2 to image 1 — reshaped [3, 3] it is the TRANSPOSE of that matrix."""
     n_pairs = len(u10_list)
     if n_pairs == 0:
         raise ValueError("u10_list must hold at least one pair")
@@ -297,11 +300,22 @@ def ransacH2el_batch(u10_list, th=4.0, conf=0.99, max_iters=10000, do_lo=True, i
                                                   mask.ctypes.data_as(C.POINTER(C.c_uint8)), st.ctypes.data_as(C.POINTER(C.c_int32)))
     _lib.check(rc)
     _tls.stats = [_lib.stats_dict(s) for s in st]
-    return model.reshape(n_pairs, 3, 3), [mask[offs[i]:offs[i + 1]].astype(bool) for i in range(n_pairs)]
+    masks = [mask[offs[i]:offs[i + 1]].astype(bool) for i in range(n_pairs)]
+    Hr = model.reshape(n_pairs, 3, 3)
+    if raw:
+        return Hr, masks
+    out = np.zeros_like(Hr)
+    for i in range(n_pairs):
+        if np.abs(Hr[i]).sum() != 0:
+            try:
+                out[i] = np.linalg.inv(Hr[i].T)
+            except np.linalg.LinAlgError:
+                pass
+    return out, masks
 
 
-def ransacH2el(u10, th=4.0, conf=0.99, max_iters=10000, do_lo=True, inl_limit=0, seed=None, device=0):
+def ransacH2el(u10, th=4.0, conf=0.99, max_iters=10000, do_lo=True, inl_limit=0, seed=None, device=0, raw=False):
     """One pair of ransacH2el_batch: returns (H [3, 3], mask [n])."""
-    H, m = ransacH2el_batch([u10], th, conf, max_iters, do_lo, inl_limit, None if seed is None else [seed], device)
+    H, m = ransacH2el_batch([u10], th, conf, max_iters, do_lo, inl_limit, None if seed is None else [seed], device, raw)
     _tls.stats = _tls.stats[0]
     return H[0], m[0]

@@ -31,8 +31,10 @@ def gather_results(models, stats, masks, n_per_pair, n_pairs_total, group=None, 
 
     models [P_r, 9] float64, stats [P_r, 16] int32, masks [sum of the rank's pair sizes] uint8.
     `n_per_pair`: an int (every pair has that many correspondences) or the sequence of ALL n_pairs_total pair sizes
-    (ragged batch, the C-ABI's offsets form).  Ranks may own different numbers of pairs / bytes (padded to the
-    maximum for the collective).  Returns (models [P,9], stats [P,16], masks) in global pair order, where masks is
+    (ragged batch, the C-ABI's offsets form).  Ranks may own different numbers of pairs / bytes: equal shards take one
+    all_gather_into_tensor of the packed records; ragged shards gather the fixed 136 B per pair (padded by at most one
+    pair) and ship each rank's masks at their own size (one broadcast per rank), never padded to the largest shard.
+    Returns (models [P,9], stats [P,16], masks) in global pair order, where masks is
     [P, n] for equal sizes and a flat [sum of all sizes] uint8 tensor for a ragged batch (pair p at
     offsets[p]:offsets[p+1] with offsets = cumsum of the sizes).
     always_collective: run the all-gather even in a one-rank group (exercises the RCCL path on a single GPU).
@@ -49,22 +51,43 @@ def gather_results(models, stats, masks, n_per_pair, n_pairs_total, group=None, 
     dev = models.device
     rng = [shard_range(n_pairs_total, r, world) for r in range(world)]
     mbytes = [int(counts[lo:hi].sum()) for lo, hi in rng]
-    rec = [(hi - lo) * 136 + mb for (lo, hi), mb in zip(rng, mbytes)]      # 72 B model + 64 B stats per pair, then the masks
-    cap = max(rec)
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     p_r = models.shape[0]
     if p_r != rng[rank][1] - rng[rank][0] or masks.numel() != mbytes[rank]:
         raise ValueError("this rank's tensors do not match its shard of the batch")
-    packed = torch.zeros(cap, dtype=torch.uint8, device=dev)
-    packed[:p_r * 72] = models.contiguous().view(torch.uint8).view(-1)
-    packed[p_r * 72:p_r * 136] = stats.contiguous().view(torch.uint8).view(-1)
-    packed[p_r * 136:p_r * 136 + mbytes[rank]] = masks.view(-1)
-    out = torch.empty((world, cap), dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(out.view(-1), packed, group=group)
-    ms, ss, ks = [], [], []
-    for r in range(world):
-        pr = rng[r][1] - rng[r][0]
-        ms.append(out[r, :pr * 72]); ss.append(out[r, pr * 72:pr * 136]); ks.append(out[r, pr * 136:pr * 136 + mbytes[r]])
+    rec = [(hi - lo) * 136 + mb for (lo, hi), mb in zip(rng, mbytes)]      # 72 B model + 64 B stats per pair, then the masks
+    if len(set(rec)) == 1:
+        # every rank holds the same number of bytes (C4: equal pairs, equal sizes): ONE collective over the packed records
+        cap = rec[0]
+        packed = torch.empty(cap, dtype=torch.uint8, device=dev)
+        packed[:p_r * 72] = models.contiguous().view(torch.uint8).view(-1)
+        packed[p_r * 72:p_r * 136] = stats.contiguous().view(torch.uint8).view(-1)
+        packed[p_r * 136:] = masks.view(-1)
+        out = torch.empty((world, cap), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(out.view(-1), packed, group=group)
+        ms = [out[r, :p_r * 72] for r in range(world)]; ss = [out[r, p_r * 72:p_r * 136] for r in range(world)]
+        ks = [out[r, p_r * 136:] for r in range(world)]
+    else:
+        # ragged shards: the fixed-size part (136 B per pair; shards differ by at most one pair) goes through one padded
+        # all-gather, the masks travel at their own size: every rank knows every shard's byte count from the global size
+        # list, so rank r's masks are one broadcast of exactly mbytes[r] bytes (no padding to the largest shard: a batch
+        # with one 50 000-correspondence pair does not make every rank ship that pair's size)
+        pmax = max(hi - lo for lo, hi in rng)
+        fixed = torch.zeros(pmax * 136, dtype=torch.uint8, device=dev)
+        fixed[:p_r * 72] = models.contiguous().view(torch.uint8).view(-1)
+        fixed[pmax * 72:pmax * 72 + p_r * 64] = stats.contiguous().view(torch.uint8).view(-1)
+        out = torch.empty((world, pmax * 136), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(out.view(-1), fixed, group=group)
+        ks = [masks.contiguous().view(-1) if r == rank else torch.empty(mbytes[r], dtype=torch.uint8, device=dev) for r in range(world)]
+        pending = []
+        for r in range(world):
+            if mbytes[r] > 0:
+                src = dist.get_global_rank(group, r) if group is not None else r
+                pending.append(dist.broadcast(ks[r], src=src, group=group, async_op=True))
+        for w in pending:
+            w.wait()
+        ms = [out[r, :(rng[r][1] - rng[r][0]) * 72] for r in range(world)]
+        ss = [out[r, pmax * 72:pmax * 72 + (rng[r][1] - rng[r][0]) * 64] for r in range(world)]
     m = torch.cat(ms).contiguous().view(torch.float64).view(-1, 9)
     st = torch.cat(ss).contiguous().view(torch.int32).view(-1, 16)
     k = torch.cat(ks)

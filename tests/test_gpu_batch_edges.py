@@ -61,6 +61,22 @@ def test_error_codes():
         pd.findFundamentalMatrix(p1, p2, seed=1, device=63)                    # no such device: no CPU fallback
 
 
+def test_tuning_fields_that_do_not_apply_are_rejected():
+    """every tuning field has its own bits (include/mi_degensac.h); one that does not apply to the call is EINVAL, not a
+    silently different meaning"""
+    p1, p2, _, _ = syn.two_view_fundamental(200, 0.5, 0.1, seed=1)
+    with pytest.raises(_lib.MiDegensacError):
+        pd.findFundamentalMatrixBatch([p1], [p2], seeds=[1], tuning=_lib.TUNE_H_SERIAL_LO)
+    with pytest.raises(_lib.MiDegensacError):
+        pd.findHomographyBatch([p1], [p2], seeds=[1], tuning=_lib.TUNE_COOP_ALL_PASSES)
+    with pytest.raises(_lib.MiDegensacError):
+        pd.findHomographyBatch([p1], [p2], seeds=[1], tuning=_lib.TUNE_LONG_SHIFT(2))
+    with pytest.raises(_lib.MiDegensacError):
+        pd.findFundamentalMatrixBatch([p1], [p2], seeds=[1], tuning=1 << 7)
+    pd.findFundamentalMatrixBatch([p1], [p2], seeds=[1], tuning=_lib.TUNE_LONG_SHIFT(2) | _lib.TUNE_SET_ASIDE(4))      # applies: accepted
+    pd.findHomographyBatch([p1], [p2], seeds=[1], tuning=_lib.TUNE_H_SERIAL_LO)
+
+
 def test_bench_under_torchrun_with_the_rccl_process_group():
     """bench.py as the driver launches it for N > 1 (python -m torch.distributed.run, backend "nccl" = RCCL), with one rank
     on this box's one GPU and --dist-always: process-group init on the device, the barrier, all_gather_into_tensor of the
@@ -78,3 +94,31 @@ def test_bench_under_torchrun_with_the_rccl_process_group():
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["parity_checked"] >= 4
     assert j["config"]["collective"].startswith("nccl")
+
+
+def test_two_ranks_over_rccl_give_the_one_rank_results(tmp_path):
+    """Runs the moment a box shows two devices: bench.py under torch.distributed.run with TWO ranks (backend nccl = RCCL over
+    xGMI), 64 pairs per GPU, against the same 128 global pairs on one rank.  Pair ids, seeds and therefore every per-pair
+    result (model, mask, counters) must not depend on the shard count; the process group must really be nccl with
+    world size 2.  Skipped on the one-GPU boxes this suite normally gets."""
+    import json, os, subprocess, sys
+    import numpy as np, torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = []
+    for world, ppg, port_no in ((1, 128, 29551), (2, 64, 29552)):
+        dump = str(tmp_path / f"w{world}.npz")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(port_no), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+               "--pairs-per-gpu", str(ppg), "--no-cpu-baseline", "--no-secondary", "--parity-pairs", "4", "--dist-always", "--dump-results", dump]
+        out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert j["n_gpus"] == world and j["config"]["pairs_total"] == 128
+        assert j["config"]["process_group"] == {"backend": "nccl", "world_size": world}
+        outs.append(np.load(dump))
+    for k in ("models", "masks"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    assert np.array_equal(outs[0]["stats"][:, :12], outs[1]["stats"][:, :12])        # words 12.. are device-clock times / variant

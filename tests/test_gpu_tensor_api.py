@@ -19,7 +19,7 @@ def _pairs(kind, sizes):
     return A, B
 
 
-def test_fundamental_tensors_match_host_batch():
+def test_fundamental_tensors_match_host_batch(oracle_port):
     import torch
     sizes = [700, 1200, 64, 2000]                                     # ragged batch
     A, B = _pairs("F", sizes); seeds = [3, 5, 7, 11]
@@ -32,10 +32,16 @@ def test_fundamental_tensors_match_host_batch():
     assert np.array_equal(F, np.asarray(Fh))
     for p in range(4):
         assert np.array_equal(m[offs[p]:offs[p + 1]], np.asarray(mh[p]))
-    assert (st.cpu().numpy()[:, 0] > 0).all()                          # samples drawn
+    stn = st.cpu().numpy()
+    assert (stn[:, 0] > 0).all()                          # samples drawn
+    for p in range(4):                                     # ... and both are the CPU oracle's results
+        Fo, mo, so = oracle_port.find_fundamental(A[p], B[p], 0.5, 0.9999, 100000, seed=seeds[p])
+        assert (int(stn[p, 0]), int(stn[p, 1])) == (so["samples"], so["lo_runs"]), p
+        assert np.array_equal(m[offs[p]:offs[p + 1]], mo), p
+        assert np.linalg.norm(F[p].ravel() - np.asarray(Fo).ravel()) <= 1e-9 * np.linalg.norm(Fo), p
 
 
-def test_homography_tensors_match_host_batch():
+def test_homography_tensors_match_host_batch(oracle_port):
     import torch
     sizes = [900, 300, 1500]
     A, B = _pairs("H", sizes); seeds = [2, 4, 6]
@@ -44,11 +50,17 @@ def test_homography_tensors_match_host_batch():
     H, m, st, offs = tensor_api.find_homography_batch_tensors(torch.from_numpy(np.concatenate(A)).to(dev),
                                                               torch.from_numpy(np.concatenate(B)).to(dev), sizes, 1.0, 0.999, 20000,
                                                               3.0, "symm_max", True, seeds=seeds)
-    H = H.cpu().numpy(); m = m.cpu().numpy()
+    H = H.cpu().numpy(); m = m.cpu().numpy(); st = st.cpu().numpy()
     for p in range(3):
         assert np.array_equal(m[offs[p]:offs[p + 1]], np.asarray(mh[p]))
         # inv() runs in numpy on the host path and in torch.linalg on the device path: same to rounding
         assert np.linalg.norm(H[p] - Hh[p]) <= 1e-9 * max(np.linalg.norm(Hh[p]), 1e-300)
+        Ho, mo, so = oracle_port.find_homography(A[p], B[p], 1.0, 0.999, 20000, 2, True, 3.0, seed=seeds[p])      # "symm_max" = error type 2
+        assert (int(st[p, 0]), int(st[p, 1])) == (so["samples"], so["lo_runs"]), p
+        assert np.array_equal(m[offs[p]:offs[p + 1]], mo), p
+        if np.abs(Ho).sum() > 0:
+            Hu = np.linalg.inv(np.asarray(Ho).T)
+            assert np.linalg.norm(H[p] - Hu) <= 1e-8 * np.linalg.norm(Hu), p
 
 
 def test_device_pipeline_descriptors_to_homography_matches_host_stages():

@@ -65,8 +65,8 @@ def test_cooperative_helpers_match_the_oracle(oracle_port):
     per owner): every run, pair by pair, against the CPU oracle (counters, masks, models), not against another GPU run"""
     A, B = _f_batch(); A = A * 3; B = B * 3; seeds = list(range(1, 13))
     for variant in (512, 256):
-        for helpers, dist in ((255, 0), (1, 0), (3, 1), (7, 0), (7, 1)):    # dist: the LO's full passes distributed too (tuning bit 5)
-            F, m = pd.findFundamentalMatrixBatch(A, B, max_iters=20000, seeds=seeds, tuning=tune(variant, 0) | (helpers << 8) | (dist << 5))
+        for helpers, dist in ((255, 0), (1, 0), (3, 1), (7, 0), (7, 1)):    # dist: the LO's full passes distributed too (TUNE_COOP_ALL_PASSES)
+            F, m = pd.findFundamentalMatrixBatch(A, B, max_iters=20000, seeds=seeds, tuning=tune(variant, 0) | _lib.TUNE_HELPERS(helpers) | (dist * _lib.TUNE_COOP_ALL_PASSES))
             _check_against_oracle(oracle_port, A, B, seeds, F, m, pd.last_stats(), (variant, helpers, dist))
 
 
@@ -79,24 +79,35 @@ def test_setting_pairs_aside_matches_the_oracle(oracle_port):
     A, B = _f_batch(); A = A * 6; B = B * 6; seeds = list(range(1, 25))
     for variant in (256, 512, 128):
         for mode in (2, 1, 0):
-            for park, lg in ((255, 0), (1, 0), (4, 1), (8, 3), (8, 7)):          # 255 = off; else units of 256 samples; lg = bits 5-7
+            for park, lg in ((255, 0), (1, 0), (4, 1), (8, 3), (8, 7)):          # 255 = off; else units of 256 samples; lg = TUNE_LONG_SHIFT
                 F, m = pd.findFundamentalMatrixBatch(A, B, max_iters=20000, seeds=seeds,
-                                                     tuning=tune(variant, mode) | (lg << 5) | (255 << 8) | (park << 16) | (4 << 24))
+                                                     tuning=tune(variant, mode) | _lib.TUNE_LONG_SHIFT(lg) | _lib.TUNE_HELPERS(255) | _lib.TUNE_SET_ASIDE(park) | _lib.TUNE_GRID_CAP(4))
                 st = pd.last_stats()
                 aside = sum(s_["set_aside"] for s_ in st)
                 assert (aside == 0) if park == 255 else (aside >= 4), (variant, mode, park, aside)
                 _check_against_oracle(oracle_port, A, B, seeds, F, m, st, (variant, mode, park, lg))
 
 
-def test_homography_variants_and_modes_agree():
+def test_homography_variants_and_modes_agree(oracle_port):
+    """every workgroup size and placement returns the same bits, and those are the CPU oracle's (masks and counters exact,
+    raw model to 1e-9)"""
     A, B = [], []
     for i, n in enumerate([1200, 400, 2500]):
         p1, p2, _, _ = syn.homography_pairs(n, 0.4, 0.5, seed=30 + i, laf=True); A.append(p1); B.append(p2)
+    ora = [oracle_port.find_homography(A[p], B[p], 1.0, 0.999, 20000, 0, True, 3.0, seed=5 + p) for p in range(3)]
     ref = None
     for variant in (512, 256, 128):
         for mode in (1, 2, 0):
             H, m = pd.findHomographyBatch(A, B, 1.0, 0.999, 20000, 3.0, "sampson", True, seeds=[5, 6, 7], tuning=tune(variant, mode))
-            assert all(s_["threads"] == variant for s_ in pd.last_stats())      # n = 2500 does not fit "both in LDS" at 512 threads
+            st = pd.last_stats()
+            assert all(s_["threads"] == variant for s_ in st)      # n = 2500 does not fit "both in LDS" at 512 threads
+            for p in range(3):
+                Ho, mo, so = ora[p]
+                assert (st[p]["samples"], st[p]["lo_runs"], st[p]["rejected"], st[p]["models"]) == (so["samples"], so["lo_runs"], so["rejected"], so["models"]), (variant, mode, p)
+                assert np.array_equal(np.asarray(m[p]), mo), (variant, mode, p)
+                if np.abs(Ho).sum() > 0:      # the batch API returns inv(raw.T) (utils.py:108)
+                    Hu = np.linalg.inv(np.asarray(Ho).T)
+                    assert np.linalg.norm(np.asarray(H[p]) - Hu) <= 1e-8 * np.linalg.norm(Hu), (variant, mode, p)
             if ref is None:
                 ref = (np.asarray(H).copy(), [np.asarray(x).copy() for x in m])
             else:
@@ -107,7 +118,7 @@ def test_homography_variants_and_modes_agree():
 def test_homography_lo_one_repetition_per_wave_equals_the_serial_order(oracle_port):
     """The homography kernel runs the ten repetitions of a local optimisation on one wave each and replays the hash
     table / best-so-far / errs[] rotation in repetition order.  Forcing the reference's serial order
-    (tuning bit 5) must give the same bits and counters for every workgroup size (2, 4, 8 waves = 5, 3, 2 rounds), with and
+    (TUNE_H_SERIAL_LO) must give the same bits and counters for every workgroup size (2, 4, 8 waves = 5, 3, 2 rounds), with and
     without the symmetric metrics, and the oracle must agree."""
     A, B = [], []
     for i, n in enumerate([5000, 700, 2500, 64, 20, 9]):

@@ -104,6 +104,13 @@ for i, pid in enumerate(range(lo, hi)):
     f, m, s = port.find_fundamental(p1, p2, max_iters=1000, seed=parallel.pair_seed(pid))
     Fr[i] = f.ravel(); mr.append(m.astype(np.uint8)); sr[i, 0] = s["samples"]
 rm, rs, rk = parallel.gather_results(torch.from_numpy(Fr), torch.from_numpy(sr), torch.from_numpy(np.concatenate(mr)), sizes, NP)
+# very uneven shards (one 5000-correspondence pair next to tiny ones): every rank ships its own bytes, results in pair order
+big = [5000, 10, 11, 12, 13]
+rngb = np.random.default_rng(7)
+allm = [rngb.integers(0, 2, size=b).astype(np.uint8) for b in big]; allF = rngb.normal(size=(NP, 9)); alls = rngb.integers(0, 1000, size=(NP, 16)).astype(np.int32)
+bm, bs, bk = parallel.gather_results(torch.from_numpy(allF[lo:hi].copy()), torch.from_numpy(alls[lo:hi].copy()),
+                                     torch.from_numpy(np.concatenate(allm[lo:hi])), big, NP)
+assert np.array_equal(bm.numpy(), allF) and np.array_equal(bs.numpy(), alls) and np.array_equal(bk.numpy(), np.concatenate(allm))
 if rank == 0:
     assert rk.numel() == sum(sizes)
     np.savez(sys.argv[2], F=gm.numpy(), st=gs.numpy(), mk=gk.numpy(), Fr=rm.numpy(), sr=rs.numpy(), mr=rk.numpy())
@@ -116,7 +123,7 @@ def test_gather_invariant_to_world_size(tmp_path):
     port.lib()
     script = tmp_path / "w.py"; script.write_text(GLOO_WORKER)
     outs = []
-    for world in [1, 2]:
+    for world in [1, 2, 3]:
         out = str(tmp_path / f"o{world}.npz")
         port_no = 29500 + os.getpid() % 1000 + world
         if world == 1:
@@ -128,6 +135,7 @@ def test_gather_invariant_to_world_size(tmp_path):
         outs.append(np.load(out))
     for k in ["F", "st", "mk", "Fr", "sr", "mr"]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+        assert np.array_equal(outs[0][k], outs[2][k]), k
     assert outs[0]["st"][:, 0].min() > 0
 
 

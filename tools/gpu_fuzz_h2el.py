@@ -18,7 +18,7 @@ for b in range(N):
     seeds = [int(x) for x in rng.integers(1, 2**31 - 1, P)]
     do_lo = bool(rng.random() < 0.8); lim = int(rng.choice([0, 0, 16, 40])); th = float(rng.choice([1.0, 4.0, 9.0])); mi = int(rng.choice([200, 2000, 10000]))
     conf = float(rng.choice([0.95, 0.99, 0.999]))
-    H, m = pd.ransacH2el_batch(U, th, conf, mi, do_lo, lim, seeds=seeds); st = pd.last_stats()
+    H, m = pd.ransacH2el_batch(U, th, conf, mi, do_lo, lim, seeds=seeds, raw=True); st = pd.last_stats()
     for p in range(P):
         if lim and U[p].shape[0] <= 14:
             continue                                              # 4-point u2h of the reference reads uninitialised memory (Htools.c:108-114)
