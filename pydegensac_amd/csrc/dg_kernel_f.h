@@ -57,6 +57,11 @@ struct dg_f_cshared {
     int n_max;
 };
 
+/* innerH with one repetition per wave (dg_innerH_waves): what a repetition starts from (its sample, the generator right after the
+ * sample's draws) and what it leaves (the generator after its own draws, their number, the best model of the repetition and
+ * its MSAC gain, the passes it made) */
+struct dg_ih_log { dg_rng g; double h[9]; double itJ; int ids[12]; int passes, draws; };
+
 struct dg_f_shared {
     dg_red red;
     dg_lsq_scratch lsq;
@@ -69,12 +74,13 @@ struct dg_f_shared {
     dg_wave_ws ww[DG_NW];                /* per-wave scratch of the wave-parallel sections */
     double   wpad[DG_WPAD];              /* extends ww[] to the size the parallel pool stage needs (2 * DG_CHUNK * 7 ints) */
     double   csH[5][9]; int csRes[5];    /* checksample: per-triplet homography and verdict */
-    union {      /* never live at the same time: innerFH belongs to the DEGENSAC branch, `ahead` to one local optimisation */
+    union {      /* never live at the same time: innerFH and innerH are separate steps of the DEGENSAC branch, `ahead` belongs to one local optimisation */
         struct {
             double   fhF[16][9], fhF2[16][9], fhTh[16];   /* innerFH: per-repetition model, its u2Fit refinement, flag threshold */
             int      fhIds[16][10], fhCnt[16], fhCnt2[16], fhRaw[160];
         };
         dg_lo_ahead ahead[DG_LO_AHEAD];
+        struct { dg_ih_log ih[DG_NW]; dg_rng ih_start, ih_work; };    /* innerH, one repetition per wave */
     };
     int n_ahead;
     long long ph[8], dbg[8], tq;
@@ -322,7 +328,7 @@ __device__ __noinline__ int dg_checksample(CTX &c, const double *F /* LDS */, co
 
 /* ---- ranH.c:18-135 + DegUtils.c:693-731: LO of the plane homography (innerH) -------------------- */
 template <int LDSPTS>
-__device__ __noinline__ unsigned dg_innerH(CTX &c, double *H /* LDS, in/out */, double th, unsigned inlLimit, unsigned char *inl_flags)
+__device__ __noinline__ unsigned dg_innerH_serial(CTX &c, double *H /* LDS, in/out */, double th, unsigned inlLimit, unsigned char *inl_flags)
 {
     dg_f_shared *S = c.S; const int n = c.n, tid = c.tid;
     int *inliers = c.K->L[3], *intbuff = c.K->L[4];
@@ -403,6 +409,195 @@ __device__ __noinline__ unsigned dg_innerH(CTX &c, double *H /* LDS, in/out */, 
         __syncthreads();
         return cnt;
     }
+}
+
+/* ---- innerH with one repetition per wave ----------------------------------------------------------------------------
+ * The ten repetitions of inHrani (ranH.c:88-135) depend on each other through the generator, the order of `inliers` and the
+ * running best only.  What a repetition draws is its sample (ssiz numbers) and one 10-subset per re-fit whose inlier list is
+ * longer than inlLimit = 10 — five of them when the plane is real, which is the common case.  So a round of DG_NW repetitions
+ * runs concurrently, one per wave, each on its own id list / MSAC-term buffer in the workspace (dg_f_cshared::wlist /
+ * wstage) and its own solver scratch (dg_f_shared::ww): wave 0 first draws the round's samples one after the other from
+ * generator states that ASSUME five subsets per earlier repetition of the round; afterwards the repetitions are committed
+ * in order as long as that assumption held (the first one always does), the generator is set to the exact state behind
+ * the last committed one, and the next round starts behind it (after putting `inliers` back into the order the last
+ * committed sample left).  Every repetition performs the arithmetic of the serial order (same fits, same passes, J as the
+ * reference's sequential sum), so results and counters are identical; dg_innerH_serial is kept behind
+ * MI_DEGENSAC_TUNE_F_SERIAL_INNERH for the equality test. */
+/* one wave's pass of homography Hm (metric HDs) over all n points: I = #(d <= thJ), J = the reference-order MSAC sum, the
+ * ordered id list at thL.  The nonzero MSAC terms go to the wave's buffer in the workspace; lane 0 adds them in point order. */
+template <int LDSPTS>
+__device__ __noinline__ dg_pass_res dg_hds_wpass(const dg_pt *P, int n, const double *Hm /* LDS */, double thJ, int *list_, double thL, double *jbuf_, int lane)
+{
+    n = __builtin_amdgcn_readfirstlane(n);
+    double H[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) H[i] = Hm[i];
+    __attribute__((address_space(1))) int *list = (__attribute__((address_space(1))) int *)list_;
+    __attribute__((address_space(1))) double *jb = (__attribute__((address_space(1))) double *)jbuf_;
+    dg_pass_res out; out.I = 0; out.J = 0; out.C = 0; out.nL = 0; out.nF = 0; out.nL2 = 0; out.nJ = 0;
+    const double t94 = thJ * 9 / 4;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned cI = 0, nJ = 0, nA = 0;
+    for (int base = 0; base < n; base += 64 * DG_PU) {
+        dg_pt q[DG_PU]; double d[DG_PU];
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) { const int j = base + 64 * u + lane; q[u] = dg_ldpt<LDSPTS>(P, j < n ? j : 0); }
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) d[u] = dg_HDs(H, q[u].x1, q[u].y1, q[u].x2, q[u].y2);
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) {
+            const int j = base + 64 * u + lane; const bool act = j < n;
+            double term = 0.0;
+            if (act && thJ != 0 && !(d[u] >= t94)) term = 1 - (d[u] / t94);
+            const bool nz = !(term == 0.0), inA = act && d[u] <= thL;
+            cI += (act && d[u] <= thJ) ? 1u : 0u;
+            const unsigned long long mJ = __ballot(nz), mA = __ballot(inA);
+            if (nz) jb[nJ + (unsigned)__popcll(mJ & below)] = term;
+            if (inA) list[nA + (unsigned)__popcll(mA & below)] = j;
+            nJ += (unsigned)__popcll(mJ); nA += (unsigned)__popcll(mA);
+        }
+    }
+    DG_WSYNC();
+    double J = 0.0; if (lane == 0) J = dg_seq_sum(jbuf_, (int)nJ);
+    out.J = __shfl(J, 0, 64);
+    out.I = dg_wave_sum_u(cI); out.nL = nA; out.nJ = nJ;
+    DG_WSYNC();
+    return out;
+}
+
+/* one repetition of inHrani + iterH (ranH.c:88-135, :18-86) by one wave */
+template <int LDSPTS>
+__device__ __noinline__ void dg_innerH_rep_wave(CTX &c, dg_ih_log *lg, int ssiz, double th, int lim, int lane, int wave)
+{
+    dg_f_shared *S = c.S; const int n = c.n; const dg_pt *P = c.P;
+    dg_wave_ws *w = &S->ww[wave];
+    int *ib = c.K->wlist + (size_t)wave * c.K->n_max; double *jb = (double *)(c.K->wstage + (size_t)wave * c.K->n_max);
+    double *h = w->H, *hl = w->F;
+    /* u2h on cnt >= 4 ids, lane j < cnt holding the j-th (Htools.c:101-133: 4 points exactly, else normalised) */
+    auto fit = [&](int id, int cnt, double *dst) {
+        DG_WSYNC();
+        dg_gather_wave(c, id, cnt, w->px, lane);
+        DG_WSYNC();
+        if (cnt == 4) { if (lane == 0) dg_u2h_4pt_mv(w->Z, w->V, w->px, dst); DG_WSYNC(); }
+        else dg_u2h_norm_w(w, w->px, cnt, dst, lane);
+    };
+    /* the ids of a list of `len` (> 4) entries the next fit uses: a random 10-subset when it is longer than inlLimit */
+    auto pick = [&](int len, int *cnt, int *draws) {
+        int id = 0;
+        *cnt = len > lim ? lim : len;
+        if (len > lim) { dg_randsubset_wave(&lg->g, ib, len, lim, lane, &id); *draws += lim; }
+        else id = lane < len ? ib[lane] : 0;
+        return id;
+    };
+    int passes = 0, draws = 0;
+    fit(lane < ssiz ? lg->ids[lane] : 0, ssiz, h);
+    const dg_pass_res r1 = dg_hds_wpass<LDSPTS>(P, n, h, th, ib, th, jb, lane); passes++;
+    double mJ = r1.J, itJ = 0; unsigned mI = r1.I;
+    if (mI >= 4) {
+        double ths = DG_TC * th; const double dth = (ths - th) / DG_ILSQ_ITERS;
+        { int cnt; const int id = pick((int)mI, &cnt, &draws); fit(id, cnt, hl); }
+        int early = 0;
+        for (int it = 0; it < DG_ILSQ_ITERS; ++it) {
+            const dg_pass_res r2 = dg_hds_wpass<LDSPTS>(P, n, hl, th, ib, ths, jb, lane); passes++;
+            if (mJ < r2.J) { mJ = r2.J; mI = r2.I; DG_WSYNC(); if (lane < 9) h[lane] = hl[lane]; DG_WSYNC(); }
+            if (r2.nL < 4) { early = 1; break; }
+            { int cnt; const int id = pick((int)r2.nL, &cnt, &draws); fit(id, cnt, hl); }
+            ths -= dth;
+        }
+        if (!early) {
+            const dg_pass_res r3 = dg_hds_wpass<LDSPTS>(P, n, hl, th, ib, th, jb, lane); passes++;
+            if (mJ < r3.J) { mJ = r3.J; mI = r3.I; DG_WSYNC(); if (lane < 9) h[lane] = hl[lane]; DG_WSYNC(); }
+        }
+        itJ = mJ;
+    }
+    DG_WSYNC();
+    if (lane < 9) lg->h[lane] = h[lane];
+    if (lane == 0) { lg->itJ = itJ; lg->passes = passes; lg->draws = draws; }
+    DG_WSYNC();
+}
+
+template <int LDSPTS>
+__device__ __noinline__ unsigned dg_innerH_waves(CTX &c, double *H /* LDS, in/out */, double th, unsigned inlLimit, unsigned char *inl_flags)
+{
+    dg_f_shared *S = c.S; const int n = c.n, tid = c.tid, lane = tid & 63, wave = tid >> 6;
+    int *inliers = c.K->L[3], *bak = c.K->L[4];
+    const int lim = (int)inlLimit;
+    dg_pass_cfg cfg = dg_cfg0(n); cfg.list = inliers; cfg.thL = th;
+    dg_pass_res r0 = dg_h_pass(c, H, cfg); c.n_hds++;
+    const int ninl = (int)r0.nL;
+    if (ninl >= 8) {
+        int ssiz = ninl / 2; if (ssiz > 12) ssiz = 12;
+        double maxJ = 0;
+        int next = 0;
+        while (next < DG_RAN_REP) {
+            const int nr = DG_RAN_REP - next < DG_NW ? DG_RAN_REP - next : DG_NW;
+            __syncthreads();
+            if (__builtin_amdgcn_readfirstlane(wave) == 0) {
+                /* the round's samples, drawn one after the other from ASSUMED generator states (5 subsets of `lim` per repetition) */
+                if (lane == 0) { S->ih_start = S->rng; S->ih_work = S->rng; }
+                for (int j = lane; j < ninl; j += 64) bak[j] = inliers[j];
+                DG_WSYNC();
+                for (int q = 0; q < nr; q++) {
+                    int id = 0;
+                    dg_randsubset_wave(&S->ih_work, inliers, ninl, ssiz, lane, &id);
+                    if (lane < ssiz) S->ih[q].ids[lane] = id;
+                    if (lane == 0) { S->ih[q].g = S->ih_work; for (int k = 0; k < 5 * lim; k++) dg_rand(&S->ih_work); }
+                    DG_WSYNC();
+                }
+            }
+            __syncthreads();
+            if (wave < nr) dg_innerH_rep_wave<LDSPTS>(c, &S->ih[wave], ssiz, th, lim, lane, wave);
+            __syncthreads();
+            /* commit in order while the assumption behind each repetition's start state held */
+            int v = 0;
+            for (int q = 0; q < nr; q++) {
+                c.n_hds += S->ih[q].passes;
+                if (maxJ < S->ih[q].itJ) { maxJ = S->ih[q].itJ; __syncthreads(); if (tid < 9) H[tid] = S->ih[q].h[tid]; __syncthreads(); }
+                v++;
+                if (S->ih[q].draws != 5 * lim) break;
+            }
+            __syncthreads();
+            if (__builtin_amdgcn_readfirstlane(wave) == 0) {
+                if (lane == 0) S->rng = S->ih[v - 1].g;               /* the exact state behind repetition next + v - 1 */
+                if (v < nr) {
+                    /* `inliers` as that repetition's sample left it: back to the round's start, the committed samples again */
+                    for (int j = lane; j < ninl; j += 64) inliers[j] = bak[j];
+                    if (lane == 0) S->ih_work = S->ih_start;
+                    DG_WSYNC();
+                    for (int q = 0; q < v; q++) {
+                        int id = 0;
+                        dg_randsubset_wave(&S->ih_work, inliers, ninl, ssiz, lane, &id);
+                        if (lane == 0) for (int k = 0; k < S->ih[q].draws; k++) dg_rand(&S->ih_work);
+                        DG_WSYNC();
+                    }
+                }
+            }
+            next += v;
+        }
+        __syncthreads();
+    }
+    /* inl[j] = (errs[0][j] <= th) with errs[0] = residuals of the (possibly refined) H */
+    {
+        double Hr[9]; for (int i = 0; i < 9; i++) Hr[i] = H[i];
+        const dg_pt *P = c.P;
+        unsigned cnt = 0;
+        for (int base = 0; base < n; base += DG_T) {
+            int j = base + tid; bool in = false;
+            if (j < n) { dg_pt p = dg_ldpt<LDSPTS>(P, j); in = dg_HDs(Hr, p.x1, p.y1, p.x2, p.y2) <= th; inl_flags[j] = in ? 1 : 0; }
+            cnt += in ? 1u : 0u;
+        }
+        cnt = dg_block_sum_u(&c.S->red, cnt, tid);
+        __syncthreads();
+        return cnt;
+    }
+}
+
+template <int LDSPTS>
+__device__ __forceinline__ unsigned dg_innerH(CTX &c, double *H /* LDS, in/out */, double th, unsigned inlLimit, unsigned char *inl_flags)
+{
+    /* one repetition per wave needs inlLimit <= 14 gathered points per fit (dg_wave_ws::px); the driver passes 10 (DegUtils.c:693-731) */
+    if (c.A->innerh_serial || inlLimit > 12) return dg_innerH_serial<LDSPTS>(c, H, th, inlLimit, inl_flags);
+    return dg_innerH_waves<LDSPTS>(c, H, th, inlLimit, inl_flags);
 }
 
 /* ---- wave-level passes (one wave, no workgroup barriers) ------------------------------------------ */

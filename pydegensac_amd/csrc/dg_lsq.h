@@ -23,7 +23,7 @@ struct dg_lsq_scratch {
 /* per-wave scratch for the wave-parallel sections (checksample's 5 triplets, innerFH's repetitions): the
  * members the templated small solvers touch have the same names as in dg_lsq_scratch */
 struct dg_wave_ws {
-    double Z[14 * 9], V[81], D[9], A1[3], A2[3], px[14 * 4];
+    double Z[24 * 9], V[81], D[9], A1[3], A2[3], px[14 * 4];     /* Z: 14 rows of an F fit or 2 x 12 rows of an H fit (innerH's repetitions, one per wave) */
     dg_eig_ws ews;
     double H[9], F[9], Ds[7], sDs[7], cpx[20];
     int idx[8], res, cnt;
