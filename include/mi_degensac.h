@@ -77,9 +77,9 @@ extern "C" {
  *             mi_degensac_find_homography_resids always does).  EINVAL on a fundamental-matrix call
  *   bit  6    fundamental matrix with helper workgroups only (bits 8-15 or automatic): distribute EVERY pass over the whole
  *             point set over the claiming workgroups, not only those over >= 8192 points (tests).  EINVAL on a homography call
- *   bit  7    fundamental matrix only: run the ten repetitions of innerH (the plane homography's local optimisation inside the
- *             DEGENSAC branch) one after the other on the whole workgroup instead of one repetition per wave (tests).
- *             EINVAL on a homography call
+ *   bit  7    fundamental matrix only: run the repetitions of the local optimisation (exp_inFranicustom) and of innerH (the
+ *             plane homography's local optimisation inside the DEGENSAC branch) one after the other on the whole workgroup
+ *             instead of one repetition per wave from speculated generator states (tests).  EINVAL on a homography call
  *   bits 8-15 helper workgroups per pair of the cooperative large-n mode (fundamental matrix, placement HBM):
  *             0 = automatic (23 helpers when n >= 8192 and the batch leaves the device mostly idle, 15 with less room), 255 = off
  *   bits 16-23 setting pairs aside (fundamental matrix, batches larger than the resident grid): a pair still running
@@ -98,7 +98,7 @@ extern "C" {
 #define MI_DEGENSAC_TUNE_SEQ_POOL     (1u << 4)
 #define MI_DEGENSAC_TUNE_H_SERIAL_LO  (1u << 5)
 #define MI_DEGENSAC_TUNE_COOP_ALL_PASSES (1u << 6)
-#define MI_DEGENSAC_TUNE_F_SERIAL_INNERH (1u << 7)
+#define MI_DEGENSAC_TUNE_F_SERIAL_REPS (1u << 7)
 #define MI_DEGENSAC_TUNE_HELPERS(h)   (((uint32_t)(h) & 255u) << 8)
 #define MI_DEGENSAC_TUNE_SET_ASIDE(t)  (((uint32_t)(t) & 255u) << 16)
 #define MI_DEGENSAC_TUNE_GRID_CAP(g)   (((uint32_t)(g) & 31u) << 24)

@@ -17,7 +17,7 @@ TUNE_PLACE_HBM, TUNE_PLACE_LDS, TUNE_PLACE_POOL_LDS = 1 << 2, 2 << 2, 3 << 2
 TUNE_SEQ_POOL = 1 << 4
 TUNE_H_SERIAL_LO = 1 << 5   # homography only: local-optimisation repetitions one after the other (default: one per wave)
 TUNE_COOP_ALL_PASSES = 1 << 6   # fundamental matrix with helper workgroups: distribute every full pass (tests)
-TUNE_F_SERIAL_INNERH = 1 << 7   # fundamental matrix: innerH's repetitions one after the other (default: one per wave; tests)
+TUNE_F_SERIAL_REPS = 1 << 7   # fundamental matrix: the repetitions of innerH and of the local optimisation one after the other (default: one per wave; tests)
 
 
 def TUNE_HELPERS(h): return (int(h) & 255) << 8          # noqa: E704  helper workgroups per pair (255 = off)

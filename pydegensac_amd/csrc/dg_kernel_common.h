@@ -167,7 +167,7 @@ struct dg_args {
     int park_long;                   /* a pair set aside with at least this many samples left goes to queue 1    */
     int lo_serial;                   /* homography: 1 = run the repetitions of a local optimisation one after the other on the whole workgroup */
     int pool_seq;                    /* 1 = always use the sequential pool-swap stage (LDS exchange-order self-check failed, or forced) */
-    int innerh_serial;               /* fundamental matrix: 1 = innerH's ten repetitions one after the other on the whole workgroup (tests) */
+    int innerh_serial;               /* fundamental matrix: 1 = the repetitions of innerH and of the local optimisation one after the other on the whole workgroup (tests) */
     int variant_threads, mode;       /* reported in the stats block */
     int *trace;                      /* debug: [0] = count, then (tag, I, J lo, J hi) records; null = off */
     int trace_cap;

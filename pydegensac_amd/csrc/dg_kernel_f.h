@@ -60,7 +60,23 @@ struct dg_f_cshared {
 /* innerH with one repetition per wave (dg_innerH_waves): what a repetition starts from (its sample, the generator right after the
  * sample's draws) and what it leaves (the generator after its own draws, their number, the best model of the repetition and
  * its MSAC gain, the passes it made) */
-struct dg_ih_log { dg_rng g; double h[9]; double itJ; int ids[12]; int passes, draws; };
+struct dg_ih_log { dg_rng g; double h[9]; double itJ; int ids[12]; int passes, draws;
+                   int pub, aborted; };    /* pub: -1 while it runs, then its draws (the later repetitions of the round watch it); aborted: stopped as stale */
+
+/* The fundamental-matrix local optimisation with one repetition per wave (dg_inFrani_waves): what a repetition starts from
+ * (sample ids, the generator right after the sample's 14 draws) and what it leaves for the in-order replay: per iteration of
+ * exp_iterFcustom the (hash, I) of its inlier set and whether the re-fit behind it drew an 8-subset; its own result. */
+struct dg_lo_it { unsigned hash; int I; int drew; };
+struct dg_lo_log {
+    dg_rng g, g0;                         /* g0: the generator right behind the sample's draws (g moves on with the repetition's own draws) */
+    int upos[28], uval[28];               /* the list slots the sample's draws stored, with the values they replaced (-1: none): undone when the repetition is not committed */
+    int ids[14];
+    int I0, drew0, nit, has_fin;          /* r0.I (< 8: the repetition ends at once), draws of the first 8-subset, iterations that hashed their set, final pass made */
+    dg_lo_it it[DG_ILSQ_ITERS];
+    double f[9], J; int I, kind0;         /* result when no iteration is cut short by the replay: model, score, metric variant of errs[0] */
+    int cut, draws, n_ex, n_fd;           /* filled by the replay: cut short by an earlier repetition's set, 8-subset draws really consumed, passes to count */
+    int pub, aborted;                     /* pub: -1 while the repetition runs, then the draws it made (the later repetitions of the round watch it); aborted: stopped as stale */
+};
 
 struct dg_f_shared {
     dg_red red;
@@ -81,6 +97,7 @@ struct dg_f_shared {
         };
         dg_lo_ahead ahead[DG_LO_AHEAD];
         struct { dg_ih_log ih[DG_NW]; dg_rng ih_start, ih_work; };    /* innerH, one repetition per wave */
+        struct { dg_lo_log lo[DG_NW]; dg_rng lo_start, lo_work; };    /* local optimisation, one repetition per wave */
     };
     int n_ahead;
     long long ph[8], dbg[8], tq;
@@ -422,47 +439,74 @@ __device__ __noinline__ unsigned dg_innerH_serial(CTX &c, double *H /* LDS, in/o
  * the last committed one, and the next round starts behind it (after putting `inliers` back into the order the last
  * committed sample left).  Every repetition performs the arithmetic of the serial order (same fits, same passes, J as the
  * reference's sequential sum), so results and counters are identical; dg_innerH_serial is kept behind
- * MI_DEGENSAC_TUNE_F_SERIAL_INNERH for the equality test. */
-/* one wave's pass of homography Hm (metric HDs) over all n points: I = #(d <= thJ), J = the reference-order MSAC sum, the
- * ordered id list at thL.  The nonzero MSAC terms go to the wave's buffer in the workspace; lane 0 adds them in point order. */
+ * MI_DEGENSAC_TUNE_F_SERIAL_REPS for the equality test. */
+/* One wave's pass over all n points (what dg_pass does for a workgroup): I = #(d <= thJ), J = the reference-order MSAC sum, the
+ * ordered id lists at thL (la, when given) and thL2 (lb, when given).  The nonzero MSAC terms of a step (DG_PU tiles of 64 points)
+ * go through `tile` (LDS, >= 64 * DG_PU doubles: the wave's solver scratch, idle during a pass) and are added, in point order,
+ * before the next step, whose points are loaded before that. */
+template <int LDSPTS, class Err>
+__device__ __forceinline__ dg_pass_res dg_wpass_impl(const dg_pt *P, int n, Err err, double thJ, int *la_, double thL, int *lb_, double thL2, double *tile_, int lane)
+{
+    __attribute__((address_space(1))) int *la = (__attribute__((address_space(1))) int *)la_, *lb = (__attribute__((address_space(1))) int *)lb_;
+    __attribute__((address_space(3))) double *t = (__attribute__((address_space(3))) double *)tile_;
+    dg_pass_res out; out.I = 0; out.J = 0; out.C = 0; out.nL = 0; out.nF = 0; out.nL2 = 0; out.nJ = 0;
+    const double t94 = thJ * 9 / 4;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned cI = 0, nJ = 0, nA = 0, nB = 0;
+    double J = 0;
+    dg_pt qn[DG_PU];
+#pragma unroll
+    for (int u = 0; u < DG_PU; u++) { const int j = u * 64 + lane; qn[u] = dg_ldpt<LDSPTS>(P, j < n ? j : 0); }
+    DG_WSYNC();
+    for (int base = 0; base < n; base += DG_PU * 64) {
+        dg_pt q[DG_PU]; double d[DG_PU];
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) q[u] = qn[u];
+        if (LDSPTS != 1) {
+#pragma unroll
+            for (int u = 0; u < DG_PU; u++) { const int j = base + DG_PU * 64 + u * 64 + lane; if (j < n) qn[u] = dg_ldpt<LDSPTS>(P, j); }
+        }
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) d[u] = err(q[u]);
+        unsigned sJ = 0;
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) {
+            const int j = base + u * 64 + lane; const bool act = j < n;
+            double term = 0.0;
+            if (act && thJ != 0 && !(d[u] >= t94)) term = 1 - (d[u] / t94);
+            const bool nz = !(term == 0.0), inA = la_ && act && d[u] <= thL, inB = lb_ && act && d[u] <= thL2;
+            cI += (act && d[u] <= thJ) ? 1u : 0u;
+            const unsigned long long mJ = __ballot(nz), mA = __ballot(inA), mB = __ballot(inB);
+            if (nz) t[sJ + (unsigned)__popcll(mJ & below)] = term;
+            if (inA) la[nA + (unsigned)__popcll(mA & below)] = j;
+            if (inB) lb[nB + (unsigned)__popcll(mB & below)] = j;
+            sJ += (unsigned)__popcll(mJ); nA += (unsigned)__popcll(mA); nB += (unsigned)__popcll(mB);
+        }
+        if (LDSPTS == 1) {
+#pragma unroll
+            for (int u = 0; u < DG_PU; u++) { const int j = base + DG_PU * 64 + u * 64 + lane; if (j < n) qn[u] = dg_ldpt<LDSPTS>(P, j); }
+        }
+        DG_WSYNC();
+        if (sJ) J = dg_seq_sum_from<3>((const double *)tile_, (int)sJ, J);
+        nJ += sJ;
+        DG_WSYNC();
+    }
+    out.I = dg_wave_sum_u(cI); out.J = J; out.nL = nA; out.nL2 = nB; out.nJ = nJ;
+    DG_WSYNC();
+    return out;
+}
+static_assert(offsetof(dg_wave_ws, Z) == 0 && offsetof(dg_wave_ws, px) + sizeof(((dg_wave_ws *)0)->px) >= 64 * DG_PU * sizeof(double) &&
+              offsetof(dg_wave_ws, ews) >= offsetof(dg_wave_ws, px) + sizeof(((dg_wave_ws *)0)->px), "a wave pass's MSAC-term tile spans dg_wave_ws::Z .. ::px");
+
+/* one wave's pass of homography Hm (metric HDs): I, J at thJ, the ordered id list at thL */
 template <int LDSPTS>
-__device__ __noinline__ dg_pass_res dg_hds_wpass(const dg_pt *P, int n, const double *Hm /* LDS */, double thJ, int *list_, double thL, double *jbuf_, int lane)
+__device__ __noinline__ dg_pass_res dg_hds_wpass(const dg_pt *P, int n, const double *Hm /* LDS */, double thJ, int *list_, double thL, double *tile, int lane)
 {
     n = __builtin_amdgcn_readfirstlane(n);
     double H[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) H[i] = Hm[i];
-    __attribute__((address_space(1))) int *list = (__attribute__((address_space(1))) int *)list_;
-    __attribute__((address_space(1))) double *jb = (__attribute__((address_space(1))) double *)jbuf_;
-    dg_pass_res out; out.I = 0; out.J = 0; out.C = 0; out.nL = 0; out.nF = 0; out.nL2 = 0; out.nJ = 0;
-    const double t94 = thJ * 9 / 4;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    unsigned cI = 0, nJ = 0, nA = 0;
-    for (int base = 0; base < n; base += 64 * DG_PU) {
-        dg_pt q[DG_PU]; double d[DG_PU];
-#pragma unroll
-        for (int u = 0; u < DG_PU; u++) { const int j = base + 64 * u + lane; q[u] = dg_ldpt<LDSPTS>(P, j < n ? j : 0); }
-#pragma unroll
-        for (int u = 0; u < DG_PU; u++) d[u] = dg_HDs(H, q[u].x1, q[u].y1, q[u].x2, q[u].y2);
-#pragma unroll
-        for (int u = 0; u < DG_PU; u++) {
-            const int j = base + 64 * u + lane; const bool act = j < n;
-            double term = 0.0;
-            if (act && thJ != 0 && !(d[u] >= t94)) term = 1 - (d[u] / t94);
-            const bool nz = !(term == 0.0), inA = act && d[u] <= thL;
-            cI += (act && d[u] <= thJ) ? 1u : 0u;
-            const unsigned long long mJ = __ballot(nz), mA = __ballot(inA);
-            if (nz) jb[nJ + (unsigned)__popcll(mJ & below)] = term;
-            if (inA) list[nA + (unsigned)__popcll(mA & below)] = j;
-            nJ += (unsigned)__popcll(mJ); nA += (unsigned)__popcll(mA);
-        }
-    }
-    DG_WSYNC();
-    double J = 0.0; if (lane == 0) J = dg_seq_sum(jbuf_, (int)nJ);
-    out.J = __shfl(J, 0, 64);
-    out.I = dg_wave_sum_u(cI); out.nL = nA; out.nJ = nJ;
-    DG_WSYNC();
-    return out;
+    return dg_wpass_impl<LDSPTS>(P, n, [&](const dg_pt &q) { return dg_HDs(H, q.x1, q.y1, q.x2, q.y2); }, thJ, list_, thL, (int *)0, 0.0, tile, lane);
 }
 
 /* one repetition of inHrani + iterH (ranH.c:88-135, :18-86) by one wave */
@@ -471,15 +515,22 @@ __device__ __noinline__ void dg_innerH_rep_wave(CTX &c, dg_ih_log *lg, int ssiz,
 {
     dg_f_shared *S = c.S; const int n = c.n; const dg_pt *P = c.P;
     dg_wave_ws *w = &S->ww[wave];
-    int *ib = c.K->wlist + (size_t)wave * c.K->n_max; double *jb = (double *)(c.K->wstage + (size_t)wave * c.K->n_max);
+    int *ib = c.K->wlist + (size_t)wave * c.K->n_max; double *jb = w->Z;                /* the pass's MSAC-term tile: Z .. px, idle during a pass */
     double *h = w->H, *hl = w->F;
+    /* an earlier repetition of this round has finished with another number of draws than this one's start state assumes:
+     * this repetition will not be committed, stop it */
+    auto stale = [&]() {
+        int bad = 0;
+        if (lane < wave) { const int d = __hip_atomic_load(&S->ih[lane].pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); bad = d >= 0 && d != 5 * lim; }
+        return __ballot(bad) != 0ull;
+    };
     /* u2h on cnt >= 4 ids, lane j < cnt holding the j-th (Htools.c:101-133: 4 points exactly, else normalised) */
     auto fit = [&](int id, int cnt, double *dst) {
         DG_WSYNC();
         dg_gather_wave(c, id, cnt, w->px, lane);
         DG_WSYNC();
         if (cnt == 4) { if (lane == 0) dg_u2h_4pt_mv(w->Z, w->V, w->px, dst); DG_WSYNC(); }
-        else dg_u2h_norm_w(w, w->px, cnt, dst, lane);
+        else dg_u2h_norm_wave_noz(w, w->px, cnt, dst, lane);
     };
     /* the ids of a list of `len` (> 4) entries the next fit uses: a random 10-subset when it is longer than inlLimit */
     auto pick = [&](int len, int *cnt, int *draws) {
@@ -498,6 +549,7 @@ __device__ __noinline__ void dg_innerH_rep_wave(CTX &c, dg_ih_log *lg, int ssiz,
         { int cnt; const int id = pick((int)mI, &cnt, &draws); fit(id, cnt, hl); }
         int early = 0;
         for (int it = 0; it < DG_ILSQ_ITERS; ++it) {
+            if (stale()) { if (lane == 0) lg->aborted = 1; DG_WSYNC(); return; }
             const dg_pass_res r2 = dg_hds_wpass<LDSPTS>(P, n, hl, th, ib, ths, jb, lane); passes++;
             if (mJ < r2.J) { mJ = r2.J; mI = r2.I; DG_WSYNC(); if (lane < 9) h[lane] = hl[lane]; DG_WSYNC(); }
             if (r2.nL < 4) { early = 1; break; }
@@ -512,7 +564,7 @@ __device__ __noinline__ void dg_innerH_rep_wave(CTX &c, dg_ih_log *lg, int ssiz,
     }
     DG_WSYNC();
     if (lane < 9) lg->h[lane] = h[lane];
-    if (lane == 0) { lg->itJ = itJ; lg->passes = passes; lg->draws = draws; }
+    if (lane == 0) { lg->itJ = itJ; lg->passes = passes; lg->draws = draws; __hip_atomic_store(&lg->pub, draws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     DG_WSYNC();
 }
 
@@ -541,7 +593,7 @@ __device__ __noinline__ unsigned dg_innerH_waves(CTX &c, double *H /* LDS, in/ou
                     int id = 0;
                     dg_randsubset_wave(&S->ih_work, inliers, ninl, ssiz, lane, &id);
                     if (lane < ssiz) S->ih[q].ids[lane] = id;
-                    if (lane == 0) { S->ih[q].g = S->ih_work; for (int k = 0; k < 5 * lim; k++) dg_rand(&S->ih_work); }
+                    if (lane == 0) { S->ih[q].g = S->ih_work; S->ih[q].pub = -1; S->ih[q].aborted = 0; for (int k = 0; k < 5 * lim; k++) dg_rand(&S->ih_work); }
                     DG_WSYNC();
                 }
             }
@@ -551,6 +603,7 @@ __device__ __noinline__ unsigned dg_innerH_waves(CTX &c, double *H /* LDS, in/ou
             /* commit in order while the assumption behind each repetition's start state held */
             int v = 0;
             for (int q = 0; q < nr; q++) {
+                if (S->ih[q].aborted) break;                     /* stopped as stale: it runs again in the next round (q >= 1 here) */
                 c.n_hds += S->ih[q].passes;
                 if (maxJ < S->ih[q].itJ) { maxJ = S->ih[q].itJ; __syncthreads(); if (tid < 9) H[tid] = S->ih[q].h[tid]; __syncthreads(); }
                 v++;

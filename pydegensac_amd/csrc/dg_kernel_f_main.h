@@ -167,7 +167,7 @@ __device__ __forceinline__ dg_score dg_iterF(CTX &c, int *inliers, double th, do
 
 /* exp_ranF.c:745-806 exp_inFranicustom.  inliers = L[0] (in/out), result model -> Fout (LDS). */
 template <int LDSPTS>
-__device__ __noinline__ dg_score dg_inFrani(CTX &c, int ninl, double th, double *Fout, int *iterID,
+__device__ __noinline__ dg_score dg_inFrani_serial(CTX &c, int ninl, double th, double *Fout, int *iterID,
                                                int mk_full, int mk_ex, int *kindBest)
 {
     dg_f_shared *S = c.S; const int tid = c.tid;
@@ -253,6 +253,257 @@ __device__ __noinline__ dg_score dg_inFrani(CTX &c, int ninl, double th, double 
     for (int j = tid; j < (int)maxS.I; j += DG_T) inliers[j] = intbuff_best[j];
     __syncthreads();
     return maxS;
+}
+
+/* ---- the local optimisation with one repetition per wave --------------------------------------------------------------
+ * The ten repetitions of exp_inFranicustom (exp_ranF.c:745-806) are chained through the generator (14 draws for the sample,
+ * then one 8-subset per re-fit of exp_iterFcustom: two of them in 62 % of the repetitions, three in 26 %), the order of
+ * `inliers`, the inlier-set hash table ("seen by an earlier repetition" ends a repetition) and the best-so-far comparison.
+ * A round runs DG_NW repetitions concurrently, one per wave, each on its own lists / MSAC-term buffer in the workspace and
+ * its own solver scratch: wave 0 draws the round's samples one after the other from generator states that ASSUME two
+ * 8-subsets per earlier repetition of the round; every wave then runs its whole repetition (same fits, same passes, J as the
+ * reference's sequential sum, the hash of every iteration's inlier set) without touching the hash table, stopping only at a
+ * set that an EARLIER round or local optimisation inserted; afterwards thread 0 replays the repetitions in order — hash
+ * lookups / inserts with the repetition's own iterID, "seen by another repetition -> empty result", the draws it really
+ * consumed — and commits them as long as the assumption behind their start state held (the first one always does).  The
+ * generator is set to the exact state behind the last committed repetition and `inliers` put back into the order its sample
+ * left; the next round starts there.  A repetition that the replay cuts short has only computed further than needed.
+ * Results and counters equal the serial order (dg_inFrani_serial, kept for the residual dump, the cooperative large-n
+ * mode and behind MI_DEGENSAC_TUNE_F_SERIAL_REPS for the equality test). */
+/* one wave's pass of model Fm under metric `kind` over all n points: I = #(d <= thJ), J = the reference-order MSAC sum, the
+ * ordered id lists at thL (la) and thL2 (lb, optional); `tile` = the wave's LDS tile for the MSAC terms (dg_wpass_impl) */
+template <int LDSPTS>
+__device__ __noinline__ dg_pass_res dg_f_wpass(const dg_pt *P, int n, int kind, const double *Fm /* LDS */, double thJ, int *la_, double thL, int *lb_, double thL2,
+                                               double *tile, int lane)
+{
+    n = __builtin_amdgcn_readfirstlane(n); kind = __builtin_amdgcn_readfirstlane(kind);
+    double F[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) F[i] = Fm[i];
+    return dg_wpass_impl<LDSPTS>(P, n, [&](const dg_pt &q) { return dg_Ferr(kind, F, q); }, thJ, la_, thL, lb_, thL2, tile, lane);
+}
+
+#define DG_LO_ASSUMED_DRAWS 16          /* two 8-subsets per repetition: the most frequent count (62 % on C2 data) */
+/* one repetition (sample lg->ids, generator lg->g right behind the sample's draws, iterID for the table lookups) by one wave:
+ * the 14-point fit and exp_iterFcustom (exp_ranF.c:621-743) */
+template <int LDSPTS>
+__device__ __noinline__ void dg_lo_rep_wave(CTX &c, dg_lo_log *lg, int ssiz, double th, int mk_full, int mk_ex, int lane, int wave)
+{
+    dg_f_shared *S = c.S; const int n = c.n, nm = c.K->n_max; const dg_pt *P = c.P;
+    dg_wave_ws *w = &S->ww[wave];
+    int *ib = c.K->wlist + (size_t)wave * nm;                                    /* this repetition's `inliers` (intbuff) */
+    int *alt = (int *)(c.K->wstage + (size_t)wave * nm);
+    double *jb = w->Z;                                                           /* the passes' MSAC-term tile: Z .. px, idle during a pass */
+    double *f = w->F, *fl = w->H, *wts = w->cpx, *ftmp = w->cpx + 8;
+    const bool small_ids = n < 65536;
+    /* an earlier repetition of this round has finished with another number of draws than this one's start state assumes:
+     * this repetition will not be committed, stop it */
+#ifdef DG_LO_PROF
+    long long tw_ = wall_clock64(); const long long tw0_ = tw_;
+#define DG_RW(i) do { if (wave == 0 && lane == 0) { long long t_ = wall_clock64(); S->lt[i] += t_ - tw_; tw_ = t_; } } while (0)
+#else
+#define DG_RW(i) do {} while (0)
+#endif
+    auto stale = [&]() {
+        int bad = 0;
+        if (lane < wave) { const int d = __hip_atomic_load(&S->lo[lane].pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); bad = d >= 0 && d != DG_LO_ASSUMED_DRAWS; }
+        return __ballot(bad) != 0ull;
+    };
+    int drawn = 0;
+    /* the sample's model */
+    DG_WSYNC();
+    dg_gather_wave(c, lane < ssiz ? lg->ids[lane] : 0, ssiz, w->px, lane);
+    DG_WSYNC();
+    dg_u2f_small_wave(w, w->px, (const double *)0, ssiz, f, lane);
+    DG_RW(8);
+    /* errs[4] = errs[0] = FDS1(f): inlidxs(.., th) and the list at th * MWM */
+    const dg_pass_res r0 = dg_f_wpass<LDSPTS>(P, n, mk_full, f, th, ib, th * DG_MWM, (int *)0, 0.0, jb, lane);
+    DG_RW(9);
+    unsigned mI = r0.I; double mJ = r0.J; int kind0 = mk_full;
+    if (lane == 0) { lg->I0 = (int)r0.I; lg->drew0 = 0; lg->nit = 0; lg->has_fin = 0; }
+    if (mI < 8) { if (lane == 0) { lg->I = 0; lg->J = 0; lg->kind0 = mk_full; __hip_atomic_store(&lg->pub, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } DG_WSYNC(); return; }
+    /* the first 8-point model */
+    {
+        const int cnt = (int)r0.nL; int id;
+        if (8 < cnt) { dg_randsubset_wave(&lg->g, ib, cnt, 8, lane, &id); if (lane == 0) lg->drew0 = 8; drawn += 8; }
+        else id = lane < cnt ? ib[lane] : 0;
+        const int use = 8 < cnt ? 8 : cnt;
+        DG_WSYNC();
+        dg_gather_wave(c, id, use, w->px, lane);
+        DG_WSYNC();
+        dg_u2f_small_wave(w, w->px, (const double *)0, use, fl, lane);
+    }
+    DG_RW(10);
+    double ths = DG_TC * th; const double dth = (ths - th) / DG_ILSQ_ITERS;
+    int it = 0, ended = 0;
+    for (; it < DG_ILSQ_ITERS; it++) {
+        if (stale()) { if (lane == 0) lg->aborted = 1; DG_WSYNC(); return; }
+        const dg_pass_res r1 = dg_f_wpass<LDSPTS>(P, n, mk_ex, fl, th, ib, th, alt, ths * DG_MWM, jb, lane);
+        const int improve = mJ < r1.J;
+        unsigned nL2 = r1.nL2;
+        /* exp_ranF.c:687-696: after a rotation `d` is the OLD errs[0]: that list is taken on the residuals of the previous best */
+        if (improve) { const dg_pass_res r2 = dg_f_wpass<LDSPTS>(P, n, kind0, f, 0.0, alt, ths * DG_MWM, (int *)0, 0.0, jb, lane); nL2 = r2.nL; }
+        const int fit = nL2 >= 8;
+        DG_WSYNC();
+        DG_RW(9);
+        const unsigned hash = dg_hash_list(ib, (int)r1.I, small_ids);
+        if (lane == 0) { lg->it[it].hash = hash; lg->it[it].I = (int)r1.I; lg->it[it].drew = 0; lg->nit = it + 1; }
+        /* a set an EARLIER round or local optimisation inserted ends the repetition here whatever the others of this round do
+         * (the table is not written before the replay) */
+        { int known = 0; if (lane == 0) known = dg_ht_contains(c.ht, hash, (int)r1.I, -1) != -1; DG_RW(11); if (__builtin_amdgcn_readfirstlane(known)) { ended = 2; break; } }
+        if (fit) {
+            const int cnt = (int)nL2; int id;
+            if (8 < cnt) { dg_randsubset_wave(&lg->g, alt, cnt, 8, lane, &id); if (lane == 0) lg->it[it].drew = 8; drawn += 8; }
+            else id = lane < cnt ? alt[lane] : 0;
+            const int use = 8 < cnt ? 8 : cnt;
+            DG_WSYNC();
+            if (lane < use) {
+                const dg_pt q = dg_ldpt<LDSPTS>(P, id);
+                double *px = w->px + 4 * lane; px[0] = q.x1; px[1] = q.y1; px[2] = q.x2; px[3] = q.y2;
+                if (mk_ex == DG_K_FDS) wts[lane] = dg_exFDs_w(fl, q.x1, q.y1, q.x2, q.y2);
+                else { double ww_; dg_exFDsSym(fl, q.x1, q.y1, q.x2, q.y2, &ww_); wts[lane] = ww_; }
+            }
+            DG_WSYNC();
+            dg_u2f_small_wave(w, w->px, wts, use, ftmp, lane);
+        }
+        if (improve) { mI = r1.I; mJ = r1.J; kind0 = mk_ex; DG_WSYNC(); if (lane < 9) f[lane] = fl[lane]; DG_WSYNC(); }
+        /* the reference builds this list (and shuffles it) in `inliers` itself */
+        for (int j = lane; j < (int)nL2; j += 64) ib[j] = alt[j];
+        DG_WSYNC();
+        if (lane < 9 && fit) fl[lane] = ftmp[lane];
+        DG_WSYNC();
+        DG_RW(10);
+        if (!fit) { ended = 1; break; }
+        ths -= dth;
+    }
+    if (!ended) {
+        const dg_pass_res r3 = dg_f_wpass<LDSPTS>(P, n, mk_full, fl, th, ib, th, (int *)0, 0.0, jb, lane);
+        if (lane == 0) lg->has_fin = 1;
+        if (mJ < r3.J) { mI = r3.I; mJ = r3.J; kind0 = mk_full; DG_WSYNC(); if (lane < 9) f[lane] = fl[lane]; DG_WSYNC(); }
+    }
+    DG_WSYNC();
+    if (lane < 9) lg->f[lane] = f[lane];
+#ifdef DG_LO_PROF
+    DG_RW(9);
+    if (wave == 0 && lane == 0) { S->lt[12] += wall_clock64() - tw0_; S->lt[13] += 100000; }
+#endif
+    if (lane == 0) { lg->I = (int)mI; lg->J = mJ; lg->kind0 = kind0; __hip_atomic_store(&lg->pub, drawn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    DG_WSYNC();
+}
+
+template <int LDSPTS>
+__device__ __noinline__ dg_score dg_inFrani_waves(CTX &c, int ninl, double th, double *Fout, int *iterID, int mk_full, int mk_ex, int *kindBest)
+{
+    dg_f_shared *S = c.S; const int tid = c.tid, lane = tid & 63, wave = tid >> 6;
+    int *inliers = c.K->L[0], *intbuff_best = c.K->L[2];
+    dg_score maxS = {0, 0, 0, 0};
+    *kindBest = mk_full;
+    if (ninl < 16) return maxS;
+    int ssiz = ninl / 2; if (ssiz > 14) ssiz = 14;
+    int next = 0;
+#ifdef DG_LO_PROF
+#define DG_LW(i) do { if (tid == 0) { long long t_ = wall_clock64(); S->lt[i] += t_ - S->ltq; S->ltq = t_; } } while (0)
+#else
+#define DG_LW(i) do {} while (0)
+#endif
+    while (next < DG_RAN_REP) {
+        const int nr = DG_RAN_REP - next < DG_NW ? DG_RAN_REP - next : DG_NW;
+        __syncthreads();
+        DG_LW(7);
+        if (__builtin_amdgcn_readfirstlane(wave) == 0) {
+            if (lane == 0) S->lo_work = S->rng;
+            DG_WSYNC();
+            for (int q = 0; q < nr; q++) {
+                /* the sample of repetition next + q: the draws, the slots they store (kept with the values they replace) */
+                dg_lo_log *g = &S->lo[q];
+                int id = 0;
+                dg_randsubset_wave_ahead(&S->lo_work, inliers, ninl, ssiz, lane, &id, g->upos, g->uval);
+                if (lane < ssiz) g->ids[lane] = id;
+                if (lane < 2 * ssiz && g->upos[lane] >= 0) { const int old = inliers[g->upos[lane]]; inliers[g->upos[lane]] = g->uval[lane]; g->uval[lane] = old; }
+                if (lane == 0) { g->g = S->lo_work; g->g0 = S->lo_work; g->pub = -1; g->aborted = 0; for (int k = 0; k < DG_LO_ASSUMED_DRAWS; k++) dg_rand(&S->lo_work); }
+                DG_WSYNC();
+            }
+        }
+        __syncthreads();
+        DG_LW(0);
+        if (wave < nr) dg_lo_rep_wave<LDSPTS>(c, &S->lo[wave], ssiz, th, mk_full, mk_ex, lane, wave);
+        __syncthreads();
+        DG_LW(1);
+        /* replay in repetition order (thread 0): the hash table with each repetition's own iterID, what it really drew */
+        if (tid == 0) {
+            int v = 0;
+            for (int q = 0; q < nr; q++) {
+                dg_lo_log *g = &S->lo[q];
+                if (g->aborted) break;                            /* stopped as stale: it runs again in the next round (q >= 1 here) */
+                const int id = *iterID + next + q + 1;
+                int draws = 0, cut = 0, n_ex = 0;
+                if (g->I0 >= 8) {
+                    draws = g->drew0;
+                    for (int i = 0; i < g->nit; i++) {
+                        n_ex++;
+                        const int ret = dg_ht_contains(c.ht, g->it[i].hash, g->it[i].I, id);
+                        if (ret == -1) dg_ht_insert(c.ht, g->it[i].hash, g->it[i].I, id);
+                        if (ret != -1 && ret != id) { cut = 1; break; }
+                        draws += g->it[i].drew;
+                    }
+                }
+                g->cut = cut; g->draws = draws; g->n_ex = n_ex; g->n_fd = (!cut && g->has_fin) ? 2 : 1;
+                v++;
+                if (draws != DG_LO_ASSUMED_DRAWS) break;
+            }
+            S->red.bi[0] = v;
+        }
+        __syncthreads();
+        DG_LW(2);
+        const int v = S->red.bi[0];
+#ifdef DG_LO_PROF
+        if (tid == 0) { S->lt[5] += 100000; S->lt[6] += 100000 * v; }
+#endif
+        for (int q = 0; q < v; q++) {
+            const dg_lo_log *g = &S->lo[q];
+            c.n_exfds += g->n_ex; c.n_fds += g->n_fd;
+            const int cut = g->cut;
+            if (!cut && maxS.J < g->J) {
+                maxS.I = (unsigned)g->I; maxS.J = g->J; maxS.Is = 0; maxS.Ilafs = 0; *kindBest = g->kind0;
+                const int *ibq = c.K->wlist + (size_t)q * c.K->n_max;
+                __syncthreads();
+                if (tid < 9) Fout[tid] = g->f[tid];
+                for (int j = tid; j < g->I; j += DG_T) intbuff_best[j] = ibq[j];
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        DG_LW(3);
+        if (__builtin_amdgcn_readfirstlane(wave) == 0) {
+            /* the list order behind repetition next + v - 1: undo the samples of the repetitions that were not committed, last first;
+             * the exact generator state behind it: the state behind its sample, then the draws it really consumed */
+            for (int q = nr - 1; q >= v; q--) {
+                if (lane < 2 * ssiz && S->lo[q].upos[lane] >= 0) inliers[S->lo[q].upos[lane]] = S->lo[q].uval[lane];
+                DG_WSYNC();
+            }
+            if (lane == 0) { S->rng = S->lo[v - 1].g0; for (int k = 0; k < S->lo[v - 1].draws; k++) dg_rand(&S->rng); }
+            DG_WSYNC();
+        }
+        next += v;
+#ifdef DG_LO_PROF
+        __syncthreads();
+#endif
+        DG_LW(4);
+    }
+    *iterID += DG_RAN_REP;
+    __syncthreads();
+    for (int j = tid; j < (int)maxS.I; j += DG_T) inliers[j] = intbuff_best[j];
+    __syncthreads();
+    return maxS;
+}
+
+template <int LDSPTS>
+__device__ __forceinline__ dg_score dg_inFrani(CTX &c, int ninl, double th, double *Fout, int *iterID, int mk_full, int mk_ex, int *kindBest)
+{
+    /* the serial order for the residual dump (its rows are written in repetition order), for the cooperative large-n mode
+     * (its passes are distributed over workgroups instead) and on request */
+    if (c.rrun || c.cb || c.A->innerh_serial || c.A->trace) return dg_inFrani_serial<LDSPTS>(c, ninl, th, Fout, iterID, mk_full, mk_ex, kindBest);
+    return dg_inFrani_waves<LDSPTS>(c, ninl, th, Fout, iterID, mk_full, mk_ex, kindBest);
 }
 
 /* One 7-point problem per lane, registers only (own register allocation: not inlined into the driver).

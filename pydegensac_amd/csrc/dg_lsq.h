@@ -23,7 +23,7 @@ struct dg_lsq_scratch {
 /* per-wave scratch for the wave-parallel sections (checksample's 5 triplets, innerFH's repetitions): the
  * members the templated small solvers touch have the same names as in dg_lsq_scratch */
 struct dg_wave_ws {
-    double Z[24 * 9], V[81], D[9], A1[3], A2[3], px[14 * 4];     /* Z: 14 rows of an F fit or 2 x 12 rows of an H fit (innerH's repetitions, one per wave) */
+    double Z[14 * 9], V[81], D[9], A1[3], A2[3], px[14 * 4];     /* Z .. px also serve as the MSAC-term tile of a wave's pass (dg_wpass_impl): idle then */
     dg_eig_ws ews;
     double H[9], F[9], Ds[7], sDs[7], cpx[20];
     int idx[8], res, cnt;
@@ -134,6 +134,30 @@ __device__ __noinline__ void dg_u2f_small_w(dg_lsq_scratch *s, const double *p, 
     }
 }
 
+/* dg_u2f_small_w on a wave's own scratch (dg_wave_ws: Z doubles as the 9 x 8 system, V as the left factor's column) */
+__device__ __noinline__ void dg_u2f_small_wave(dg_wave_ws *s, const double *p, const double *wts /* LDS or 0 */, int len, double *F, int lane)
+{
+    if (len > 8) {
+        dg_u2f_norm_w(s, p, wts, len, F, lane);
+    } else {
+        for (int e = lane; e < 72; e += 64) {
+            const int r = e >> 3, i = e & 7, k = r / 3, l = r - 3*k;
+            double z = 0.;
+            if (i < len) {
+                const double a = l == 2 ? 1.0 : p[4*i + l], b = k == 2 ? 1.0 : p[4*i + 2 + k];
+                z = b * a;
+            }
+            const int wi = e % 9;
+            if (wts && wi < len && wi < 8) z *= wts[wi];
+            s->Z[e] = z;
+        }
+        DG_WSYNC();
+        dg_svd_lastcol_9x8_wave(s->Z, s->V, lane);
+        if (lane == 0) { for (int i = 0; i < 9; i++) F[i] = s->V[i]; dg_singulF(F); }
+        DG_WSYNC();
+    }
+}
+
 /* > 4 points: normalised DLT for any scratch type with members Z (>= 18*len), V, D, A1, A2, ews */
 template <class SC>
 __device__ __forceinline__ void dg_u2h_norm_w(SC *s, const double *p, int len, double *H, int lane)
@@ -151,6 +175,45 @@ __device__ __forceinline__ void dg_u2h_norm_w(SC *s, const double *p, int len, d
     if (lane == 0) for (int i = 0; i < 3; i++) { s->A1[i] = A1[i]; s->A2[i] = A2[i]; }
     DG_WSYNC();
     dg_cov9_wave(s->V, s->Z, 2*len, lane);
+    DG_WSYNC();
+    dg_eig_sym_wave(s->V, s->D, lane, &s->ews);
+    if (lane == 0) { for (int i = 0; i < 9; i++) H[i] = s->V[i]; dg_denormH(H, s->A1, s->A2); }
+    DG_WSYNC();
+}
+
+/* dg_u2h_norm_w without the 2 len x 9 design matrix in LDS (a wave's own scratch holds 14 rows): the 45 lanes of the normal
+ * matrix form the entries of the DLT rows on the fly from the normalised coordinates — the same products and the same
+ * sums in the same order as lin_hgN + cov_mat (Htools.c:60-99, utools.c:170-184), so the same bits.  len <= 14. */
+__device__ __forceinline__ void dg_u2h_norm_wave_noz(dg_wave_ws *s, const double *p, int len, double *H, int lane)
+{
+    double A1[3], A2[3];
+    dg_normu_small(p, len, A1, A2);
+    /* normalised coordinates of point i: Z[4 i] = a0, a1, b0, b1 */
+    if (lane < len) {
+        const int i = lane;
+        s->Z[4*i] = p[4*i] * A1[0] + A1[1]; s->Z[4*i+1] = p[4*i+1] * A1[0] + A1[2];
+        s->Z[4*i+2] = p[4*i+2] * A2[0] + A2[1]; s->Z[4*i+3] = p[4*i+3] * A2[0] + A2[2];
+    }
+    if (lane == 0) for (int i = 0; i < 3; i++) { s->A1[i] = A1[i]; s->A2[i] = A2[i]; }
+    DG_WSYNC();
+    if (lane < 45) {
+        int ie = 0; while ((ie+1)*(ie+2)/2 <= lane) ie++;
+        const int je = lane - ie*(ie+1)/2;
+        /* entry c of DLT row r (0: the x row, 1: the y row) of a point: (b_j, 0, -a0 b_j) resp. (0, b_j, -a1 b_j), j = c / 3 */
+        auto zent = [](int r, int c, double a0, double a1, double b0, double b1) {
+            const int j = c / 3, m = c - 3 * j;
+            const double bj = j == 0 ? b0 : (j == 1 ? b1 : 1.0);
+            if (m == 2) return -(r == 0 ? a0 : a1) * bj;
+            return m == r ? bj : 0.0;
+        };
+        double val = 0;
+        for (int k = 0; k < len; k++) {
+            const double a0 = s->Z[4*k], a1 = s->Z[4*k+1], b0 = s->Z[4*k+2], b1 = s->Z[4*k+3];
+            val += zent(0, ie, a0, a1, b0, b1) * zent(0, je, a0, a1, b0, b1);
+            val += zent(1, ie, a0, a1, b0, b1) * zent(1, je, a0, a1, b0, b1);
+        }
+        s->V[9*ie+je] = val; s->V[ie+9*je] = val;
+    }
     DG_WSYNC();
     dg_eig_sym_wave(s->V, s->D, lane, &s->ews);
     if (lane == 0) { for (int i = 0; i < 9; i++) H[i] = s->V[i]; dg_denormH(H, s->A1, s->A2); }

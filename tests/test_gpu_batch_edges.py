@@ -72,7 +72,7 @@ def test_tuning_fields_that_do_not_apply_are_rejected():
     with pytest.raises(ValueError):
         pd.findHomographyBatch([p1], [p2], seeds=[1], tuning=_lib.TUNE_LONG_SHIFT(2))
     with pytest.raises(ValueError):
-        pd.findHomographyBatch([p1], [p2], seeds=[1], tuning=_lib.TUNE_F_SERIAL_INNERH)
+        pd.findHomographyBatch([p1], [p2], seeds=[1], tuning=_lib.TUNE_F_SERIAL_REPS)
     pd.findFundamentalMatrixBatch([p1], [p2], seeds=[1], tuning=_lib.TUNE_LONG_SHIFT(2) | _lib.TUNE_SET_ASIDE(4))      # applies: accepted
     pd.findHomographyBatch([p1], [p2], seeds=[1], tuning=_lib.TUNE_H_SERIAL_LO)
 

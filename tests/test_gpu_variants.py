@@ -70,27 +70,29 @@ def test_cooperative_helpers_match_the_oracle(oracle_port):
             _check_against_oracle(oracle_port, A, B, seeds, F, m, pd.last_stats(), (variant, helpers, dist))
 
 
-def test_innerH_one_repetition_per_wave_equals_the_serial_order(oracle_port):
-    """The DEGENSAC branch's innerH (ranH.c:18-135) runs its ten repetitions one per wave from speculated generator states
-    and commits them in order (dg_innerH_waves); the serial order is kept behind TUNE_F_SERIAL_INNERH.  Plane-dominated
-    scenes (every pair has DEGENSAC events, Ih > 0), every workgroup size = rounds of 8 / 4 / 2 repetitions, placements
-    LDS and workspace: both orders against the CPU oracle pair by pair (counters incl. the H passes, masks, models)."""
+def test_repetitions_one_per_wave_equal_the_serial_order(oracle_port):
+    """The local optimisation (exp_inFranicustom, exp_ranF.c:745-806) and the DEGENSAC branch's innerH (ranH.c:18-135) run
+    their ten repetitions one per wave from speculated generator states and commit them in order (dg_inFrani_waves,
+    dg_innerH_waves); the serial order is kept behind TUNE_F_SERIAL_REPS.  Plane-dominated scenes (DEGENSAC events, Ih > 0)
+    and ordinary ones (several LO runs), every workgroup size = rounds of 8 / 4 / 2 repetitions, placements LDS and
+    workspace: both orders against the CPU oracle pair by pair (counters incl. every kind of pass, masks, models)."""
     A, B = [], []
-    for i, (n, pf, ir) in enumerate([(1500, 0.7, 0.4), (400, 0.9, 0.5), (2000, 0.6, 0.4), (800, 0.8, 0.3), (1200, 0.5, 0.6), (300, 0.95, 0.6)]):
+    for i, (n, pf, ir) in enumerate([(1500, 0.7, 0.4), (400, 0.9, 0.5), (2000, 0.6, 0.4), (800, 0.8, 0.3), (1200, 0.5, 0.6), (300, 0.95, 0.6),
+                                     (2000, 0.0, 0.4), (900, 0.0, 0.25), (150, 0.0, 0.5), (40, 0.0, 0.8)]):
         p1, p2, _, _ = syn.two_view_fundamental(n, ir, 0.1, seed=70 + i, plane_fraction=pf); A.append(p1); B.append(p2)
-    seeds = [11, 12, 13, 14, 15, 16]
+    seeds = [11, 12, 13, 14, 15, 16, 17, 18, 19, 20]
     ora = [oracle_port.find_fundamental(A[p], B[p], 0.5, 0.9999, 20000, seed=seeds[p]) for p in range(len(A))]
-    assert sum(o[2]["Ih"] > 0 for o in ora) >= 4, "the scenes must reach innerH"
+    assert sum(o[2]["Ih"] > 0 for o in ora) >= 4 and sum(o[2]["lo_runs"] >= 2 for o in ora) >= 4, "the scenes must reach innerH and run several local optimisations"
     for variant in (512, 256, 128):
         for mode in (1, 0):
-            for serial in (0, _lib.TUNE_F_SERIAL_INNERH):
+            for serial in (0, _lib.TUNE_F_SERIAL_REPS):
                 F, m = pd.findFundamentalMatrixBatch(A, B, max_iters=20000, seeds=seeds, tuning=tune(variant, mode) | serial)
                 st = pd.last_stats()
                 for p in range(len(A)):
                     Fo, mo, so = ora[p]
                     key = lambda s_: (s_["samples"], s_["lo_runs"], s_["degen"], s_["Ih"], s_["models"])
                     assert key(st[p]) == key(so), (variant, mode, serial, p, st[p], so)
-                    assert st[p]["h_passes"] == so["hds_passes"], (variant, mode, serial, p)
+                    assert (st[p]["h_passes"], st[p]["full_passes"], st[p]["ex_passes"]) == (so["hds_passes"], so["full_passes"], so["ex_passes"]), (variant, mode, serial, p)
                     assert np.array_equal(np.asarray(m[p]), mo.astype(bool)), (variant, mode, serial, p)
                     a = np.asarray(F[p]).ravel(); b = np.asarray(Fo).ravel()
                     assert np.linalg.norm(a - b) <= 1e-9 * np.linalg.norm(b), (variant, mode, serial, p)

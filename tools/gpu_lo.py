@@ -21,6 +21,9 @@ rc=L.mi_degensac_find_fundamental_batch_dev(d_a.data_ptr(),d_b.data_ptr(),d_off.
 torch.cuda.synchronize()
 ph=d_ph.cpu().numpy().astype(np.float64)/1e5; st=d_st.cpu().numpy()
 names=["other","init pass","first fit","EX pass","Ss pass","hash||fit","commit","final pass","u2f14","-","reps taken from look-ahead (count x 1e5)","reps fitted (count x 1e5)"]
+if os.environ.get("MI_DEGENSAC_TUNING", "0") in ("0", "1", "2", "3"):      # default = one repetition per wave (dg_inFrani_waves): its own timers
+    names=["round: planning","round: repetitions (barrier to barrier)","round: replay","round: commit","round: generator / list restore","rounds (count x 1e5)","repetitions committed (count x 1e5)","between rounds",
+           "wave 0: 14-point fit","wave 0: passes","wave 0: 8-point fits","wave 0: hash + lookup","wave 0: whole repetitions","wave 0: repetitions (count x 1e5)"]
 lo=st[:,1].mean()
 print("lo_runs mean",lo,"ex_passes mean",st[:,9].mean())
 for i,nm in enumerate(names):

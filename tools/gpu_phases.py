@@ -17,7 +17,7 @@ dev=torch.device('cuda',0)
 d_a=torch.from_numpy(a).to(dev); d_b=torch.from_numpy(b).to(dev); d_off=torch.from_numpy(offs).to(dev)
 d_seeds=torch.from_numpy(parallel.pair_seeds(0,P).astype(np.int64)).to(dev).to(torch.int32)
 d_F=torch.zeros((P,9),dtype=torch.float64,device=dev); d_mask=torch.zeros(P*N,dtype=torch.uint8,device=dev); d_st=torch.zeros((P,16),dtype=torch.int32,device=dev)
-d_ph=torch.zeros((P,16),dtype=torch.int64,device=dev)
+d_ph=torch.zeros((2*P+4096,16),dtype=torch.int64,device=dev)   # + the workgroups' exit times and the set-aside records of the dev build
 L.mi_degensac_debug_phases(C.c_void_p(d_ph.data_ptr()))
 prm=_lib.make_params(0.5,0.9999,MI,0,True,0.0,True)
 for it in range(2):
@@ -25,7 +25,7 @@ for it in range(2):
     rc=L.mi_degensac_find_fundamental_batch_dev(d_a.data_ptr(),d_b.data_ptr(),d_off.data_ptr(),offs.ctypes.data_as(C.POINTER(C.c_int64)),P,2,C.byref(prm),d_seeds.data_ptr(),0,None,d_F.data_ptr(),d_mask.data_ptr(),d_st.data_ptr())
     torch.cuda.synchronize(); dt=time.perf_counter()-t
 print("rc",rc,"batch ms",dt*1e3)
-ph=d_ph.cpu().numpy().astype(np.float64)/1e5  # ms
+ph=d_ph.cpu().numpy()[:P].astype(np.float64)/1e5  # ms
 st=d_st.cpu().numpy()
 names=["sample","solve","score","commit+misc","LO","degen","tail","total","innerH","rFtH_gen","rFtH_score","rFtH_trig","chain","draws","pool","d7"]
 print("mean ms per pair:", {n:round(float(ph[:,i].mean()),3) for i,n in enumerate(names)})
