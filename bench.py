@@ -451,7 +451,8 @@ def main():
                                  "below it: inputs once, then model tables, lists and scratch"},
             "parity_checked": r["n_checked"], "parity_checked_set_aside": r["n_aside_checked"],
             "kernel_variant": {"threads": int(local_st[0, 14]), "placement": int(local_st[0, 15]) & 255},
-            "pairs_set_aside": int((local_st[:, 15] >> 8).sum()),        # pairs written back after the discovery round and resumed by priority
+            "pairs_set_aside": int(((local_st[:, 15] >> 8) & 1).sum()),
+            "pairs_streamed": int(((local_st[:, 15] >> 9) & 1).sum()),   # pairs whose sample stream / solves / scoring moved to a producer workgroup (stream mode)        # pairs written back after the discovery round and resumed by priority
         }
         if world == 1:
             out["single_call_ms"] = single_call_ms()

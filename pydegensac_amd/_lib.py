@@ -163,8 +163,16 @@ def make_params(px_th, conf, max_iters, error_type, sym_check, laf_coef, degen=T
                   float(laf_coef), int(flags), int(tuning))
 
 
+def set_stream_mode(mode):
+    """stream mode of the fundamental-matrix kernel (include/mi_degensac.h): -1 automatic, 0 off, odd > 0 = on with test bits; returns the previous mode"""
+    f = lib().mi_degensac_set_stream_mode
+    f.restype = C.c_int; f.argtypes = [C.c_int]
+    return int(f(int(mode)))
+
+
 def stats_dict(st):
     d = {k: int(v) for k, v in zip(STAT_NAMES, st)}
-    d["set_aside"] = d["placement"] >> 8          # the pair was written back to its workspace once and resumed later
+    d["set_aside"] = (d["placement"] >> 8) & 1    # the pair was written back to its workspace once and resumed later
+    d["streamed"] = (d["placement"] >> 9) & 1     # the pair took chunks from a producer workgroup (stream mode)
     d["placement"] &= 255
     return d

@@ -125,6 +125,31 @@ struct dg_coop_job {
 struct dg_coop_rec { unsigned I, nL, nL2, nJ; };
 #define DG_COOP_MAX_SLICES 64
 
+/* Stream mode (fundamental matrix, placements LDS / pool-in-LDS): a pair with many samples left gets a PRODUCER workgroup — any
+ * workgroup of the launch that has run out of pairs — which takes over the outcome-independent part of the pair's main loop:
+ * the sample stream (seed chain, draws, pool swaps), the 7-point solves and the screening / scoring of every chunk, with a
+ * bound tau it reads from the owner.  The owner keeps the pair's state and only commits the chunks in order (and runs the
+ * local optimisations and the DEGENSAC branch they trigger), so its events overlap the sampling instead of alternating with
+ * it.  Hand-over = the image the owner writes for setting a pair aside (the complete state between two chunks, wl.off_park):
+ * the producer resumes that image in producer mode, skips the chunks the owner has meanwhile committed (sampler stages only)
+ * and then leaves one dg_stream_ent per chunk in the owner's ring.  One control block per resident workgroup (owner slot).
+ * Flags on the first 128-byte line, touched with agent-scope atomics only; the payload (image, ring entries) is plain memory
+ * behind the usual release / acquire pair (MI355X_MICROARCH.md, inter-workgroup visibility). */
+enum { DG_ST_IDLE = 0, DG_ST_REQ = 1, DG_ST_BUSY = 2, DG_ST_ATTACHED = 3, DG_ST_RELEASED = 4 };
+struct dg_stream_cb {
+    int state;                /* DG_ST_*: IDLE -> REQ (image valid) -> ATTACHED (a producer took it) -> RELEASED (producer gone) -> IDLE; BUSY = the owner rewrites the image */
+    int head;                 /* chunks the producer has published: sequence numbers < head are in the ring */
+    int tail;                 /* chunks the owner has consumed */
+    int stop;                 /* the owner is done with the pair */
+    int owner_sam;            /* the sample the owner stands at (chunks that start before it are of no use) */
+    int max_sam;              /* the owner's current sample budget */
+    unsigned long long tau_bits;   /* the owner's current bound min(maxS.J, maxSs.J), as the bits of a double */
+    int fpad[24];
+    /* second line: written by the owner before the release that opens the request */
+    int pair, wsid, img_sam, ppad[29];
+};
+static_assert(sizeof(dg_stream_cb) == 256, "stream control block = two 128-byte lines");
+
 struct dg_args {
     const double *pts1, *pts2;       /* [total, dim] */
     const long long *offsets;        /* [n_pairs + 1] */
@@ -169,6 +194,17 @@ struct dg_args {
     int pool_seq;                    /* 1 = always use the sequential pool-swap stage (LDS exchange-order self-check failed, or forced) */
     int innerh_serial;               /* fundamental matrix: 1 = the repetitions of innerH and of the local optimisation one after the other on the whole workgroup (tests) */
     int variant_threads, mode;       /* reported in the stats block */
+    /* stream mode (dg_stream_cb): */
+    int stream_on;                   /* 0 = off */
+    int stream_min_sam, stream_min_left;   /* a pair asks for a producer once it has drawn stream_min_sam samples and has at least stream_min_left left */
+    int stream_depth;                /* ring entries per owner */
+    int stream_test;                 /* bit 0: the owner re-scores every chunk it takes from the ring (tests the stale-bound path); bit 1: ask for a producer
+                                        whether or not unstarted pairs remain */
+    size_t stream_ent_bytes;         /* bytes per ring entry (>= sizeof(dg_stream_ent) of every variant) */
+    dg_stream_cb *scb;               /* [n_res] */
+    char *ring;                      /* [n_res][stream_depth] entries */
+    int *done_pairs;                 /* pairs finished (header): workgroups without work leave when it reaches n_pairs */
+    int *err_flag;                   /* set when a wait of the stream mode times out (results are then invalid) */
     int *trace;                      /* debug: [0] = count, then (tag, I, J lo, J hi) records; null = off */
     int trace_cap;
     long long *phase_out;            /* debug: [n_pairs][8] 100 MHz ticks per phase (sample, solve, score, commit+events, LO, degen, tail, total) */

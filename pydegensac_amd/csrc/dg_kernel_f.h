@@ -122,6 +122,20 @@ struct dg_f_shared {
     dg_f_cshared K;                      /* the pair's workspace views (dg_f_ctx::K) */
 };
 
+/* stream mode: one chunk as the producer workgroup leaves it in the owner's ring.  Past the first samples nearly every model
+ * of a chunk fails the screens, so the entry is compact: the sample stream itself (seeds, drawn ids: what an event of the commit
+ * re-seeds from and gathers, and what the owner needs to solve and score the chunk itself should the bound have fallen), the
+ * number of models of every sample, and the few models whose MSAC gain exceeds the bound the producer used (with more than
+ * DG_STREAM_EV_MAX of them — the first chunks of a pair — `overflow` tells the owner to solve and score the chunk itself). */
+struct dg_stream_ev { double model[9]; double J; unsigned I; short k; unsigned char r, pad; unsigned char ridx[4]; };
+#define DG_STREAM_EV_MAX 40
+struct dg_stream_ent {
+    int cn, Mtot, n_ev, overflow; double tau_used, pad1;
+    unsigned seeds[DG_CHUNK]; int draws[DG_CHUNK][8];
+    unsigned char nv[DG_CHUNK];
+    dg_stream_ev ev[DG_STREAM_EV_MAX];
+};
+
 /* ------------------------------------------------------------------------------------------------ */
 /* ------------------------------------------------------------------------------------------------ */
 template <int LDSPTS>

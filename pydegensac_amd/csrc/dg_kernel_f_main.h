@@ -1378,14 +1378,94 @@ __device__ __noinline__ dg_pass_res dg_coop_pass(CTX &c, const double *Fm /* LDS
     return out;
 }
 
+/* ---- stream mode (dg_stream_cb, dg_stream_ent) -------------------------------------------------------------------- */
+#define DG_STREAM_TIMEOUT 400000000ll         /* 4 s of the 100 MHz clock: a wait that long is a bug; flag it and go on instead of hanging */
+__device__ __forceinline__ dg_stream_ent *dg_stream_entry(const dg_args &A, int oslot, int seq)
+{
+    return (dg_stream_ent *)(A.ring + ((size_t)oslot * A.stream_depth + (size_t)(seq % A.stream_depth)) * A.stream_ent_bytes);
+}
+/* whole workgroup: wait until *flag (agent-scope) satisfies `pred` or the owner's stop flag is up (stop = null: ignore); returns the
+ * value seen (workgroup-uniform), -1 on timeout / stop.  The whole first wave polls behind a scalar branch. */
+template <class Pred>
+__device__ __forceinline__ int dg_stream_wait(const dg_args &A, int *flag, int *stop, Pred pred, int *bc /* LDS */)
+{
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
+        const long long t0 = wall_clock64();
+        int v;
+        for (;;) {
+            v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (pred(v)) break;
+            if (stop && __builtin_amdgcn_readfirstlane(__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { v = -1; break; }
+            if (wall_clock64() - t0 > DG_STREAM_TIMEOUT) { if (threadIdx.x == 0) __hip_atomic_store(A.err_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = -1; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *bc = v;                                                             /* every lane stores the same value */
+    }
+    __syncthreads();
+    return *bc;
+}
+/* whole workgroup: the payload written so far becomes visible device-wide, then *flag = v */
+__device__ __forceinline__ void dg_stream_publish(int *flag, int v)
+{
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+/* A workgroup without a pair: the owner slot of a pair that asks for a producer (its request is taken), or -1 once every
+ * pair of the launch is finished. */
+__device__ __forceinline__ int dg_stream_find(const dg_args &A, int *bc /* LDS */)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    for (;;) {
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
+            int res = -2;
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(A.done_pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= A.n_pairs) res = -1;
+            else if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(A.done_pairs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= 0) {
+                /* no open request (done_pairs[1] counts them): nothing to scan; hundreds of idle workgroups poll these two words only */
+                for (int q = 0; q < 8; q++) __builtin_amdgcn_s_sleep(127);
+            } else {
+                int found = -1;
+                for (int j = (int)((blockIdx.x + lane) % (unsigned)A.n_res), q = 0; q < A.n_res && found < 0; q += 64, j = (j + 64) % A.n_res)
+                    if (q + lane < A.n_res && __hip_atomic_load(&A.scb[j].state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == DG_ST_REQ) found = j;
+                const unsigned long long m = __ballot(found >= 0);
+                if (m) {
+                    const int j = __builtin_amdgcn_readlane(found, __ffsll((long long)m) - 1);
+                    int ok = 0;
+                    if (threadIdx.x == 0) {
+                        int e = DG_ST_REQ; ok = __hip_atomic_compare_exchange_strong(&A.scb[j].state, &e, DG_ST_ATTACHED, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+                        if (ok) __hip_atomic_fetch_add(A.done_pairs + 1, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (__builtin_amdgcn_readfirstlane(ok)) { res = j; __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+                } else __builtin_amdgcn_s_sleep(64);
+            }
+            *bc = res;
+        }
+        __syncthreads();
+        const int r = *bc;
+        if (r != -2) return r;
+    }
+}
+
 /* the whole driver for ONE pair, run by one workgroup on workspace `wsid` (a resident workgroup starts on the workspace
  * of its own index).  resume != 0: `wsid` holds the image of a pair that was set aside, continue it.
  * Returns -1 when the pair is finished, else the pair was set aside and the return value is the spare workspace the
  * workgroup continues on. */
 template <int T, int LDSPTS>
+/* resume == 2: PRODUCER of the stream mode: continue the image in `wsid` (the owner's workspace) on this workgroup's own
+ * workspace `own_wsid`, for the owner at slot `oslot`: sample, solve and score chunk after chunk into the owner's ring, never commit. */
 __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsigned char *dyn_smem, const int pair, const int slot, const int wsid,
-                                         const int resume, int &coop_gen)
+                                         const int resume, int &coop_gen, const int own_wsid, const int oslot)
 {
+    const int producer = resume == 2;
+    dg_stream_cb *const scb = A.stream_on ? A.scb + oslot : (dg_stream_cb *)0;
+    int head_seen = 0;               /* owner: ring entries below this sequence number are known to be visible */
+    int strm = 0, img_sam = 0;       /* owner: 0 = own sample stream, 1 = asked for a producer (image written), 2 = takes its chunks from the ring */
     const int coopK = LDSPTS == 0 ? A.coop_k : 0;
     dg_coop_cb *const cb = coopK > 0 ? A.coop + slot : (dg_coop_cb *)0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1395,10 +1475,11 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     const double th = pr.th;
 
     char *ws = A.ws + (size_t)wsid * A.wl.stride;
+    char *const wsown = A.ws + (size_t)own_wsid * A.wl.stride;          /* = ws unless this workgroup is another pair's producer */
     CTX c;
     c.S = S; c.K = (const __attribute__((address_space(3))) dg_f_cshared *)&S->K; c.n = n; c.tid = tid; c.A = &A; c.off = off;
     __syncthreads();                                       /* nobody still reads the previous pair's views */
-    if (tid == 0) dg_fill_views(&S->K, ws, A.wl);
+    if (tid == 0) dg_fill_views(&S->K, wsown, A.wl);
     __syncthreads();
     c.ht.heads = (int *)(ws + A.wl.off_ht); c.ht.count = c.ht.heads + 64; c.ht.ent = c.ht.heads + 80;
     c.seeds = S->seeds3[0]; c.draws = S->draws3[0];
@@ -1498,14 +1579,102 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     dg_copy16(S, pk, sizeof(dg_f_shared), tid);
     dg_copy16(dyn_smem, pk + DG_PARK_DYN_OFF, (size_t)A.dyn_bytes, tid);
     __syncthreads();
-    if (tid == 0) dg_fill_views(&S->K, ws, A.wl);         /* the image carries the views of the same workspace; written again all the same */
+    if (tid == 0) dg_fill_views(&S->K, wsown, A.wl);      /* the image carries the views of the workspace it was written from */
     D = S->park;
     { const long long waited = wall_clock64() - D.t_parked; D.t_start += waited; D.t_best += waited; }   /* reported times = time the pair was being worked on */
     c.n_fds = D.n_fds; c.n_exfds = D.n_exfds; c.n_hds = D.n_hds; c.n_aux = D.n_aux;
     DG_DEVT(if (tid == 0) S->tq = DG_CLK());
     __syncthreads();
   }
+    /* the image of the pair for a producer = the image of a pair that is set aside */
+    auto write_image = [&]() {
+        D.n_fds = c.n_fds; D.n_exfds = c.n_exfds; D.n_hds = c.n_hds; D.n_aux = c.n_aux; D.t_parked = wall_clock64();
+        __syncthreads();
+        if (tid == 0) S->park = D;
+        __syncthreads();
+        char *pk = ws + A.wl.off_park;
+        dg_copy16(pk, S, sizeof(dg_f_shared), tid);
+        dg_copy16(pk + DG_PARK_DYN_OFF, dyn_smem, (size_t)A.dyn_bytes, tid);
+        if (tid == 0) { scb->pair = pair; scb->wsid = wsid; scb->img_sam = no_sam; }
+    };
     while (!done && no_sam < max_sam) {
+        int ff = 0, tail_p = 0;      /* producer: the owner is already past this chunk: sampler stages only; the owner's position */
+        const int seq = no_sam / DG_CHUNK;
+        dg_stream_ent *ent = (dg_stream_ent *)0;
+        if (producer) {
+            /* what the owner says: done?  its budget, its position, its bound */
+            __syncthreads();
+            if (tid == 0) {
+                S->itmp[24] = __hip_atomic_load(&scb->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                S->itmp[25] = __hip_atomic_load(&scb->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                S->itmp[26] = __hip_atomic_load(&scb->max_sam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            const int stop_ = S->itmp[24], tail_ = S->itmp[25], omax_ = S->itmp[26];
+            tail_p = tail_;
+            __syncthreads();
+            if (stop_) break;
+            if (omax_ < max_sam) max_sam = omax_;
+            if (no_sam >= max_sam) break;
+            ff = seq < tail_;
+            if (!ff) {
+                /* room in the ring: the slot of this chunk is free once the owner is done with chunk seq - depth */
+                if (seq - tail_ >= A.stream_depth) {
+                    const int depth_ = A.stream_depth;
+                    if (dg_stream_wait(A, &scb->tail, &scb->stop, [=](int t) { return seq - t < depth_; }, &S->itmp[28]) < 0) break;
+                }
+                ent = dg_stream_entry(A, oslot, seq);
+            }
+        } else if (scb) {
+            if (strm >= 1 && tid == 0) {
+                /* the owner's position, budget and bound for the producer */
+                const double tau_ = maxS.J < maxSs.J ? maxS.J : maxSs.J;
+                __hip_atomic_store(&scb->tau_bits, (unsigned long long)__double_as_longlong(tau_ < 0 ? 0.0 : tau_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&scb->max_sam, max_sam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&scb->tail, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (strm < 2 && !legacy_sym && no_sam >= A.stream_min_sam && max_sam - no_sam >= A.stream_min_left && (strm == 1 || (seq & 3) == 0)) {
+                /* ask for a producer (or renew an unanswered request with a fresh image; or see whether the producer has caught up) */
+                __syncthreads();
+                if (tid == 0) {
+                    int act = 0;                        /* 1 = write the image (the block is mine), 2 = switch to the ring */
+                    if (strm == 0) {
+                        if ((A.stream_test & 2) || __hip_atomic_load(A.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= A.n_pairs) {
+                            int e = DG_ST_IDLE;
+                            if (__hip_atomic_compare_exchange_strong(&scb->state, &e, DG_ST_BUSY, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) act = 1;
+                        }
+                    } else {
+                        const int st_ = __hip_atomic_load(&scb->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (st_ == DG_ST_REQ) {
+                            if (no_sam - img_sam >= 8192) {
+                                int e = DG_ST_REQ;
+                                if (__hip_atomic_compare_exchange_strong(&scb->state, &e, DG_ST_BUSY, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                                    act = 1; __hip_atomic_fetch_add(A.done_pairs + 1, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                            }
+                        } else if (__hip_atomic_load(&scb->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > seq) act = 2;
+                    }
+                    S->itmp[30] = act;
+                }
+                __syncthreads();
+                const int act = S->itmp[30];
+                __syncthreads();
+                if (act == 1) {
+                    if (tid == 0) {
+                        const double tau_ = maxS.J < maxSs.J ? maxS.J : maxSs.J;
+                        __hip_atomic_store(&scb->tau_bits, (unsigned long long)__double_as_longlong(tau_ < 0 ? 0.0 : tau_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&scb->max_sam, max_sam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&scb->tail, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&scb->head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&scb->stop, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    write_image();
+                    dg_stream_publish(&scb->state, DG_ST_REQ);
+                    if (tid == 0) __hip_atomic_fetch_add(A.done_pairs + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    strm = 1; img_sam = no_sam; park_on = 0;
+                } else if (act == 2) strm = 2;
+            }
+        }
         if (park_on && no_sam >= A.park_sam) {
             /* still running after park_sam samples: set the pair aside if unstarted pairs remain and a spare workspace is left */
             park_on = 0;
@@ -1548,9 +1717,69 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         c.seeds = S->seeds3[cur]; c.draws = S->draws3[cur]; chunk_base = no_sam;
         DG_PH(3);
         DG_PH(0);
+        int Mtot = 0, nxt = cur, cn2 = 0;
+      int full = 1;                   /* the chunk's 7-point solves and scoring run in this workgroup */
+      if (strm == 2) {
+        /* ================= the chunk comes from the producer's ring ================= */
+        if (seq >= head_seen) {
+            const int h_ = dg_stream_wait(A, &scb->head, (int *)0, [=](int h) { return h > seq; }, &S->itmp[28]);
+            if (h_ < 0) { done = 1; break; }
+            head_seen = h_;          /* everything below it is visible after this one acquire */
+        }
+        const dg_stream_ent *e_ = dg_stream_entry(A, oslot, seq);
+        for (int i = tid; i < DG_CHUNK; i += DG_T) {
+            S->seeds3[cur][i] = e_->seeds[i];
+#pragma unroll
+            for (int q = 0; q < 8; q++) S->draws3[cur][i][q] = e_->draws[i][q];
+        }
+        if (tid == 0) { S->itmp[24] = e_->cn; S->itmp[25] = e_->Mtot; S->itmp[26] = e_->n_ev; S->itmp[27] = e_->overflow; S->dtmp[31] = e_->tau_used; }
+        __syncthreads();
+        const int cn_ = S->itmp[24], n_ev = S->itmp[26], ovf = S->itmp[27];
+        const double tau_used = S->dtmp[31], tau_now = A.hist_out ? 0.0 : (maxS.J < maxSs.J ? maxS.J : maxSs.J);
+        chunk = cn_ < max_sam - no_sam ? cn_ : max_sam - no_sam;
+        /* more models above the producer's bound than an entry holds (the first chunks of a pair), or the bound has fallen since
+         * the producer screened this chunk (a DEGENSAC completion can lower maxS.J: its screens are no superset any more):
+         * solve and score the chunk here, from the entry's drawn ids */
+        full = ovf || tau_used > tau_now || (A.stream_test & 1);
+        __syncthreads();
+        if (!full) {
+            /* the commit's tables from the entry: models per sample -> slots, every score 0 except the entry's models */
+            const unsigned char nvb = tid < DG_CHUNK ? e_->nv[tid] : (unsigned char)0;
+            const unsigned v = (tid < chunk && nvb != 255) ? (unsigned)nvb : 0u;     /* only the samples this pair still draws count (its budget may end inside the chunk) */
+            unsigned incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            if (lane == 63) S->wave_cnt[wave] = incl;
+            __syncthreads();
+            unsigned wbase = 0;
+            for (int w = 0; w < wave; w++) wbase += S->wave_cnt[w];
+            const unsigned excl = wbase + incl - v;
+            if (tid < DG_CHUNK) {
+                S->moff[tid] = (unsigned short)excl; S->nv[tid] = nvb; S->nsolv[tid] = 0;
+                for (unsigned r = 0; r < v; r++) S->mslot[excl + r] = (unsigned short)(tid * 3 + r);
+            }
+            if (tid == DG_T - 1) S->moff[DG_CHUNK] = (unsigned short)(excl + v);
+            __syncthreads();
+            Mtot = (int)S->moff[DG_CHUNK];
+            for (int i = tid; i < Mtot; i += DG_T) { c.K->res_I[i] = 0; c.K->res_J[i] = 0; }
+            __syncthreads();
+            for (int e = tid; e < n_ev; e += DG_T) {
+                const dg_stream_ev *ev = &e_->ev[e];
+                const int k_ = ev->k, r_ = ev->r, mi = (int)S->moff[k_] + r_;
+                c.K->res_I[mi] = ev->I; c.K->res_J[mi] = ev->J;
+#pragma unroll
+                for (int j = 0; j < 9; j++) c.K->gmodels[(size_t)(k_ * 3 + r_) * 9 + j] = ev->model[j];
+#pragma unroll
+                for (int q = 0; q < 4; q++) S->ridx[k_][q] = ev->ridx[q];
+            }
+            __syncthreads();
+            c.n_fds += Mtot;
+        }
+      }
+      if (full) {
         /* ================= solve: one 7-point problem per lane ================= */
         int nvalid = 0, nullbad = 0; unsigned rixp = 0;
-        if (tid < chunk) {
+        if (!ff && tid < chunk) {
             int r_ = dg_solve7_lane(P, c.draws[tid], c.K->gmodels + (size_t)tid * 27, &rixp, (double *)&S->ww[wave]);
             if (r_ < 0) nullbad = 1; else nvalid = r_;
         }
@@ -1576,10 +1805,17 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             if (tid == DG_T - 1) S->moff[DG_CHUNK] = (unsigned short)(excl + v);
             __syncthreads();
         }
-        const int Mtot = __builtin_amdgcn_readfirstlane((int)S->moff[DG_CHUNK]);
+        Mtot = ff ? 0 : __builtin_amdgcn_readfirstlane((int)S->moff[DG_CHUNK]);
         /* cooperative mode: the chunk's models are scored by whoever claims the units: the helpers of this slot at once,
          * this workgroup after its sampler stages (dg_coop_cb) */
-        const double tau_c = A.hist_out ? 0.0 : (maxS.J < maxSs.J ? maxS.J : maxSs.J);
+        double tau_c = A.hist_out ? 0.0 : (maxS.J < maxSs.J ? maxS.J : maxSs.J);
+        if (producer) {     /* the owner's bound as it stands now (it may fall later: the owner checks tau_used when it takes the chunk) */
+            __syncthreads();
+            if (tid == 0) S->dtmp[31] = __longlong_as_double((long long)__hip_atomic_load(&scb->tau_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            __syncthreads();
+            tau_c = S->dtmp[31];
+            __syncthreads();
+        }
         const bool coop_screen = th != 0 && tau_c >= 4.0;
         int coop_units = 0;
         if (LDSPTS == 0 && coopK > 0) {
@@ -1599,12 +1835,13 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
 
         DG_PH(1);
         /* ====== score chunk c (waves 2.., one wave per model, points streamed from LDS)  ||  pool swaps of chunk c+1 (wave 0)  ||  seeds + draws of chunk c+2 (wave 1) ====== */
-        const int nxt = cur == 2 ? 0 : cur + 1, nx2 = nxt == 2 ? 0 : nxt + 1;
-        int cn2;
+        nxt = cur == 2 ? 0 : cur + 1; const int nx2 = nxt == 2 ? 0 : nxt + 1;
         {
             cn2 = max_sam - (no_sam + chunk_s[cur] + chunk_s[nxt]); if (cn2 > DG_CHUNK) cn2 = DG_CHUNK; if (cn2 < 0) cn2 = 0;
+            if (strm == 2) cn2 = 0;                        /* the sample stream comes from the producer */
             chunk_s[nx2] = cn2;
-            if (wave == 0) {
+            if (strm == 2) { /* no sampler stages */ }
+            else if (wave == 0) {
                 if (chunk_s[nxt] > 0) dg_sample_pool<7, LDSPTS>(chunk_s[nxt], n, pool, S->draws3[nxt], S->alm3[nxt], pscr, lane, S->dbg);
             } else if (wave == 1) {
                 if (cn2 > 0) { unsigned sd = dg_sample_chain<7>(seed, cn2, S->seeds3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }   /* its draws: after the barrier, one wave per 64 samples */
@@ -1616,9 +1853,9 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             {
                 const int NS = DG_NW >= 4 ? DG_NW - 2 : DG_NW, wsi = DG_NW >= 4 ? wave - 2 : wave;
                 const int capw = (int)((sizeof(dg_lsq_scratch) / NS) & ~(size_t)15);
-                if (!(LDSPTS == 0 && coopK > 0) && wsi >= 0)
+                if (!(LDSPTS == 0 && coopK > 0) && wsi >= 0 && !ff)
                     dg_score_chunk_F<LDSPTS>(P, n, c.K->gmodels, S->mslot, Mtot, wsi, NS, mk_full, th,
-                                             A.hist_out ? 0.0 : (maxS.J < maxSs.J ? maxS.J : maxSs.J), S->ext, (char *)&S->lsq + (size_t)wsi * capw, capw,
+                                             tau_c, S->ext, (char *)&S->lsq + (size_t)wsi * capw, capw,
                                              (double *)(c.K->wstage + (size_t)wave * c.K->n_max), c.K->res_I, c.K->res_J, lane);
             }
         }
@@ -1667,6 +1904,51 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             for (int rd = wave; rd < DG_CHUNK / 64; rd += DG_NW) dg_sample_draws_round<7>(rd, cn2, n, S->seeds3[nx2], S->draws3[nx2], S->alm3[nx2], lane, S->dbg);
         }
         DG_PH(2);
+        if (producer) {
+            /* leave the chunk in the owner's ring (or just count it when the owner is past it) and go on: a producer never commits */
+            if (!ff) {
+                __syncthreads();
+                if (tid == 0) S->itmp[24] = 0;
+                __syncthreads();
+                for (int i = tid; i < DG_CHUNK; i += DG_T) {
+                    ent->seeds[i] = S->seeds3[cur][i];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) ent->draws[i][q] = S->draws3[cur][i][q];
+                }
+                if (tid < DG_CHUNK) {
+                    const unsigned char nvb = tid < chunk ? S->nv[tid] : (unsigned char)0;
+                    ent->nv[tid] = nvb;
+                    if (tid < chunk && nvb != 255)
+                        for (int r = 0; r < (int)nvb; r++) {
+                            const int mi = (int)S->moff[tid] + r;
+                            const double J_ = c.K->res_J[mi];
+                            if (J_ > tau_c) {            /* only such a model can be an event of the commit */
+                                const int sl = atomicAdd(&S->itmp[24], 1);
+                                if (sl < DG_STREAM_EV_MAX) {
+                                    dg_stream_ev *ev = &ent->ev[sl];
+                                    ev->J = J_; ev->I = c.K->res_I[mi]; ev->k = (short)tid; ev->r = (unsigned char)r; ev->pad = 0;
+#pragma unroll
+                                    for (int j = 0; j < 9; j++) ev->model[j] = c.K->gmodels[(size_t)S->mslot[mi] * 9 + j];
+#pragma unroll
+                                    for (int q = 0; q < 4; q++) ev->ridx[q] = S->ridx[tid][q];
+                                }
+                            }
+                        }
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    const int ne = S->itmp[24];
+                    ent->cn = chunk; ent->Mtot = Mtot; ent->n_ev = ne < DG_STREAM_EV_MAX ? ne : DG_STREAM_EV_MAX; ent->overflow = ne > DG_STREAM_EV_MAX ? 1 : 0; ent->tau_used = tau_c;
+                }
+            }
+            /* one release (a write-back of this XCD's L2) per batch of chunks while the producer is far ahead of the owner */
+            if ((seq & 7) == 7 || seq - tail_p < 16 || no_sam + chunk >= max_sam) dg_stream_publish(&scb->head, seq + 1);
+            no_sam += chunk;
+            __syncthreads();
+            cur = nxt;
+            continue;
+        }
+      }
         /* ================= commit: replay exp_ranF.c:1334-1577 in order ================= */
         int k;
         for (k = 0; k < chunk; k++) {
@@ -1859,6 +2141,13 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         }
         if (!done) cur = nxt;
     }
+    if (producer) {
+        /* the producer leaves (everything it wrote is published): the owner may reuse its control block */
+        dg_stream_publish(&scb->head, no_sam / DG_CHUNK + (no_sam % DG_CHUNK ? 1 : 0));
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&scb->state, DG_ST_RELEASED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return -1;
+    }
 
     /* ---- "If there were no LOs, do at least one NOW!"  exp_ranF.c:1580-1697 ---- */
     if (!iter_cnt && !degen_cnt && non_degen) {
@@ -1996,8 +2285,30 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         st[0] = no_sam; st[1] = iter_cnt; st[2] = 0; st[3] = (int)maxS.I; st[4] = c.n_fds + c.n_exfds;
         st[5] = degen_cnt; st[6] = Ihmax; st[7] = best_sample; st[8] = c.n_fds; st[9] = c.n_exfds;
         st[10] = c.n_hds; st[11] = c.n_aux; st[12] = (int)(t_best - t_start); st[13] = (int)(t_end - t_start);
-        st[14] = A.variant_threads; st[15] = A.mode | (resume ? 256 : 0);      /* bit 8: the pair was set aside and resumed */
+        st[14] = A.variant_threads; st[15] = A.mode | (resume ? 256 : 0) | (strm == 2 ? 512 : 0);      /* bit 8: the pair was set aside and resumed; bit 9: its chunks came from a producer workgroup */
     }
+    if (scb && strm >= 1) {
+        /* take the request back, or tell the producer to stop and wait until it has left */
+        __syncthreads();
+        int gone = 0;
+        if (tid == 0) {
+            int e = DG_ST_REQ; gone = __hip_atomic_compare_exchange_strong(&scb->state, &e, DG_ST_IDLE, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0; S->itmp[30] = gone;
+            if (gone) __hip_atomic_fetch_add(A.done_pairs + 1, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        gone = S->itmp[30];
+        __syncthreads();
+        if (!gone) {
+            if (tid == 0) __hip_atomic_store(&scb->stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dg_stream_wait(A, &scb->state, (int *)0, [](int st_) { return st_ == DG_ST_RELEASED; }, &S->itmp[28]);
+            if (tid == 0) {
+                __hip_atomic_store(&scb->head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&scb->stop, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&scb->state, DG_ST_IDLE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (A.done_pairs && tid == 0) __hip_atomic_fetch_add(A.done_pairs, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     DG_PH(6);
 #ifdef DG_LO_PROF
     if (A.phase_out && tid == 0) { for (int i = 0; i < 16; i++) A.phase_out[(size_t)pair * 16 + i] = S->lt[i]; }
@@ -2057,8 +2368,14 @@ __global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_fundamental_kernel(dg_a
             if (e < 0) e = dg_park_take(As, &next_parked, 1);
             if (e >= 0) { pair = (int)(e >> 32); wsid = (int)(e & 0xffffffffll); resume = 1; }   /* the image lives in the pair's own workspace */
         }
+        int img_wsid = wsid, oslot = slot;
+        if (pair < 0 && As.stream_on) {
+            /* nothing left to own: produce for a pair that asks for it, until every pair of the launch is finished */
+            const int j = dg_stream_find(As, &next_pair);
+            if (j >= 0) { pair = As.scb[j].pair; img_wsid = As.scb[j].wsid; oslot = j; resume = 2; }
+        }
         if (pair < 0) break;
-        const int spare = dg_f_pair<T, LDSPTS>(As, &Sh, dyn_smem, pair, slot, wsid, resume, coop_gen);
+        const int spare = dg_f_pair<T, LDSPTS>(As, &Sh, dyn_smem, pair, slot, img_wsid, resume, coop_gen, wsid, oslot);
         if (spare >= 0) wsid = spare;                /* the pair was set aside with its workspace */
     }
     if (LDSPTS == 0 && As.coop_k > 0 && threadIdx.x == 0)          /* retire the slot: its helpers leave */
