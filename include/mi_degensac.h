@@ -142,6 +142,10 @@ enum {
  * it takes from the producer again, bit 1 = pairs ask for a producer even while unstarted pairs remain.  Process-wide; returns the
  * previous mode.  Also settable once through the environment variable MI_DEGENSAC_STREAM. */
 int mi_degensac_set_stream_mode(int mode);
+/* Homography: workgroups that have run out of pairs take whole repetitions of the local optimisations of the pairs that still
+ * run (results never depend on it).  1 = on (default), 0 = off.  Process-wide; returns the previous mode.  Environment:
+ * MI_DEGENSAC_HJOB. */
+int mi_degensac_set_hjob_mode(int mode);
 
 /* ---- contexts ---------------------------------------------------------------------------------- */
 typedef struct mi_degensac_ctx mi_degensac_ctx;

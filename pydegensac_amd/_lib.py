@@ -170,6 +170,13 @@ def set_stream_mode(mode):
     return int(f(int(mode)))
 
 
+def set_hjob_mode(mode):
+    """homography helper workgroups (include/mi_degensac.h): 1 on, 0 off; returns the previous mode"""
+    f = lib().mi_degensac_set_hjob_mode
+    f.restype = C.c_int; f.argtypes = [C.c_int]
+    return int(f(int(mode)))
+
+
 def stats_dict(st):
     d = {k: int(v) for k, v in zip(STAT_NAMES, st)}
     d["set_aside"] = (d["placement"] >> 8) & 1    # the pair was written back to its workspace once and resumed later

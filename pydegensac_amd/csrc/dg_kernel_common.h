@@ -72,7 +72,9 @@ struct dg_ws_layout {
  * The repetitions only depend on each other through the inlier-set hash table, the best-so-far score and the rotation of
  * the errs[] buffers; dg_inHranic_waves replays those in repetition order from these records. */
 struct dg_hrep_it { double hl[9]; double J; unsigned hash; int I; };
-struct dg_hrep_log {
+/* (one record per 128-byte-aligned block: repetitions of one job may be written by workgroups on different XCDs, whose L2s are
+ * not coherent with each other; two records in one cache line could lose one writer's bytes at write-back) */
+struct alignas(128) dg_hrep_log {
     double h0[9]; double J0; int I0;       /* the sample's model and its score at th */
     int nit;                               /* iterations of exp_iterHcustom that scored their model (0..4) */
     int last_short;                        /* 1: the last of them left fewer than 4 ids for the next fit (exp_ranH.c:366) */
@@ -150,6 +152,21 @@ struct dg_stream_cb {
 };
 static_assert(sizeof(dg_stream_cb) == 256, "stream control block = two 128-byte lines");
 
+/* Homography kernel: the ten repetitions of a local optimisation (exp_ranH.c:415-467) are independent jobs once their samples are
+ * drawn (dg_inHranic_waves): every wave claims whole repetitions from this block — the owner's waves, and the waves of HELPER
+ * workgroups, i.e. workgroups of the launch that have run out of pairs.  A helper reads the pair's points, the sample and the
+ * hash table in the owner's workspace (read-only while the job is open), works on its own staging area and LDS, and leaves
+ * the repetition's 600-byte record (dg_hrep_log) in the owner's workspace; the owner replays the records in order.
+ * Flags on the first 128-byte line (agent-scope atomics only), the job's parameters on the second. */
+struct dg_hjob_cb {
+    int gen;                  /* generation of the open job, 0 = none */
+    int next;                 /* (gen << 8) | repetitions claimed so far */
+    int done;                 /* repetitions finished */
+    int fpad[29];
+    int n, kind, ssiz, wsid; double th; int ppad[26];
+};
+static_assert(sizeof(dg_hjob_cb) == 256, "job control block = two 128-byte lines");
+
 struct dg_args {
     const double *pts1, *pts2;       /* [total, dim] */
     const long long *offsets;        /* [n_pairs + 1] */
@@ -203,7 +220,9 @@ struct dg_args {
     size_t stream_ent_bytes;         /* bytes per ring entry (>= sizeof(dg_stream_ent) of every variant) */
     dg_stream_cb *scb;               /* [n_res] */
     char *ring;                      /* [n_res][stream_depth] entries */
-    int *done_pairs;                 /* pairs finished (header): workgroups without work leave when it reaches n_pairs */
+    int *done_pairs;                 /* [0] pairs finished (header): workgroups without work leave when it reaches n_pairs; [1] open producer requests
+                                        (stream mode); [2] open local-optimisation jobs (homography helpers) */
+    dg_hjob_cb *hjob;                /* homography: [n_res] job control blocks, or null (no helper workgroups) */
     int *err_flag;                   /* set when a wait of the stream mode times out (results are then invalid) */
     int *trace;                      /* debug: [0] = count, then (tag, I, J lo, J hi) records; null = off */
     int trace_cap;

@@ -154,6 +154,7 @@ struct dg_f_ctx {
     double *rrun;            /* diagnostics: the 62 x n residual rows of the current LO run, or null */
     dg_coop_cb *cb; int *coop_gen; int coop_slot;   /* cooperative large-n mode: this owner's control block (null = off) */
     double *hlt;             /* homography kernel: [DG_NW][DG_HLT] doubles of LDS, one block per wave (one-repetition-per-wave LO) */
+    int hjob_gen;            /* homography kernel: generation of this slot's last local-optimisation job (dg_hjob_cb) */
 
     __device__ __forceinline__ dg_pt pt(int i) const { return P[i]; }
     /* LAF point sets u_1 (which=1: +a12,+a22) and u_2 (which=2: +a11,+a21): bindings.cpp:337-409 */

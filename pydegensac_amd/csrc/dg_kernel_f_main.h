@@ -1431,8 +1431,11 @@ __device__ __forceinline__ int dg_stream_find(const dg_args &A, int *bc /* LDS *
                 for (int q = 0; q < 8; q++) __builtin_amdgcn_s_sleep(127);
             } else {
                 int found = -1;
-                for (int j = (int)((blockIdx.x + lane) % (unsigned)A.n_res), q = 0; q < A.n_res && found < 0; q += 64, j = (j + 64) % A.n_res)
-                    if (q + lane < A.n_res && __hip_atomic_load(&A.scb[j].state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == DG_ST_REQ) found = j;
+                /* (uniform trip count: every lane looks at its slots of every round) */
+                for (int q = 0; q < A.n_res; q += 64) {
+                    const int j = (int)((blockIdx.x + (unsigned)(q + lane)) % (unsigned)A.n_res);
+                    if (q + lane < A.n_res && found < 0 && __hip_atomic_load(&A.scb[j].state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == DG_ST_REQ) found = j;
+                }
                 const unsigned long long m = __ballot(found >= 0);
                 if (m) {
                     const int j = __builtin_amdgcn_readlane(found, __ffsll((long long)m) - 1);

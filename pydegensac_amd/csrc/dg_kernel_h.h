@@ -551,7 +551,46 @@ __device__ __noinline__ void dg_hrep_wave(CTX &c, int kind, dg_hrep_log *lg, int
     if (lane == 0) { lg->If = (int)rf.I; lg->Jf = rf.J; lg->has_fin = 1; }
 }
 
-/* exp_inHranicustom with the repetitions spread over the waves; ninl >= 8; same results as dg_inHranic */
+/* ---- repetitions as claimable jobs (dg_hjob_cb) -------------------------------------------------------------------- */
+/* one wave (all 64 lanes, uniform control flow: the retry loop runs on the whole wave behind scalar branches and only the
+ * atomic itself sits under `lane == 0` — a compare-and-swap loop under a per-lane branch, inside code with workgroup barriers
+ * around it, was seen to make the compiler split the wave around those barriers): claim a repetition of job generation g
+ * (cb = null: from the workgroup's own counter in LDS); -1 = none left */
+__device__ __forceinline__ int dg_hjob_claim(dg_hjob_cb *cb, int g, int *lds_next, int lane)
+{
+    if (!cb) {
+        int q = 0;
+        if (lane == 0) q = atomicAdd(lds_next, 1);
+        q = __builtin_amdgcn_readfirstlane(q);
+        return q < DG_RAN_REP ? q : -1;
+    }
+    for (;;) {
+        const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&cb->next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if ((v >> 8) != g || (v & 255) >= DG_RAN_REP) return -1;
+        int ok = 0;
+        if (lane == 0) { int e = v; ok = __hip_atomic_compare_exchange_strong(&cb->next, &e, v + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0; }
+        if (__builtin_amdgcn_readfirstlane(ok)) return v & 255;
+    }
+}
+/* one wave: work on job g until no repetition is left to claim */
+template <int LDSPTS>
+__device__ __forceinline__ void dg_hjob_work(CTX &c, dg_hjob_cb *cb, int g, int *lds_next, int kind, dg_hrep_log *logs, int ssiz, double th, char *wb, int lane, int wave)
+{
+    for (;;) {
+        const int r = dg_hjob_claim(cb, g, lds_next, lane);
+        if (r < 0) break;
+        dg_hrep_wave<LDSPTS>(c, kind, &logs[r], ssiz, th, c.hlt + (size_t)DG_HLT * wave, wb, lane, wave);
+        if (cb) {
+            /* the record is in the owner's workspace: visible before the count goes up */
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(&cb->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+/* exp_inHranicustom with the repetitions as jobs claimed by waves (this workgroup's, and helper workgroups' when the launch has
+ * any); ninl >= 8; same results as dg_inHranic */
 template <int LDSPTS>
 __device__ __forceinline__ dg_score dg_inHranic_waves(CTX &c, int kind, int ninl, double th, double *Hout, int *iterID, dg_hbufs &B)
 {
@@ -562,6 +601,8 @@ __device__ __forceinline__ dg_score dg_inHranic_waves(CTX &c, int kind, int ninl
     { int t = B.pe[2]; B.pe[2] = B.pe[0]; B.pe[0] = t; }
     dg_hrep_log *logs = (dg_hrep_log *)c.K->hrep;
     char *wb = c.K->hrep + dg_hrep_logs_bytes() + (size_t)wave * dg_hrep_wave_bytes(c.K->n_max);
+    /* helpers can only read the points where the owner keeps them in its workspace */
+    dg_hjob_cb *cb = (LDSPTS != 1 && c.A->hjob) ? c.A->hjob + c.coop_slot : (dg_hjob_cb *)0;
     __syncthreads();
     if (tid < 64) {
         for (int r = 0; r < DG_RAN_REP; r++) {
@@ -571,57 +612,155 @@ __device__ __forceinline__ dg_score dg_inHranic_waves(CTX &c, int kind, int ninl
             DG_WSYNC();
         }
     }
+    if (tid == 0) S->itmp[20] = 0;
     __syncthreads();
-    /* rounds of DG_NW repetitions; after each round thread 0 replays, in repetition order, what those repetitions decide
-     * (hash table, best-so-far, buffer rotation), so the next round's repetitions already meet the sets this round inserted */
-    int pe0 = B.pe[0], pe1 = B.pe[1], pe2 = B.pe[2], nh = 0, id = *iterID;       /* replay state (thread 0) */
-    unsigned mI = 0; double mJ = 0;
-    for (int r0 = 0; r0 < DG_RAN_REP; r0 += DG_NW) {
-        if (r0 + wave < DG_RAN_REP) dg_hrep_wave<LDSPTS>(c, kind, &logs[r0 + wave], ssiz, th, c.hlt + (size_t)DG_HLT * wave, wb, lane, wave);
-        __syncthreads();
+    int g = 0;
+    if (cb) {
+        /* open the job: parameters, then one release (points, samples and the hash table of this pair are plain memory), then the generation */
+        g = (c.hjob_gen = (c.hjob_gen % 0x7fffff) + 1);
         if (tid == 0) {
-            for (int r = r0; r < r0 + DG_NW && r < DG_RAN_REP; r++) {
-                const dg_hrep_log *g = &logs[r];
-                for (int i = 0; i < 9; i++) S->bufF[pe0][i] = g->h0[i];
-                ++id; nh++;
-                int pd = pe1; unsigned ScI = 0; double ScJ = 0; const double *hres = g->h0;
-                if (g->I0 >= 4) {
-                    unsigned mlI = (unsigned)g->I0; double mlJ = g->J0; bool dead = false, done = false;
-                    for (int it = 0; it < g->nit; it++) {
-                        const dg_hrep_it *q = &g->it[it];
-                        nh++;
-                        for (int i = 0; i < 9; i++) S->bufF[pd][i] = q->hl[i];
-                        const int ret = dg_ht_contains(c.ht, q->hash, q->I, id);
-                        if (ret == -1) dg_ht_insert(c.ht, q->hash, q->I, id);
-                        if (ret != -1 && ret != id) { dead = true; break; }
-                        if (mlJ < q->J) { mlI = (unsigned)q->I; mlJ = q->J; const int t = pe0; pe1 = t; pe0 = pd; pd = pe1; hres = q->hl; }
-                        if (it == g->nit - 1 && g->last_short) done = true;
-                    }
-                    if (!dead && !done) {
-                        nh++;
-                        for (int i = 0; i < 9; i++) S->bufF[pd][i] = g->hf[i];
-                        if (mlJ < g->Jf) { mlI = (unsigned)g->If; mlJ = g->Jf; pe1 = pe0; pe0 = pd; hres = g->hf; }
-                    }
-                    if (!dead) { ScI = mlI; ScJ = mlJ; }
-                }
-                if (mJ < ScJ) {
-                    mI = ScI; mJ = ScJ;
-                    { const int t = pe2; pe2 = pe0; pe0 = t; }
-                    for (int i = 0; i < 9; i++) Hout[i] = hres[i];
-                }
-            }
-            if (r0 + DG_NW >= DG_RAN_REP) {
-                { const int t = pe2; pe2 = pe0; pe0 = t; }
-                S->red.bi[0] = pe0; S->red.bi[1] = pe1; S->red.bi[2] = pe2; S->red.bi[3] = nh; S->red.bi[4] = (int)mI; S->red.bc[0] = mJ;
-            }
+            cb->n = c.n; cb->kind = kind; cb->ssiz = ssiz; cb->wsid = c.coop_slot; cb->th = th;
+            __hip_atomic_store(&cb->done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&cb->next, g << 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(wave) == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) { __hip_atomic_store(&cb->gen, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_fetch_add(c.A->done_pairs + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         }
         __syncthreads();
     }
+    dg_hjob_work<LDSPTS>(c, cb, g, &S->itmp[20], kind, logs, ssiz, th, wb, lane, wave);
+    __syncthreads();
+    if (cb) {
+        /* repetitions that helpers claimed may still run */
+        if (__builtin_amdgcn_readfirstlane(wave) == 0) {
+            const long long t0 = wall_clock64();
+            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&cb->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < DG_RAN_REP) {
+                if (wall_clock64() - t0 > 400000000ll) { if (lane == 0) __hip_atomic_store(c.A->err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (lane == 0) { __hip_atomic_store(&cb->gen, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_fetch_add(c.A->done_pairs + 2, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        }
+        __syncthreads();
+    }
+    /* thread 0 replays, in repetition order, what the repetitions decide (hash table, best-so-far, buffer rotation) */
+    if (tid == 0) {
+        int pe0 = B.pe[0], pe1 = B.pe[1], pe2 = B.pe[2], nh = 0, id = *iterID;
+        unsigned mI = 0; double mJ = 0;
+        for (int r = 0; r < DG_RAN_REP; r++) {
+            const dg_hrep_log *g_ = &logs[r];
+            for (int i = 0; i < 9; i++) S->bufF[pe0][i] = g_->h0[i];
+            ++id; nh++;
+            int pd = pe1; unsigned ScI = 0; double ScJ = 0; const double *hres = g_->h0;
+            if (g_->I0 >= 4) {
+                unsigned mlI = (unsigned)g_->I0; double mlJ = g_->J0; bool dead = false, fin = false;
+                for (int it = 0; it < g_->nit; it++) {
+                    const dg_hrep_it *q = &g_->it[it];
+                    nh++;
+                    for (int i = 0; i < 9; i++) S->bufF[pd][i] = q->hl[i];
+                    const int ret = dg_ht_contains(c.ht, q->hash, q->I, id);
+                    if (ret == -1) dg_ht_insert(c.ht, q->hash, q->I, id);
+                    if (ret != -1 && ret != id) { dead = true; break; }
+                    if (mlJ < q->J) { mlI = (unsigned)q->I; mlJ = q->J; const int t = pe0; pe1 = t; pe0 = pd; pd = pe1; hres = q->hl; }
+                    if (it == g_->nit - 1 && g_->last_short) fin = true;
+                }
+                if (!dead && !fin) {
+                    nh++;
+                    for (int i = 0; i < 9; i++) S->bufF[pd][i] = g_->hf[i];
+                    if (mlJ < g_->Jf) { mlI = (unsigned)g_->If; mlJ = g_->Jf; pe1 = pe0; pe0 = pd; hres = g_->hf; }
+                }
+                if (!dead) { ScI = mlI; ScJ = mlJ; }
+            }
+            if (mJ < ScJ) {
+                mI = ScI; mJ = ScJ;
+                { const int t = pe2; pe2 = pe0; pe0 = t; }
+                for (int i = 0; i < 9; i++) Hout[i] = hres[i];
+            }
+        }
+        { const int t = pe2; pe2 = pe0; pe0 = t; }
+        S->red.bi[0] = pe0; S->red.bi[1] = pe1; S->red.bi[2] = pe2; S->red.bi[3] = nh; S->red.bi[4] = (int)mI; S->red.bc[0] = mJ;
+    }
+    __syncthreads();
     B.pe[0] = S->red.bi[0]; B.pe[1] = S->red.bi[1]; B.pe[2] = S->red.bi[2];
     c.n_hds += S->red.bi[3]; *iterID += DG_RAN_REP;
     maxS.I = (unsigned)S->red.bi[4]; maxS.J = S->red.bc[0];
     __syncthreads();
     return maxS;
+}
+
+/* A workgroup that has run out of pairs: the owner slot of an open job, or -1 once every pair of the launch is finished */
+__device__ __forceinline__ int dg_hjob_find(const dg_args &A, int *bc /* LDS */)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    for (;;) {
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
+            int res = -2;
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(A.done_pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= A.n_pairs) res = -1;
+            else if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(A.done_pairs + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= 0) {
+                for (int q = 0; q < 4; q++) __builtin_amdgcn_s_sleep(127);
+            } else {
+                int found = -1;
+                /* (uniform trip count: every lane looks at its slots of every round) */
+                for (int q = 0; q < A.n_res; q += 64) {
+                    const int j = (int)((blockIdx.x + (unsigned)(q + lane)) % (unsigned)A.n_res);
+                    if (q + lane < A.n_res && found < 0) {
+                        const int g = __hip_atomic_load(&A.hjob[j].gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (g > 0) { const int v = __hip_atomic_load(&A.hjob[j].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if ((v >> 8) == g && (v & 255) < DG_RAN_REP) found = j; }
+                    }
+                }
+                const unsigned long long m = __ballot(found >= 0);
+                if (m) { res = __builtin_amdgcn_readlane(found, __ffsll((long long)m) - 1); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+                else __builtin_amdgcn_s_sleep(32);
+            }
+            *bc = res;
+        }
+        __syncthreads();
+        const int r = *bc;
+        if (r != -2) return r;
+    }
+}
+
+/* helper workgroup: repetitions of the job that is open at owner slot `oslot` (this workgroup's own workspace `slot` is free) */
+template <int T, int LDSPTS>
+__device__ __forceinline__ void dg_h_help(const dg_args &A, dg_f_shared *S, double *hlt, const int oslot, const int slot)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    dg_hjob_cb *cb = A.hjob + oslot;
+    char *ws = A.ws + (size_t)slot * A.wl.stride, *wso = A.ws + (size_t)oslot * A.wl.stride;
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(wave) == 0) {
+        /* the generation first, then (behind an acquire) the parameters: they are at least as new as that generation, and a claim
+         * of that generation only succeeds while they are still its own (the owner opens the next job after the last repetition) */
+        int g_ = 0;
+        if (tid == 0) { dg_fill_views(&S->K, ws, A.wl); g_ = __hip_atomic_load(&cb->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (tid == 0) { S->itmp[24] = g_; S->itmp[25] = cb->n; S->itmp[26] = cb->kind; S->itmp[27] = cb->ssiz; S->dtmp[31] = cb->th; }
+    }
+    __syncthreads();
+    const int g = S->itmp[24], n = S->itmp[25], kind = S->itmp[26], ssiz = S->itmp[27]; const double th = S->dtmp[31];
+    __syncthreads();
+    if (g <= 0) return;
+    if (n < 8 || n > A.wl.n_max || ssiz < 4 || ssiz > 12 || kind < 0 || kind > 4) {      /* never the case for an open job: refuse instead of reading wild memory */
+        if (tid == 0) __hip_atomic_store(A.err_flag, 16 + (n < 8 || n > A.wl.n_max ? 1 : 0) + (ssiz < 4 || ssiz > 12 ? 2 : 0) + (kind < 0 || kind > 4 ? 4 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    /* (the parameters belong to generation g as long as a claim of generation g succeeds: the owner does not open the next job
+     * before every repetition of this one is done) */
+    dg_f_ctx<0> c;                  /* the owner's points are read through global loads whatever this kernel's own placement is */
+    c.S = S; c.K = (const __attribute__((address_space(3))) dg_f_cshared *)&S->K; c.n = n; c.tid = tid; c.A = &A; c.off = 0;
+    c.ht.heads = (int *)(wso + A.wl.off_ht); c.ht.count = c.ht.heads + 64; c.ht.ent = c.ht.heads + 80;     /* the owner's table: lookups only */
+    c.seeds = S->seeds3[0]; c.draws = S->draws3[0];
+    c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0; c.rrun = 0; c.hlt = hlt;
+    c.cb = (dg_coop_cb *)0; c.coop_gen = (int *)0; c.coop_slot = slot; c.hjob_gen = 0;
+    c.P = (const dg_pt *)(wso + A.wl.off_pts); c.pool = (int *)0;
+    dg_hrep_log *logs = (dg_hrep_log *)(wso + A.wl.off_hrep);
+    char *wb = c.K->hrep + dg_hrep_logs_bytes() + (size_t)wave * dg_hrep_wave_bytes(c.K->n_max);
+    dg_hjob_work<0>(c, cb, g, (int *)0, kind, logs, ssiz, th, wb, lane, wave);
+    __syncthreads();
 }
 
 /* one LO run of the driver (exp_ranH.c:678-747 / :795-861).  e4 = model behind errs[4].  Returns 1 if accepted. */
@@ -709,7 +848,7 @@ __device__ __noinline__ int dg_solve4_lane(const dg_pt *P, const int *ids, int k
 
 /* ---------------------------------------------------------------------------------------------- */
 template <int T, int LDSPTS>
-__device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsigned char *dyn_smem, double *hlt, const int pair, const int slot)
+__device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsigned char *dyn_smem, double *hlt, const int pair, const int slot, int &hjob_gen)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long off = A.offsets[pair];
@@ -728,7 +867,7 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
     c.ht.heads = (int *)(ws + A.wl.off_ht); c.ht.count = c.ht.heads + 64; c.ht.ent = c.ht.heads + 80;
     c.seeds = S->seeds3[0]; c.draws = S->draws3[0];
     c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0; c.rrun = 0; c.hlt = hlt;
-    c.cb = (dg_coop_cb *)0; c.coop_gen = (int *)0; c.coop_slot = 0;
+    c.cb = (dg_coop_cb *)0; c.coop_gen = (int *)0; c.coop_slot = slot; c.hjob_gen = hjob_gen;
     dg_pt *Pw; int *pool;
     /* LDSPTS: 1 = point set and sampler pool in LDS, 2 = pool in LDS / points in the HBM workspace (L2), 0 = both in HBM */
     if (LDSPTS == 1) { Pw = (dg_pt *)dyn_smem; pool = (int *)(dyn_smem + (size_t)n * sizeof(dg_pt)); }
@@ -978,6 +1117,8 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
         st[5] = 0; st[6] = 0; st[7] = best_sample; st[8] = c.n_hds; st[9] = 0; st[10] = 0; st[11] = 0;
         st[12] = (int)(t_best - t_start); st[13] = (int)(t_end - t_start); st[14] = A.variant_threads; st[15] = A.mode;
     }
+    hjob_gen = c.hjob_gen;
+    if (A.done_pairs && tid == 0) __hip_atomic_fetch_add(A.done_pairs, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     DG_PHH(6);
     DG_DEVT(if (A.phase_out && tid == 0) { S->ph[7] = DG_CLK() - t_start; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + i] = S->ph[i]; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + 8 + i] = S->dbg[i]; });
 #undef DG_PHH
@@ -996,10 +1137,19 @@ __global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_homography_kernel(dg_ar
     __shared__ dg_args As;
     if (threadIdx.x == 0) As = A;
     __syncthreads();
+    int hjob_gen = 0;
     for (;;) {
         const int pair = dg_next_pair(As, &next_pair);
         if (pair < 0) break;
-        dg_h_pair<T, LDSPTS>(As, &Sh, dyn_smem, &Hlt[0][0], pair, (int)blockIdx.x);
+        dg_h_pair<T, LDSPTS>(As, &Sh, dyn_smem, &Hlt[0][0], pair, (int)blockIdx.x, hjob_gen);
+    }
+    /* out of pairs: help the local optimisations of the pairs that still run, until every pair of the launch is finished */
+    if (As.hjob) {
+        for (;;) {
+            const int j = dg_hjob_find(As, &next_pair);
+            if (j < 0) break;
+            dg_h_help<T, LDSPTS>(As, &Sh, &Hlt[0][0], j, (int)blockIdx.x);
+        }
     }
 }
 
