@@ -12,10 +12,11 @@ def data(P):
     offs = np.arange(P + 1, dtype=np.int64) * N
     return (torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev), torch.from_numpy(offs).to(dev), offs,
             torch.from_numpy(parallel.pair_seeds(0, P).astype(np.int64)).to(dev).to(torch.int32))
-def run(P, d, reps=3):
+TUNES = [int(x, 0) for x in sys.argv[1:]] or [0]
+def run(P, d, reps=3, tune=0):
     d_a, d_b, d_off, offs, d_seeds = d
     d_H = torch.zeros((P, 9), dtype=torch.float64, device=dev); d_mask = torch.zeros(P * N, dtype=torch.uint8, device=dev); d_st = torch.zeros((P, 16), dtype=torch.int32, device=dev)
-    prm = _lib.make_params(2.0, 0.999, 50000, 0, True, 3.0, True, 0, 0)
+    prm = _lib.make_params(2.0, 0.999, 50000, 0, True, 3.0, True, 0, tune)
     ts = []
     for it in range(reps + 1):
         torch.cuda.synchronize(); t = time.perf_counter()
@@ -26,9 +27,10 @@ def run(P, d, reps=3):
     return min(ts[1:]), float(np.mean(ts[1:])), int(st[0, 14]), int(st[0, 15]), float(st[:, 13].max() / 1e5), float(st[:, 13].mean() / 1e5), d_H.cpu().numpy(), d_mask.cpu().numpy()
 for P in (1024, 256):
     d = data(P); ref = None
-    for mode in (1, 0):
+    for tune in TUNES:
+      for mode in (1, 0):
         _lib.set_hjob_mode(mode)
-        best, mean, thr, plc, longest, meanp, H, m = run(P, d)
+        best, mean, thr, plc, longest, meanp, H, m = run(P, d, tune=tune)
         same = "" if ref is None else " identical: %s" % (np.array_equal(ref[0], H) and np.array_equal(ref[1], m))
         ref = ref or (H, m)
         print(f"C3 x {P:4d} helpers {mode}: best {best:6.2f} ms mean {mean:6.2f} ms  threads {thr} placement {plc}  longest pair {longest:5.1f} ms mean pair {meanp:5.2f} ms{same}", flush=True)
