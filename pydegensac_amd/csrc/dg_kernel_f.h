@@ -77,6 +77,13 @@ struct dg_lo_log {
     int cut, draws, n_ex, n_fd;           /* filled by the replay: cut short by an earlier repetition's set, 8-subset draws really consumed, passes to count */
     int pub, aborted;                     /* pub: -1 while the repetition runs, then the draws it made (the later repetitions of the round watch it); aborted: stopped as stale */
 };
+/* cooperative large-n mode: the repetitions of a round are units of stage 4, one claiming workgroup each; their records live in
+ * the owner's workspace (DG_LOJOB_BYTES at the end of the stage-3 staging): a header, then one record per repetition on its own
+ * 128-byte lines (records are written by workgroups on different XCDs) */
+#define DG_LOJOB_STRIDE 768
+#define DG_LOJOB_BYTES (128 + DG_RAN_REP * DG_LOJOB_STRIDE)
+static_assert(sizeof(dg_lo_log) <= DG_LOJOB_STRIDE, "dg_lo_log does not fit its slot");
+struct dg_lo_job { int n, ssiz, mk_full, mk_ex; double th; };
 
 struct dg_f_shared {
     dg_red red;
@@ -155,6 +162,7 @@ struct dg_f_ctx {
     dg_coop_cb *cb; int *coop_gen; int coop_slot;   /* cooperative large-n mode: this owner's control block (null = off) */
     double *hlt;             /* homography kernel: [DG_NW][DG_HLT] doubles of LDS, one block per wave (one-repetition-per-wave LO) */
     int hjob_gen;            /* homography kernel: generation of this slot's last local-optimisation job (dg_hjob_cb) */
+    int lo_assumed, lo_prev; /* cooperative large-n mode: 8-subset draws the last committed repetition of a local optimisation consumed (the start states of the next ones assume it) */
 
     __device__ __forceinline__ dg_pt pt(int i) const { return P[i]; }
     /* LAF point sets u_1 (which=1: +a12,+a22) and u_2 (which=2: +a11,+a21): bindings.cpp:337-409 */

@@ -391,7 +391,13 @@ __device__ __noinline__ void dg_lo_rep_wave(CTX &c, dg_lo_log *lg, int ssiz, dou
     DG_WSYNC();
 }
 
-template <int LDSPTS>
+template <int LDSPTS> __device__ __forceinline__ void dg_lo_round_coop(CTX &c, int nr, int ssiz, double th, int mk_full, int mk_ex);
+__device__ __forceinline__ char *dg_coop_lojob(const dg_args &A, int slot);
+__device__ __forceinline__ int *dg_coop_lo_list(const dg_args &A, int slot, int k);
+/* COOP (cooperative large-n mode): a round is all the repetitions that are left, each run by one claiming workgroup of the
+ * pair (stage 4; dg_lo_rep_wg) on records and lists in the owner's workspace, and the draws assumed per repetition are the
+ * ones the last committed repetition consumed (long lists: 8 + 4 x 8, where 2000-point pairs mostly stop after 16) */
+template <int LDSPTS, bool COOP>
 __device__ __noinline__ dg_score dg_inFrani_waves(CTX &c, int ninl, double th, double *Fout, int *iterID, int mk_full, int mk_ex, int *kindBest)
 {
     dg_f_shared *S = c.S; const int tid = c.tid, lane = tid & 63, wave = tid >> 6;
@@ -401,13 +407,18 @@ __device__ __noinline__ dg_score dg_inFrani_waves(CTX &c, int ninl, double th, d
     if (ninl < 16) return maxS;
     int ssiz = ninl / 2; if (ssiz > 14) ssiz = 14;
     int next = 0;
+    constexpr int NRMAX = COOP ? DG_RAN_REP : DG_NW;
+    char *glog = (char *)0;
+    if constexpr (COOP) glog = dg_coop_lojob(*c.A, c.coop_slot) + 128;
+    auto LG = [&](int q) -> dg_lo_log * { if constexpr (COOP) return (dg_lo_log *)(glog + (size_t)DG_LOJOB_STRIDE * q); else return &S->lo[q]; };
+    int assumed = COOP ? c.lo_assumed : DG_LO_ASSUMED_DRAWS;
 #ifdef DG_LO_PROF
 #define DG_LW(i) do { if (tid == 0) { long long t_ = wall_clock64(); S->lt[i] += t_ - S->ltq; S->ltq = t_; } } while (0)
 #else
 #define DG_LW(i) do {} while (0)
 #endif
     while (next < DG_RAN_REP) {
-        const int nr = DG_RAN_REP - next < DG_NW ? DG_RAN_REP - next : DG_NW;
+        const int nr = DG_RAN_REP - next < NRMAX ? DG_RAN_REP - next : NRMAX;
         __syncthreads();
         DG_LW(7);
         if (__builtin_amdgcn_readfirstlane(wave) == 0) {
@@ -415,25 +426,26 @@ __device__ __noinline__ dg_score dg_inFrani_waves(CTX &c, int ninl, double th, d
             DG_WSYNC();
             for (int q = 0; q < nr; q++) {
                 /* the sample of repetition next + q: the draws, the slots they store (kept with the values they replace) */
-                dg_lo_log *g = &S->lo[q];
+                dg_lo_log *g = LG(q);
                 int id = 0;
                 dg_randsubset_wave_ahead(&S->lo_work, inliers, ninl, ssiz, lane, &id, g->upos, g->uval);
                 if (lane < ssiz) g->ids[lane] = id;
                 if (lane < 2 * ssiz && g->upos[lane] >= 0) { const int old = inliers[g->upos[lane]]; inliers[g->upos[lane]] = g->uval[lane]; g->uval[lane] = old; }
-                if (lane == 0) { g->g = S->lo_work; g->g0 = S->lo_work; g->pub = -1; g->aborted = 0; for (int k = 0; k < DG_LO_ASSUMED_DRAWS; k++) dg_rand(&S->lo_work); }
+                if (lane == 0) { g->g = S->lo_work; g->g0 = S->lo_work; g->pub = -1; g->aborted = 0; for (int k = 0; k < assumed; k++) dg_rand(&S->lo_work); }
                 DG_WSYNC();
             }
         }
         __syncthreads();
         DG_LW(0);
-        if (wave < nr) dg_lo_rep_wave<LDSPTS>(c, &S->lo[wave], ssiz, th, mk_full, mk_ex, lane, wave);
+        if constexpr (COOP) dg_lo_round_coop<LDSPTS>(c, nr, ssiz, th, mk_full, mk_ex);
+        else { if (wave < nr) dg_lo_rep_wave<LDSPTS>(c, &S->lo[wave], ssiz, th, mk_full, mk_ex, lane, wave); }
         __syncthreads();
         DG_LW(1);
         /* replay in repetition order (thread 0): the hash table with each repetition's own iterID, what it really drew */
         if (tid == 0) {
             int v = 0;
             for (int q = 0; q < nr; q++) {
-                dg_lo_log *g = &S->lo[q];
+                dg_lo_log *g = LG(q);
                 if (g->aborted) break;                            /* stopped as stale: it runs again in the next round (q >= 1 here) */
                 const int id = *iterID + next + q + 1;
                 int draws = 0, cut = 0, n_ex = 0;
@@ -449,7 +461,7 @@ __device__ __noinline__ dg_score dg_inFrani_waves(CTX &c, int ninl, double th, d
                 }
                 g->cut = cut; g->draws = draws; g->n_ex = n_ex; g->n_fd = (!cut && g->has_fin) ? 2 : 1;
                 v++;
-                if (draws != DG_LO_ASSUMED_DRAWS) break;
+                if (draws != assumed) break;
             }
             S->red.bi[0] = v;
         }
@@ -460,12 +472,12 @@ __device__ __noinline__ dg_score dg_inFrani_waves(CTX &c, int ninl, double th, d
         if (tid == 0) { S->lt[5] += 100000; S->lt[6] += 100000 * v; }
 #endif
         for (int q = 0; q < v; q++) {
-            const dg_lo_log *g = &S->lo[q];
+            const dg_lo_log *g = LG(q);
             c.n_exfds += g->n_ex; c.n_fds += g->n_fd;
             const int cut = g->cut;
             if (!cut && maxS.J < g->J) {
                 maxS.I = (unsigned)g->I; maxS.J = g->J; maxS.Is = 0; maxS.Ilafs = 0; *kindBest = g->kind0;
-                const int *ibq = c.K->wlist + (size_t)q * c.K->n_max;
+                const int *ibq = COOP ? dg_coop_lo_list(*c.A, c.coop_slot, 2 * q) : c.K->wlist + (size_t)q * c.K->n_max;
                 __syncthreads();
                 if (tid < 9) Fout[tid] = g->f[tid];
                 for (int j = tid; j < g->I; j += DG_T) intbuff_best[j] = ibq[j];
@@ -478,18 +490,23 @@ __device__ __noinline__ dg_score dg_inFrani_waves(CTX &c, int ninl, double th, d
             /* the list order behind repetition next + v - 1: undo the samples of the repetitions that were not committed, last first;
              * the exact generator state behind it: the state behind its sample, then the draws it really consumed */
             for (int q = nr - 1; q >= v; q--) {
-                if (lane < 2 * ssiz && S->lo[q].upos[lane] >= 0) inliers[S->lo[q].upos[lane]] = S->lo[q].uval[lane];
+                if (lane < 2 * ssiz && LG(q)->upos[lane] >= 0) inliers[LG(q)->upos[lane]] = LG(q)->uval[lane];
                 DG_WSYNC();
             }
-            if (lane == 0) { S->rng = S->lo[v - 1].g0; for (int k = 0; k < S->lo[v - 1].draws; k++) dg_rand(&S->rng); }
+            if (lane == 0) { S->rng = LG(v - 1)->g0; for (int k = 0; k < LG(v - 1)->draws; k++) dg_rand(&S->rng); }
             DG_WSYNC();
         }
         next += v;
+        if constexpr (COOP) {
+            /* the assumption follows the committed repetitions, but one odd count (a repetition cut short) does not change it */
+            for (int q = 0; q < v; q++) { const int d = LG(q)->draws; if (d == c.lo_prev || c.lo_prev < 0) assumed = d; c.lo_prev = d; }
+        }
 #ifdef DG_LO_PROF
         __syncthreads();
 #endif
         DG_LW(4);
     }
+    if constexpr (COOP) c.lo_assumed = assumed;
     *iterID += DG_RAN_REP;
     __syncthreads();
     for (int j = tid; j < (int)maxS.I; j += DG_T) inliers[j] = intbuff_best[j];
@@ -500,10 +517,14 @@ __device__ __noinline__ dg_score dg_inFrani_waves(CTX &c, int ninl, double th, d
 template <int LDSPTS>
 __device__ __forceinline__ dg_score dg_inFrani(CTX &c, int ninl, double th, double *Fout, int *iterID, int mk_full, int mk_ex, int *kindBest)
 {
-    /* the serial order for the residual dump (its rows are written in repetition order), for the cooperative large-n mode
-     * (its passes are distributed over workgroups instead) and on request */
-    if (c.rrun || c.cb || c.A->innerh_serial || c.A->trace) return dg_inFrani_serial<LDSPTS>(c, ninl, th, Fout, iterID, mk_full, mk_ex, kindBest);
-    return dg_inFrani_waves<LDSPTS>(c, ninl, th, Fout, iterID, mk_full, mk_ex, kindBest);
+    /* the serial order for the residual dump (its rows are written in repetition order) and on request */
+    if (c.rrun || c.A->innerh_serial || c.A->trace) return dg_inFrani_serial<LDSPTS>(c, ninl, th, Fout, iterID, mk_full, mk_ex, kindBest);
+    if (c.cb) {
+        /* cooperative large-n mode: whole repetitions go to the claiming workgroups (the serial order distributes every pass instead) */
+        if constexpr (LDSPTS == 0) return dg_inFrani_waves<LDSPTS, true>(c, ninl, th, Fout, iterID, mk_full, mk_ex, kindBest);
+        else return dg_inFrani_serial<LDSPTS>(c, ninl, th, Fout, iterID, mk_full, mk_ex, kindBest);
+    }
+    return dg_inFrani_waves<LDSPTS, false>(c, ninl, th, Fout, iterID, mk_full, mk_ex, kindBest);
 }
 
 /* One 7-point problem per lane, registers only (own register allocation: not inlined into the driver).
@@ -1133,6 +1154,21 @@ __device__ __forceinline__ dg_coop_ws dg_coop_views(const dg_args &A, int slot)
     return v;
 }
 #define DG_COOP_GEN_MASK 0xfffff
+#ifndef DG_COOP_SPW
+#define DG_COOP_SPW 1            /* stage 1: point slices per claiming workgroup (C5: 85.4 ms with 3, 82.8 with 2, 80.4 with 1: a unit's claim and its release cost ~3 us) */
+#endif
+/* stage 4 (repetitions of a local optimisation as units): the job header + records (DG_LOJOB_BYTES behind the stage-3 staging),
+ * and list k (0 .. 2 DG_RAN_REP - 1; repetition q: `inliers` = list 2q, the second list = 2q + 1) from the per-wave area */
+__device__ __forceinline__ char *dg_coop_lojob(const dg_args &A, int slot)
+{
+    char *ws = A.ws + (size_t)slot * A.wl.stride;
+    return ws + A.wl.off_job + ((sizeof(dg_coop_job) + 255) & ~(size_t)255) + ((DG_COOP_MAX_SLICES * sizeof(dg_coop_rec) + 255) & ~(size_t)255)
+              + (((size_t)A.wl.n_max * (2 * sizeof(int) + sizeof(double)) + 255) & ~(size_t)255);
+}
+__device__ __forceinline__ int *dg_coop_lo_list(const dg_args &A, int slot, int k)
+{
+    return (int *)(A.ws + (size_t)slot * A.wl.stride + A.wl.off_wave) + (size_t)k * A.wl.n_max;
+}
 
 /* Owner, whole workgroup: publish a stage of `n_units` units (<= 4095).  Parameters first (plain), the claim counter and
  * the unit count with agent-scope atomics, one release, then the generation. */
@@ -1279,9 +1315,122 @@ __device__ __forceinline__ void dg_coop_unit_pass(dg_f_shared *S, const dg_coop_
     if (tid == 0) { dg_coop_rec rc; rc.I = r.I; rc.nL = r.nL; rc.nL2 = r.nL2; rc.nJ = r.nJ; v.rec[u] = rc; }
 }
 
+/* Stage 4, one unit = repetition u of the current round of a local optimisation (exp_ranF.c:621-743 behind the sample of
+ * exp_ranF.c:771), by the whole claiming workgroup: the same fits, passes, hashes and record as dg_lo_rep_wave, with
+ * workgroup passes over all n points (ordered MSAC terms in LDS + this workgroup's HBM buffer), the hash of a set on wave 1
+ * while wave 0 draws and fits the next 8-subset.  The table is only looked up. */
+template <int T>
+__device__ __noinline__ void dg_lo_rep_wg(dg_f_shared *S, const dg_pt *P, const int n, const dg_ht &ht, dg_lo_log *lg, int *ib, int *alt, double *jbuf,
+                                          const int ssiz, const double th, const int mk_full, const int mk_ex, const int tid)
+{
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *f = S->f, *fl = S->fLO, *ftmp = S->ftmp, *px = S->lsq.px, *wts = S->lsq.part[0];
+    const bool small_ids = n < 65536;
+    auto pass = [&](const double *Fm, int kind, int wantJ, double thJ, int *la, double thL, int *lb, double thL2) -> dg_pass_res {
+        double F[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) F[i] = Fm[i];
+        dg_pass_cfg cfg = dg_cfg0(n); cfg.wantJ = wantJ; cfg.thJ = thJ; cfg.list = la; cfg.thL = thL; cfg.list2 = lb; cfg.thL2 = thL2;
+        cfg.jbuf = jbuf; cfg.jl = (double *)S->ww; cfg.jl_cap = (int)(DG_JBUF_LDS_BYTES / sizeof(double));
+        return dg_pass(&S->red, cfg, [&](int pid, int) { return dg_Ferr(kind, F, dg_ldpt<0>(P, pid)); }, tid);
+    };
+    auto gather = [&](int id, int len) {
+        if (lane < len) { const dg_pt q = dg_ldpt<0>(P, id); double *o = px + 4 * lane; o[0] = q.x1; o[1] = q.y1; o[2] = q.x2; o[3] = q.y2; }
+    };
+    __syncthreads();
+    if (wv == 0) {
+        gather(lane < ssiz ? lg->ids[lane] : 0, ssiz);
+        DG_WSYNC();
+        dg_u2f_small_w(&S->lsq, px, (const double *)0, ssiz, f, lane);
+    }
+    __syncthreads();
+    const dg_pass_res r0 = pass(f, mk_full, 1, th, ib, th * DG_MWM, (int *)0, 0.0);
+    unsigned mI = r0.I; double mJ = r0.J; int kind0 = mk_full, drawn = 0;
+    if (tid == 0) { lg->I0 = (int)r0.I; lg->drew0 = 0; lg->nit = 0; lg->has_fin = 0; }
+    if (mI < 8) { if (tid == 0) { lg->I = 0; lg->J = 0; lg->kind0 = mk_full; lg->pub = 0; } __syncthreads(); return; }
+    if (wv == 0) {
+        const int cnt = (int)r0.nL; int id;
+        if (8 < cnt) { dg_randsubset_wave(&lg->g, ib, cnt, 8, lane, &id); if (lane == 0) lg->drew0 = 8; }
+        else id = lane < cnt ? ib[lane] : 0;
+        const int use = 8 < cnt ? 8 : cnt;
+        DG_WSYNC();
+        gather(id, use);
+        DG_WSYNC();
+        dg_u2f_small_w(&S->lsq, px, (const double *)0, use, fl, lane);
+    }
+    if ((int)r0.nL > 8) drawn += 8;
+    __syncthreads();
+    double ths = DG_TC * th; const double dth = (ths - th) / DG_ILSQ_ITERS;
+    int ended = 0;
+    for (int it = 0; it < DG_ILSQ_ITERS; it++) {
+        const dg_pass_res r1 = pass(fl, mk_ex, 1, th, ib, th, alt, ths * DG_MWM);
+        const int improve = mJ < r1.J;
+        unsigned nL2 = r1.nL2;
+        /* exp_ranF.c:687-696: after a rotation `d` is the OLD errs[0]: that list is taken on the residuals of the previous best */
+        if (improve) { const dg_pass_res r2 = pass(f, kind0, 0, 0.0, alt, ths * DG_MWM, (int *)0, 0.0); nL2 = r2.nL; }
+        const int fit = nL2 >= 8;
+        __syncthreads();
+        if (wv == 1 || (T == 64 && wv == 0)) {
+            const unsigned hash = dg_hash_list(ib, (int)r1.I, small_ids);
+            if (lane == 0) {
+                lg->it[it].hash = hash; lg->it[it].I = (int)r1.I; lg->nit = it + 1;
+                /* a set an EARLIER round or local optimisation inserted ends the repetition here whatever the others of this round do */
+                S->itmp[0] = dg_ht_contains(ht, hash, (int)r1.I, -1) != -1;
+            }
+        }
+        if (wv == 0) {
+            const int cnt = (int)nL2; int id = 0;
+            if (lane == 0) lg->it[it].drew = (fit && 8 < cnt) ? 8 : 0;
+            if (fit) {
+                if (8 < cnt) dg_randsubset_wave(&lg->g, alt, cnt, 8, lane, &id);
+                else id = lane < cnt ? alt[lane] : 0;
+                const int use = 8 < cnt ? 8 : cnt;
+                DG_WSYNC();
+                if (lane < use) {
+                    const dg_pt q = dg_ldpt<0>(P, id);
+                    double *o = px + 4 * lane; o[0] = q.x1; o[1] = q.y1; o[2] = q.x2; o[3] = q.y2;
+                    if (mk_ex == DG_K_FDS) wts[lane] = dg_exFDs_w(fl, q.x1, q.y1, q.x2, q.y2);
+                    else { double ww_; dg_exFDsSym(fl, q.x1, q.y1, q.x2, q.y2, &ww_); wts[lane] = ww_; }
+                }
+                DG_WSYNC();
+                dg_u2f_small_w(&S->lsq, px, wts, use, ftmp, lane);
+            }
+        }
+        if (fit && nL2 > 8) drawn += 8;
+        __syncthreads();
+        if (S->itmp[0]) { ended = 2; break; }
+        if (improve) { mI = r1.I; mJ = r1.J; kind0 = mk_ex; if (tid < 9) f[tid] = fl[tid]; }
+        /* the reference builds this list (and shuffles it) in `inliers` itself */
+        for (int j = tid; j < (int)nL2; j += T) ib[j] = alt[j];
+        if (tid < 9 && fit) fl[tid] = ftmp[tid];
+        __syncthreads();
+        if (!fit) { ended = 1; break; }
+        ths -= dth;
+    }
+    if (!ended) {
+        const dg_pass_res r3 = pass(fl, mk_full, 1, th, ib, th, (int *)0, 0.0);
+        if (tid == 0) lg->has_fin = 1;
+        if (mJ < r3.J) { mI = r3.I; mJ = r3.J; kind0 = mk_full; __syncthreads(); if (tid < 9) f[tid] = fl[tid]; }
+    }
+    __syncthreads();
+    if (tid < 9) lg->f[tid] = f[tid];
+    if (tid == 0) { lg->I = (int)mI; lg->J = mJ; lg->kind0 = kind0; lg->pub = drawn; }
+    __syncthreads();
+}
+template <int T>
+__device__ __forceinline__ void dg_coop_unit_rep(const dg_args &A, dg_f_shared *S, const dg_coop_ws &v, int slot, int u, double *jbuf, int tid)
+{
+    char *lj = dg_coop_lojob(A, slot);
+    const dg_lo_job *job = (const dg_lo_job *)lj;
+    char *ws = A.ws + (size_t)slot * A.wl.stride;
+    dg_ht ht; ht.heads = (int *)(ws + A.wl.off_ht); ht.count = ht.heads + 64; ht.ent = ht.heads + 80;
+    dg_lo_rep_wg<T>(S, v.P, job->n, ht, (dg_lo_log *)(lj + 128 + (size_t)DG_LOJOB_STRIDE * u), dg_coop_lo_list(A, slot, 2 * u), dg_coop_lo_list(A, slot, 2 * u + 1),
+                    jbuf, job->ssiz, job->th, job->mk_full, job->mk_ex, tid);
+}
+
 /* Whole workgroup (owner or helper): work on generation G until it has no unclaimed unit left */
 template <int T>
-__device__ __forceinline__ void dg_coop_work(dg_f_shared *S, const dg_coop_ws &v, dg_coop_cb *cb, int G, double *jbuf, int *bc /* LDS */, int tid)
+__device__ __forceinline__ void dg_coop_work(const dg_args &A, int slot, dg_f_shared *S, const dg_coop_ws &v, dg_coop_cb *cb, int G, double *jbuf, int *bc /* LDS */, int tid)
 {
     for (;;) {
         const int u = dg_coop_claim(cb, G, bc);
@@ -1296,8 +1445,10 @@ __device__ __forceinline__ void dg_coop_work(dg_f_shared *S, const dg_coop_ws &v
             dg_coop_unit_screen<T>(S, v, cb, lo, hi, tau, tid);
         } else if (stage == 2) {
             dg_coop_unit_exact<T>(S, v, cb, (int)v.surv[u], jbuf, tid);
-        } else {
+        } else if (stage == 3) {
             dg_coop_unit_pass<T>(S, v, u, tid);
+        } else {
+            dg_coop_unit_rep<T>(A, S, v, slot, u, jbuf, tid);
         }
         dg_coop_unit_done(cb);
     }
@@ -1326,7 +1477,7 @@ __device__ __forceinline__ void dg_f_helper(const dg_args &A, dg_f_shared *S, co
         __syncthreads();
         if (g < 0) break;
         last = g;
-        dg_coop_work<T>(S, v, cb, g, jbuf, bc, tid);
+        dg_coop_work<T>(A, slot, S, v, cb, g, jbuf, bc, tid);
     }
 }
 
@@ -1350,7 +1501,7 @@ __device__ __noinline__ dg_pass_res dg_coop_pass(CTX &c, const double *Fm /* LDS
         jb->has_list = cfg.list ? 1 : 0; jb->has_list2 = cfg.list2 ? 1 : 0; jb->slice = slice; jb->n = n; jb->pad = 0;
     }
     dg_coop_publish(cb, *c.coop_gen, 3, n_units, 0, n, kind, slice, 0, cfg.thJ, S->ext, 0.0);
-    dg_coop_work<DG_T>(S, v, cb, *c.coop_gen, (double *)(A.ws + (size_t)c.coop_slot * A.wl.stride + A.wl.off_hjbuf), &S->itmp[28], tid);
+    dg_coop_work<DG_T>(A, c.coop_slot, S, v, cb, *c.coop_gen, (double *)(A.ws + (size_t)c.coop_slot * A.wl.stride + A.wl.off_hjbuf), &S->itmp[28], tid);
     if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
         while (__hip_atomic_load(&cb->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_units) __builtin_amdgcn_s_sleep(2);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1376,6 +1527,23 @@ __device__ __noinline__ dg_pass_res dg_coop_pass(CTX &c, const double *Fm /* LDS
     if (cfg.wantJ) out.J = S->red.bc[0];
     __syncthreads();
     return out;
+}
+
+/* Owner, whole workgroup: one round of a local optimisation's repetitions as stage 4 (the records of the round's nr repetitions
+ * are planned in the workspace); returns when all of them are finished and visible */
+template <int LDSPTS>
+__device__ __forceinline__ void dg_lo_round_coop(CTX &c, int nr, int ssiz, double th, int mk_full, int mk_ex)
+{
+    dg_f_shared *S = c.S; const dg_args &A = *c.A; dg_coop_cb *cb = c.cb; const int tid = c.tid;
+    const dg_coop_ws v = dg_coop_views(A, c.coop_slot);
+    if (tid == 0) { dg_lo_job *job = (dg_lo_job *)dg_coop_lojob(A, c.coop_slot); job->n = c.n; job->ssiz = ssiz; job->mk_full = mk_full; job->mk_ex = mk_ex; job->th = th; }
+    dg_coop_publish(cb, *c.coop_gen, 4, nr, 0, c.n, mk_full, 0, 0, th, S->ext, 0.0);
+    dg_coop_work<DG_T>(A, c.coop_slot, S, v, cb, *c.coop_gen, (double *)(A.ws + (size_t)c.coop_slot * A.wl.stride + A.wl.off_hjbuf), &S->itmp[28], tid);
+    if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
+        while (__hip_atomic_load(&cb->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nr) __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
 }
 
 /* ---- stream mode (dg_stream_cb, dg_stream_ent) -------------------------------------------------------------------- */
@@ -1487,7 +1655,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     c.ht.heads = (int *)(ws + A.wl.off_ht); c.ht.count = c.ht.heads + 64; c.ht.ent = c.ht.heads + 80;
     c.seeds = S->seeds3[0]; c.draws = S->draws3[0];
     c.n_fds = c.n_exfds = c.n_hds = c.n_aux = 0; c.rrun = 0; c.hlt = (double *)0;
-    c.cb = cb; c.coop_gen = &coop_gen; c.coop_slot = slot;
+    c.cb = cb; c.coop_gen = &coop_gen; c.coop_slot = slot; c.lo_assumed = DG_LO_ASSUMED_DRAWS; c.lo_prev = -1;
     dg_pt *Pw; int *pool;
     /* LDSPTS: 1 = point set and sampler pool in LDS, 2 = pool in LDS / points in the HBM workspace (L2), 0 = both in HBM */
     if (LDSPTS == 1) { Pw = (dg_pt *)dyn_smem; pool = (int *)(dyn_smem + (size_t)n * sizeof(dg_pt)); }
@@ -1825,9 +1993,9 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             const dg_coop_ws cv = dg_coop_views(A, slot);
             unsigned short *gms = (unsigned short *)(ws + A.wl.off_mslot);
             for (int i = tid; i < Mtot; i += DG_T) { gms[i] = S->mslot[i]; cv.cnt[i] = 0u; if (!coop_screen) cv.surv[i] = (unsigned short)i; }
-            /* stage 1: screening counts over slices of the point set (about three slices per claiming workgroup, at least
+            /* stage 1: screening counts over slices of the point set (DG_COOP_SPW slices per claiming workgroup, at least
              * four tiles each); without a bound to beat, straight to stage 2 with every model */
-            int slice = (n + 3 * (coopK + 1) - 1) / (3 * (coopK + 1)); if (slice < 64 * DG_PU * 4) slice = 64 * DG_PU * 4;
+            int slice = (n + DG_COOP_SPW * (coopK + 1) - 1) / (DG_COOP_SPW * (coopK + 1)); if (slice < 64 * DG_PU * 4) slice = 64 * DG_PU * 4;
             slice = (slice + 64 * DG_PU - 1) / (64 * DG_PU) * (64 * DG_PU);
             coop_units = coop_screen ? (n + slice - 1) / slice : Mtot;
             /* level 2 only: the cooperative mode is for large point sets with few inliers, where random models have far
@@ -1873,7 +2041,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             int units = coop_units;
             for (int st = coop_screen ? 1 : 2; st <= 2; st++) {
                 __syncthreads();
-                dg_coop_work<T>(S, cv, cb, coop_gen, jb0, &S->itmp[28], tid);
+                dg_coop_work<T>(A, slot, S, cv, cb, coop_gen, jb0, &S->itmp[28], tid);
                 if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
                     while (__hip_atomic_load(&cb->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < units) __builtin_amdgcn_s_sleep(2);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

@@ -62,12 +62,15 @@ _ORACLE_CACHE = {}
 
 def test_cooperative_helpers_match_the_oracle(oracle_port):
     """cooperative large-n mode forced on a small batch (placement HBM, 1 / 3 / 7 helper workgroups per pair, several pairs
-    per owner): every run, pair by pair, against the CPU oracle (counters, masks, models), not against another GPU run"""
+    per owner): every run, pair by pair, against the CPU oracle (counters, masks, models), not against another GPU run.
+    The local optimisation's repetitions run as units of their own (stage 4: one claiming workgroup per repetition, speculated
+    generator states, in-order replay); with TUNE_F_SERIAL_REPS they run one after the other with every pass distributed."""
     A, B = _f_batch(); A = A * 3; B = B * 3; seeds = list(range(1, 13))
-    for variant in (512, 256):
-        for helpers, dist in ((255, 0), (1, 0), (3, 1), (7, 0), (7, 1)):    # dist: the LO's full passes distributed too (TUNE_COOP_ALL_PASSES)
-            F, m = pd.findFundamentalMatrixBatch(A, B, max_iters=20000, seeds=seeds, tuning=tune(variant, 0) | _lib.TUNE_HELPERS(helpers) | (dist * _lib.TUNE_COOP_ALL_PASSES))
-            _check_against_oracle(oracle_port, A, B, seeds, F, m, pd.last_stats(), (variant, helpers, dist))
+    for variant in (512, 256, 128):
+        for helpers, dist, serial in ((255, 0, 0), (1, 0, 0), (3, 1, 0), (7, 0, 0), (7, 1, 0), (3, 1, 1), (7, 0, 1), (12, 0, 0)):    # dist: the LO's full passes distributed too (TUNE_COOP_ALL_PASSES)
+            F, m = pd.findFundamentalMatrixBatch(A, B, max_iters=20000, seeds=seeds, tuning=tune(variant, 0) | _lib.TUNE_HELPERS(helpers) | (dist * _lib.TUNE_COOP_ALL_PASSES)
+                                                 | (serial * _lib.TUNE_F_SERIAL_REPS))
+            _check_against_oracle(oracle_port, A, B, seeds, F, m, pd.last_stats(), (variant, helpers, dist, serial))
 
 
 def test_repetitions_one_per_wave_equal_the_serial_order(oracle_port):
