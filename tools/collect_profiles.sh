@@ -17,6 +17,9 @@ tail -1 $O/bench_line_c5.json > profiles/${R}_bench_line_c5.json
 grep -v amdgpu.ids $O/ab_f.log > profiles/${R}_ab_fundamental.log
 grep -v amdgpu.ids $O/ab_h.log > profiles/${R}_ab_homography.log
 grep -v amdgpu.ids $O/host_batch.log > profiles/${R}_host_batch.log
+grep -v amdgpu.ids $O/phases_c5.log | cut -c1-1200 > profiles/${R}_phases_c5.log
+grep -v amdgpu.ids $O/phases_c3.log | cut -c1-1200 > profiles/${R}_phases_c3.log
+grep -v amdgpu.ids $O/phases_c2_1024.log | grep -v '^pair ' | cut -c1-1200 > profiles/${R}_phases_c2_1024.log
 python - <<'PY'
 import json
 out = {}

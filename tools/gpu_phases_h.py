@@ -29,3 +29,7 @@ ph = d_ph.cpu().numpy().astype(np.float64) / 1e5; st = d_st.cpu().numpy()
 names = ["solve", "score||sample", "commit", "LO", "-", "-", "tail", "total", "LO passes", "LO lsq+eig (long lists)", "LO hash", "LO small fits", "LO checks|gather", "lsq_par", "eig", "(mark)"]
 print("mean ms per pair:", {n: round(float(ph[:, i].mean()), 3) for i, n in enumerate(names) if n not in ("-", "(mark)")})
 print("samples mean", st[:, 0].mean(), "lo_runs mean", st[:, 1].mean(), "threads", st[0, 14], "placement", st[0, 15] & 255)
+# the longest pairs of the launch (a one-generation launch ends with its slowest pair)
+order = np.argsort(-ph[:, 7])[:8]
+for p in order:
+    print("pair", int(p), {n: round(float(ph[p, i]), 2) for i, n in enumerate(names) if n not in ("-", "(mark)", "lsq_par", "eig")}, "samples", int(st[p, 0]), "lo_runs", int(st[p, 1]), "models", int(st[p, 4]), "best_sample", int(st[p, 7]))

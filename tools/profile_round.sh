@@ -24,4 +24,8 @@ for p in 8192 16384; do python bench.py --steps 2 --warmup 1 --pairs-per-gpu $p 
 python tools/gpu_host_batch.py 4096 > $O/host_batch.log 2>&1
 python tools/gpu_ab.py base nostream serial > $O/ab_f.log 2>&1
 python tools/gpu_ab_h.py 0 > $O/ab_h.log 2>&1
+# phase tables (development build: tools/libmi_degensac_dev.so = `make -C pydegensac_amd/csrc dev` of the same sources)
+python tools/gpu_phases.py 1 50000 0.1 200000 > $O/phases_c5.log 2>&1
+python tools/gpu_phases_h.py 1024 > $O/phases_c3.log 2>&1
+python tools/gpu_phases.py 1024 > $O/phases_c2_1024.log 2>&1
 find $O -name "*.csv" | head -30; tail -1 $O/pmc_summary.log; tail -1 $O/sum_c3.log; tail -1 $O/sum_c5.log; cut -c1-400 $O/bench_line.json
