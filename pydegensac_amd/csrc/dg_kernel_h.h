@@ -777,7 +777,19 @@ __device__ __noinline__ int dg_h_lo(CTX &c, int kind, const double *e4, double t
     dg_pass_res ra = dg_hm_pass(c, kind, e4, ca);
     DG_HT(0);
     DG_TRACE(c, 1, ra.nL, no_sam);
-    dg_u2h_list(c, c.K->L[0], (int)ra.nL, S->f);
+    if (c.hlt && c.K->hrep && (int)ra.nL > 12) {
+        /* the long-list fit on ONE wave with the streaming least squares of the per-wave repetitions (every reference-order sum from
+         * an LDS tile): the workgroup form spends a barrier round trip per block of the list, and at 128 threads has only two waves
+         * to spread its sums over */
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
+            char *wb = c.K->hrep + dg_hrep_logs_bytes();
+            const int nm = c.K->n_max;
+            dg_pt *stage = (dg_pt *)((double *)((int *)wb + 2 * (size_t)nm) + nm);
+            dg_u2h_wave<LDSPTS>(c, &S->ww[0], c.hlt, c.K->L[0], (int)ra.nL, stage, S->f, tid & 63);
+        }
+        __syncthreads();
+    } else dg_u2h_list(c, c.K->L[0], (int)ra.nL, S->f);
     DG_HT(1);
     DG_BUFSET(S, B0, S->f);
     dg_pass_cfg cb = dg_cfg0(n); cb.wantJ = 1; cb.thJ = th; cb.list = c.K->L[0]; cb.thL = th;
