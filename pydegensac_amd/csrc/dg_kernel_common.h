@@ -213,6 +213,7 @@ struct dg_args {
     int variant_threads, mode;       /* reported in the stats block */
     /* stream mode (dg_stream_cb): */
     int stream_on;                   /* 0 = off */
+    int stream_early;                /* 1: the launch has a spare workgroup per pair from the start (small batches, single calls): pairs ask at once */
     int stream_min_sam, stream_min_left;   /* a pair asks for a producer once it has drawn stream_min_sam samples and has at least stream_min_left left */
     int stream_depth;                /* ring entries per owner */
     int stream_test;                 /* bit 0: the owner re-scores every chunk it takes from the ring (tests the stale-bound path); bit 1: ask for a producer

@@ -1804,13 +1804,13 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                 __hip_atomic_store(&scb->max_sam, max_sam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&scb->tail, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (strm < 2 && !legacy_sym && no_sam >= A.stream_min_sam && max_sam - no_sam >= A.stream_min_left && (strm == 1 || (seq & 3) == 0)) {
+            if (strm < 2 && !legacy_sym && no_sam >= A.stream_min_sam && max_sam - no_sam >= A.stream_min_left && (strm == 1 || (seq & 3) == 0 || no_sam < 1024)) {
                 /* ask for a producer (or renew an unanswered request with a fresh image; or see whether the producer has caught up) */
                 __syncthreads();
                 if (tid == 0) {
                     int act = 0;                        /* 1 = write the image (the block is mine), 2 = switch to the ring */
                     if (strm == 0) {
-                        if ((A.stream_test & 2) || __hip_atomic_load(A.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= A.n_pairs) {
+                        if ((A.stream_test & 2) || A.stream_early || __hip_atomic_load(A.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= A.n_pairs) {
                             int e = DG_ST_IDLE;
                             if (__hip_atomic_compare_exchange_strong(&scb->state, &e, DG_ST_BUSY, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) act = 1;
                         }
@@ -2237,6 +2237,13 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                 }
             }
             if (no_sam == DG_ITER_SAM && non_degen) do_iterate = 1;
+            /* a producer that runs ahead screens with the owner's bound: tell it as soon as the bound or the budget moves (an event
+             * can keep this workgroup busy for milliseconds before the next chunk starts) */
+            if (scb && strm >= 1 && tid == 0) {
+                const double tau_ = maxS.J < maxSs.J ? maxS.J : maxSs.J;
+                __hip_atomic_store(&scb->tau_bits, (unsigned long long)__double_as_longlong(tau_ < 0 ? 0.0 : tau_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&scb->max_sam, max_sam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
 
             if (do_iterate) {
                 if (!rng_ready) {
@@ -2274,6 +2281,11 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                 if (new_max && !pr.legacy) {
                     int new_sam = dg_nsamples((int)maxS.I + 1, n, 7, pr.conf);
                     if (new_sam < max_sam) max_sam = new_sam;
+                }
+                if (scb && strm >= 1 && tid == 0) {
+                    const double tau_ = maxS.J < maxSs.J ? maxS.J : maxSs.J;
+                    __hip_atomic_store(&scb->tau_bits, (unsigned long long)__double_as_longlong(tau_ < 0 ? 0.0 : tau_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&scb->max_sam, max_sam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 DG_PH(4);
             }
