@@ -1949,13 +1949,17 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
       }
       if (full) {
         /* ================= solve: one 7-point problem per lane ================= */
+        /* With eight waves the solves run on the scoring waves INSIDE the phase below, next to the sampler stages of waves 0 and 1
+         * (the seed chain of chunk c + 2 is the longest of the three): see solve_fused. */
+        const bool fuse = DG_NW >= 8 && !(LDSPTS == 0 && coopK > 0) && strm != 2 && !ff;
+        if (fuse) { __syncthreads(); if (tid == 0) { S->itmp[21] = 0; S->itmp[22] = 0; } __syncthreads(); }
         int nvalid = 0, nullbad = 0; unsigned rixp = 0;
-        if (!ff && tid < chunk) {
+        if (!fuse && !ff && tid < chunk) {
             int r_ = dg_solve7_lane(P, c.draws[tid], c.K->gmodels + (size_t)tid * 27, &rixp, (double *)&S->ww[wave]);
             if (r_ < 0) nullbad = 1; else nvalid = r_;
         }
         /* ordered slots: exclusive scan of nvalid over the lanes of the chunk */
-        {
+        if (!fuse) {
             unsigned v = (unsigned)nvalid, incl = v;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
@@ -1976,7 +1980,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             if (tid == DG_T - 1) S->moff[DG_CHUNK] = (unsigned short)(excl + v);
             __syncthreads();
         }
-        Mtot = ff ? 0 : __builtin_amdgcn_readfirstlane((int)S->moff[DG_CHUNK]);
+        Mtot = (ff || fuse) ? 0 : __builtin_amdgcn_readfirstlane((int)S->moff[DG_CHUNK]);
         /* cooperative mode: the chunk's models are scored by whoever claims the units: the helpers of this slot at once,
          * this workgroup after its sampler stages (dg_coop_cb) */
         double tau_c = A.hist_out ? 0.0 : (maxS.J < maxSs.J ? maxS.J : maxSs.J);
@@ -2024,8 +2028,51 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             {
                 const int NS = DG_NW >= 4 ? DG_NW - 2 : DG_NW, wsi = DG_NW >= 4 ? wave - 2 : wave;
                 const int capw = (int)((sizeof(dg_lsq_scratch) / NS) & ~(size_t)15);
+                int Ms = Mtot;
+                if (fuse && wsi >= 0) {
+                    /* solve_fused: scoring wave b < 4 solves the samples 64 b .. 64 b + 63 of the chunk (its scratch: its own scoring
+                     * table, not yet in use), the ordered model slots come from the four block totals, and the scoring waves meet at two
+                     * LDS counters instead of workgroup barriers (waves 0 and 1 are inside their sampler stages) */
+                    constexpr int NB = DG_CHUNK / 64;
+                    int nv_ = 0, nb_ = 0; unsigned rx = 0, incl = 0; const int k_ = wsi * 64 + lane;
+                    if (wsi < NB) {
+                        if (k_ < chunk) {
+                            const int r_ = dg_solve7_lane(P, c.draws[k_], c.K->gmodels + (size_t)k_ * 27, &rx, (double *)((char *)&S->lsq + (size_t)wsi * capw));
+                            if (r_ < 0) nb_ = 1; else nv_ = r_;
+                        }
+                        incl = (unsigned)nv_;
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+                        if (lane == 63) S->wave_cnt[wsi] = incl;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) __hip_atomic_fetch_add(&S->itmp[21], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&S->itmp[21], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < NB) __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    unsigned tot = 0, wbase = 0;
+#pragma unroll
+                    for (int b = 0; b < NB; b++) { const unsigned t = S->wave_cnt[b]; if (b < wsi) wbase += t; tot += t; }
+                    if (wsi < NB) {
+                        const unsigned excl = wbase + incl - (unsigned)nv_;
+                        if (k_ < chunk) {
+                            S->moff[k_] = (unsigned short)excl;
+                            S->nv[k_] = nb_ ? 255 : (unsigned char)nv_;
+                            S->nsolv[k_] = (unsigned char)((rx >> 8) & 3u);
+                            for (int r = 0; r < nv_; r++) {
+                                S->ridx[k_][r] = (unsigned char)((rx >> (2*r)) & 3u);
+                                S->mslot[excl + r] = (unsigned short)(k_ * 3 + r);
+                            }
+                        }
+                        if (wsi == 0 && lane == 0) S->moff[DG_CHUNK] = (unsigned short)tot;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) __hip_atomic_fetch_add(&S->itmp[22], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&S->itmp[22], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < NB) __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    Ms = (int)__builtin_amdgcn_readfirstlane(tot);
+                }
                 if (!(LDSPTS == 0 && coopK > 0) && wsi >= 0 && !ff)
-                    dg_score_chunk_F<LDSPTS>(P, n, c.K->gmodels, S->mslot, Mtot, wsi, NS, mk_full, th,
+                    dg_score_chunk_F<LDSPTS>(P, n, c.K->gmodels, S->mslot, Ms, wsi, NS, mk_full, th,
                                              tau_c, S->ext, (char *)&S->lsq + (size_t)wsi * capw, capw,
                                              (double *)(c.K->wstage + (size_t)wave * c.K->n_max), c.K->res_I, c.K->res_J, lane);
             }
@@ -2068,6 +2115,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             }
         }
         __syncthreads();
+        if (fuse) { Mtot = __builtin_amdgcn_readfirstlane((int)S->moff[DG_CHUNK]); c.n_fds += Mtot; }
         if (cn2 > 0) seed = (unsigned)S->itmp[31];
         /* the draws of chunk c+2 (its seeds are complete now): the rounds of 64 samples are independent, one wave each; nothing
          * reads them before the pool stage of the next iteration, which sits behind the barriers of the commit */
