@@ -143,7 +143,7 @@ struct dg_stream_cb {
     int head;                 /* chunks the producer has published: sequence numbers < head are in the ring */
     int tail;                 /* chunks the owner has consumed */
     int stop;                 /* the owner is done with the pair */
-    int owner_sam;            /* the sample the owner stands at (chunks that start before it are of no use) */
+    int owner_sam;            /* since when the pair has been worked on (wall_clock64 >> 10): producers take the oldest of the requests with the most samples left */
     int max_sam;              /* the owner's current sample budget */
     unsigned long long tau_bits;   /* the owner's current bound min(maxS.J, maxSs.J), as the bits of a double */
     int fpad[24];

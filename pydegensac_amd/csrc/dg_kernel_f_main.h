@@ -1598,15 +1598,26 @@ __device__ __forceinline__ int dg_stream_find(const dg_args &A, int *bc /* LDS *
                 /* no open request (done_pairs[1] counts them): nothing to scan; hundreds of idle workgroups poll these two words only */
                 for (int q = 0; q < 8; q++) __builtin_amdgcn_s_sleep(127);
             } else {
-                int found = -1;
-                /* (uniform trip count: every lane looks at its slots of every round) */
+                /* the open request with the most samples left (pairs that have cut their budget end soon by themselves; the ones that
+                 * keep all of it are the ones that end the launch): key = (samples left, slot); uniform trip counts throughout */
+                long long key = -1;
                 for (int q = 0; q < A.n_res; q += 64) {
                     const int j = (int)((blockIdx.x + (unsigned)(q + lane)) % (unsigned)A.n_res);
-                    if (q + lane < A.n_res && found < 0 && __hip_atomic_load(&A.scb[j].state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == DG_ST_REQ) found = j;
+                    if (q + lane < A.n_res && __hip_atomic_load(&A.scb[j].state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == DG_ST_REQ) {
+                        int left = __hip_atomic_load(&A.scb[j].max_sam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                 - DG_CHUNK * __hip_atomic_load(&A.scb[j].tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (left < 0) left = 0;
+                        /* ... and among those the pair that has been running longest: a pair that has just started also has its whole budget */
+                        int age = (int)(wall_clock64() >> 10) - __hip_atomic_load(&A.scb[j].owner_sam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        age = age < 0 ? 0 : (age > 0xfffff ? 0xfffff : age);
+                        const long long k_ = ((long long)(left >> 12) << 40) | ((long long)age << 16) | (long long)(unsigned)(j & 0xffff);
+                        key = k_ > key ? k_ : key;
+                    }
                 }
-                const unsigned long long m = __ballot(found >= 0);
-                if (m) {
-                    const int j = __builtin_amdgcn_readlane(found, __ffsll((long long)m) - 1);
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) { const long long t = __shfl_xor(key, o, 64); key = t > key ? t : key; }
+                if (key >= 0) {
+                    const int j = __builtin_amdgcn_readfirstlane((int)(key & 0xffffll));
                     int ok = 0;
                     if (threadIdx.x == 0) {
                         int e = DG_ST_REQ; ok = __hip_atomic_compare_exchange_strong(&A.scb[j].state, &e, DG_ST_ATTACHED, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
@@ -1838,6 +1849,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                         __hip_atomic_store(&scb->tail, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(&scb->head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(&scb->stop, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&scb->owner_sam, (int)(t_start >> 10), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* since when the pair runs (10 us units) */
                     }
                     write_image();
                     dg_stream_publish(&scb->state, DG_ST_REQ);
