@@ -21,6 +21,10 @@
 #endif
 #define DG_MCAP    96          /* models scored per LDS sub-batch                                  */
 #define DG_HT_CAP  4096        /* LO inlier-set hash entries per pair                              */
+/* one table of chunk models, [3 * DG_CHUNK][9] doubles; the cooperative mode has two (+ DG_PRE_BYTES: what the early solves of the
+ * next chunk leave per sample) */
+#define DG_MTAB_BYTES ((((size_t)3 * DG_CHUNK * 9 * sizeof(double)) + 255) & ~(size_t)255)
+#define DG_PRE_BYTES  ((size_t)DG_CHUNK * 2 * sizeof(int))
 
 /* rtools.h:4-15 */
 #define DG_ITER_SAM 50
@@ -110,7 +114,8 @@ struct dg_coop_cb {
      * stage cannot end before every claimed unit is done, so they are stable while a claimer reads them) */
     int stage, n_units, Mtot, n, kind, slice, use_l1, err;
     double th, ext[4];
-    double ppad[7];
+    int mtab, mpad;       /* which of the two model tables holds the chunk that is being scored (the other one receives the next chunk's solves) */
+    double ppad[6];
 };
 static_assert(sizeof(dg_coop_cb) == 256, "control block = two 128-byte lines");
 

@@ -1254,7 +1254,7 @@ __device__ __forceinline__ void dg_coop_unit_screen(dg_f_shared *S, const dg_coo
         /* all lanes write an entry (the tile loop runs over nb entries); models that need no counting get a zero model */
         double F[9];
         {
-            const double *gp = v.gmodels + (size_t)v.gms[have ? mi : wave] * 9;
+            const double *gp = v.gmodels + (size_t)cb->mtab * (DG_MTAB_BYTES / sizeof(double)) + (size_t)v.gms[have ? mi : wave] * 9;
 #pragma unroll
             for (int q = 0; q < 9; q++) F[q] = gp[q];
         }
@@ -1287,7 +1287,7 @@ __device__ __forceinline__ void dg_coop_unit_exact(dg_f_shared *S, const dg_coop
 {
     const int n = cb->n, kind = cb->kind; const double th = cb->th;
     double F[9];
-    const double *gp = v.gmodels + (size_t)v.gms[mi] * 9;
+    const double *gp = v.gmodels + (size_t)cb->mtab * (DG_MTAB_BYTES / sizeof(double)) + (size_t)v.gms[mi] * 9;
 #pragma unroll
     for (int q = 0; q < 9; q++) F[q] = gp[q];
     dg_pass_cfg cfg = dg_cfg0(n); cfg.wantJ = 1; cfg.thJ = th; cfg.jbuf = jbuf;
@@ -1647,6 +1647,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     const int producer = resume == 2;
     dg_stream_cb *const scb = A.stream_on ? A.scb + oslot : (dg_stream_cb *)0;
     int head_seen = 0;               /* owner: ring entries below this sequence number are known to be visible */
+    int mtab = 0, presolved = 0;     /* cooperative mode: the model table of the current chunk; samples of the current chunk that were solved during the previous chunk's scoring */
     int strm = 0, img_sam = 0;       /* owner: 0 = own sample stream, 1 = asked for a producer (image written), 2 = takes its chunks from the ring */
     const int coopK = LDSPTS == 0 ? A.coop_k : 0;
     dg_coop_cb *const cb = coopK > 0 ? A.coop + slot : (dg_coop_cb *)0;
@@ -1742,6 +1743,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
 #define DG_PH(i) DG_DEVT(if (tid == 0) { long long tq2_ = DG_CLK(); S->ph[i] += tq2_ - S->tq; S->tq = tq2_; })
     /* software pipeline: chunk c is scored while chunk c+1 gets its pool swaps and chunk c+2 its seeds and draws */
     cur = 0; chunk_s[0] = chunk_s[1] = chunk_s[2] = 0; chunk_base = 0;
+    if (tid == 0) S->itmp[23] = 0;
     {
         int cn0 = max_sam - no_sam; if (cn0 > DG_CHUNK) cn0 = DG_CHUNK; if (cn0 < 0) cn0 = 0;
         int cn1 = max_sam - no_sam - cn0; if (cn1 > DG_CHUNK) cn1 = DG_CHUNK; if (cn1 < 0) cn1 = 0;
@@ -1780,6 +1782,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         if (tid == 0) { scb->pair = pair; scb->wsid = wsid; scb->img_sam = no_sam; }
     };
     while (!done && no_sam < max_sam) {
+        int pre_cnt = 0;             /* cooperative mode: samples of the next chunk solved during this one's scoring */
         int ff = 0, tail_p = 0;      /* producer: the owner is already past this chunk: sampler stages only; the owner's position */
         const int seq = no_sam / DG_CHUNK;
         dg_stream_ent *ent = (dg_stream_ent *)0;
@@ -1966,6 +1969,10 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         const bool fuse = DG_NW >= 8 && !(LDSPTS == 0 && coopK > 0) && strm != 2 && !ff;
         if (fuse) { __syncthreads(); if (tid == 0) { S->itmp[21] = 0; S->itmp[22] = 0; } __syncthreads(); }
         int nvalid = 0, nullbad = 0; unsigned rixp = 0;
+        if (presolved >= chunk && chunk > 0) {
+            /* cooperative mode: this chunk's 7-point problems were solved while the helpers scored the previous chunk */
+            if (tid < chunk) { const int *pre = (const int *)(ws + A.wl.off_models + 2 * DG_MTAB_BYTES) + 2 * tid; const int a_ = pre[0]; nvalid = a_ & 0xff; nullbad = (a_ >> 8) & 1; rixp = (unsigned)pre[1]; }
+        } else
         if (!fuse && !ff && tid < chunk) {
             int r_ = dg_solve7_lane(P, c.draws[tid], c.K->gmodels + (size_t)tid * 27, &rixp, (double *)&S->ww[wave]);
             if (r_ < 0) nullbad = 1; else nvalid = r_;
@@ -2017,6 +2024,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             /* level 2 only: the cooperative mode is for large point sets with few inliers, where random models have far
              * more points inside the looser level-1 band than the bound to beat (C5: thousands against a few hundred), so
              * level 1 would pass nearly every model on to exact scoring */
+            if (tid == 0) cb->mtab = mtab;                 /* (published by the release of dg_coop_publish: same wave) */
             if (coop_units > 0) dg_coop_publish(cb, coop_gen, coop_screen ? 1 : 2, coop_units, Mtot, n, mk_full, slice, 0, th, S->ext, tau_c);
         }
 
@@ -2027,9 +2035,25 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             cn2 = max_sam - (no_sam + chunk_s[cur] + chunk_s[nxt]); if (cn2 > DG_CHUNK) cn2 = DG_CHUNK; if (cn2 < 0) cn2 = 0;
             if (strm == 2) cn2 = 0;                        /* the sample stream comes from the producer */
             chunk_s[nx2] = cn2;
+            /* cooperative mode, eight waves: while the helpers score this chunk, waves 2-5 solve the NEXT chunk's 7-point problems as soon
+             * as wave 0 has its drawn ids (an LDS flag, no barrier: wave 1 is inside the seed chain), into the other model table */
+            const bool presolve = DG_NW >= 8 && LDSPTS == 0 && coopK > 0 && strm != 2 && chunk_s[nxt] > 0 && !A.hist_out;
+            if (presolve) pre_cnt = chunk_s[nxt];
             if (strm == 2) { /* no sampler stages */ }
             else if (wave == 0) {
                 if (chunk_s[nxt] > 0) dg_sample_pool<7, LDSPTS>(chunk_s[nxt], n, pool, S->draws3[nxt], S->alm3[nxt], pscr, lane, S->dbg);
+                if (presolve) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); if (lane == 0) __hip_atomic_store(&S->itmp[23], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            } else if (presolve && wave >= 2 && wave < 2 + DG_CHUNK / 64) {
+                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&S->itmp[23], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const int k_ = (wave - 2) * 64 + lane;
+                if (k_ < chunk_s[nxt]) {
+                    unsigned rx = 0;
+                    double *tab = (double *)(ws + A.wl.off_models + (size_t)(mtab ^ 1) * DG_MTAB_BYTES);
+                    const int r_ = dg_solve7_lane(P, S->draws3[nxt][k_], tab + (size_t)k_ * 27, &rx, (double *)((char *)&S->lsq + (size_t)(wave - 2) * 1024));
+                    int *pre = (int *)(ws + A.wl.off_models + 2 * DG_MTAB_BYTES) + 2 * k_;
+                    pre[0] = r_ < 0 ? 0x100 : r_; pre[1] = (int)rx;
+                }
             } else if (wave == 1) {
                 if (cn2 > 0) { unsigned sd = dg_sample_chain<7>(seed, cn2, S->seeds3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }   /* its draws: after the barrier, one wave per 64 samples */
             }
@@ -2127,6 +2151,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             }
         }
         __syncthreads();
+        if (tid == 0) S->itmp[23] = 0;                 /* the "drawn ids of the next chunk are ready" flag of the early solves */
         if (fuse) { Mtot = __builtin_amdgcn_readfirstlane((int)S->moff[DG_CHUNK]); c.n_fds += Mtot; }
         if (cn2 > 0) seed = (unsigned)S->itmp[31];
         /* the draws of chunk c+2 (its seeds are complete now): the rounds of 64 samples are independent, one wave each; nothing
@@ -2382,7 +2407,11 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             if (kf >= 0) { if (tid < 7) S->lastIds[tid] = c.draws[kf][tid]; D.has_last = 1; }
             __syncthreads();
         }
-        if (!done) cur = nxt;
+        if (!done) {
+            cur = nxt;
+            presolved = pre_cnt;
+            if (pre_cnt > 0) { mtab ^= 1; if (tid == 0) S->K.gmodels = (double *)(ws + A.wl.off_models + (size_t)mtab * DG_MTAB_BYTES); }
+        }
     }
     if (producer) {
         /* the producer leaves (everything it wrote is published): the owner may reuse its control block */
