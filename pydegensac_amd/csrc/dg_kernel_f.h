@@ -518,6 +518,46 @@ __device__ __forceinline__ dg_pass_res dg_wpass_impl(const dg_pt *P, int n, Err 
     DG_WSYNC();
     return out;
 }
+/* One wave's share of a pass that a workgroup splits into point slices (dg_lo_rep_wg): the points [lo, hi), ids and MSAC terms
+ * compacted in point order into slice-local outputs (la / lb / jout start at the slice's first slot); no sum: the caller adds the
+ * slices' terms one after the other.  Returns I, nL, nL2, nJ of the slice. */
+template <class Err>
+__device__ __forceinline__ dg_pass_res dg_wpass_slice(const dg_pt *P, int lo, int hi, Err err, double thJ, int *la_, double thL, int *lb_, double thL2, double *jout_, int lane)
+{
+    __attribute__((address_space(1))) int *la = (__attribute__((address_space(1))) int *)la_, *lb = (__attribute__((address_space(1))) int *)lb_;
+    __attribute__((address_space(1))) double *jo = (__attribute__((address_space(1))) double *)jout_;
+    dg_pass_res out; out.I = 0; out.J = 0; out.C = 0; out.nL = 0; out.nF = 0; out.nL2 = 0; out.nJ = 0;
+    const double t94 = thJ * 9 / 4;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned cI = 0, nJ = 0, nA = 0, nB = 0;
+    dg_pt qn[DG_PU];
+#pragma unroll
+    for (int u = 0; u < DG_PU; u++) { const int j = lo + u * 64 + lane; qn[u] = dg_ldpt<0>(P, j < hi ? j : 0); }
+    for (int base = lo; base < hi; base += DG_PU * 64) {
+        dg_pt q[DG_PU]; double d[DG_PU];
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) q[u] = qn[u];
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) { const int j = base + DG_PU * 64 + u * 64 + lane; if (j < hi) qn[u] = dg_ldpt<0>(P, j); }
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) d[u] = err(q[u]);
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) {
+            const int j = base + u * 64 + lane; const bool act = j < hi;
+            double term = 0.0;
+            if (jout_ && act && !(d[u] >= t94)) term = 1 - (d[u] / t94);
+            const bool nz = !(term == 0.0), inA = la_ && act && d[u] <= thL, inB = lb_ && act && d[u] <= thL2;
+            cI += (act && d[u] <= thJ) ? 1u : 0u;
+            const unsigned long long mJ = __ballot(nz), mA = __ballot(inA), mB = __ballot(inB);
+            if (nz) jo[nJ + (unsigned)__popcll(mJ & below)] = term;
+            if (inA) la[nA + (unsigned)__popcll(mA & below)] = j;
+            if (inB) lb[nB + (unsigned)__popcll(mB & below)] = j;
+            nJ += (unsigned)__popcll(mJ); nA += (unsigned)__popcll(mA); nB += (unsigned)__popcll(mB);
+        }
+    }
+    out.I = dg_wave_sum_u(cI); out.nL = nA; out.nL2 = nB; out.nJ = nJ;
+    return out;
+}
 static_assert(offsetof(dg_wave_ws, Z) == 0 && offsetof(dg_wave_ws, px) + sizeof(((dg_wave_ws *)0)->px) >= 64 * DG_PU * sizeof(double) &&
               offsetof(dg_wave_ws, ews) >= offsetof(dg_wave_ws, px) + sizeof(((dg_wave_ws *)0)->px), "a wave pass's MSAC-term tile spans dg_wave_ws::Z .. ::px");
 

@@ -1158,7 +1158,8 @@ __device__ __forceinline__ dg_coop_ws dg_coop_views(const dg_args &A, int slot)
 #define DG_COOP_SPW 1            /* stage 1: point slices per claiming workgroup (C5: 85.4 ms with 3, 82.8 with 2, 80.4 with 1: a unit's claim and its release cost ~3 us) */
 #endif
 /* stage 4 (repetitions of a local optimisation as units): the job header + records (DG_LOJOB_BYTES behind the stage-3 staging),
- * and list k (0 .. 2 DG_RAN_REP - 1; repetition q: `inliers` = list 2q, the second list = 2q + 1) from the per-wave area */
+ * and list k (0 .. 4 DG_RAN_REP - 1; repetition q: `inliers` = list 2q, the second list = 2q + 1, the slice-local staging of its
+ * passes = lists 2 DG_RAN_REP + 2q and + 2q + 1) from the per-wave area */
 __device__ __forceinline__ char *dg_coop_lojob(const dg_args &A, int slot)
 {
     char *ws = A.ws + (size_t)slot * A.wl.stride;
@@ -1320,19 +1321,45 @@ __device__ __forceinline__ void dg_coop_unit_pass(dg_f_shared *S, const dg_coop_
  * workgroup passes over all n points (ordered MSAC terms in LDS + this workgroup's HBM buffer), the hash of a set on wave 1
  * while wave 0 draws and fits the next 8-subset.  The table is only looked up. */
 template <int T>
-__device__ __noinline__ void dg_lo_rep_wg(dg_f_shared *S, const dg_pt *P, const int n, const dg_ht &ht, dg_lo_log *lg, int *ib, int *alt, double *jbuf,
+__device__ __noinline__ void dg_lo_rep_wg(dg_f_shared *S, const dg_pt *P, const int n, const dg_ht &ht, dg_lo_log *lg, int *ib, int *alt, int *sA, int *sB, double *jbuf,
                                           const int ssiz, const double th, const int mk_full, const int mk_ex, const int tid)
 {
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *f = S->f, *fl = S->fLO, *ftmp = S->ftmp, *px = S->lsq.px, *wts = S->lsq.part[0];
     const bool small_ids = n < 65536;
+    /* a pass = one point slice per wave (no workgroup barrier inside, lists and MSAC terms compacted into slice-local staging), then
+     * the lists copied to their places in slice order while one lane adds the terms slice after slice: the lists and the J of
+     * dg_pass over all points (a workgroup pass of 50 000 points: ~100 us; this: ~35) */
     auto pass = [&](const double *Fm, int kind, int wantJ, double thJ, int *la, double thL, int *lb, double thL2) -> dg_pass_res {
         double F[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) F[i] = Fm[i];
-        dg_pass_cfg cfg = dg_cfg0(n); cfg.wantJ = wantJ; cfg.thJ = thJ; cfg.list = la; cfg.thL = thL; cfg.list2 = lb; cfg.thL2 = thL2;
-        cfg.jbuf = jbuf; cfg.jl = (double *)S->ww; cfg.jl_cap = (int)(DG_JBUF_LDS_BYTES / sizeof(double));
-        return dg_pass(&S->red, cfg, [&](int pid, int) { return dg_Ferr(kind, F, dg_ldpt<0>(P, pid)); }, tid);
+        constexpr int NWt = T / 64;
+        const int sl = (((n + NWt - 1) / NWt) + 63) & ~63;
+        const int lo = wv * sl < n ? wv * sl : n, hi = lo + sl < n ? lo + sl : n;
+        unsigned *wc = (unsigned *)S->lsq.svw;
+        __syncthreads();
+        const dg_pass_res r = dg_wpass_slice(P, lo, hi, [&](const dg_pt &q) { return dg_Ferr(kind, F, q); }, thJ, la ? sA + lo : (int *)0, thL, lb ? sB + lo : (int *)0, thL2,
+                                             wantJ ? jbuf + lo : (double *)0, lane);
+        if (lane == 0) { wc[4 * wv] = r.I; wc[4 * wv + 1] = r.nL; wc[4 * wv + 2] = r.nL2; wc[4 * wv + 3] = r.nJ; }
+        __syncthreads();
+        dg_pass_res out; out.I = 0; out.J = 0; out.C = 0; out.nL = 0; out.nF = 0; out.nL2 = 0; out.nJ = 0;
+        unsigned offA = 0, offB = 0;
+#pragma unroll
+        for (int w = 0; w < NWt; w++) {
+            if (w < wv) { offA += wc[4 * w + 1]; offB += wc[4 * w + 2]; }
+            out.I += wc[4 * w]; out.nL += wc[4 * w + 1]; out.nL2 += wc[4 * w + 2]; out.nJ += wc[4 * w + 3];
+        }
+        if (la) for (int k = lane; k < (int)r.nL; k += 64) la[offA + k] = sA[lo + k];
+        if (lb) for (int k = lane; k < (int)r.nL2; k += 64) lb[offB + k] = sB[lo + k];
+        if (wantJ && tid == T - 64) {
+            double J = 0.0;
+            for (int w = 0; w < NWt; w++) { const int l_ = w * sl < n ? w * sl : n; J = dg_seq_sum_from<1>(jbuf + l_, (int)wc[4 * w + 3], J); }
+            S->red.bc[0] = J;
+        }
+        __syncthreads();
+        if (wantJ) out.J = S->red.bc[0];
+        return out;
     };
     auto gather = [&](int id, int len) {
         if (lane < len) { const dg_pt q = dg_ldpt<0>(P, id); double *o = px + 4 * lane; o[0] = q.x1; o[1] = q.y1; o[2] = q.x2; o[3] = q.y2; }
@@ -1425,7 +1452,7 @@ __device__ __forceinline__ void dg_coop_unit_rep(const dg_args &A, dg_f_shared *
     char *ws = A.ws + (size_t)slot * A.wl.stride;
     dg_ht ht; ht.heads = (int *)(ws + A.wl.off_ht); ht.count = ht.heads + 64; ht.ent = ht.heads + 80;
     dg_lo_rep_wg<T>(S, v.P, job->n, ht, (dg_lo_log *)(lj + 128 + (size_t)DG_LOJOB_STRIDE * u), dg_coop_lo_list(A, slot, 2 * u), dg_coop_lo_list(A, slot, 2 * u + 1),
-                    jbuf, job->ssiz, job->th, job->mk_full, job->mk_ex, tid);
+                    dg_coop_lo_list(A, slot, 2 * DG_RAN_REP + 2 * u), dg_coop_lo_list(A, slot, 2 * DG_RAN_REP + 2 * u + 1), jbuf, job->ssiz, job->th, job->mk_full, job->mk_ex, tid);
 }
 
 /* Whole workgroup (owner or helper): work on generation G until it has no unclaimed unit left */
