@@ -1674,11 +1674,15 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     const int producer = resume == 2;
     dg_stream_cb *const scb = A.stream_on ? A.scb + oslot : (dg_stream_cb *)0;
     int head_seen = 0;               /* owner: ring entries below this sequence number are known to be visible */
+    int gpar = 0, pend_draws = 0;    /* deep pipeline: the seed buffer this iteration's chain writes; the chunk in slot nx2 still needs its draws (its seeds are in the other buffer) */
     int mtab = 0, presolved = 0;     /* cooperative mode: the model table of the current chunk; samples of the current chunk that were solved during the previous chunk's scoring */
     int strm = 0, img_sam = 0;       /* owner: 0 = own sample stream, 1 = asked for a producer (image written), 2 = takes its chunks from the ring */
     const int coopK = LDSPTS == 0 ? A.coop_k : 0;
     dg_coop_cb *const cb = coopK > 0 ? A.coop + slot : (dg_coop_cb *)0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    /* cooperative mode with eight waves: the sampler runs one chunk further ahead (pool swaps of chunk c + 2, seed chain of chunk c + 3),
+     * so that the 7-point problems of chunk c + 1 can be solved from the start of the phase in which the helpers score chunk c */
+    const bool deep = DG_NW >= 8 && LDSPTS == 0 && coopK > 0 && !A.hist_out;
     const long long off = A.offsets[pair];
     const int n = (int)(A.offsets[pair + 1] - off);
     const dg_params &pr = A.prm;
@@ -1779,8 +1783,14 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             unsigned sd = seed;
             if (cn0 > 0) sd = dg_sample_chunk<7, LDSPTS>(sd, cn0, n, pool, S->seeds3[0], S->draws3[0], S->alm3[0], pscr, lane);
             if (cn1 > 0) sd = dg_sample_draws<7>(sd, cn1, n, S->seeds3[1], S->draws3[1], S->alm3[1], lane);
+            if (deep) {
+                int cn2_ = max_sam - no_sam - cn0 - cn1; if (cn2_ > DG_CHUNK) cn2_ = DG_CHUNK; if (cn2_ < 0) cn2_ = 0;
+                if (cn1 > 0) dg_sample_pool<7, LDSPTS>(cn1, n, pool, S->draws3[1], S->alm3[1], pscr, lane, S->dbg);
+                if (cn2_ > 0) sd = dg_sample_draws<7>(sd, cn2_, n, S->seeds3[2], S->draws3[2], S->alm3[2], lane);
+            }
             if (lane == 0) S->itmp[31] = (int)sd;
         }
+        if (deep) { int cn2_ = max_sam - no_sam - cn0 - cn1; if (cn2_ > DG_CHUNK) cn2_ = DG_CHUNK; if (cn2_ < 0) cn2_ = 0; chunk_s[2] = cn2_; }
         __syncthreads();
         seed = (unsigned)S->itmp[31];
     }
@@ -1809,7 +1819,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         if (tid == 0) { scb->pair = pair; scb->wsid = wsid; scb->img_sam = no_sam; }
     };
     while (!done && no_sam < max_sam) {
-        int pre_cnt = 0;             /* cooperative mode: samples of the next chunk solved during this one's scoring */
+        int pre_cnt = 0, cn3 = 0;    /* cooperative mode: samples of the next chunk solved during this one's scoring; size of the chunk whose seed chain runs in this iteration (deep pipeline) */
         int ff = 0, tail_p = 0;      /* producer: the owner is already past this chunk: sampler stages only; the owner's position */
         const int seq = no_sam / DG_CHUNK;
         dg_stream_ent *ent = (dg_stream_ent *)0;
@@ -2059,20 +2069,29 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         /* ====== score chunk c (waves 2.., one wave per model, points streamed from LDS)  ||  pool swaps of chunk c+1 (wave 0)  ||  seeds + draws of chunk c+2 (wave 1) ====== */
         nxt = cur == 2 ? 0 : cur + 1; const int nx2 = nxt == 2 ? 0 : nxt + 1;
         {
-            cn2 = max_sam - (no_sam + chunk_s[cur] + chunk_s[nxt]); if (cn2 > DG_CHUNK) cn2 = DG_CHUNK; if (cn2 < 0) cn2 = 0;
-            if (strm == 2) cn2 = 0;                        /* the sample stream comes from the producer */
-            chunk_s[nx2] = cn2;
-            /* cooperative mode, eight waves: while the helpers score this chunk, waves 2-5 solve the NEXT chunk's 7-point problems as soon
-             * as wave 0 has its drawn ids (an LDS flag, no barrier: wave 1 is inside the seed chain), into the other model table */
-            const bool presolve = DG_NW >= 8 && LDSPTS == 0 && coopK > 0 && strm != 2 && chunk_s[nxt] > 0 && !A.hist_out;
+            if (deep) {
+                /* chunk c + 1 has its drawn ids, chunk c + 2 its draws (slot nx2); the chunk behind them gets its seeds now (into the
+                 * workspace: all three LDS slots are live) and its draws after the commit, in the slot this chunk leaves */
+                cn3 = max_sam - (no_sam + chunk_s[cur] + chunk_s[nxt] + chunk_s[nx2]); if (cn3 > DG_CHUNK) cn3 = DG_CHUNK; if (cn3 < 0) cn3 = 0;
+            } else {
+                cn2 = max_sam - (no_sam + chunk_s[cur] + chunk_s[nxt]); if (cn2 > DG_CHUNK) cn2 = DG_CHUNK; if (cn2 < 0) cn2 = 0;
+                if (strm == 2) cn2 = 0;                        /* the sample stream comes from the producer */
+                chunk_s[nx2] = cn2;
+            }
+            /* deep pipeline: while the helpers score this chunk, waves 2-5 solve the NEXT chunk's 7-point problems into the other model table */
+            const bool presolve = deep && chunk_s[nxt] > 0;
             if (presolve) pre_cnt = chunk_s[nxt];
+            unsigned *const gseedT = (unsigned *)(ws + A.wl.off_models + 2 * DG_MTAB_BYTES + DG_PRE_BYTES) + (size_t)gpar * DG_CHUNK;
+            const unsigned *const gseedP = (const unsigned *)(ws + A.wl.off_models + 2 * DG_MTAB_BYTES + DG_PRE_BYTES) + (size_t)(gpar ^ 1) * DG_CHUNK;
             if (strm == 2) { /* no sampler stages */ }
             else if (wave == 0) {
-                if (chunk_s[nxt] > 0) dg_sample_pool<7, LDSPTS>(chunk_s[nxt], n, pool, S->draws3[nxt], S->alm3[nxt], pscr, lane, S->dbg);
-                if (presolve) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); if (lane == 0) __hip_atomic_store(&S->itmp[23], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                const int ps = deep ? nx2 : nxt;
+                if (deep && pend_draws) {          /* the draws of that chunk come from waves 6 and 7 (below) */
+                    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&S->itmp[23], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < 2) __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
+                if (chunk_s[ps] > 0) dg_sample_pool<7, LDSPTS>(chunk_s[ps], n, pool, S->draws3[ps], S->alm3[ps], pscr, lane, S->dbg);
             } else if (presolve && wave >= 2 && wave < 2 + DG_CHUNK / 64) {
-                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&S->itmp[23], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) __builtin_amdgcn_s_sleep(1);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 const int k_ = (wave - 2) * 64 + lane;
                 if (k_ < chunk_s[nxt]) {
                     unsigned rx = 0;
@@ -2081,8 +2100,19 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                     int *pre = (int *)(ws + A.wl.off_models + 2 * DG_MTAB_BYTES) + 2 * k_;
                     pre[0] = r_ < 0 ? 0x100 : r_; pre[1] = (int)rx;
                 }
+            } else if (deep && pend_draws && wave >= 6 && wave < 8) {
+                /* the draws of the chunk whose seeds the previous iteration chained (two rounds of 64 samples per wave), into the slot
+                 * the previous chunk left; wave 0 waits for them before that chunk's pool swaps */
+                const int cnp = chunk_s[nx2];
+                for (int rd = 2 * (wave - 6); rd < 2 * (wave - 6) + 2 && rd < DG_CHUNK / 64; rd++) {
+                    dg_sample_draws_round<7>(rd, cnp, n, gseedP, S->draws3[nx2], S->alm3[nx2], lane, S->dbg);
+                    const int i_ = rd * 64 + lane; if (i_ < cnp) S->seeds3[nx2][i_] = gseedP[i_];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_fetch_add(&S->itmp[23], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else if (wave == 1) {
-                if (cn2 > 0) { unsigned sd = dg_sample_chain<7>(seed, cn2, S->seeds3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }   /* its draws: after the barrier, one wave per 64 samples */
+                if (cn3 > 0) { unsigned sd = dg_sample_chain<7>(seed, cn3, gseedT, lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }
+                else if (cn2 > 0) { unsigned sd = dg_sample_chain<7>(seed, cn2, S->seeds3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }   /* its draws: after the barrier, one wave per 64 samples */
             }
             /* cooperative mode: the helpers score every group (a whole workgroup per group); the owner's waves only sample.
              * Otherwise: waves 2.. score while waves 0 and 1 run their sampler stages (the critical path); with two
@@ -2178,9 +2208,9 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             }
         }
         __syncthreads();
-        if (tid == 0) S->itmp[23] = 0;                 /* the "drawn ids of the next chunk are ready" flag of the early solves */
+        if (tid == 0) S->itmp[23] = 0;                 /* deep pipeline: the "draws are ready" count of waves 6 and 7 */
         if (fuse) { Mtot = __builtin_amdgcn_readfirstlane((int)S->moff[DG_CHUNK]); c.n_fds += Mtot; }
-        if (cn2 > 0) seed = (unsigned)S->itmp[31];
+        if (cn2 > 0 || cn3 > 0) seed = (unsigned)S->itmp[31];
         /* the draws of chunk c+2 (its seeds are complete now): the rounds of 64 samples are independent, one wave each; nothing
          * reads them before the pool stage of the next iteration, which sits behind the barriers of the commit */
         if (cn2 > 0 && wave < DG_CHUNK / 64) {
@@ -2435,6 +2465,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             __syncthreads();
         }
         if (!done) {
+            if (deep) { chunk_s[cur] = cn3; pend_draws = cn3 > 0; gpar ^= 1; }     /* its draws: next iteration, waves 6 and 7, into the slot this chunk leaves */
             cur = nxt;
             presolved = pre_cnt;
             if (pre_cnt > 0) { mtab ^= 1; if (tid == 0) S->K.gmodels = (double *)(ws + A.wl.off_models + (size_t)mtab * DG_MTAB_BYTES); }
