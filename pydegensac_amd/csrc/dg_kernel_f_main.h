@@ -1819,6 +1819,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         if (tid == 0) { scb->pair = pair; scb->wsid = wsid; scb->img_sam = no_sam; }
     };
     while (!done && no_sam < max_sam) {
+        int coop_no_ev = 0;          /* cooperative mode: the screen left no survivor: no model of this chunk can be an event of the commit */
         int pre_cnt = 0, cn3 = 0;    /* cooperative mode: samples of the next chunk solved during this one's scoring; size of the chunk whose seed chain runs in this iteration (deep pipeline) */
         int ff = 0, tail_p = 0;      /* producer: the owner is already past this chunk: sampler stages only; the owner's position */
         const int seq = no_sam / DG_CHUNK;
@@ -2180,11 +2181,11 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             double *jb0 = (double *)(ws + A.wl.off_hjbuf);
             int units = coop_units;
             for (int st = coop_screen ? 1 : 2; st <= 2; st++) {
-                __syncthreads();
-                dg_coop_work<T>(A, slot, S, cv, cb, coop_gen, jb0, &S->itmp[28], tid);
+                dg_coop_work<T>(A, slot, S, cv, cb, coop_gen, jb0, &S->itmp[28], tid);          /* (starts with a workgroup barrier) */
                 if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
                     while (__hip_atomic_load(&cb->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < units) __builtin_amdgcn_s_sleep(2);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    /* stage 1 leaves device counters that are read with agent-scope atomic loads below; only stage 2 leaves plain data */
+                    if (st == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
                 __syncthreads();
                 if (st == 2) break;
@@ -2203,7 +2204,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                     __syncthreads();
                 }
                 units = (int)ns;
-                if (units == 0) break;
+                if (units == 0) { coop_no_ev = 1; break; }
                 dg_coop_publish(cb, coop_gen, 2, units, Mtot, n, mk_full, 0, 0, th, S->ext, tau_c);
             }
         }
@@ -2270,17 +2271,20 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                 /* past sample 50 a sample without an "event" (a model beating maxS or maxSs) has no side effect
                  * but no_sam++: jump to the next event sample, found by all lanes in parallel */
                 track = 0;
-                const double tau = maxS.J < maxSs.J ? maxS.J : maxSs.J;
-                bool ev = false;
-                if (tid >= k && tid < chunk && S->nv[tid] != 255)
-                    for (int r = 0; r < S->nv[tid]; r++) ev = ev || (tau < c.K->res_J[S->moff[tid] + r]);
-                unsigned long long bal = __ballot(ev);
-                __syncthreads();
-                if (lane == 0) S->wave_cnt[wave] = bal ? (unsigned)(wave * 64 + __ffsll((long long)bal) - 1) : 0xffffffffu;
-                __syncthreads();
-                unsigned kE = S->wave_cnt[0];
-                for (int w = 1; w < DG_NW; w++) kE = S->wave_cnt[w] < kE ? S->wave_cnt[w] : kE;
-                int stop = kE == 0xffffffffu ? chunk : (int)kE;
+                int stop = chunk;
+                if (!coop_no_ev) {             /* (no survivor of the screen: every score of the chunk is 0, nothing to look for) */
+                    const double tau = maxS.J < maxSs.J ? maxS.J : maxSs.J;
+                    bool ev = false;
+                    if (tid >= k && tid < chunk && S->nv[tid] != 255)
+                        for (int r = 0; r < S->nv[tid]; r++) ev = ev || (tau < c.K->res_J[S->moff[tid] + r]);
+                    unsigned long long bal = __ballot(ev);
+                    __syncthreads();
+                    if (lane == 0) S->wave_cnt[wave] = bal ? (unsigned)(wave * 64 + __ffsll((long long)bal) - 1) : 0xffffffffu;
+                    __syncthreads();
+                    unsigned kE = S->wave_cnt[0];
+                    for (int w = 1; w < DG_NW; w++) kE = S->wave_cnt[w] < kE ? S->wave_cnt[w] : kE;
+                    stop = kE == 0xffffffffu ? chunk : (int)kE;
+                }
                 int skip = stop - k; if (skip > max_sam - no_sam) skip = max_sam - no_sam;
                 no_sam += skip; k += skip;
                 if (k >= chunk || no_sam >= max_sam) break;
