@@ -100,6 +100,23 @@ __device__ __forceinline__ double dg_HDs(const double *H, double u0, double u1, 
     return p;
 }
 
+/* Screening form of dg_HDs (main loop of the homography kernel): could this point's Sampson error be below tb?  The error is
+ * r' (J J')^-1 r with J = [a b c 0; d e 0 c] (pinvJ is J' (J J')^-1 in closed form, Htools.c:135-159), i.e. q / det with
+ * M = J J' = [m11 m12; m12 m22], q = m22 r1^2 - 2 m12 r1 r2 + m11 r2^2, det = m11 m22 - m12^2: no division, no pinvJ.
+ * Conservative: tb carries a relative margin of 1e-6 (the two evaluations agree to 1e-9 while det > 1e-7 m11 m22), and a point
+ * whose M is worse conditioned than that, or that yields a NaN, counts as a candidate.  So #(candidates) >= #(dg_HDs < t) >= J. */
+__device__ __forceinline__ bool dg_HDs_maybe_below(const double *H, double u0, double u1, double u3, double u4, double tb)
+{
+    const double w = H[2] * u3 + H[5] * u4 + H[8];
+    const double r1 = (H[0] * u3 + H[3] * u4 + H[6]) - u0 * w, r2 = (H[1] * u3 + H[4] * u4 + H[7]) - u1 * w;
+    const double a = H[0] - H[2] * u0, b = H[3] - H[5] * u0, d = H[1] - H[2] * u1, e = H[4] - H[5] * u1;
+    const double cc = w * w;
+    const double m11 = a * a + b * b + cc, m22 = d * d + e * e + cc, m12 = a * d + b * e;
+    const double det = m11 * m22 - m12 * m12, q = m22 * r1 * r1 - 2 * m12 * r1 * r2 + m11 * r2 * r2;
+    const bool well = det > 1e-7 * (m11 * m22);
+    return !(well && q > tb * det);
+}
+
 /* ---- the 7-point solver, one sample per lane, everything in registers ------------------------- */
 /* Row i of the 7x9 system is the i-th DRAWN correspondence, entries u2_k*u1_l (lin_fm Ftools.c:15-37
  * + rsampleT rtools.c:74-92).  Gauss-Jordan with partial pivoting exactly as utools.c:97-167 for the

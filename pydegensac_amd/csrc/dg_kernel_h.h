@@ -859,6 +859,45 @@ __device__ __noinline__ int dg_solve4_lane(const dg_pt *P, const int *ids, int k
 }
 
 /* ---------------------------------------------------------------------------------------------- */
+/* Main-loop screen, one wave: the candidate counts (dg_HDs_maybe_below at tb) of the four models g0, g0 + stride, ... of a chunk's model
+ * table in ONE sweep over the points, the next step's points in flight (a sweep is bound by the latency of its point loads, not by
+ * the 45 flops of a bound).  Own register allocation: four models + two steps of points do not fit next to the driver's state. */
+struct dg_u4 { unsigned v[4]; };
+template <int LDSPTS>
+__device__ __noinline__ dg_u4 dg_h_screen4(const dg_pt *P, int n, const double *gmodels, int g0, int stride, int Mtot, double tb, int lane)
+{
+    n = __builtin_amdgcn_readfirstlane(n);
+    double Hg[4][9];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int mj = g0 + j * stride;
+        const double *gs = gmodels + (size_t)(mj < Mtot ? mj : g0) * 18;
+#pragma unroll
+        for (int q = 0; q < 9; q++) Hg[j][q] = gs[q];
+    }
+    unsigned cb_[4] = {0u, 0u, 0u, 0u};
+    dg_pt qn[DG_PU];
+#pragma unroll
+    for (int u = 0; u < DG_PU; u++) { const int p = 64 * u + lane; qn[u] = dg_ldpt<LDSPTS>(P, p < n ? p : 0); }
+    for (int base = 0; base < n; base += 64 * DG_PU) {
+        dg_pt qq[DG_PU];
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) qq[u] = qn[u];
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) { const int p = base + 64 * DG_PU + 64 * u + lane; if (p < n) qn[u] = dg_ldpt<LDSPTS>(P, p); }
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) {
+            const bool act = base + 64 * u + lane < n;
+#pragma unroll
+            for (int j = 0; j < 4; j++) cb_[j] += (act && dg_HDs_maybe_below(Hg[j], qq[u].x1, qq[u].y1, qq[u].x2, qq[u].y2, tb)) ? 1u : 0u;
+        }
+    }
+    dg_u4 out;
+#pragma unroll
+    for (int j = 0; j < 4; j++) out.v[j] = dg_wave_sum_u(cb_[j]);
+    return out;
+}
+
 template <int T, int LDSPTS>
 __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsigned char *dyn_smem, double *hlt, const int pair, const int slot, int &hjob_gen)
 {
@@ -909,7 +948,9 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
     /* software pipeline: chunk c is scored while chunk c+1 gets its pool swaps and chunk c+2 its seeds and draws */
     int cur = 0, chunk_s[3] = {0, 0, 0}, chunk_base = 0;
     {
-        int cn0 = max_sam - no_sam; if (cn0 > DG_CHUNK) cn0 = DG_CHUNK; if (cn0 < 0) cn0 = 0;
+        /* the first chunk is 64 samples whatever the variant's chunk size: the first local optimisation runs at sample 50 and leaves the
+         * bound that lets the chunks behind it be screened (below) instead of scored */
+        int cn0 = max_sam - no_sam; if (cn0 > 64) cn0 = 64; if (cn0 < 0) cn0 = 0;
         int cn1 = max_sam - no_sam - cn0; if (cn1 > DG_CHUNK) cn1 = DG_CHUNK; if (cn1 < 0) cn1 = 0;
         chunk_s[0] = cn0; chunk_s[1] = cn1;
         if (wave == 0) {
@@ -966,40 +1007,43 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
                 if (cn2 > 0) { unsigned sd = dg_sample_chain<4>(seed, cn2, S->seeds3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }   /* its draws: after the barrier */
             }
             /* static round-robin over the scoring waves: waves 2.. when there are more than two, else both waves after their sampler stage */
+            /* Screen (Sampson metric): once a local optimisation has run, a sample past the 50th only matters if its J beats
+             * tau = min(maxS.J, maxSs.J) (the commit below), and J <= #(d < 9/4 th) <= the division-free candidate count of
+             * dg_HDs_maybe_below: a model whose count does not exceed tau gets J = 0 without the exact pass (pinvJ: eight divisions
+             * per point).  Every model still counts as scored (n_hds), as in the fundamental-matrix kernel. */
+            const double tau_s = (kind == 0 && iter_cnt > 0 && no_sam >= DG_ITER_SAM && th != 0 && !c.rrun && !A.trace) ? (maxS.J < maxSs.J ? maxS.J : maxSs.J) : 0.0;
             if (wave >= DG_SW0) {
-                for (int mi = wave - DG_SW0; mi < Mtot; mi += DG_NW - DG_SW0) {
-
-                    double H[9], Hinv[9], H1[9];
+                constexpr int STR = DG_NW - DG_SW0;
+                /* exact score of model mi: I, and J as the reference's sequential sum over the nonzero terms in point order */
+                auto exact = [&](const int mi) {
+                    /* this wave's pass (dg_hm_wpass: the next step's points in flight, J added tile by tile in point order) from this
+                     * wave's block of the local optimisation's LDS tables, which are idle in the main loop */
+                    double *lt = c.hlt + (size_t)DG_HLT * wave, *Hm = lt + 64 * DG_PU, *z18 = Hm + 16;
                     const double *g = c.K->gmodels + (size_t)mi * 18;
+                    DG_WSYNC();
+                    if (lane < 9) Hm[lane] = g[lane];
+                    DG_WSYNC();
+                    const dg_pass_res r = dg_hm_wpass<LDSPTS>(P, n, kind, Hm, z18, th, (int *)0, 0.0, (int *)0, 0.0, lt, lane);
+                    if (lane == 0) { c.K->res_I[mi] = r.I; c.K->res_J[mi] = r.J; }
+                };
+                if (tau_s > 0) {
+                    /* four models of this wave per sweep over the points (a sweep is bound by the latency of its point loads, not by
+                     * the 45 flops of a bound), the next step's points in flight */
+                    const double tb = (th * 9 / 4) * (1.0 + 1e-6);
+                    for (int g0 = wave - DG_SW0; g0 < Mtot; g0 += 4 * STR) {
+                        const dg_u4 cb_ = dg_h_screen4<LDSPTS>(P, n, c.K->gmodels, g0, STR, Mtot, tb, lane);
 #pragma unroll
-                    for (int j = 0; j < 9; j++) { H[j] = g[j]; H1[j] = g[9+j]; }
-                    Hinv[0] = H[0]; Hinv[1] = H[3]; Hinv[2] = H[6]; Hinv[3] = H[1]; Hinv[4] = H[4]; Hinv[5] = H[7]; Hinv[6] = H[2]; Hinv[7] = H[5]; Hinv[8] = H[8];
-                    /* I, and J as the reference's sequential sum (dg_seq_sum) over the nonzero terms in point order */
-                    unsigned cI = 0, cnt = 0; const double t94 = th * 9 / 4;
-                    double *jbuf = (double *)(c.K->wstage + (size_t)wave * c.K->n_max);
-                    for (int base = 0; base < n; base += 64 * DG_PU) {
-                        dg_pt qq[DG_PU]; double dd[DG_PU];
-#pragma unroll
-                        for (int u = 0; u < DG_PU; u++) { const int p = base + 64 * u + lane; qq[u] = dg_ldpt<LDSPTS>(P, p < n ? p : 0); }
-#pragma unroll
-                        for (int u = 0; u < DG_PU; u++) dd[u] = dg_Herr(kind, H, Hinv, H1, qq[u]);
-#pragma unroll
-                        for (int u = 0; u < DG_PU; u++) {
-                            const bool act = base + 64 * u + lane < n; const double d = dd[u];
-                            double term = 0.0; if (act && th != 0 && !(d >= t94)) term = 1 - (d / t94);
-                            cI += (act && d <= th) ? 1u : 0u;
-                            const bool nz = !(term == 0.0);
-                            const unsigned long long bJ = __ballot(nz);
-                            if (nz) ((__attribute__((address_space(1))) double *)jbuf)[cnt + (unsigned)__popcll(bJ & ((1ull << lane) - 1ull))] = term;
-                            cnt += (unsigned)__popcll(bJ);
+                        for (int j = 0; j < 4; j++) {
+                            const int mj = g0 + j * STR;
+                            const unsigned tot_ = cb_.v[j];
+                            if (mj < Mtot) {
+                                if (!((double)tot_ > tau_s)) { if (lane == 0) { c.K->res_I[mj] = 0; c.K->res_J[mj] = 0; } }
+                                else exact(mj);
+                            }
                         }
                     }
-                    DG_WSYNC();
-                    double J = 0.0; if (lane == 0) J = dg_seq_sum(jbuf, (int)cnt);
-                    J = __shfl(J, 0, 64);
-                    unsigned I = dg_wave_sum_u(cI);
-                    DG_WSYNC();
-                    if (lane == 0) { c.K->res_I[mi] = I; c.K->res_J[mi] = J; }
+                } else {
+                    for (int mi = wave - DG_SW0; mi < Mtot; mi += STR) exact(mi);
                 }
             }
         }
