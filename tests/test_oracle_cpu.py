@@ -164,3 +164,44 @@ def test_h_symmetric_metrics_match_reference(oracle_port, oracle_ref):
             getattr(R, name)(None, dp(u), dp(H), dp(d1), n)      # lin (Z) is unused by these metrics
             P.dg_oracle_HDS_full(kind, dp(u), dp(H), dp(d2), n)
             assert np.array_equal(d1, d2), name
+
+
+def test_sampson_bound_of_the_homography_screen_is_a_superset(oracle_port):
+    """The homography kernel's main loop skips the exact score of a model whose division-free candidate count (dg_geom.h:
+    dg_HDs_maybe_below, restated here operation by operation) does not exceed the bound to beat.  That is only sound if every point
+    the reference's HDs (Htools.c:161-200, through pinvJ) puts below the threshold is a candidate: random, scaled, near-singular and
+    rank-deficient models, points on a line / at the origin / far away."""
+    rng = np.random.default_rng(5)
+
+    def maybe_below(H, u0, u1, u3, u4, tb):
+        w = H[2] * u3 + H[5] * u4 + H[8]
+        r1 = (H[0] * u3 + H[3] * u4 + H[6]) - u0 * w; r2 = (H[1] * u3 + H[4] * u4 + H[7]) - u1 * w
+        a = H[0] - H[2] * u0; b = H[3] - H[5] * u0; d = H[1] - H[2] * u1; e = H[4] - H[5] * u1
+        cc = w * w
+        m11 = a * a + b * b + cc; m22 = d * d + e * e + cc; m12 = a * d + b * e
+        det = m11 * m22 - m12 * m12; q = m22 * r1 * r1 - 2 * m12 * r1 * r2 + m11 * r2 * r2
+        with np.errstate(invalid="ignore"):
+            well = det > 1e-7 * (m11 * m22)
+            return ~(well & (q > tb * det))
+
+    n = 4000; checked = 0
+    for trial in range(60):
+        scale = [1.0, 1e-3, 1e3, 1e-6][trial % 4]
+        H = rng.normal(size=9) * scale
+        if trial % 5 == 1: H[6:9] = 0                                   # rank-deficient
+        if trial % 5 == 2: H = np.eye(3).ravel() + 1e-9 * rng.normal(size=9)   # identity-like: many points are inliers
+        if trial % 5 == 3: H[2] = H[5] = 0; H[8] = 1e-12                 # affine with a vanishing last entry
+        p1 = rng.uniform(-2000, 2000, size=(n, 2)); p2 = rng.uniform(-2000, 2000, size=(n, 2))
+        if trial % 3 == 0: p2 = p1 + rng.normal(size=(n, 2))              # close pairs (inliers of identity-like models)
+        if trial % 7 == 0: p1[:, 1] = 2 * p1[:, 0] + 1                    # points on a line
+        p1[:5] = 0; p2[:5] = 0
+        u = np.ones((n, 6)); u[:, 0:2] = p1; u[:, 3:5] = p2
+        d = np.zeros(n)
+        oracle_port.lib().dg_oracle_HDs(oracle_port.dp(u), oracle_port.dp(H.copy()), oracle_port.dp(d), n)
+        for t in (0.25, 4.0, 400.0):
+            t94 = t * 9 / 4
+            inl = d < t94                                                  # NaN residuals compare false in the reference as well
+            cand = maybe_below(H, p1[:, 0], p1[:, 1], p2[:, 0], p2[:, 1], t94 * (1.0 + 1e-6))
+            assert not np.any(inl & ~cand), (trial, t, int(np.sum(inl & ~cand)))
+            checked += int(inl.sum())
+    assert checked > 10000                                                 # the check saw real inliers, not only empty sets
