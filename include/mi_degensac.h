@@ -136,8 +136,11 @@ enum {
     MI_ST_PLACEMENT = 15    /* bits 0-7: 0 = points + pool in HBM, 1 = both in LDS, 2 = pool in LDS; bit 8: the pair was set aside once */
 };
 
-/* Stream mode (fundamental matrix): a pair with many samples left hands the outcome-independent part of its main loop
- * (sample stream, 7-point solves, screening / scoring) to a workgroup that has run out of pairs; results never depend on it.
+/* Stream mode (fundamental matrix): a pair hands the outcome-independent part of its main loop (sample stream, 7-point
+ * solves, screening / scoring) to a workgroup that has run out of pairs; results never depend on it.  Every pair of a launch that
+ * uses the mode (automatic: batches of at most two pairs per resident workgroup) posts its request with its first chunk; idle
+ * workgroups take the request with the most samples left, the oldest first.  MI_DEGENSAC_STREAM_MIN_SAM=<n> (environment, read
+ * once) makes pairs ask only after n samples; MI_DEGENSAC_STREAM_DEPTH=<chunks> bounds the ring.
  * mode: -1 = automatic (default), 0 = off, odd values > 0 = on with test bits in (mode >> 1): bit 0 = the owner scores every chunk
  * it takes from the producer again, bit 1 = pairs ask for a producer even while unstarted pairs remain.  Process-wide; returns the
  * previous mode.  Also settable once through the environment variable MI_DEGENSAC_STREAM. */
