@@ -1776,7 +1776,10 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     cur = 0; chunk_s[0] = chunk_s[1] = chunk_s[2] = 0; chunk_base = 0;
     if (tid == 0) S->itmp[23] = 0;
     {
-        int cn0 = max_sam - no_sam; if (cn0 > DG_CHUNK) cn0 = DG_CHUNK; if (cn0 < 0) cn0 = 0;
+        /* the first chunk is 64 samples when nothing counts chunks of DG_CHUNK (the stream mode's ring does): the first local optimisation
+         * runs at sample 50 and leaves the bound with which the samples behind it are screened instead of scored */
+        const int first = (A.stream_on || coopK > 0) ? DG_CHUNK : (DG_CHUNK < 64 ? DG_CHUNK : 64);
+        int cn0 = max_sam - no_sam; if (cn0 > first) cn0 = first; if (cn0 < 0) cn0 = 0;
         int cn1 = max_sam - no_sam - cn0; if (cn1 > DG_CHUNK) cn1 = DG_CHUNK; if (cn1 < 0) cn1 = 0;
         chunk_s[0] = cn0; chunk_s[1] = cn1;
         if (wave == 0) {
