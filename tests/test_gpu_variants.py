@@ -211,3 +211,18 @@ def test_sequential_pool_stage_fallback_matches_goldens():
     _lib.check(L.mi_degensac_sample_stream_ex(777, 2000, 7, 600, 0, 0, out.ctypes.data_as(C.POINTER(C.c_int32))))
     _lib.check(L.mi_degensac_sample_stream_ex(777, 2000, 7, 600, 0, 1, out2.ctypes.data_as(C.POINTER(C.c_int32))))
     assert np.array_equal(out, out2)
+
+
+def test_cooperative_owner_runs_several_pairs_in_a_row(oracle_port):
+    """more pairs than owner slots (512 threads: 256 resident workgroups / 24 = 10 owners for 30 pairs): every owner and its helpers
+    go through several pairs one after the other — the per-pair state of the cooperative mode (model table in use, early solves,
+    the deep sampler pipeline's pending draws, the draws assumed by the local optimisation's stage 4) must start afresh; pair by pair
+    against the CPU oracle"""
+    A, B = [], []
+    for i in range(30):
+        p1, p2, _, _ = syn.two_view_fundamental(600 + 37 * (i % 40), 0.35 + 0.01 * (i % 20), 0.1, seed=200 + i, plane_fraction=0.6 if i % 5 == 0 else 0.0)
+        A.append(p1); B.append(p2)
+    seeds = list(range(11, 41))
+    for variant, helpers in ((512, 23), (256, 23), (128, 7)):
+        F, m = pd.findFundamentalMatrixBatch(A, B, max_iters=20000, seeds=seeds, tuning=tune(variant, 0) | _lib.TUNE_HELPERS(helpers))
+        _check_against_oracle(oracle_port, A, B, seeds, F, m, pd.last_stats(), (variant, helpers, "several pairs per owner"))
