@@ -122,7 +122,8 @@ typedef struct mi_degensac_params {
 enum {
     MI_ST_SAMPLES = 0,      /* minimal samples drawn (data_out[0])                                  */
     MI_ST_LO_RUNS = 1,      /* local optimisations run (data_out[1])                                */
-    MI_ST_REJECTED = 2,     /* H: samples rejected before scoring (data_out[2])                     */
+    MI_ST_REJECTED = 2,     /* H: samples rejected before scoring (data_out[2]); F: candidates turned down by the LAF
+                               consistency check (S.Ilafs < maxS.Ilafs, exp_ranF.c:1410, :1553, :1681)                 */
     MI_ST_I = 3,            /* inlier count of the returned model (driver return value)             */
     MI_ST_MODELS = 4,       /* models scored against all N points through the metric pointers       */
     MI_ST_DEGEN = 5,        /* F: DEGENSAC plane-and-parallax completions                           */

@@ -707,6 +707,7 @@ static dg_score exp_inFranicustom(dg_ctx *c, const double *u, int len, int *inli
 /* sym + LAF consistency of a candidate, shared shape of exp_ranF.c:1383-1411 / :1526-1556 / :1654-1682.
  * Returns 0 if the candidate must be rejected. */
 static int g_legacy_sym = 0;      /* exp_ransacFcustom's symmetric check: all points instead of the inliers (exp_ranF.c:943-953) */
+static __thread int g_laf_rej = 0;         /* candidates the LAF check turned down (`S.Ilafs < maxS.Ilafs`, exp_ranF.c:1410 / :1553 / :1681): stats[DG_ST_REJECTED] of the F driver */
 static int f_checks(const double *u, const double *u_1, const double *u_2, int len, const double *f, const int *inliers,
                     dg_score *S, const dg_score *maxS, int doSymCheck, double SymCheck_th, int DO_LAF_CHECK,
                     double th_laf_check, fdsidx_fn FDS1idx, double *d_check, double *err_laf)
@@ -730,7 +731,7 @@ static int f_checks(const double *u, const double *u_1, const double *u_2, int l
         FDS1idx(u_2, f, err_laf, len, inliers, S->I);
         for (j = 0; j < (int)S->I; j++) if (err_laf[inliers[j]] <= th_laf_check) S->Ilafs++;
         S->Ilafs = S->Ilafs < (unsigned)p1_inliers ? S->Ilafs : (unsigned)p1_inliers;
-        if (S->Ilafs < maxS->Ilafs) return 0;
+        if (S->Ilafs < maxS->Ilafs) { g_laf_rej++; return 0; }
     }
     return 1;
 }
@@ -755,7 +756,7 @@ static int exp_ransacFcustomLAF(dg_ctx *c, const double *u, const double *u_1, c
     const double th_laf_check = laf_coef * th; double *err_laf;
     double A[81], sol[81]; int nullspace_buff[18], nullsize, best_sample = 0;
 
-    g_legacy_sym = legacy;
+    g_legacy_sym = legacy; g_laf_rej = 0;
     dg_srand(&c->rng, seed0);                               /* srand(time(NULL)), :1277 */
     c->ht_n = 0;                                            /* htInit, :1290 */
     pool = (int *)malloc(len * sizeof(int));
@@ -956,7 +957,7 @@ static int exp_ransacFcustomLAF(dg_ctx *c, const double *u, const double *u_1, c
     free(d_check); free(err_laf); free(pool); free(err); free(errorsBest); free(inliers); free(HDsv);
     g_legacy_sym = 0;
     if (stats) {
-        stats[DG_ST_SAMPLES] = no_sam; stats[DG_ST_LO_RUNS] = iter_cnt; stats[DG_ST_REJECTED] = 0;
+        stats[DG_ST_SAMPLES] = no_sam; stats[DG_ST_LO_RUNS] = iter_cnt; stats[DG_ST_REJECTED] = g_laf_rej;
         stats[DG_ST_I] = (int)maxS.I; stats[DG_ST_MODELS] = (int)(c->n_fds + c->n_exfds);
         stats[DG_ST_DEGEN] = degen_cnt; stats[DG_ST_IH] = Ihmax; stats[DG_ST_BEST_SAMPLE] = best_sample;
         stats[8] = (int)c->n_fds; stats[9] = (int)c->n_exfds; stats[10] = (int)c->n_hds; stats[11] = (int)c->n_fds_direct;

@@ -107,6 +107,7 @@ struct dg_f_shared {
         struct { dg_lo_log lo[DG_NW]; dg_rng lo_start, lo_work; };    /* local optimisation, one repetition per wave */
     };
     int n_ahead;
+    int n_lafrej;                        /* candidates the LAF check turned down (thread 0 counts; MI_ST_REJECTED of the F driver) */
     long long ph[8], dbg[8], tq;
 #ifdef DG_LO_PROF
     long long lt[16], ltq;
@@ -324,7 +325,7 @@ __device__ __forceinline__ int dg_f_checks(CTX &c, const double *f, const int *l
         dg_pass_res r1 = dg_pass(&c.S->red, cfg, [&](int pid, int) { return dg_Ferr(mkind, F, c.laf_pt(pid, 1)); }, c.tid);
         dg_pass_res r2 = dg_pass(&c.S->red, cfg, [&](int pid, int) { return dg_Ferr(mkind, F, c.laf_pt(pid, 2)); }, c.tid);
         S.Ilafs = r2.C < r1.C ? r2.C : r1.C;
-        if (S.Ilafs < maxS.Ilafs) return 0;
+        if (S.Ilafs < maxS.Ilafs) { if (c.tid == 0) c.S->n_lafrej++; return 0; }
     }
     return 1;
 }

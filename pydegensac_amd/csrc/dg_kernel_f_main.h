@@ -1746,6 +1746,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     dg_ht_init(c.ht, tid);
     if (A.hist_out) for (int j = tid; j < n + 3; j += DG_T) A.hist_out[(size_t)off + 3 * (size_t)pair + j] = 0;
     if (tid < 9) { S->F[tid] = 0; S->FBest[tid] = 0; }
+    if (tid == 0) S->n_lafrej = 0;
     __syncthreads();
     if (tid < 4) { double e = 0.; for (int w = 0; w < DG_NW; w++) e = fmax(e, S->extw[w][tid]); S->ext[tid] = e; }
     __syncthreads();
@@ -2619,7 +2620,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     if (A.stats_out && tid == 0) {
         int *st = A.stats_out + (size_t)pair * 16;
         long long t_end = wall_clock64();
-        st[0] = no_sam; st[1] = iter_cnt; st[2] = 0; st[3] = (int)maxS.I; st[4] = c.n_fds + c.n_exfds;
+        st[0] = no_sam; st[1] = iter_cnt; st[2] = S->n_lafrej; st[3] = (int)maxS.I; st[4] = c.n_fds + c.n_exfds;
         st[5] = degen_cnt; st[6] = Ihmax; st[7] = best_sample; st[8] = c.n_fds; st[9] = c.n_exfds;
         st[10] = c.n_hds; st[11] = c.n_aux; st[12] = (int)(t_best - t_start); st[13] = (int)(t_end - t_start);
         st[14] = A.variant_threads; st[15] = A.mode | (resume ? 256 : 0) | (strm == 2 ? 512 : 0);      /* bit 8: the pair was set aside and resumed; bit 9: its chunks came from a producer workgroup */

@@ -56,8 +56,10 @@ def gather_results(models, stats, masks, n_per_pair, n_pairs_total, group=None, 
     if p_r != rng[rank][1] - rng[rank][0] or masks.numel() != mbytes[rank]:
         raise ValueError("this rank's tensors do not match its shard of the batch")
     rec = [(hi - lo) * 136 + mb for (lo, hi), mb in zip(rng, mbytes)]      # 72 B model + 64 B stats per pair, then the masks
-    if len(set(rec)) == 1:
-        # every rank holds the same number of bytes (C4: equal pairs, equal sizes): ONE collective over the packed records
+    if len({hi - lo for lo, hi in rng}) == 1 and len(set(mbytes)) == 1:
+        # every rank holds the same number of pairs AND of mask bytes (C4: equal pairs, equal sizes): ONE collective over the
+        # packed records.  Equal record sizes alone are not enough: 2 pairs of 100 and 1 pair of 336 both pack to 472 bytes,
+        # and the slices below use this rank's own pair count for every rank's record.
         cap = rec[0]
         packed = torch.empty(cap, dtype=torch.uint8, device=dev)
         packed[:p_r * 72] = models.contiguous().view(torch.uint8).view(-1)

@@ -19,11 +19,18 @@ def _project(K, R, t, X):
     return x[:, :2] / x[:, 2:3]
 
 
-def two_view_fundamental(n=2000, inlier_ratio=0.4, sigma=0.1, seed=0, plane_fraction=0.0):
+def two_view_fundamental(n=2000, inlier_ratio=0.4, sigma=0.1, seed=0, plane_fraction=0.0, laf=False, laf_bad=0.25, laf_sigma=0.05):
     """C2 / C2b / C5 generator: two pinhole views of a random 3-D cloud + uniform outliers.
 
     Returns (pts1 [n,2], pts2 [n,2], is_inlier [n] bool, F_gt [3,3]) with x2^T F_gt x1 = 0.
     plane_fraction > 0 puts that share of the inlier 3-D points on the plane z = 6 + 0.1 x (C2b).
+    laf=True returns [n,6] rows (x, y, a11, a12, a21, a22) as findFundamentalMatrix takes them with
+    laf_consistensy_coef > 0 (utils.py:111-146; the binding turns every row into the two extra points
+    (x + a11, y + a21) and (x + a12, y + a22), bindings.cpp:337-409): the frame of an inlier is spanned by
+    the projections of two 3-D neighbours of its point, so both extra points obey the same epipolar geometry
+    (noise laf_sigma px), except for a share laf_bad of the inliers whose image-2 frame is random — their
+    extra points fail the LAF check, so S.Ilafs < S.I and candidates do get rejected on it
+    (exp_ranF.c:1394-1411); outliers carry random frames in both images.
     """
     rng = np.random.default_rng(seed)
     n_in = int(round(n * inlier_ratio))
@@ -43,6 +50,21 @@ def two_view_fundamental(n=2000, inlier_ratio=0.4, sigma=0.1, seed=0, plane_frac
     pts1 = np.concatenate([p1, o1]); pts2 = np.concatenate([p2, o2])
     lab = np.concatenate([np.ones(n_in, bool), np.zeros(n_out, bool)])
     perm = rng.permutation(n)
+    if laf:
+        # separate generator: the point coordinates and the permutation above are those of laf=False
+        lrng = np.random.default_rng([seed, 0x1AF])
+        A1 = np.empty((n, 4)); A2 = np.empty((n, 4))
+        A1[n_in:] = lrng.normal(0, 8.0, (n_out, 4)); A2[n_in:] = lrng.normal(0, 8.0, (n_out, 4))
+        for col, (k0, k1) in enumerate([(0, 2), (1, 3)]):         # column 0 of the frame = (a11, a21), column 1 = (a12, a22)
+            d = lrng.normal(0, 1.0, (n_in, 3)); d[:, 2] *= 0.3
+            d *= (lrng.uniform(0.04, 0.12, n_in) / np.linalg.norm(d, axis=1))[:, None]
+            q1 = _project(K, np.eye(3), np.zeros(3), X + d) + lrng.normal(0, laf_sigma, (n_in, 2))
+            q2 = _project(K, R, t, X + d) + lrng.normal(0, laf_sigma, (n_in, 2))
+            A1[:n_in, k0] = q1[:, 0] - p1[:, 0]; A1[:n_in, k1] = q1[:, 1] - p1[:, 1]
+            A2[:n_in, k0] = q2[:, 0] - p2[:, 0]; A2[:n_in, k1] = q2[:, 1] - p2[:, 1]
+        bad = lrng.random(n_in) < laf_bad
+        A2[:n_in][bad] = lrng.normal(0, 8.0, (int(bad.sum()), 4))
+        pts1 = np.concatenate([pts1, A1], 1); pts2 = np.concatenate([pts2, A2], 1)
     tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
     Kinv = np.linalg.inv(K)
     F = Kinv.T @ tx @ R @ Kinv

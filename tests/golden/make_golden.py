@@ -35,6 +35,14 @@ F_CASES = [
     # BASELINE configs at their stated size (round 2)
     ("F_c5_full", dict(n=50000, inlier_ratio=0.1, sigma=0.1, seed=0), dict(max_iters=200000, conf=0.9999)),
     ("F_c2b_full", dict(n=2000, inlier_ratio=0.4, sigma=0.1, seed=1, plane_fraction=0.7), dict(max_iters=100000)),
+    # findFundamentalMatrix with [N, 6] input and laf_consistensy_coef > 0 (utils.py:111-146; exp_ranF.c:1394-1411, :1536-1556,
+    # :1664-1682): a quarter (or half) of the inliers carry a frame that fails the check, so it does reject candidates (round 5)
+    ("F_laf_sampson", dict(n=2000, inlier_ratio=0.4, sigma=0.1, seed=0, laf=True), dict(laf_coef=3.0)),
+    ("F_laf_symm_epipolar", dict(n=2000, inlier_ratio=0.4, sigma=0.1, seed=0, laf=True), dict(laf_coef=3.0, error_type=1)),
+    ("F_laf_plane_sampson", dict(n=2000, inlier_ratio=0.4, sigma=0.1, seed=1, plane_fraction=0.7, laf=True), dict(laf_coef=2.0, max_iters=20000)),
+    ("F_laf_plane_symm_epipolar", dict(n=2000, inlier_ratio=0.4, sigma=0.1, seed=1, plane_fraction=0.7, laf=True), dict(laf_coef=2.0, error_type=1, max_iters=20000)),
+    ("F_laf_half_bad_nosym", dict(n=1000, inlier_ratio=0.5, sigma=0.3, seed=4, laf=True, laf_bad=0.5), dict(laf_coef=1.0, sym_check=False, px_th=1.0)),
+    ("F_laf_n300_tight", dict(n=300, inlier_ratio=0.6, sigma=0.3, seed=5, laf=True, laf_sigma=0.5), dict(laf_coef=1.0, max_iters=5000)),
 ]
 H_CASES = [
     ("H_c3_sampson", dict(n=5000, inlier_ratio=0.4, sigma=0.5, seed=0), dict(px_th=2.0, error_type=0)),

@@ -111,6 +111,14 @@ allm = [rngb.integers(0, 2, size=b).astype(np.uint8) for b in big]; allF = rngb.
 bm, bs, bk = parallel.gather_results(torch.from_numpy(allF[lo:hi].copy()), torch.from_numpy(alls[lo:hi].copy()),
                                      torch.from_numpy(np.concatenate(allm[lo:hi])), big, NP)
 assert np.array_equal(bm.numpy(), allF) and np.array_equal(bs.numpy(), alls) and np.array_equal(bk.numpy(), np.concatenate(allm))
+# shards with EQUAL packed record sizes but different pair counts (world 2: 2 x 100 and 1 x 336 are both 472 bytes): must not
+# take the one-collective path, whose slices assume this rank's pair count for every rank
+eq = [100, 100, 336]
+alle = [rngb.integers(0, 2, size=b).astype(np.uint8) for b in eq]; eF = rngb.normal(size=(3, 9)); es = rngb.integers(0, 1000, size=(3, 16)).astype(np.int32)
+elo, ehi = parallel.shard_range(3, rank, world)
+em, est, ek = parallel.gather_results(torch.from_numpy(eF[elo:ehi].copy()), torch.from_numpy(es[elo:ehi].copy()),
+                                      torch.from_numpy(np.concatenate(alle[elo:ehi]) if ehi > elo else np.zeros(0, np.uint8)), eq, 3)
+assert em.shape == (3, 9) and np.array_equal(em.numpy(), eF) and np.array_equal(est.numpy(), es) and np.array_equal(ek.numpy(), np.concatenate(alle))
 if rank == 0:
     assert rk.numel() == sum(sizes)
     np.savez(sys.argv[2], F=gm.numpy(), st=gs.numpy(), mk=gk.numpy(), Fr=rm.numpy(), sr=rs.numpy(), mr=rk.numpy())

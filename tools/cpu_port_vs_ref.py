@@ -8,6 +8,9 @@ from oracle import port, ref
 from pydegensac_amd import synthetic as syn
 
 
+LAF_STATS = [0, 0]          # F cases with the LAF check on; of those, cases in which it turned a candidate down
+
+
 def run(N, rng_seed, verbose=True):
     """Returns (cases whose mask or counters differ, cases whose model differs by > 1e-9, worst model difference)."""
     rng = np.random.default_rng(rng_seed)
@@ -17,10 +20,12 @@ def run(N, rng_seed, verbose=True):
         if rng.random() < 0.6:
             ir = float(rng.uniform(0.1, 0.8)); sg = float(rng.choice([0.05, 0.1, 0.5, 1.0])); pf = float(rng.choice([0.0, 0.0, 0.6, 0.9]))
             et = int(rng.choice([0, 1])); sym = bool(rng.random() < 0.7); dg = bool(rng.random() < 0.7); th = float(rng.choice([0.5, 1.0, 2.0]))
-            p1, p2, _, _ = syn.two_view_fundamental(n, ir, sg, seed=case, plane_fraction=pf)
-            Mp, mp, sp = port.find_fundamental(p1, p2, th, 0.9999, mi, et, sym, 0.0, dg, seed=seed)
-            Mr, mr, sr = ref.find_fundamental(p1, p2, th, 0.9999, mi, et, sym, 0.0, dg, seed=seed)
-            tag = f"F n={n} ir={ir:.2f} sig={sg} pf={pf} et={et} sym={sym} dg={dg} th={th} mi={mi}"
+            laf = bool(rng.random() < 0.4); lc = float(rng.choice([1.0, 2.0, 3.0])) if laf else 0.0; lbad = float(rng.choice([0.1, 0.25, 0.5]))
+            p1, p2, _, _ = syn.two_view_fundamental(n, ir, sg, seed=case, plane_fraction=pf, laf=laf, laf_bad=lbad, laf_sigma=float(rng.choice([0.05, 0.5])))
+            Mp, mp, sp = port.find_fundamental(p1, p2, th, 0.9999, mi, et, sym, lc, dg, seed=seed)
+            Mr, mr, sr = ref.find_fundamental(p1, p2, th, 0.9999, mi, et, sym, lc, dg, seed=seed)
+            tag = f"F n={n} ir={ir:.2f} sig={sg} pf={pf} et={et} sym={sym} dg={dg} th={th} mi={mi} laf={lc} bad={lbad} laf_rej={sp['rejected']}"
+            LAF_STATS[0] += laf; LAF_STATS[1] += sp["rejected"] > 0
         else:
             if n < 12:
                 n = 12                          # n <= 10 goes through the reference's 4-point u2h path (uninitialised reads)
@@ -53,4 +58,4 @@ if __name__ == "__main__":
     t0 = time.time()
     bad, loose, worst, skipped = run(N, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     print(f"{N - bad}/{N} identical masks and counters ({skipped} without a model: counters only); model beyond 1e-9 in {loose} "
-          f"(worst {worst:.2e}) in {time.time() - t0:.0f} s")
+          f"(worst {worst:.2e}) in {time.time() - t0:.0f} s; F + LAF cases {LAF_STATS[0]}, with LAF rejections {LAF_STATS[1]}")

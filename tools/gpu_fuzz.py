@@ -7,6 +7,9 @@ import numpy as np
 import pydegensac_amd as pd
 from pydegensac_amd import synthetic as syn
 from oracle import port
+LAF_STATS = [0, 0]          # F cases run with the LAF check on; of those, cases in which it turned a candidate down
+
+
 def run(N, rng_seed, verbose=True):
     """Returns (cases with different results, cases where only sample / LO counters differ)."""
     rng = np.random.default_rng(rng_seed)
@@ -20,10 +23,16 @@ def run(N, rng_seed, verbose=True):
             if rng.random() < 0.6:
                 ir = float(rng.uniform(0.1, 0.8)); sg = float(rng.choice([0.05, 0.1, 0.5, 1.0])); pf = float(rng.choice([0.0, 0.0, 0.6, 0.9]))
                 et = int(rng.choice([0, 1])); sym = bool(rng.random() < 0.7); dg = bool(rng.random() < 0.7); th = float(rng.choice([0.5, 1.0, 2.0]))
-                p1, p2, _, _ = syn.two_view_fundamental(n, ir, sg, seed=case, plane_fraction=pf)
-                Mg, mg = pd.findFundamentalMatrix_(p1, p2, th, 0.9999, mi, et, sym, 0.0, dg, seed=seed, tuning=tn); sg_ = pd.last_stats()
-                Mo, mo, so = port.find_fundamental(p1, p2, th, 0.9999, mi, et, sym, 0.0, dg, seed=seed)
-                tag = f"F n={n} ir={ir:.2f} sig={sg} pf={pf} et={et} sym={sym} dg={dg} th={th} mi={mi}"
+                # [N, 6] input with laf_consistensy_coef > 0 in four cases of ten (exp_ranF.c:1394-1411, :1536-1556, :1664-1682), the
+                # final LAF filter (MI_DEGENSAC_FLAG_FINAL_LAF_FILTER, :1724-1739) in half of those
+                laf = bool(rng.random() < 0.4); lc = float(rng.choice([1.0, 2.0, 3.0])) if laf else 0.0
+                lbad = float(rng.choice([0.1, 0.25, 0.5])); fin = int(laf and rng.random() < 0.5)
+                p1, p2, _, _ = syn.two_view_fundamental(n, ir, sg, seed=case, plane_fraction=pf, laf=laf, laf_bad=lbad, laf_sigma=float(rng.choice([0.05, 0.5])))
+                Mg, mg = pd.findFundamentalMatrix_(p1, p2, th, 0.9999, mi, et, sym, lc, dg, seed=seed, flags=fin, tuning=tn); sg_ = pd.last_stats()
+                Mo, mo, so = port.find_fundamental(p1, p2, th, 0.9999, mi, et, sym, lc, dg, seed=seed, final_laf_filter=bool(fin))
+                tag = f"F n={n} ir={ir:.2f} sig={sg} pf={pf} et={et} sym={sym} dg={dg} th={th} mi={mi} laf={lc} bad={lbad} fin={fin} laf_rej={so['rejected']}"
+                if sg_["rejected"] != so["rejected"]: sg_ = dict(sg_, samples=-1)      # the LAF check's rejections are part of the trajectory
+                LAF_STATS[0] += laf; LAF_STATS[1] += so["rejected"] > 0
             else:
                 if n < 8: n = 8
                 ir = float(rng.uniform(0.15, 0.8)); sg = float(rng.choice([0.2, 0.5, 1.0])); laf = bool(rng.random() < 0.5)
@@ -78,4 +87,5 @@ if __name__ == "__main__":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     t0 = time.time()
     br, bt = run(N, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-    print(f"{N - br - bt}/{N} identical (results differ in {br}, trajectory counters only in {bt}) in {time.time() - t0:.1f} s")
+    print(f"{N - br - bt}/{N} identical (results differ in {br}, trajectory counters only in {bt}) in {time.time() - t0:.1f} s; "
+          f"F + LAF cases {LAF_STATS[0]}, with candidates rejected by the LAF check {LAF_STATS[1]}")
