@@ -120,15 +120,17 @@ def _cpu_worker(args):
     from pydegensac_amd import parallel
     from oracle import ref
     ref.lib()
-    models = 0; t_used = 0.0; n = 0
+    models = 0; t_used = 0.0; n = 0; recs = []
     for p in ids:
         p1, p2 = make_pair(p)
         t = _t.perf_counter()
-        _, _, st = cpu_call(ref, p1, p2, parallel.pair_seed(p), count_models=True)
+        M, m, st = cpu_call(ref, p1, p2, parallel.pair_seed(p), count_models=True)
         t_used += _t.perf_counter() - t; models += st["models"]; n += 1
+        # what the reference returned for this pair: compared with the timed GPU batch afterwards (parity_against_cpu_leg)
+        recs.append((p, st["samples"], st["lo_runs"], st["I"], st["models"], np.packbits(m), np.asarray(M, dtype=np.float64).ravel().copy()))
         if t_used > budget:
             break
-    return models, t_used, n
+    return models, t_used, n, recs
 
 
 def cpu_baseline_all_cores(cfg_name, budget_s=8.0):
@@ -148,7 +150,8 @@ def cpu_baseline_all_cores(cfg_name, budget_s=8.0):
         wall = time.perf_counter() - t
         models = sum(r[0] for r in res); busy = max(r[1] for r in res); pairs = sum(r[2] for r in res)
         return {"value": models / busy, "unit": "models/s", "cores": cores, "kind": "reference",
-                "sample": f"{pairs} pairs over {cores} processes, {busy:.1f} s of solver time per process ({wall:.1f} s wall incl. start-up)"}
+                "sample": f"{pairs} pairs over {cores} processes, {busy:.1f} s of solver time per process ({wall:.1f} s wall incl. start-up)",
+                "_records": [x for r in res for x in r[3]]}
     except Exception as e:                                     # never let the side measurement break the bench line
         return {"value": None, "error": str(e)[:200]}
 
@@ -213,6 +216,32 @@ def parity_check(which, cfg_pairs, n_check, lo, models, masks, stats):
         if (na == 0) != (nb == 0) or (nb and np.linalg.norm(a / na - b / nb) > 1e-6):
             raise SystemExit(f"parity check failed: pair {lo + p} model differs")
     return len(pick), n_aside_checked
+
+
+def parity_against_cpu_leg(records, lo, models, masks, stats):
+    """Every pair the all-cores CPU leg ran through the UNMODIFIED reference (oracle/_ref) against the same pair of the timed GPU
+    batch: sample / LO / scored-model counters and inlier count equal, mask bit for bit, model within 1e-6 relative Frobenius
+    (north_star's tolerance).  Any mismatch ends the bench (SystemExit).  Returns (pairs checked, of them set-aside pairs)."""
+    P = models.shape[0]; n_ok = 0; n_aside = 0
+    for pid, samples, lo_runs, I, n_models, mbits, M in records:
+        p = pid - lo
+        if p < 0 or p >= P:
+            continue
+        st = stats[p]
+        if (int(st[0]), int(st[1]), int(st[3]), int(st[4])) != (samples, lo_runs, I, n_models):
+            raise SystemExit(f"parity check failed (reference leg): pair {pid} counters {[int(x) for x in st[:5]]} vs reference {(samples, lo_runs, I, n_models)}")
+        na, nb = np.linalg.norm(models[p]), np.linalg.norm(M)
+        if nb == 0 or not np.isfinite(M).all():
+            if na != 0:
+                raise SystemExit(f"parity check failed (reference leg): pair {pid}: the reference found no model")
+        else:
+            mo = np.unpackbits(mbits)[:masks.shape[1]].astype(bool)
+            if not np.array_equal(masks[p].astype(bool), mo):
+                raise SystemExit(f"parity check failed (reference leg): pair {pid} mask differs in {(masks[p].astype(bool) != mo).sum()} bits")
+            if na == 0 or np.linalg.norm(models[p].ravel() / na - M / nb) > 1e-6:
+                raise SystemExit(f"parity check failed (reference leg): pair {pid} model differs")
+        n_ok += 1; n_aside += int((st[15] >> 8) & 1)
+    return n_ok, n_aside
 
 
 def single_call_ms(reps=7):
@@ -300,7 +329,8 @@ def measure(pairs_per_gpu, steps, warmup, parity_pairs, world, rank, local_rank,
     if parity_pairs > 0:
         n_checked, n_aside_checked = parity_check(CFG["which"], P, parity_pairs, lo, d_F.cpu().numpy().reshape(P, 9),
                                                   d_mask.cpu().numpy().reshape(P, N_CORR), local_st)
-    return dict(dt=dt, st=st, local_st=local_st, kms=kms, alg_bytes=alg_bytes, gmask=gmask, gm=gm, total_pairs=total_pairs, P=P,
+    return dict(dt=dt, st=st, local_st=local_st, kms=kms, alg_bytes=alg_bytes, gmask=gmask, gm=gm, total_pairs=total_pairs, P=P, lo=lo,
+                host_models=d_F.cpu().numpy().reshape(P, 9), host_masks=d_mask.cpu().numpy().reshape(P, N_CORR),
                 n_checked=n_checked, n_aside_checked=n_aside_checked, homography=homography,
                 kernel=L.mi_degensac_kernel_name(int(homography)).decode())
 
@@ -465,7 +495,17 @@ def main():
                 cb["time_to_best_ms"]["gpu_same_pairs"] = {"mean": float(g_.mean()), "p50": float(np.median(g_)), "max": float(g_.max())}
             allc = cpu_baseline_all_cores(args.config)
             if allc is not None:
+                recs = allc.pop("_records", None)
                 out["cpu_baseline_all_cores"] = allc
+                if recs:
+                    # the whole CPU leg doubles as the parity sample: every pair it ran, against the timed GPU batch
+                    n_ref, n_ref_aside = parity_against_cpu_leg(recs, r["lo"], r["host_models"], r["host_masks"], local_st)
+                    out["parity_checked_vs_restatement"] = out["parity_checked"]
+                    out["parity_checked"] = out["parity_checked"] + n_ref
+                    out["parity_checked_set_aside"] = out["parity_checked_set_aside"] + n_ref_aside
+                    out["parity_checked_vs_reference"] = {"pairs": n_ref, "set_aside": n_ref_aside,
+                        "what": "every pair of the all-cores CPU leg (the unmodified reference, oracle/_ref) against the same pair of the timed GPU "
+                                "batch: samples, LO runs, inlier count, scored-model count equal; mask bit-exact; model <= 1e-6 relative Frobenius"}
         if world == 1 and not args.no_secondary and args.config == "c2":
             # the other BASELINE configurations, short runs inside the same driver-timed process (about a minute together)
             sec = {}

@@ -66,6 +66,14 @@ extern "C" {
                                                  the final mask against the model the driver computed LAST, not the best one
                                                  (exp_ranF.c:943-953, :1196-1203); error_type 0 without it = exp_ransacF */
 
+/* per-call scheduling switches (results never depend on them).  They win over the process-wide defaults below
+ * (mi_degensac_set_stream_mode / mi_degensac_set_hjob_mode and their environment variables): */
+#define MI_DEGENSAC_FLAG_NO_STREAM   4u       /* fundamental matrix: no producer workgroups for this call (stream mode off)           */
+#define MI_DEGENSAC_FLAG_STREAM_ON   8u       /* fundamental matrix: stream mode on whatever the batch size                            */
+#define MI_DEGENSAC_FLAG_STREAM_TEST(b) (((uint32_t)(b) & 3u) << 8)   /* with STREAM_ON: bit 0 = the owner scores every chunk it takes from
+                                                 the producer again, bit 1 = pairs ask for a producer even while unstarted pairs remain */
+#define MI_DEGENSAC_FLAG_NO_HJOB     16u      /* homography: no helper workgroups for the local optimisations of this call             */
+
 /* tuning word (0 = let the library decide; results never depend on it, only speed does):
  *   bits 0-1  kernel variant    1 = latency (512-thread workgroups)   2 = throughput (256-thread, 2 pairs per CU)
  *                               3 = high throughput (128-thread, up to 4 pairs per CU)
@@ -134,7 +142,11 @@ enum {
                                while it is set aside (batches) is not counted: ticks = time it was being worked on */
     MI_ST_TICKS_TOTAL = 13, /* ... to the pair's end                                                */
     MI_ST_THREADS = 14,     /* workgroup size of the kernel variant that ran (512 / 256 / 128)      */
-    MI_ST_PLACEMENT = 15    /* bits 0-7: 0 = points + pool in HBM, 1 = both in LDS, 2 = pool in LDS; bit 8: the pair was set aside once */
+    MI_ST_PLACEMENT = 15    /* bits 0-7: 0 = points + pool in HBM, 1 = both in LDS, 2 = pool in LDS; bit 8: the pair was set aside once;
+                               bit 9: its chunks came from a producer workgroup (stream mode); bit 10: a hand-over wait of the launch
+                               timed out before this pair ended and its results were DISCARDED (zero model, all-zero mask, I = 0) —
+                               the asynchronous *_dev entry points report the failure this way, the host-pointer entry points run
+                               such pairs again without producers / helpers and set bit 11 on the pairs they re-ran */
 };
 
 /* Stream mode (fundamental matrix): a pair hands the outcome-independent part of its main loop (sample stream, 7-point
@@ -142,14 +154,28 @@ enum {
  * uses the mode (automatic: batches of at most two pairs per resident workgroup) posts its request with its first chunk; idle
  * workgroups take the request with the most samples left, the oldest first.  MI_DEGENSAC_STREAM_MIN_SAM=<n> (environment, read
  * once) makes pairs ask only after n samples; MI_DEGENSAC_STREAM_DEPTH=<chunks> bounds the ring.
- * mode: -1 = automatic (default), 0 = off, odd values > 0 = on with test bits in (mode >> 1): bit 0 = the owner scores every chunk
- * it takes from the producer again, bit 1 = pairs ask for a producer even while unstarted pairs remain.  Process-wide; returns the
- * previous mode.  Also settable once through the environment variable MI_DEGENSAC_STREAM. */
-int mi_degensac_set_stream_mode(int mode);
+ * mode: -1 = automatic (default), 0 = off, values > 0 = on with test bits in (mode >> 1): bit 0 = the owner scores every chunk
+ * it takes from the producer again, bit 1 = pairs ask for a producer even while unstarted pairs remain.  This is the process-wide
+ * DEFAULT (returns the previous one; environment: MI_DEGENSAC_STREAM); a call chooses for itself with MI_DEGENSAC_FLAG_NO_STREAM /
+ * MI_DEGENSAC_FLAG_STREAM_ON in params.flags. */
+int mi_degensac_set_stream_mode(int mode);      /* any mode > 0 turns the mode on; its test bits are (mode >> 1).  Default of the calls that
+                                                   set neither MI_DEGENSAC_FLAG_NO_STREAM nor MI_DEGENSAC_FLAG_STREAM_ON */
 /* Homography: workgroups that have run out of pairs take whole repetitions of the local optimisations of the pairs that still
- * run (results never depend on it).  1 = on (default), 0 = off.  Process-wide; returns the previous mode.  Environment:
- * MI_DEGENSAC_HJOB. */
-int mi_degensac_set_hjob_mode(int mode);
+ * run (results never depend on it).  1 = on (default), 0 = off.  Process-wide DEFAULT (returns the previous one; environment:
+ * MI_DEGENSAC_HJOB); a call switches them off for itself with MI_DEGENSAC_FLAG_NO_HJOB in params.flags. */
+int mi_degensac_set_hjob_mode(int mode);        /* default of the calls that do not set MI_DEGENSAC_FLAG_NO_HJOB */
+/* Hand-overs between workgroups (stream mode, homography helpers, the cooperative large-n mode) never wait for a workgroup that
+ * may not have been dispatched; a wait for a RUNNING workgroup gives up after 4 s of device wall clock.  The launch then raises
+ * its error word, every pair that ends afterwards discards its results (MI_ST_PLACEMENT bit 10), and the host-pointer entry
+ * points run those pairs again in a second launch without producers / helpers (bit 11) instead of failing the call.  Test hook:
+ * the limit of the stream mode's data waits in 100 MHz ticks (0 = fault injection: every data wait fails at once; < 0 restores the
+ * default); returns the previous limit. */
+long long mi_degensac_set_wait_ticks(long long ticks);
+/* Memory: the library caches one scratch buffer per (device, stream): one workspace per resident workgroup (about 0.65 MB at
+ * n = 2000) plus, for fundamental-matrix batches larger than the resident grid, one spare workspace per queued pair (within half
+ * of the free memory, at most 24 GB) and, in stream mode, one ring of at most 512 chunk entries of 13.5 KB per resident workgroup
+ * (within a quarter of the free memory, at most 8 GB; about 2.7 GB at the default max_iters on a whole device).  A buffer more
+ * than four times larger than eight launches in a row needed is given back; mi_degensac_release_scratch frees it at once. */
 
 /* ---- contexts ---------------------------------------------------------------------------------- */
 typedef struct mi_degensac_ctx mi_degensac_ctx;
@@ -179,6 +205,15 @@ int mi_degensac_find_homography_batch(const double *pts1, const double *pts2, co
                                       int n_pairs, int dim, const mi_degensac_params *prm,
                                       const uint32_t *seeds, int device,
                                       double *H, uint8_t *mask, int32_t *stats);
+/* ONE batch over several devices from one process (no collective: the host gathers): device devices[k] gets the k-th contiguous
+ * block of pairs (blocks as even as possible, the first n_pairs % n_devices hold one pair more), one host thread per block;
+ * seeds travel with their pairs, so results do not depend on the device list.  A device may be listed more than once. */
+int mi_degensac_find_fundamental_batch_multi(const double *pts1, const double *pts2, const int64_t *offsets, int n_pairs, int dim,
+                                             const mi_degensac_params *prm, const uint32_t *seeds, const int *devices, int n_devices,
+                                             double *F, uint8_t *mask, int32_t *stats);
+int mi_degensac_find_homography_batch_multi(const double *pts1, const double *pts2, const int64_t *offsets, int n_pairs, int dim,
+                                            const mi_degensac_params *prm, const uint32_t *seeds, const int *devices, int n_devices,
+                                            double *H, uint8_t *mask, int32_t *stats);
 /* the same on an explicit context (its device, its stream, its staging buffers); blocking */
 int mi_degensac_ctx_find_fundamental_batch(mi_degensac_ctx *ctx, const double *pts1, const double *pts2,
                                            const int64_t *offsets, int n_pairs, int dim,
@@ -321,6 +356,13 @@ int mi_degensac_mat3(int op, const double *in, int count, int device, double *ou
  * exact residual is < 9/4 th (kind 0 = Sampson, 1 = symmetric epipolar).  Models in batches of 64 per wave, as in the kernels. */
 int mi_degensac_screen_counts(const double *pts1, const double *pts2, int n, int dim, const double *models, int n_models,
                               int kind, double th, int device, uint32_t *c1, uint32_t *c2);
+
+/* the homography main loop's screen (dg_geom.h dg_HDs_maybe_below, swept by dg_h_screen4 four models per wave): cnt[m] = points
+ * that may lie below 9/4 th under the Sampson metric of model m (division-free bound, threshold x (1 + 1e-6)); cand (nullable,
+ * [n_models * n]) = the per-point verdicts.  Every point whose exact HDs residual (Htools.c:161-200) is < 9/4 th must be a
+ * candidate, and cnt[m] must equal the number of candidates. */
+int mi_degensac_screen_counts_h(const double *pts1, const double *pts2, int n, int dim, const double *models, int n_models,
+                                double th, int device, uint32_t *cnt, uint8_t *cand);
 
 /* ---- misc -------------------------------------------------------------------------------------- */
 int         mi_degensac_device_count(void);

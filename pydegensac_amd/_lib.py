@@ -11,6 +11,11 @@ STAT_NAMES = ["samples", "lo_runs", "rejected", "I", "models", "degen", "Ih", "b
               "full_passes", "ex_passes", "h_passes", "aux_passes", "ticks_best", "ticks_total", "threads", "placement"]
 FLAG_FINAL_LAF_FILTER = 1
 FLAG_LEGACY_F = 2            # exp_ransacF / exp_ransacFcustom sample-budget rule (include/mi_degensac.h)
+# per-call scheduling switches (results never depend on them; they win over set_stream_mode / set_hjob_mode)
+FLAG_NO_STREAM, FLAG_STREAM_ON, FLAG_NO_HJOB = 4, 8, 16
+
+
+def FLAG_STREAM_TEST(b): return (int(b) & 3) << 8        # noqa: E704  with FLAG_STREAM_ON: bit 0 = owner re-scores, bit 1 = ask at once
 # params.tuning (include/mi_degensac.h MI_DEGENSAC_TUNE_*): speed knobs only, results never depend on them
 TUNE_LATENCY, TUNE_THROUGHPUT, TUNE_THROUGHPUT4 = 1, 2, 3   # kernel variant: 512- / 256- / 128-thread workgroups
 TUNE_PLACE_HBM, TUNE_PLACE_LDS, TUNE_PLACE_POOL_LDS = 1 << 2, 2 << 2, 3 << 2
@@ -87,6 +92,11 @@ def lib():
         for name in ("mi_degensac_find_fundamental_batch", "mi_degensac_find_homography_batch"):
             f = getattr(l, name); f.restype = C.c_int
             f.argtypes = [dp, dp, lp, C.c_int, C.c_int, pp, up, C.c_int, dp, bp, ip]
+        for name in ("mi_degensac_find_fundamental_batch_multi", "mi_degensac_find_homography_batch_multi"):
+            f = getattr(l, name); f.restype = C.c_int
+            f.argtypes = [dp, dp, lp, C.c_int, C.c_int, pp, up, ip, C.c_int, dp, bp, ip]
+        l.mi_degensac_set_wait_ticks.restype = C.c_longlong
+        l.mi_degensac_set_wait_ticks.argtypes = [C.c_longlong]
         l.mi_degensac_ransac_h2el_batch.restype = C.c_int
         l.mi_degensac_ransac_h2el_batch.argtypes = [dp, lp, C.c_int, C.POINTER(H2elParams), up, C.c_int, dp, bp, ip]
         l.mi_degensac_ransac_h2el_batch_dev.restype = C.c_int
@@ -138,6 +148,8 @@ def lib():
         l.mi_degensac_mat3.argtypes = [C.c_int, dp, C.c_int, C.c_int, dp, ip]
         l.mi_degensac_screen_counts.restype = C.c_int
         l.mi_degensac_screen_counts.argtypes = [dp, dp, C.c_int, C.c_int, dp, C.c_int, C.c_int, C.c_double, C.c_int, up, up]
+        l.mi_degensac_screen_counts_h.restype = C.c_int
+        l.mi_degensac_screen_counts_h.argtypes = [dp, dp, C.c_int, C.c_int, dp, C.c_int, C.c_double, C.c_int, up, bp]
         l.mi_degensac_last_error.restype = C.c_char_p
         l.mi_degensac_version.restype = C.c_char_p
         l.mi_degensac_kernel_name.restype = C.c_char_p
@@ -177,9 +189,17 @@ def set_hjob_mode(mode):
     return int(f(int(mode)))
 
 
+def set_wait_ticks(ticks):
+    """test hook: limit of the stream mode's data waits in 100 MHz device ticks (0: every data wait fails at once; < 0: the default
+    4 s); returns the previous limit"""
+    return int(lib().mi_degensac_set_wait_ticks(int(ticks)))
+
+
 def stats_dict(st):
     d = {k: int(v) for k, v in zip(STAT_NAMES, st)}
     d["set_aside"] = (d["placement"] >> 8) & 1    # the pair was written back to its workspace once and resumed later
     d["streamed"] = (d["placement"] >> 9) & 1     # the pair took chunks from a producer workgroup (stream mode)
+    d["discarded"] = (d["placement"] >> 10) & 1   # a hand-over wait of the launch timed out: results discarded (zero model / mask)
+    d["rerun"] = (d["placement"] >> 11) & 1       # ... and the host-pointer entry point ran the pair again without helpers
     d["placement"] &= 255
     return d

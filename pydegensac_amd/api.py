@@ -189,7 +189,7 @@ def _error_type(table, error_type):
         raise ValueError("Error type should be on of {}. Got {} instead".format(list(table.keys()), error_type))
 
 
-def _batch(which, pts1_list, pts2_list, px_th, conf, max_iters, error_type_int, sym, laf, degen, seeds, device, tuning=0, flags=0):
+def _batch(which, pts1_list, pts2_list, px_th, conf, max_iters, error_type_int, sym, laf, degen, seeds, device, tuning=0, flags=0, devices=None):
     n_pairs = len(pts1_list)
     if n_pairs == 0 or len(pts2_list) != n_pairs:
         raise ValueError("pts1_list and pts2_list must hold the same, non-zero number of pairs")
@@ -212,10 +212,20 @@ def _batch(which, pts1_list, pts2_list, px_th, conf, max_iters, error_type_int, 
     prm = _lib.make_params(px_th, conf, max_iters, error_type_int, sym, laf, degen, flags, tuning)
     model = np.zeros((n_pairs, 9)); mask = np.zeros(int(offs[-1]), np.uint8); st = np.zeros((n_pairs, 16), np.int32)
     sd = np.ascontiguousarray(seeds, dtype=np.uint32)
-    fn = _lib.lib().mi_degensac_find_fundamental_batch if which == "F" else _lib.lib().mi_degensac_find_homography_batch
-    rc = fn(_lib.dptr(A), _lib.dptr(B), offs.ctypes.data_as(C.POINTER(C.c_int64)), n_pairs, dim, C.byref(prm),
-            sd.ctypes.data_as(C.POINTER(C.c_uint32)), int(device), _lib.dptr(model),
-            mask.ctypes.data_as(C.POINTER(C.c_uint8)), st.ctypes.data_as(C.POINTER(C.c_int32)))
+    if devices is not None:
+        # one process, several GPUs: device devices[k] gets the k-th contiguous block of pairs, one host thread each (no collective)
+        dv = np.ascontiguousarray(list(devices), dtype=np.int32)
+        if dv.ndim != 1 or dv.size == 0:
+            raise ValueError("devices must be a non-empty list of device indices")
+        fn = _lib.lib().mi_degensac_find_fundamental_batch_multi if which == "F" else _lib.lib().mi_degensac_find_homography_batch_multi
+        rc = fn(_lib.dptr(A), _lib.dptr(B), offs.ctypes.data_as(C.POINTER(C.c_int64)), n_pairs, dim, C.byref(prm),
+                sd.ctypes.data_as(C.POINTER(C.c_uint32)), dv.ctypes.data_as(C.POINTER(C.c_int32)), int(dv.size), _lib.dptr(model),
+                mask.ctypes.data_as(C.POINTER(C.c_uint8)), st.ctypes.data_as(C.POINTER(C.c_int32)))
+    else:
+        fn = _lib.lib().mi_degensac_find_fundamental_batch if which == "F" else _lib.lib().mi_degensac_find_homography_batch
+        rc = fn(_lib.dptr(A), _lib.dptr(B), offs.ctypes.data_as(C.POINTER(C.c_int64)), n_pairs, dim, C.byref(prm),
+                sd.ctypes.data_as(C.POINTER(C.c_uint32)), int(device), _lib.dptr(model),
+                mask.ctypes.data_as(C.POINTER(C.c_uint8)), st.ctypes.data_as(C.POINTER(C.c_int32)))
     _lib.check(rc)
     _tls.stats = [_lib.stats_dict(s) for s in st]
     masks = [mask[offs[i]:offs[i + 1]].astype(bool) for i in range(n_pairs)]
@@ -224,14 +234,16 @@ def _batch(which, pts1_list, pts2_list, px_th, conf, max_iters, error_type_int, 
 
 def findFundamentalMatrixBatch(pts1_list, pts2_list, px_th=0.5, conf=0.9999, max_iters=100000,
                                laf_consistensy_coef=-1.0, error_type="sampson", symmetric_error_check=True,
-                               enable_degeneracy_check=True, seeds=None, device=0, tuning=0):
+                               enable_degeneracy_check=True, seeds=None, device=0, tuning=0, flags=0, devices=None):
     """Independent image pairs in one launch (persistent workgroups, one pair at a time each).
-    Returns (F [P,3,3], [mask_p])."""
+    devices=[d0, d1, ...]: ONE process drives several GPUs — device dk gets the k-th contiguous block of pairs (as
+    parallel.shard_range), one host thread per device, results gathered on the host; seeds travel with their pairs, so the
+    results are those of one device.  Returns (F [P,3,3], [mask_p])."""
     et = _error_type(error_type_dict_fundamental, error_type)
     if seeds is None:
         seeds = (_time_seed() + np.arange(len(pts1_list))) & 0xFFFFFFFF
     return _batch("F", pts1_list, pts2_list, px_th, conf, max_iters, et, symmetric_error_check,
-                  max(0, laf_consistensy_coef), enable_degeneracy_check, seeds, device, tuning)
+                  max(0, laf_consistensy_coef), enable_degeneracy_check, seeds, device, tuning, flags, devices)
 
 
 def ransacF_legacy(pts1, pts2, px_th=0.5, conf=0.9999, max_iters=100000, error_type="sampson", seed=None, device=0, tuning=0,
@@ -256,13 +268,14 @@ def ransacF_legacy_batch(pts1_list, pts2_list, px_th=0.5, conf=0.9999, max_iters
 
 
 def findHomographyBatch(pts1_list, pts2_list, px_th=1.0, conf=0.999, max_iters=50000, laf_consistensy_coef=-1.0,
-                        error_type="sampson", symmetric_error_check=True, seeds=None, device=0, tuning=0):
-    """Batch homographies; returns the user-facing H_out = inv(H.T) per pair (zeros when none found)."""
+                        error_type="sampson", symmetric_error_check=True, seeds=None, device=0, tuning=0, flags=0, devices=None):
+    """Batch homographies; returns the user-facing H_out = inv(H.T) per pair (zeros when none found).
+    devices=[...]: one process, several GPUs (see findFundamentalMatrixBatch)."""
     et = _error_type(error_type_dict_homography, error_type)
     if seeds is None:
         seeds = (_time_seed() + np.arange(len(pts1_list))) & 0xFFFFFFFF
     H, masks = _batch("H", pts1_list, pts2_list, px_th, conf, max_iters, et, symmetric_error_check,
-                      max(0, laf_consistensy_coef), True, seeds, device, tuning)
+                      max(0, laf_consistensy_coef), True, seeds, device, tuning, flags, devices)
     out = np.zeros_like(H)
     for i in range(len(H)):
         if np.abs(H[i]).sum() != 0:
@@ -275,8 +288,9 @@ def ransacH2el_batch(u10_list, th=4.0, conf=0.99, max_iters=10000, do_lo=True, i
     ellipse-to-ellipse correspondences, two per sample.  u10: [n, 10] = x1 y1 a1 b1 c1 x2 y2 a2 b2 c2 with the local affine
     frame [a 0; b c] of each image.  th is the threshold on the squared transfer error.  Returns (H [P, 3, 3], list of
     masks); `last_stats()` has the counters.  H follows findHomography's convention: the conventional row-major matrix that
-    maps image 1 to image 2, H_out = inv(H_raw.T) (utils.py:108), zeros when no model was found (or when the raw model is
-    singular).  raw=True returns the driver's own array instead: the reference's internal model as the C-ABI documents it,
+    maps image 1 to image 2, H_out = inv(H_raw.T) (utils.py:108), zeros — with an all-false mask, as findHomography does
+    (utils.py:104-107) — when no model was found or the raw model is singular.  (Before round 4 this function returned the raw
+    array; callers that relied on that pass raw=True.)  raw=True returns the driver's own array instead: the reference's internal model as the C-ABI documents it,
     9 doubles stored column-wise that map image 2 to image 1 — reshaped [3, 3] it is the TRANSPOSE of that matrix."""
     n_pairs = len(u10_list)
     if n_pairs == 0:
@@ -311,6 +325,8 @@ def ransacH2el_batch(u10_list, th=4.0, conf=0.99, max_iters=10000, do_lo=True, i
                 out[i] = np.linalg.inv(Hr[i].T)
             except np.linalg.LinAlgError:
                 pass
+        if np.abs(out[i]).sum() == 0:
+            masks[i] = np.zeros_like(masks[i])       # findHomography's convention: no model, no inliers (utils.py:104-107)
     return out, masks
 
 

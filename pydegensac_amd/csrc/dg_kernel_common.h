@@ -229,9 +229,13 @@ struct dg_args {
     int *done_pairs;                 /* [0] pairs finished (header): workgroups without work leave when it reaches n_pairs; [1] open producer requests
                                         (stream mode); [2] open local-optimisation jobs (homography helpers) */
     dg_hjob_cb *hjob;                /* homography: [n_res] job control blocks, or null (no helper workgroups) */
-    int *err_flag;                   /* set when a wait of the stream mode times out (results are then invalid) */
+    int *err_flag;                   /* set when a hand-over wait times out: every pair that ends afterwards discards its results (zero model, zero mask,
+                                        bit 10 of stats[15]) and the host-pointer entry points run those pairs again without helpers (dg_discard_if_failed) */
     int *trace;                      /* debug: [0] = count, then (tag, I, J lo, J hi) records; null = off */
     int trace_cap;
+    int wait_ticks;                  /* limit of the stream mode's data waits in 100 MHz ticks (4 s; the test hook mi_degensac_set_wait_ticks shortens it).
+                                        Sits in the padding behind trace_cap: the homography kernel at 256 threads has exactly 80 KB of static LDS
+                                        (this block is copied into LDS), and one more 8-byte field halves its residency */
     long long *phase_out;            /* debug: [n_pairs][8] 100 MHz ticks per phase (sample, solve, score, commit+events, LO, degen, tail, total) */
 };
 

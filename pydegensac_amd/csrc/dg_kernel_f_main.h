@@ -1582,7 +1582,7 @@ __device__ __forceinline__ dg_stream_ent *dg_stream_entry(const dg_args &A, int 
 /* whole workgroup: wait until *flag (agent-scope) satisfies `pred` or the owner's stop flag is up (stop = null: ignore); returns the
  * value seen (workgroup-uniform), -1 on timeout / stop.  The whole first wave polls behind a scalar branch. */
 template <class Pred>
-__device__ __forceinline__ int dg_stream_wait(const dg_args &A, int *flag, int *stop, Pred pred, int *bc /* LDS */)
+__device__ __forceinline__ int dg_stream_wait(const dg_args &A, int *flag, int *stop, Pred pred, int *bc /* LDS */, const long long limit = DG_STREAM_TIMEOUT)
 {
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
@@ -1590,9 +1590,9 @@ __device__ __forceinline__ int dg_stream_wait(const dg_args &A, int *flag, int *
         int v;
         for (;;) {
             v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (pred(v)) break;
+            if (pred(v) && limit != 0) break;                        /* limit 0 = fault injection (tests): every data wait fails at once */
             if (stop && __builtin_amdgcn_readfirstlane(__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { v = -1; break; }
-            if (wall_clock64() - t0 > DG_STREAM_TIMEOUT) { if (threadIdx.x == 0) __hip_atomic_store(A.err_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = -1; break; }
+            if (wall_clock64() - t0 > limit) { if (threadIdx.x == 0) __hip_atomic_store(A.err_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = -1; break; }
             __builtin_amdgcn_s_sleep(8);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1848,7 +1848,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                 /* room in the ring: the slot of this chunk is free once the owner is done with chunk seq - depth */
                 if (seq - tail_ >= A.stream_depth) {
                     const int depth_ = A.stream_depth;
-                    if (dg_stream_wait(A, &scb->tail, &scb->stop, [=](int t) { return seq - t < depth_; }, &S->itmp[28]) < 0) break;
+                    if (dg_stream_wait(A, &scb->tail, &scb->stop, [=](int t) { return seq - t < depth_; }, &S->itmp[28], A.wait_ticks) < 0) break;
                 }
                 ent = dg_stream_entry(A, oslot, seq);
             }
@@ -1950,7 +1950,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
       if (strm == 2) {
         /* ================= the chunk comes from the producer's ring ================= */
         if (seq >= head_seen) {
-            const int h_ = dg_stream_wait(A, &scb->head, (int *)0, [=](int h) { return h > seq; }, &S->itmp[28]);
+            const int h_ = dg_stream_wait(A, &scb->head, (int *)0, [=](int h) { return h > seq; }, &S->itmp[28], A.wait_ticks);
             if (h_ < 0) { done = 1; break; }
             head_seen = h_;          /* everything below it is visible after this one acquire */
         }
@@ -2670,6 +2670,25 @@ __device__ __forceinline__ int dg_next_pair(const dg_args &A, int *bc /* LDS */)
     return A.order ? A.order[t] : t;
 }
 
+/* whole workgroup, after a pair has ended: when a hand-over wait of this launch has timed out (dg_args::err_flag), the pair's
+ * results may rest on incomplete data, so they are discarded where every caller sees it — zero model, zero mask, bit 10 of
+ * stats[15] — instead of being returned as a success (the asynchronous entry points have no other way to report it; the
+ * host-pointer entry points run the flagged pairs again without producers / helpers). */
+__device__ __noinline__ void dg_discard_if_failed(const dg_args &A, const int pair, int *bc /* LDS */)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) *bc = __hip_atomic_load(A.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int failed = *bc;
+    __syncthreads();
+    if (!failed) return;
+    const long long off = A.offsets[pair];
+    const int n = (int)(A.offsets[pair + 1] - off);
+    for (int j = (int)threadIdx.x; j < n; j += (int)blockDim.x) A.mask_out[(size_t)off + j] = 0;
+    if (threadIdx.x < 9) A.model_out[(size_t)pair * 9 + threadIdx.x] = 0.0;
+    if (A.stats_out && threadIdx.x == 0) { A.stats_out[(size_t)pair * 16 + 3] = 0; A.stats_out[(size_t)pair * 16 + 15] |= 1024; }
+}
+
 template <int T, int LDSPTS>
 __global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_fundamental_kernel(dg_args A)
 {
@@ -2715,6 +2734,7 @@ __global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_fundamental_kernel(dg_a
         if (pair < 0) break;
         const int spare = dg_f_pair<T, LDSPTS>(As, &Sh, dyn_smem, pair, slot, img_wsid, resume, coop_gen, wsid, oslot);
         if (spare >= 0) wsid = spare;                /* the pair was set aside with its workspace */
+        else if (resume != 2) dg_discard_if_failed(As, pair, &next_pair);
     }
     if (LDSPTS == 0 && As.coop_k > 0 && threadIdx.x == 0)          /* retire the slot: its helpers leave */
         __hip_atomic_store(&As.coop[slot].gen, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

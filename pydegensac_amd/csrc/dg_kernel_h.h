@@ -1198,6 +1198,7 @@ __global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_homography_kernel(dg_ar
         const int pair = dg_next_pair(As, &next_pair);
         if (pair < 0) break;
         dg_h_pair<T, LDSPTS>(As, &Sh, dyn_smem, &Hlt[0][0], pair, (int)blockIdx.x, hjob_gen);
+        dg_discard_if_failed(As, pair, &next_pair);
     }
     /* out of pairs: help the local optimisations of the pairs that still run, until every pair of the launch is finished */
     if (As.hjob) {

@@ -7,6 +7,8 @@
 #include <atomic>
 #include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 #include "../../include/mi_degensac.h"
 #define DG_T 512
@@ -117,6 +119,41 @@ extern "C" int mi_degensac_screen_counts(const double *pts1, const double *pts2,
     HIPCHK(hipGetLastError()); HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(c1, d1.p, (size_t)n_models * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(c2, d2.p, (size_t)n_models * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+/* ---- unit level: the homography main loop's screen (dg_HDs_maybe_below / dg_h_screen4, gfx950 build) -------------------- */
+__global__ void dg_screen_counts_h_kernel(const dg_pt *P, int n, const double *gm /* 18 doubles per model */, int n_models, double tb,
+                                          unsigned *cnt, unsigned char *cand)
+{
+    const int lane = threadIdx.x, g0 = blockIdx.x * 4;
+    const dg_u4 c4 = dg_h_screen4<0>(P, n, gm, g0, 1, n_models, tb, lane);       /* the sweep the kernel runs: four models per wave */
+    if (lane < 4 && g0 + lane < n_models) cnt[g0 + lane] = c4.v[lane];
+    if (cand)                                                                     /* ... and the per-point verdicts of the same bound */
+        for (int j = 0; j < 4 && g0 + j < n_models; j++)
+            for (int i = lane; i < n; i += 64) {
+                const dg_pt q = P[i];
+                cand[(size_t)(g0 + j) * n + i] = dg_HDs_maybe_below(gm + (size_t)(g0 + j) * 18, q.x1, q.y1, q.x2, q.y2, tb) ? 1 : 0;
+            }
+}
+
+extern "C" int mi_degensac_screen_counts_h(const double *pts1, const double *pts2, int n, int dim, const double *models, int n_models,
+        double th, int device, uint32_t *cnt, uint8_t *cand)
+{
+    DG_UNIT_ENTER(device);
+    if (n <= 0 || n_models <= 0 || (dim != 2 && dim != 6) || !cnt) { set_err("bad argument"); return MI_DEGENSAC_EINVAL; }
+    std::vector<dg_pt> hp((size_t)n); std::vector<double> hm((size_t)n_models * 18, 0.0);
+    for (int i = 0; i < n; i++) { dg_pt q; q.x1 = pts1[(size_t)i * dim]; q.y1 = pts1[(size_t)i * dim + 1]; q.x2 = pts2[(size_t)i * dim]; q.y2 = pts2[(size_t)i * dim + 1]; hp[i] = q; }
+    for (int m = 0; m < n_models; m++) for (int j = 0; j < 9; j++) hm[(size_t)m * 18 + j] = models[(size_t)m * 9 + j];
+    DevBuf<dg_pt> dp; DevBuf<double> dm; DevBuf<uint32_t> dc; DevBuf<uint8_t> dk;
+    if (dp.alloc(n) || dm.alloc((size_t)n_models * 18) || dc.alloc(n_models) || (cand && dk.alloc((size_t)n_models * n))) { set_err("device allocation failed"); return MI_DEGENSAC_ENOMEM; }
+    HIPCHK(hipMemcpy(dp.p, hp.data(), (size_t)n * sizeof(dg_pt), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dm.p, hm.data(), hm.size() * 8, hipMemcpyHostToDevice));
+    const double tb = (th * 9 / 4) * (1.0 + 1e-6);            /* the kernel's own bound (dg_kernel_h.h, main loop) */
+    hipLaunchKernelGGL(dg_screen_counts_h_kernel, dim3((n_models + 3) / 4), dim3(64), 0, 0, dp.p, n, dm.p, n_models, tb, dc.p, cand ? dk.p : nullptr);
+    HIPCHK(hipGetLastError()); HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(cnt, dc.p, (size_t)n_models * 4, hipMemcpyDeviceToHost));
+    if (cand) HIPCHK(hipMemcpy(cand, dk.p, (size_t)n_models * n, hipMemcpyDeviceToHost));
     return 0;
 }
 

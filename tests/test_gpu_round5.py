@@ -1,0 +1,177 @@
+"""GPU: what round 5 added to the boundary — one batch over several devices from one process, per-call scheduling flags,
+hand-over time-outs that discard and re-run instead of failing (or returning invalid results), the homography screen on gfx950."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import pydegensac_amd as pd
+from pydegensac_amd import _lib, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _f_batch(P=11):
+    A, B = [], []
+    for i in range(P):
+        n = [300, 2000, 800, 1500, 64, 1000][i % 6]
+        p1, p2, _, _ = syn.two_view_fundamental(n, 0.4, 0.1, seed=900 + i, plane_fraction=0.7 if i % 4 == 1 else 0.0); A.append(p1); B.append(p2)
+    return A, B, [77 + 3 * i for i in range(P)]
+
+
+def _key(st):
+    return [(x["samples"], x["lo_runs"], x["models"], x["degen"], x["I"], x["best_sample"]) for x in st]
+
+
+def test_one_batch_over_a_device_list_equals_one_device(oracle_port):
+    """devices=[0, 0] / [0, 0, 0]: contiguous shards as parallel.shard_range, one host thread per entry, host gather.
+    (One GPU here, listed several times: two or three concurrent launches on it.)  Bit-identical to the one-shard call."""
+    A, B, seeds = _f_batch(11)
+    F0, m0 = pd.findFundamentalMatrixBatch(A, B, max_iters=20000, seeds=seeds); s0 = pd.last_stats()
+    for devs in ([0], [0, 0], [0, 0, 0], [0] * 12):
+        F1, m1 = pd.findFundamentalMatrixBatch(A, B, max_iters=20000, seeds=seeds, devices=devs); s1 = pd.last_stats()
+        assert np.array_equal(np.asarray(F0), np.asarray(F1)), devs
+        assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(m0, m1)), devs
+        assert _key(s0) == _key(s1), devs
+    for p in (1, 5, 10):
+        Fo, mo, so = oracle_port.find_fundamental(A[p], B[p], 0.5, 0.9999, 20000, seed=seeds[p])
+        assert np.array_equal(np.asarray(m0[p]), mo) and s0[p]["samples"] == so["samples"]
+    Hs = [syn.homography_pairs(n, 0.4, 0.5, seed=50 + i, laf=True)[:2] for i, n in enumerate([500, 3000, 1200, 800, 2000])]
+    HA = [h[0] for h in Hs]; HB = [h[1] for h in Hs]
+    H0, k0 = pd.findHomographyBatch(HA, HB, 2.0, 0.999, 20000, 3.0, seeds=[5, 6, 7, 8, 9])
+    H1, k1 = pd.findHomographyBatch(HA, HB, 2.0, 0.999, 20000, 3.0, seeds=[5, 6, 7, 8, 9], devices=[0, 0])
+    assert np.array_equal(np.asarray(H0), np.asarray(H1)) and all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(k0, k1))
+    with pytest.raises(_lib.MiDegensacError):
+        pd.findFundamentalMatrixBatch(A, B, seeds=seeds, devices=[0, 63])           # no such device: ENODEV, nothing half-written is returned
+    with pytest.raises(ValueError):
+        pd.findFundamentalMatrixBatch(A, B, seeds=seeds, devices=[])
+
+
+def test_scheduling_flags_are_per_call(oracle_port):
+    """MI_DEGENSAC_FLAG_NO_STREAM / _STREAM_ON / _NO_HJOB choose for ONE call, whatever the process-wide default says."""
+    A, B, seeds = _f_batch(8)
+    prev = _lib.set_stream_mode(0)                          # process default: off
+    try:
+        F0, m0 = pd.findFundamentalMatrixBatch(A, B, max_iters=30000, seeds=seeds); s0 = pd.last_stats()
+        assert sum(s_["streamed"] for s_ in s0) == 0
+        F1, m1 = pd.findFundamentalMatrixBatch(A, B, max_iters=30000, seeds=seeds, flags=_lib.FLAG_STREAM_ON | _lib.FLAG_STREAM_TEST(2)); s1 = pd.last_stats()
+        assert sum(s_["streamed"] for s_ in s1) >= 1
+        _lib.set_stream_mode(1)                             # process default: on; the call says no
+        F2, m2 = pd.findFundamentalMatrixBatch(A, B, max_iters=30000, seeds=seeds, flags=_lib.FLAG_NO_STREAM); s2 = pd.last_stats()
+        assert sum(s_["streamed"] for s_ in s2) == 0
+    finally:
+        _lib.set_stream_mode(prev)
+    for F, m, s in ((F1, m1, s1), (F2, m2, s2)):
+        assert np.array_equal(np.asarray(F0), np.asarray(F)) and all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(m0, m)) and _key(s0) == _key(s)
+    p1, p2, _, _ = syn.homography_pairs(3000, 0.4, 0.5, seed=4, laf=True)
+    Ha, ka = pd.findHomographyBatch([p1] * 3, [p2] * 3, 2.0, 0.999, 20000, 3.0, seeds=[1, 2, 3]); sa = pd.last_stats()
+    Hb, kb = pd.findHomographyBatch([p1] * 3, [p2] * 3, 2.0, 0.999, 20000, 3.0, seeds=[1, 2, 3], flags=_lib.FLAG_NO_HJOB); sb = pd.last_stats()
+    assert np.array_equal(np.asarray(Ha), np.asarray(Hb)) and all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(ka, kb)) and _key(sa) == _key(sb)
+
+
+def test_a_hand_over_time_out_is_discarded_and_rerun_not_returned(oracle_port):
+    """Fault injection (wait limit 0): every data wait of the stream mode fails, owners give up on their producers.  The host-pointer entry points
+    must still return the oracle's results (the affected pairs run again without producers: stats bit 11); the asynchronous entry
+    point must not return invalid numbers as a success: affected pairs come back as zero model + zero mask + stats bit 10."""
+    import torch
+    A, B, seeds = _f_batch(8)
+    ora = [oracle_port.find_fundamental(A[p], B[p], 0.5, 0.9999, 30000, seed=seeds[p]) for p in range(len(A))]
+    prev = _lib.set_wait_ticks(0)
+    try:
+        flags = _lib.FLAG_STREAM_ON | _lib.FLAG_STREAM_TEST(2)
+        F, m = pd.findFundamentalMatrixBatch(A, B, max_iters=30000, seeds=seeds, flags=flags); st = pd.last_stats()
+        assert sum(s_["rerun"] for s_ in st) >= 1, "the tiny limit must have tripped at least one wait"
+        for p, (Fo, mo, so) in enumerate(ora):
+            assert (st[p]["samples"], st[p]["lo_runs"], st[p]["I"]) == (so["samples"], so["lo_runs"], so["I"]), p
+            assert np.array_equal(np.asarray(m[p]), mo), p
+            assert np.linalg.norm(np.asarray(F[p]).ravel() - Fo.ravel()) <= 1e-9 * np.linalg.norm(Fo), p
+            assert st[p]["discarded"] == 0
+        # the asynchronous device-pointer entry point: nothing to retry with, the failure must be visible in the outputs
+        dev = torch.device("cuda", 0)
+        offs = np.zeros(len(A) + 1, np.int64); offs[1:] = np.cumsum([a.shape[0] for a in A])
+        d_a = torch.from_numpy(np.concatenate(A)).to(dev); d_b = torch.from_numpy(np.concatenate(B)).to(dev); d_off = torch.from_numpy(offs).to(dev)
+        d_seeds = torch.tensor(seeds, dtype=torch.int32, device=dev)
+        d_F = torch.full((len(A), 9), 7.0, dtype=torch.float64, device=dev); d_mask = torch.full((int(offs[-1]),), 3, dtype=torch.uint8, device=dev)
+        d_st = torch.zeros((len(A), 16), dtype=torch.int32, device=dev)
+        prm = _lib.make_params(0.5, 0.9999, 30000, 0, True, 0.0, True, flags)
+        stream = torch.cuda.current_stream(dev)
+        _lib.check(_lib.lib().mi_degensac_find_fundamental_batch_dev(d_a.data_ptr(), d_b.data_ptr(), d_off.data_ptr(), offs.ctypes.data_as(C.POINTER(C.c_int64)),
+                   len(A), 2, C.byref(prm), d_seeds.data_ptr(), 0, C.c_void_p(stream.cuda_stream), d_F.data_ptr(), d_mask.data_ptr(), d_st.data_ptr()))
+        torch.cuda.synchronize(dev)
+        hs = d_st.cpu().numpy(); hF = d_F.cpu().numpy(); hm = d_mask.cpu().numpy()
+        n_disc = 0
+        for p, (Fo, mo, so) in enumerate(ora):
+            if (hs[p, 15] >> 10) & 1:
+                n_disc += 1
+                assert not hF[p].any() and not hm[offs[p]:offs[p + 1]].any() and hs[p, 3] == 0, p
+            else:
+                assert np.array_equal(hm[offs[p]:offs[p + 1]].astype(bool), mo) and hs[p, 0] == so["samples"], p
+        assert n_disc >= 1
+    finally:
+        _lib.set_wait_ticks(prev)
+    F, m = pd.findFundamentalMatrixBatch(A, B, max_iters=30000, seeds=seeds, flags=_lib.FLAG_STREAM_ON | _lib.FLAG_STREAM_TEST(2)); st = pd.last_stats()
+    assert sum(s_["rerun"] + s_["discarded"] for s_ in st) == 0 and sum(s_["streamed"] for s_ in st) >= 1      # with the default limit nothing trips
+
+
+def test_environment_tuning_word_is_masked_not_rejected():
+    """MI_DEGENSAC_TUNING is process-wide and meets both kinds of call: a homography-only bit in it must not fail fundamental-matrix
+    calls (and the other way round); the same bit in params.tuning of the wrong call is still an error."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np, pydegensac_amd as pd\n"
+            "from pydegensac_amd import synthetic as syn, _lib\n"
+            "a, b, _, _ = syn.two_view_fundamental(300, 0.5, 0.1, seed=1)\n"
+            "F, m = pd.findFundamentalMatrix(a, b, 0.5, 0.9999, 2000, seed=3)\n"
+            "h1, h2, _, _ = syn.homography_pairs(300, 0.5, 0.5, seed=1)\n"
+            "H, k = pd.findHomography(h1, h2, 2.0, 0.999, 2000, seed=3)\n"
+            "assert np.asarray(m).sum() > 50 and np.asarray(k).sum() > 50\n"
+            "try:\n"
+            "    pd.findFundamentalMatrix_(a, b, tuning=_lib.TUNE_H_SERIAL_LO, seed=1); raise SystemExit(3)\n"
+            "except ValueError:\n"
+            "    pass\n"
+            "print('ok')\n") % ROOT
+    env = dict(os.environ, MI_DEGENSAC_TUNING=str(_lib.TUNE_H_SERIAL_LO | _lib.TUNE_F_SERIAL_REPS | _lib.TUNE_COOP_ALL_PASSES | _lib.TUNE_LONG_SHIFT(2)))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-800:]
+
+
+def test_homography_screen_on_the_device_is_a_superset(oracle_port):
+    """mi_degensac_screen_counts_h: the gfx950 build of dg_HDs_maybe_below (per point) and of the four-models-per-sweep count
+    (dg_h_screen4) against the reference's HDs (Htools.c:161-200, through the oracle): every point below 9/4 th is a candidate,
+    and the swept count equals the number of candidates."""
+    L = _lib.lib(); rng = np.random.default_rng(5); n = 3000; checked = 0
+    for trial in range(24):
+        scale = [1.0, 1e-3, 1e3, 1e-6][trial % 4]
+        M = rng.normal(size=(7, 9)) * scale
+        M[1, 6:9] = 0; M[2] = np.eye(3).ravel() + 1e-9 * rng.normal(size=9); M[3, 2] = M[3, 5] = 0; M[3, 8] = 1e-12
+        M[4] = syn.H_1_6.T.ravel() if hasattr(syn, "H_1_6") else M[4]
+        p1 = rng.uniform(-2000, 2000, size=(n, 2)); p2 = rng.uniform(-2000, 2000, size=(n, 2))
+        if trial % 3 == 0: p2 = p1 + rng.normal(size=(n, 2))
+        if trial % 7 == 0: p1[:, 1] = 2 * p1[:, 0] + 1
+        p1[:5] = 0; p2[:5] = 0
+        u = np.ones((n, 6)); u[:, 0:2] = p1; u[:, 3:5] = p2
+        for th in (0.25, 4.0, 400.0):
+            cnt = np.zeros(7, np.uint32); cand = np.zeros((7, n), np.uint8)
+            _lib.check(L.mi_degensac_screen_counts_h(_lib.dptr(p1), _lib.dptr(p2), n, 2, _lib.dptr(M), 7, th, 0,
+                                                     cnt.ctypes.data_as(C.POINTER(C.c_uint32)), cand.ctypes.data_as(C.POINTER(C.c_uint8))))
+            for k in range(7):
+                d = np.zeros(n)
+                oracle_port.lib().dg_oracle_HDs(oracle_port.dp(u), oracle_port.dp(M[k].copy()), oracle_port.dp(d), n)
+                inl = d < th * 9 / 4
+                assert not np.any(inl & (cand[k] == 0)), (trial, th, k, int(np.sum(inl & (cand[k] == 0))))
+                assert int(cnt[k]) == int(cand[k].sum()), (trial, th, k)
+                checked += int(inl.sum())
+    assert checked > 10000
+
+
+def test_h2el_no_model_means_no_inliers():
+    """findHomography's convention (utils.py:104-107) for ransacH2el's user-facing return: a zero H comes with an all-false mask"""
+    u10, _ = syn.ellipse_pairs(300, 0.0, 1.0, 301, 0.05)
+    H, m = pd.ransacH2el(u10, 4.0, 0.99, 500, seed=1)
+    if not np.asarray(H).any():
+        assert not np.asarray(m).any()
+    Hr, mr = pd.ransacH2el(u10, 4.0, 0.99, 500, seed=1, raw=True)          # the driver's own arrays are returned untouched
+    assert np.asarray(mr).shape == np.asarray(m).shape

@@ -227,3 +227,42 @@ def test_ellipse_ransac_validates_its_input_before_touching_the_device():
         pd.ransacH2el_batch([])
     with pytest.raises(ValueError):
         pd.ransacH2el_batch([u, u], seeds=[1])
+
+
+def test_cv2_keypoint_list_branch_with_a_stub_cv2_module():
+    """utils.py:57-66: a list of cv2.KeyPoint goes through convert_cv2_kpts_to_xyA; a list of anything else is a ValueError.
+    OpenCV is absent from this image, so the branch runs against a stub `cv2` module that only has the KeyPoint type (pt, size,
+    angle — everything the reference's converter reads, utils.py:24-41); the module is reloaded so its `import cv2` sees the stub."""
+    import importlib
+    import types
+    import pydegensac_amd.api as api
+
+    class KeyPoint:
+        def __init__(self, x, y, size, angle):
+            self.pt = (x, y); self.size = size; self.angle = angle
+
+    stub = types.ModuleType("cv2"); stub.KeyPoint = KeyPoint
+    had = sys.modules.get("cv2")
+    sys.modules["cv2"] = stub
+    try:
+        importlib.reload(api)
+        assert api.OPENCV_HERE
+        kps = [KeyPoint(10.0 + i, 20.0 - i, 4.0 + 0.5 * i, 30.0 * i) for i in range(6)]
+        out = api.convert_and_check(kps)
+        assert out.shape == (6, 6) and out.dtype == np.float64
+        for i, kp in enumerate(kps):
+            a = np.deg2rad(kp.angle); s = kp.size
+            assert np.allclose(out[i], [kp.pt[0], kp.pt[1], s * np.cos(a), s * np.sin(a), -s * np.sin(a), s * np.cos(a)], atol=1e-12)
+        with pytest.raises(ValueError):
+            api.convert_and_check([(1.0, 2.0)] * 6)               # a list, but not of cv2.KeyPoint (utils.py:58-61)
+        with pytest.raises(ValueError):
+            api.convert_and_check((1, 2, 3))                      # neither an array nor a list (utils.py:68-70)
+    finally:
+        if had is None:
+            sys.modules.pop("cv2", None)
+        else:
+            sys.modules["cv2"] = had
+        importlib.reload(api)
+    assert not api.OPENCV_HERE or had is not None
+    with pytest.raises(ValueError):
+        api.convert_and_check([object()] * 6)                     # without OpenCV: "Cannot import cv2" (utils.py:66)

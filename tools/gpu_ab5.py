@@ -1,0 +1,45 @@
+"""A/B timing inside ONE process on ONE box: C2 batches, every configuration in turn, `reps` launches each (best and mean).
+usage: gpu_ab5.py P[,P2...] name=flags:tuning[:env=val,...] ...      e.g.  gpu_ab5.py 4096 base=0:0 stream=8:0 t128=0:3
+Results of every configuration are compared with the first one's (must be identical)."""
+import sys, os, time, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from pydegensac_amd import synthetic as syn, _lib, parallel
+L = _lib.lib()
+Ps = [int(x) for x in sys.argv[1].split(",")]
+cfgs = []
+for a in sys.argv[2:]:
+    name, rest = a.split("=", 1); parts = rest.split(":")
+    cfgs.append((name, int(parts[0], 0), int(parts[1], 0) if len(parts) > 1 else 0))
+N = 2000
+dev = torch.device('cuda', 0)
+def data(P):
+    a = np.empty((P * N, 2)); b = np.empty((P * N, 2))
+    for i in range(P):
+        p1, p2, _, _ = syn.two_view_fundamental(N, 0.4, 0.1, seed=i); a[i*N:(i+1)*N] = p1; b[i*N:(i+1)*N] = p2
+    offs = np.arange(P + 1, dtype=np.int64) * N
+    return (torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev), torch.from_numpy(offs).to(dev), offs,
+            torch.from_numpy(parallel.pair_seeds(0, P).astype(np.int64)).to(dev).to(torch.int32))
+def run(P, d, flags, tuning, reps=3):
+    d_a, d_b, d_off, offs, d_seeds = d
+    d_F = torch.zeros((P, 9), dtype=torch.float64, device=dev); d_mask = torch.zeros(P * N, dtype=torch.uint8, device=dev); d_st = torch.zeros((P, 16), dtype=torch.int32, device=dev)
+    prm = _lib.make_params(0.5, 0.9999, 100000, 0, True, 0.0, True, flags, tuning)
+    ts = []
+    for it in range(reps + 1):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        rc = L.mi_degensac_find_fundamental_batch_dev(d_a.data_ptr(), d_b.data_ptr(), d_off.data_ptr(), offs.ctypes.data_as(C.POINTER(C.c_int64)), P, 2, C.byref(prm),
+                                                      d_seeds.data_ptr(), 0, None, d_F.data_ptr(), d_mask.data_ptr(), d_st.data_ptr())
+        _lib.check(rc)
+        torch.cuda.synchronize(); ts.append((time.perf_counter() - t) * 1e3)
+    st = d_st.cpu().numpy()
+    busy = float(st[:, 13].astype(np.float64).sum() / 1e5)
+    return min(ts[1:]), float(np.mean(ts[1:])), int(((st[:, 15] >> 9) & 1).sum()), float(st[:, 13].max() / 1e5), busy, d_F.cpu().numpy(), d_mask.cpu().numpy(), st
+for P in Ps:
+    d = data(P); ref = None
+    for rnd in range(2):                                  # every configuration twice, interleaved (drift of the box shows)
+        for name, flags, tuning in cfgs:
+            best, mean, streamed, longest, busy, F, m, st = run(P, d, flags, tuning)
+            same = ""
+            if ref is not None: same = " identical: %s" % (np.array_equal(ref[0], F) and np.array_equal(ref[1], m) and np.array_equal(ref[2][:, :12], st[:, :12]))
+            else: ref = (F, m, st)
+            print(f"P={P:5d} {name:12s} best {best:7.2f} ms  mean {mean:7.2f} ms  streamed {streamed:4d}  longest pair {longest:6.1f} ms  sum of pair times {busy:9.1f} ms ({busy / 512:6.1f} per 512 slots){same}", flush=True)
