@@ -244,6 +244,24 @@ def parity_against_cpu_leg(records, lo, models, masks, stats):
     return n_ok, n_aside
 
 
+def models_by_arithmetic(screen, models, ex_passes):
+    """What share of this rank's counted models (MI_ST_MODELS, the reference-equivalent count behind `achieved`) ran which arithmetic
+    over all N points: from the kernel's own counters (mi_degensac_diag.d_screen) of the main loop's scoring phase."""
+    if screen is None:
+        return None
+    l1, l2, exact, allm = (int(x) for x in screen)
+    if allm <= 0:
+        return None
+    return {"main_loop_models": allm, "entered_level1_fp32_screen": l1, "entered_level2_fp64_screen": l2, "exact_metric_in_main_loop": exact,
+            "exact_metric_in_events_at_least": models - (allm if allm < models else models),
+            "share_exact_in_main_loop": exact / allm, "share_stopped_at_level1": (l1 - l2) / allm if l1 else 0.0,
+            "share_stopped_at_level2": (l2 - exact) / allm if l2 else 0.0,
+            "note": "every counted model costs the reference one pass of 32 B x N; here a main-loop model whose inlier bound cannot beat the best "
+                    "score stops at a division-free screen over all N points (level 1: fp32, two points per instruction; level 2: fp64) and only "
+                    "the survivors run the exact metric in the reference's operation order; main_loop_models includes samples speculated past the "
+                    "final budget, which MI_ST_MODELS does not count"}
+
+
 def single_call_ms(reps=7):
     """wall time of ONE call through the host-pointer API (pageable numpy arrays in, numpy out: staging over PCIe, one
     pair on one CU, sync): the reference's own use case.  Median over `reps` seeds after one warm-up call."""
@@ -286,7 +304,10 @@ def measure(pairs_per_gpu, steps, warmup, parity_pairs, world, rank, local_rank,
     prm = _lib.make_params(PRM["px_th"], PRM["conf"], PRM["max_iters"], PRM["error_type"], PRM["sym"], PRM["laf"], PRM["degen"])
     L = _lib.lib()
     stream = torch.cuda.current_stream(dev)
-    entry = L.mi_degensac_find_homography_batch_dev if homography else L.mi_degensac_find_fundamental_batch_dev
+    entry = L.mi_degensac_find_homography_batch_dev_ex if homography else L.mi_degensac_find_fundamental_batch_dev_ex
+    # main-loop models by the arithmetic they got (mi_degensac_diag.d_screen; fundamental matrix only): feeds roofline.models_by_arithmetic
+    d_scr = torch.zeros((P, 4), dtype=torch.int32, device=dev)
+    diag = _lib.Diag(None, 0, 0, None, None if homography else d_scr.data_ptr())
 
     def step(timed_events=None):
         if timed_events:
@@ -294,7 +315,7 @@ def measure(pairs_per_gpu, steps, warmup, parity_pairs, world, rank, local_rank,
         rc = entry(d_a.data_ptr(), d_b.data_ptr(), d_off.data_ptr(),
                    offs.ctypes.data_as(C.POINTER(C.c_int64)), P, DIM, C.byref(prm),
                    d_seeds.data_ptr(), local_rank, C.c_void_p(stream.cuda_stream),
-                   d_F.data_ptr(), d_mask.data_ptr(), d_st.data_ptr())
+                   d_F.data_ptr(), d_mask.data_ptr(), d_st.data_ptr(), C.byref(diag))
         _lib.check(rc)
         if timed_events:
             timed_events[1].record(stream)
@@ -330,6 +351,7 @@ def measure(pairs_per_gpu, steps, warmup, parity_pairs, world, rank, local_rank,
         n_checked, n_aside_checked = parity_check(CFG["which"], P, parity_pairs, lo, d_F.cpu().numpy().reshape(P, 9),
                                                   d_mask.cpu().numpy().reshape(P, N_CORR), local_st)
     return dict(dt=dt, st=st, local_st=local_st, kms=kms, alg_bytes=alg_bytes, gmask=gmask, gm=gm, total_pairs=total_pairs, P=P, lo=lo,
+                screen=None if homography else d_scr.cpu().numpy().astype(np.int64).sum(0),
                 host_models=d_F.cpu().numpy().reshape(P, 9), host_masks=d_mask.cpu().numpy().reshape(P, N_CORR),
                 n_checked=n_checked, n_aside_checked=n_aside_checked, homography=homography,
                 kernel=L.mi_degensac_kernel_name(int(homography)).decode())
@@ -475,6 +497,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.config, P),
                          "kernel": r["kernel"], "kernel_ms": kms,
+                         "models_by_arithmetic": models_by_arithmetic(r.get("screen"), int(local_st[:, 4].sum()), int(local_st[:, 9].sum())),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "achieved = algorithmic bytes (models scored x 32 B x N, SURVEY 8d) / kernel time; the point set is "
                                  "LDS/L2-resident, so `traffic` (HBM bytes per launch from the committed PMC passes, profiles/) is far "

@@ -282,6 +282,13 @@ typedef struct mi_degensac_diag {
                                  [1] LO runs, [2 + I] number of samples whose best model had I inliers.  Device buffer of
                                  total_points + 3 * n_pairs ints, or NULL.  Every model is scored exactly when this is set (the
                                  screening passes are skipped): results are unchanged, the call is slower.               */
+    int32_t *d_screen;        /* fundamental matrix only: per pair 4 ints at d_screen[4 * pair]: the models of the main loop's scoring phase
+                                 (every chunk the pair's own workgroup scored, including samples speculated past the final budget) by the
+                                 arithmetic they got: [0] entered the level-1 screen (single precision, two points per instruction),
+                                 [1] entered the level-2 screen (double precision, the point's own denominator), [2] scored with the exact
+                                 metric in the reference's operation order, [3] all of them.  MI_ST_MODELS counts every one of [3] (minus
+                                 the speculated tail) as a reference-equivalent "model scored" although only [2] ran the exact arithmetic
+                                 over all points.  Device buffer of 4 * n_pairs ints, or NULL; costs nothing measurable.            */
 } mi_degensac_diag;
 int mi_degensac_find_fundamental_batch_dev_ex(const double *d_pts1, const double *d_pts2, const int64_t *d_offsets,
         const int64_t *offsets_host, int n_pairs, int dim, const mi_degensac_params *prm, const uint32_t *d_seeds, int device,

@@ -39,6 +39,11 @@ class Params(C.Structure):
                 ("laf_consistensy_coef", C.c_double), ("flags", C.c_uint32), ("tuning", C.c_uint32)]
 
 
+class Diag(C.Structure):
+    """mi_degensac_diag (include/mi_degensac.h): optional device buffers of the *_batch_dev_ex entry points"""
+    _fields_ = [("d_resids", C.c_void_p), ("resid_runs", C.c_int32), ("reserved", C.c_int32), ("d_hist", C.c_void_p), ("d_screen", C.c_void_p)]
+
+
 class H2elParams(C.Structure):
     _fields_ = [("th", C.c_double), ("conf", C.c_double), ("max_iters", C.c_int32), ("do_lo", C.c_int32),
                 ("inl_limit", C.c_int32), ("reserved", C.c_int32)]
@@ -106,6 +111,10 @@ def lib():
             f = getattr(l, name); f.restype = C.c_int
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, lp, C.c_int, C.c_int, pp, C.c_void_p, C.c_int, C.c_void_p,
                           C.c_void_p, C.c_void_p, C.c_void_p]
+        for name in ("mi_degensac_find_fundamental_batch_dev_ex", "mi_degensac_find_homography_batch_dev_ex"):
+            f = getattr(l, name); f.restype = C.c_int
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, lp, C.c_int, C.c_int, pp, C.c_void_p, C.c_int, C.c_void_p,
+                          C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Diag)]
         for name in ("mi_degensac_ctx_find_fundamental_batch", "mi_degensac_ctx_find_homography_batch"):
             f = getattr(l, name); f.restype = C.c_int
             f.argtypes = [C.c_void_p, dp, dp, lp, C.c_int, C.c_int, pp, up, dp, bp, ip]

@@ -187,9 +187,12 @@ struct dg_args {
                                         :670-672, :729-730; exp_ranH.c likewise), [offsets[pair] * resid_runs * 62 + (run * 62 + row) * n + j];
                                         rows the reference never writes for a run are NaN; null = off                        */
     int resid_runs;                  /* LO runs per pair the dump has room for                                   */
+    int lo_width;                    /* fundamental matrix: repetitions of a local optimisation started per round of speculated generator states
+                                        (0 = one per wave; sits in the padding behind resid_runs) */
     int *hist_out;                   /* optional diagnostics (F driver): the reference's data_out (exp_ranF.c:1495, :1758-1759): per pair
                                         n + 3 ints at hist_out[offsets[pair] + 3 * pair]: [0] samples, [1] LO runs, [2 + I] = number of samples
                                         whose best root had I inliers.  Needs every model scored exactly: switches the screens off. null = off */
+    int *screen_out;                 /* optional diagnostics (F driver): [n_pairs, 4] main-loop models by arithmetic (dg_f_shared::scnt); null = off */
     int *ticket;                     /* device counter, zeroed per launch: persistent workgroups pull the next pair from it */
     const int *order;                /* optional processing order (ticket t -> pair order[t]); null = identity              */
     int coop_k;                      /* helper workgroups per owner (0 = every workgroup owns pairs)            */

@@ -108,6 +108,8 @@ struct dg_f_shared {
     };
     int n_ahead;
     int n_lafrej;                        /* candidates the LAF check turned down (thread 0 counts; MI_ST_REJECTED of the F driver) */
+    unsigned scnt[4];                    /* main-loop models by the arithmetic they got (dg_score_chunk_F): [0] entered the level-1 screen (fp32, packed),
+                                            [1] entered level 2 (fp64, the point's own denominator), [2] scored with the exact metric, [3] all models scored */
     long long ph[8], dbg[8], tq;
 #ifdef DG_LO_PROF
     long long lt[16], ltq;

@@ -353,7 +353,11 @@ __device__ __noinline__ void dg_lo_rep_wave(CTX &c, dg_lo_log *lg, int ssiz, dou
         { int known = 0; if (lane == 0) known = dg_ht_contains(c.ht, hash, (int)r1.I, -1) != -1; DG_RW(11); if (__builtin_amdgcn_readfirstlane(known)) { ended = 2; break; } }
         if (fit) {
             const int cnt = (int)nL2; int id;
-            if (8 < cnt) { dg_randsubset_wave(&lg->g, alt, cnt, 8, lane, &id); if (lane == 0) lg->it[it].drew = 8; drawn += 8; }
+            if (8 < cnt) {
+                dg_randsubset_wave(&lg->g, alt, cnt, 8, lane, &id); if (lane == 0) lg->it[it].drew = 8; drawn += 8;
+                /* more draws than the later repetitions of this round assume: they will not be committed whatever follows — tell them now */
+                if (drawn > DG_LO_ASSUMED_DRAWS && lane == 0) __hip_atomic_store(&lg->pub, drawn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             else id = lane < cnt ? alt[lane] : 0;
             const int use = 8 < cnt ? 8 : cnt;
             DG_WSYNC();
@@ -407,7 +411,9 @@ __device__ __noinline__ dg_score dg_inFrani_waves(CTX &c, int ninl, double th, d
     if (ninl < 16) return maxS;
     int ssiz = ninl / 2; if (ssiz > 14) ssiz = 14;
     int next = 0;
-    constexpr int NRMAX = COOP ? DG_RAN_REP : DG_NW;
+    /* repetitions per round: one per wave, or fewer (dg_args::lo_width): every repetition behind the first rests on an assumption that
+     * holds 63 % of the time, so a wide round buys latency with wasted wave time */
+    const int NRMAX = COOP ? DG_RAN_REP : ((c.A->lo_width > 0 && c.A->lo_width < DG_NW) ? c.A->lo_width : DG_NW);
     char *glog = (char *)0;
     if constexpr (COOP) glog = dg_coop_lojob(*c.A, c.coop_slot) + 128;
     auto LG = [&](int q) -> dg_lo_log * { if constexpr (COOP) return (dg_lo_log *)(glog + (size_t)DG_LOJOB_STRIDE * q); else return &S->lo[q]; };
@@ -734,7 +740,8 @@ template <int LDSPTS>
 __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const double *gmodels, const unsigned short *mslot,
                                              int Mtot, int ws, int NS, int kind, double th, double tauJ, const double *ext /* LDS[4] */,
                                              char *tab /* LDS, this wave's */, int tab_bytes,
-                                             double *jbuf /* this wave's scratch, >= n doubles */, unsigned *res_I, double *res_J, int lane)
+                                             double *jbuf /* this wave's scratch, >= n doubles */, unsigned *res_I, double *res_J, int lane,
+                                             unsigned *scnt /* LDS[4]: dg_f_shared::scnt */)
 {
     /* workgroup-uniform arguments arrive in vector registers (separate function): make the loop control scalar again */
     n = __builtin_amdgcn_readfirstlane(n); Mtot = __builtin_amdgcn_readfirstlane(Mtot); ws = __builtin_amdgcn_readfirstlane(ws);
@@ -758,7 +765,9 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
             for (int j = 0; j < 9; j++) F[j] = gp[j];
         }
         unsigned long long surv = __ballot(have);
+        unsigned n_all = (unsigned)nb, n_l1 = 0, n_l2 = 0;
         if (use_l1) {
+            n_l1 = (unsigned)nb;
             unsigned C1 = 0;
             for (int s0 = 0; s0 < nb; s0 += B1) {
                 const int sb = nb - s0 < B1 ? nb - s0 : B1;
@@ -783,6 +792,7 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
         if (use_bound && surv) {
             const bool mine = (surv >> lane) & 1ull;
             const int myrank = __popcll(surv & lt_mask), ns = __popcll(surv);
+            n_l2 = (unsigned)ns;
             unsigned C2 = 0;
             for (int s0 = 0; s0 < ns; s0 += B2) {
                 const int sb = ns - s0 < B2 ? ns - s0 : B2;
@@ -802,6 +812,12 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
             const bool keep = mine && ((double)C2 > tauJ);
             if (mine && !keep) { res_I[mi] = 0; res_J[mi] = 0; }
             surv = __ballot(keep);
+        }
+        if (lane == 0) {                 /* four LDS adds per batch of up to 64 models */
+            __hip_atomic_fetch_add(&scnt[0], n_l1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&scnt[1], n_l2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&scnt[2], (unsigned)__popcll(surv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&scnt[3], n_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         for (unsigned long long m = surv; m; m &= m - 1ull) {
             const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
@@ -1746,7 +1762,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     dg_ht_init(c.ht, tid);
     if (A.hist_out) for (int j = tid; j < n + 3; j += DG_T) A.hist_out[(size_t)off + 3 * (size_t)pair + j] = 0;
     if (tid < 9) { S->F[tid] = 0; S->FBest[tid] = 0; }
-    if (tid == 0) S->n_lafrej = 0;
+    if (tid == 0) { S->n_lafrej = 0; S->scnt[0] = S->scnt[1] = S->scnt[2] = S->scnt[3] = 0; }
     __syncthreads();
     if (tid < 4) { double e = 0.; for (int w = 0; w < DG_NW; w++) e = fmax(e, S->extw[w][tid]); S->ext[tid] = e; }
     __syncthreads();
@@ -2172,7 +2188,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                 if (!(LDSPTS == 0 && coopK > 0) && wsi >= 0 && !ff)
                     dg_score_chunk_F<LDSPTS>(P, n, c.K->gmodels, S->mslot, Ms, wsi, NS, mk_full, th,
                                              tau_c, S->ext, (char *)&S->lsq + (size_t)wsi * capw, capw,
-                                             (double *)(c.K->wstage + (size_t)wave * c.K->n_max), c.K->res_I, c.K->res_J, lane);
+                                             (double *)(c.K->wstage + (size_t)wave * c.K->n_max), c.K->res_I, c.K->res_J, lane, S->scnt);
             }
         }
         c.n_fds += Mtot;   /* provisional: models past the termination point are subtracted below */
@@ -2617,6 +2633,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     }
     if (tid < 9) A.model_out[(size_t)pair * 9 + tid] = accepted ? S->F[tid] : 0.0;
     if (A.hist_out && tid == 0) { int *hist = A.hist_out + (size_t)off + 3 * (size_t)pair; hist[0] = no_sam; hist[1] = iter_cnt; }
+    if (A.screen_out && tid == 0) { int *so = A.screen_out + (size_t)pair * 4; for (int i = 0; i < 4; i++) so[i] = (int)S->scnt[i]; }
     if (A.stats_out && tid == 0) {
         int *st = A.stats_out + (size_t)pair * 16;
         long long t_end = wall_clock64();

@@ -1181,7 +1181,10 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
 }
 
 template <int T, int LDSPTS>
-__global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_homography_kernel(dg_args A)
+/* at 256 threads this kernel's static LDS (dg_f_shared + the argument block + 5 KB per wave) is just above 80 KB: one workgroup per CU
+ * whatever the register count, so it is compiled for one wave per SIMD there (the 512- and 128-thread variants are the ones the host picks) */
+#define DG_MINW_H (DG_T == 256 ? 1 : DG_MINW)
+__global__ __launch_bounds__(DG_T, DG_MINW_H) void dg_find_homography_kernel(dg_args A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
     __shared__ dg_f_shared Sh;
