@@ -170,13 +170,16 @@ def source_id():
 def pmc_traffic(cfg_name, pairs_per_gpu):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/README.md):
     2 x FETCH_SIZE + WRITE_SIZE KiB (MI355X_MICROARCH.md: FETCH_SIZE under-reports coalesced reads 2x on gfx950).
-    Counters cannot be read from inside the process, so the figure comes from profiles/r4_pmc_<config>.json, which
+    Counters cannot be read from inside the process, so the figure comes from profiles/r5_pmc_<config>.json (older rounds' files as a fallback), which
     tools/pmc_summary.py writes next to the rocprofv3 CSVs together with the hash of the kernel sources it was measured
     on and the batch size; any mismatch with this build / this batch gives null instead of a stale number."""
-    path = os.path.join(ROOT, "profiles", f"r4_pmc_{cfg_name}.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", f"r3_pmc_{cfg_name}.json")
-    if not os.path.exists(path):
+    path = None
+    for rnd in ("r5", "r4", "r3"):
+        cand = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{cfg_name}.json")
+        if os.path.exists(cand):
+            path = cand
+            break
+    if path is None:
         return None
     try:
         m = json.load(open(path))

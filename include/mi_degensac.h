@@ -371,6 +371,11 @@ int mi_degensac_screen_counts(const double *pts1, const double *pts2, int n, int
 int mi_degensac_screen_counts_h(const double *pts1, const double *pts2, int n, int dim, const double *models, int n_models,
                                 double th, int device, uint32_t *cnt, uint8_t *cand);
 
+/* the wave forms of the reference's srand() / rand() (one multiply-add per state word instead of 341 dependent steps; up to 31
+ * outputs per step as three interleaved prefix sums): out[i] = the (skip + i + 1)-th rand() after srand(seed), generated `block`
+ * (1..31) values at a time.  Must equal libc's sequence. */
+int mi_degensac_rng_wave(uint32_t seed, int skip, int block, int count, int device, int32_t *out);
+
 /* ---- misc -------------------------------------------------------------------------------------- */
 int         mi_degensac_device_count(void);
 const char *mi_degensac_last_error(void);

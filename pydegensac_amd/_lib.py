@@ -159,6 +159,8 @@ def lib():
         l.mi_degensac_screen_counts.argtypes = [dp, dp, C.c_int, C.c_int, dp, C.c_int, C.c_int, C.c_double, C.c_int, up, up]
         l.mi_degensac_screen_counts_h.restype = C.c_int
         l.mi_degensac_screen_counts_h.argtypes = [dp, dp, C.c_int, C.c_int, dp, C.c_int, C.c_double, C.c_int, up, bp]
+        l.mi_degensac_rng_wave.restype = C.c_int
+        l.mi_degensac_rng_wave.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, ip]
         l.mi_degensac_last_error.restype = C.c_char_p
         l.mi_degensac_version.restype = C.c_char_p
         l.mi_degensac_kernel_name.restype = C.c_char_p

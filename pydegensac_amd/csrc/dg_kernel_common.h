@@ -250,6 +250,7 @@ struct dg_args {
 static __constant__ unsigned dg_rng_C[8][32];
 static __constant__ unsigned dg_rng_Ct[32][8];     /* transposed copy: one 32-byte scalar load per term j */
 static __constant__ unsigned dg_rng_G[32];
+static __constant__ unsigned dg_rng_T[31][32];     /* [j][p]: coefficient (mod 2^32) of the initial word r_j in ring word p after srandom's 310 discarded steps */
 
 __device__ __forceinline__ unsigned dg_mulmod31(unsigned a, unsigned b)
 {
@@ -296,6 +297,54 @@ __device__ __forceinline__ unsigned dg_rng_next_seed_wave(unsigned seed, int lan
     return dg_wave_sum_u(term) >> 1;
 }
 
+/* ---- the generator on one wave ---------------------------------------------------------------------------------
+ * dg_srand / dg_rand (dg_dev_small.h) are the reference's libc calls step by step on one lane: 341 dependent steps per srand, a
+ * few dependent LDS round trips per rand — 50 us and 0.15 us.  Both are linear over Z/2^32, so a wave does them at once:
+ *   dg_srand_wave: ring word p after the 310 discarded steps = sum_j T[j][p] r_j with r_0 = seed, r_j = r_1 16807^(j-1) mod (2^31-1)
+ *                  (T filled by the host from unit vectors, like dg_rng_C): one multiply-add per term, lane p owns word p;
+ *   dg_rand_block: the next n <= 31 outputs.  With s[0..30] the ring in chronological order (s[0] = r[f] is 31 steps old, s[28] = r[b]),
+ *                  o_1 = s[0] + s[28], o_2 = s[1] + s[29], o_3 = s[2] + s[30], o_t = s[t-1] + o_(t-3): three interleaved prefix sums,
+ *                  i.e. o_(j+1) = (s[j] + s[j-3] + s[j-6] + ...) + s[28 + j mod 3]; lane j < n stores it where step j + 1 would.
+ * Same state, same outputs as the step-by-step calls (tests/test_gpu_units.py::test_wave_generator_equals_libc). */
+__device__ __forceinline__ void dg_srand_wave(dg_rng *g, unsigned seed, int lane)
+{
+    if (seed == 0) seed = 1;
+    const unsigned r1 = dg_lcg_first((int)seed);
+    const unsigned rj = lane == 0 ? seed : (lane < 31 ? dg_mulmod31(r1, dg_rng_G[(lane - 1) & 31]) : 0u);
+    const int p = lane < 31 ? lane : 0;
+    unsigned acc = 0;
+#pragma unroll
+    for (int j = 0; j < 31; j++) acc += dg_rng_T[j][p] * (unsigned)__builtin_amdgcn_readlane((int)rj, j);
+    DG_WSYNC();
+    if (lane < 31) g->r[lane] = (int32_t)acc;
+    if (lane == 0) { g->f = 3; g->b = 0; }             /* 310 = 10 x 31 steps: the ring pointers are back where srandom put them */
+    DG_WSYNC();
+}
+/* all 64 lanes of one wave, n <= 31: lane i < n returns what the (i + 1)-th dg_rand(g) from here would; the state moves n steps */
+__device__ __forceinline__ int dg_rand_block(dg_rng *g, int n, int lane)
+{
+    const int f = g->f, b = g->b;
+    int idx = f + (lane < 31 ? lane : 30); if (idx >= 31) idx -= 31;
+    const unsigned s = (unsigned)g->r[idx];
+    unsigned x = lane < 31 ? s : 0u, t;
+    t = (unsigned)__shfl_up((int)x, 3, 64);  if (lane >= 3)  x += t;
+    t = (unsigned)__shfl_up((int)x, 6, 64);  if (lane >= 6)  x += t;
+    t = (unsigned)__shfl_up((int)x, 12, 64); if (lane >= 12) x += t;
+    t = (unsigned)__shfl_up((int)x, 24, 64); if (lane >= 24) x += t;
+    const unsigned o = x + (unsigned)__shfl((int)s, 28 + lane % 3, 64);
+    DG_WSYNC();                                        /* every lane has read the ring before any lane writes it */
+    if (lane < n) g->r[idx] = (int32_t)o;
+    if (lane == 0) { int nf = f + n, nb = b + n; g->f = nf >= 31 ? nf - 31 : nf; g->b = nb >= 31 ? nb - 31 : nb; }
+    DG_WSYNC();
+    return (int)(o >> 1);
+}
+/* all 64 lanes of one wave: n calls of dg_rand(g) whose values nobody reads */
+__device__ __forceinline__ void dg_rand_skip(dg_rng *g, int n, int lane)
+{
+    n = __builtin_amdgcn_readfirstlane(n);
+    while (n > 0) { const int m = n > 31 ? 31 : n; (void)dg_rand_block(g, m, lane); n -= m; }
+}
+
 /* ---- LO hash table: the reference's 64 chained buckets (hash.c:49-96, hash.h:21-32) ------------ */
 struct dg_ht { int *heads; int *ent; int *count; };     /* ent: [cap][4] = hash, length, iterID, next */
 __device__ __forceinline__ void dg_ht_init(dg_ht &h, int tid)
@@ -340,8 +389,10 @@ __device__ __forceinline__ int dg_randsubset(dg_rng *g, int *pool, int max_sz, i
  * *id = for lane j < siz, the id at subset position j (list[max_sz - siz + j]).  Returns the subset's offset. */
 __device__ __forceinline__ int dg_randsubset_wave(dg_rng *g, int *pool, int max_sz, int siz, int lane, int *id)
 {
+    /* the siz draws at once (dg_rand_block, <= 31 of them): lane i holds draw i */
     int myS = 0;
-    for (int i = 0; i < siz; i++) {
+    if (siz <= 31) { const int raw_ = dg_rand_block(g, siz, lane); if (lane < siz) myS = raw_ % (max_sz - lane); }
+    else for (int i = 0; i < siz; i++) {
         int s = 0;
         if (lane == 0) s = dg_rand(g) % (max_sz - i);
         s = __builtin_amdgcn_readfirstlane(s);
@@ -372,8 +423,10 @@ __device__ __forceinline__ int dg_randsubset_wave(dg_rng *g, int *pool, int max_
  * time; storing the slots later (and adopting the generator) has the same effect as the call itself. */
 __device__ __forceinline__ void dg_randsubset_wave_ahead(dg_rng *g, const int *pool, int max_sz, int siz, int lane, int *id, int *pos_out, int *val_out)
 {
+    /* the siz draws at once (dg_rand_block, <= 31 of them): lane i holds draw i */
     int myS = 0;
-    for (int i = 0; i < siz; i++) {
+    if (siz <= 31) { const int raw_ = dg_rand_block(g, siz, lane); if (lane < siz) myS = raw_ % (max_sz - lane); }
+    else for (int i = 0; i < siz; i++) {
         int s = 0;
         if (lane == 0) s = dg_rand(g) % (max_sz - i);
         s = __builtin_amdgcn_readfirstlane(s);

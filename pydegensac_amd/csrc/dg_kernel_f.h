@@ -659,8 +659,9 @@ __device__ __noinline__ unsigned dg_innerH_waves(CTX &c, double *H /* LDS, in/ou
                     int id = 0;
                     dg_randsubset_wave(&S->ih_work, inliers, ninl, ssiz, lane, &id);
                     if (lane < ssiz) S->ih[q].ids[lane] = id;
-                    if (lane == 0) { S->ih[q].g = S->ih_work; S->ih[q].pub = -1; S->ih[q].aborted = 0; for (int k = 0; k < 5 * lim; k++) dg_rand(&S->ih_work); }
+                    if (lane == 0) { S->ih[q].g = S->ih_work; S->ih[q].pub = -1; S->ih[q].aborted = 0; }
                     DG_WSYNC();
+                    dg_rand_skip(&S->ih_work, 5 * (int)lim, lane);
                 }
             }
             __syncthreads();
@@ -686,8 +687,7 @@ __device__ __noinline__ unsigned dg_innerH_waves(CTX &c, double *H /* LDS, in/ou
                     for (int q = 0; q < v; q++) {
                         int id = 0;
                         dg_randsubset_wave(&S->ih_work, inliers, ninl, ssiz, lane, &id);
-                        if (lane == 0) for (int k = 0; k < S->ih[q].draws; k++) dg_rand(&S->ih_work);
-                        DG_WSYNC();
+                        dg_rand_skip(&S->ih_work, S->ih[q].draws, lane);
                     }
                 }
             }
@@ -844,7 +844,12 @@ __device__ __noinline__ void dg_innerFH(CTX &c, const int *idxH, unsigned lenH, 
     __syncthreads();
     /* dual_sample consumes exactly 6 + 4 rand() outputs per repetition, whatever they are: lane 0 draws them all,
      * then one lane per repetition replays its two sparse permutations */
-    if (tid == 0) for (unsigned q = 0; q < repCount * 10; ++q) S->fhRaw[q] = dg_rand(&S->rng);
+    if (__builtin_amdgcn_readfirstlane(wave) == 0)
+        for (int q0 = 0; q0 < (int)repCount * 10; q0 += 30) {              /* 30 draws = three repetitions per block */
+            const int m = (int)repCount * 10 - q0 < 30 ? (int)repCount * 10 - q0 : 30;
+            const int v = dg_rand_block(&S->rng, m, lane);
+            if (lane < m) S->fhRaw[q0 + lane] = v;
+        }
     __syncthreads();
     if (tid < (int)repCount) {
         const unsigned rep = (unsigned)tid;

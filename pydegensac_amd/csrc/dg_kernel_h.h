@@ -940,7 +940,7 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
     int best_sample = 0, accepted = 0, done = 0; long long t_best = t_start;
     double *e4 = S->FBest;                                   /* model behind errs[4] (last so-far-best sample) */
 
-    if (tid == 0) { dg_srand(&S->rng, A.seeds[pair]); S->itmp[31] = dg_rand(&S->rng); }
+    if (__builtin_amdgcn_readfirstlane(wave) == 0) { dg_srand_wave(&S->rng, A.seeds[pair], lane); const int v_ = dg_rand_block(&S->rng, 1, lane); if (lane == 0) S->itmp[31] = v_; }
     __syncthreads();
     unsigned seed = (unsigned)S->itmp[31];
     __syncthreads();
@@ -1111,7 +1111,7 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
             if (no_sam >= DG_ITER_SAM && iter_cnt == 0 && maxSs.I > 4) do_iterate = 1;
             if (do_iterate) {
                 __syncthreads();
-                if (tid == 0) { dg_srand(&S->rng, c.seeds[k]); for (int i = 0; i < 5; i++) dg_rand(&S->rng); }
+                if (__builtin_amdgcn_readfirstlane(wave) == 0) { dg_srand_wave(&S->rng, c.seeds[k], lane); dg_rand_skip(&S->rng, 5, lane); }
                 __syncthreads();
                 iter_cnt++;
                 DG_PHH(2);
@@ -1132,7 +1132,7 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
     /* ---- "If there were no LOs, do at least one NOW!"  exp_ranH.c:759-862 ---- */
     if (iter_cnt == 0) {
         __syncthreads();
-        if (tid == 0 && no_sam > 0) { int li = no_sam - 1 - chunk_base; if (li < 0) li = 0; dg_srand(&S->rng, c.seeds[li]); for (int i = 0; i < 5; i++) dg_rand(&S->rng); }
+        if (__builtin_amdgcn_readfirstlane(wave) == 0 && no_sam > 0) { int li = no_sam - 1 - chunk_base; if (li < 0) li = 0; dg_srand_wave(&S->rng, c.seeds[li], lane); dg_rand_skip(&S->rng, 5, lane); }
         __syncthreads();
         iter_cnt++;
         DG_PHH(2);

@@ -157,6 +157,30 @@ extern "C" int mi_degensac_screen_counts_h(const double *pts1, const double *pts
     return 0;
 }
 
+/* ---- unit level: the wave forms of srand / rand (dg_srand_wave, dg_rand_skip, dg_rand_block) -------------------------------- */
+__global__ void dg_rng_wave_kernel(unsigned seed, int skip, int block, int count, int *out)
+{
+    __shared__ dg_rng g;
+    const int lane = threadIdx.x;
+    dg_srand_wave(&g, seed, lane);
+    dg_rand_skip(&g, skip, lane);
+    for (int q0 = 0; q0 < count; q0 += block) {
+        const int m = count - q0 < block ? count - q0 : block;
+        const int v = dg_rand_block(&g, m, lane);
+        if (lane < m) out[q0 + lane] = v;
+    }
+}
+extern "C" int mi_degensac_rng_wave(uint32_t seed, int skip, int block, int count, int device, int32_t *out)
+{
+    DG_UNIT_ENTER(device);
+    if (block < 1 || block > 31 || count < 0 || skip < 0 || !out) { set_err("bad argument"); return MI_DEGENSAC_EINVAL; }
+    DevBuf<int> d; if (d.alloc((size_t)count)) { set_err("device allocation failed"); return MI_DEGENSAC_ENOMEM; }
+    hipLaunchKernelGGL(dg_rng_wave_kernel, dim3(1), dim3(64), 0, 0, seed, skip, block, count, d.p);
+    HIPCHK(hipGetLastError()); HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, d.p, (size_t)count * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 __global__ void dg_sample_stream_kernel(unsigned seed0, int n, int ssz, int iters, int seq_pool, int *pool_g, int *out)
 {
     /* the main kernels' sampler (dg_sample_chunk), chunk by chunk, run by one wave: with the pool in LDS (n <= 4096:

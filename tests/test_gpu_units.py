@@ -268,3 +268,22 @@ def test_screening_counts_are_supersets_of_the_exact_band():
                 assert (c1 >= exact).all(), (kind, th, int(np.argmax(exact.astype(np.int64) - c1)))
                 assert (exact > 0).any() and (c1[:300] < n).any()                 # the test has teeth: bands are hit, level 1 rejects
 
+
+
+def test_wave_generator_equals_libc(oracle_port):
+    """dg_srand_wave / dg_rand_skip / dg_rand_block (one wave: a 31 x 31 linear map for srand, three interleaved prefix sums for up to
+    31 outputs at once) against the oracle's libc-faithful srand() / rand() (itself pinned on libc in tests/test_oracle_cpu.py):
+    every block size, skips that wrap the ring, seeds 0, 1, 2^31 - 1, 2^31, 2^32 - 1."""
+    import ctypes as C
+    from pydegensac_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    seeds = [0, 1, 2, 12345, 2**31 - 1, 2**31, 2**32 - 1] + [int(x) for x in rng.integers(1, 2**32 - 1, 12)]
+    for i, seed in enumerate(seeds):
+        for block in ([1, 2, 3, 8, 14, 16, 30, 31] if i < 4 else [int(rng.integers(1, 32))]):
+            skip = int(rng.integers(0, 200)); count = 400
+            got = np.zeros(count, np.int32)
+            _lib.check(L.mi_degensac_rng_wave(seed, skip, block, count, 0, got.ctypes.data_as(C.POINTER(C.c_int32))))
+            want = np.zeros(skip + count, np.int32)
+            oracle_port.lib().dg_oracle_rand_stream(C.c_uint(seed), skip + count, oracle_port.ip(want))
+            assert np.array_equal(got, want[skip:]), (seed, block, skip, int(np.argmax(got != want[skip:])))
