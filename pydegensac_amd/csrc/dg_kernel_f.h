@@ -965,8 +965,12 @@ __device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, doub
     __syncthreads();
     unsigned max_i = 3, m_i = 4, max_sam = MAX_SAM;
     unsigned no_sam = 1;
+    /* batch size: the candidates behind the first one that beats m_i are thrown away (the loop restarts behind it), and records are
+     * front-loaded — with m_i = 4 nearly every candidate beats it, later ones rarely do.  So batches start small and double while
+     * they bring no hit: the first hits cost a handful of scored candidates each instead of a full batch */
+    int Bcap = 4 * DG_NW < DG_CHUNK ? 4 * DG_NW : DG_CHUNK;
     while (no_sam < 2*max_sam) {
-        int B = (int)(2*max_sam - no_sam); if (B > DG_CHUNK) B = DG_CHUNK;
+        int B = (int)(2*max_sam - no_sam); if (B > Bcap) B = Bcap;
         __syncthreads();
         long long tg0 = DG_CLK();
         if (tid == 0) {
@@ -1009,7 +1013,7 @@ __device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, doub
         __syncthreads();
         unsigned bE = S->wave_cnt[0];
         for (int w = 1; w < DG_NW; w++) bE = S->wave_cnt[w] < bE ? S->wave_cnt[w] : bE;
-        if (bE == 0xffffffffu) { no_sam += (unsigned)B; c.n_aux += B; continue; }
+        if (bE == 0xffffffffu) { no_sam += (unsigned)B; c.n_aux += B; Bcap = 2 * Bcap < DG_CHUNK ? 2 * Bcap : DG_CHUNK; continue; }
         /* roll back to the state right after iteration bE */
         __syncthreads();
         if (tid == 0) {

@@ -303,7 +303,7 @@ __device__ __forceinline__ void dg_h2_pair(const dg_args &A, dg_f_shared *S, con
     dg_score maxS = {0, 0, 0, 0}, maxSs = {0, 0, 0, 0};
     dg_h2bufs B; B.pe[0] = 0; B.pe[1] = 1; B.pe[2] = 2; B.pe[3] = 3; B.pe[4] = 3;
     int no_sam = 0, max_sam = pr.max_iters, iter_cnt = 0, best_sample = 0; long long t_best = t_start;
-    if (tid == 0) { dg_srand(&S->rng, A.seeds[pair]); S->itmp[31] = dg_rand(&S->rng); }
+    if (tid < 64) { dg_srand_wave(&S->rng, A.seeds[pair], tid); const int v_ = dg_rand_block(&S->rng, 1, tid); if (tid == 0) S->itmp[31] = v_; }
     __syncthreads();
     unsigned seed = (unsigned)S->itmp[31];
     while (no_sam < max_sam) {
@@ -311,10 +311,15 @@ __device__ __forceinline__ void dg_h2_pair(const dg_args &A, dg_f_shared *S, con
         int new_max = 0, do_iterate = 0;
         __syncthreads();
         if (tid < 64) {
+            /* srand(seed), the two draws of randsubset and the next seed: one wave step each (dg_srand_wave, dg_rand_block) */
+            dg_srand_wave(&S->rng, seed, tid);
+            const int d3_ = dg_rand_block(&S->rng, 3, tid);
+            const int dr0 = __builtin_amdgcn_readlane(d3_, 0), dr1 = __builtin_amdgcn_readlane(d3_, 1), dr2 = __builtin_amdgcn_readlane(d3_, 2);
             if (tid == 0) {
-                dg_srand(&S->rng, seed);
-                dg_randsubset(&S->rng, pool, n, 2);
-                S->itmp[31] = dg_rand(&S->rng);
+                /* rtools.c:25-39 randsubset(pool, n, 2) on the two draws */
+                { const int s = dr0 % n, j = n - 1; const int q = pool[s]; pool[s] = pool[j]; pool[j] = q; }
+                { const int s = dr1 % (n - 1), j = n - 2; const int q = pool[s]; pool[s] = pool[j]; pool[j] = q; }
+                S->itmp[31] = dr2;
                 S->itmp[28] = pool[n - 2]; S->itmp[29] = pool[n - 1];
             }
             DG_WSYNC();
