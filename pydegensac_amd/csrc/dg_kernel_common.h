@@ -183,6 +183,7 @@ struct dg_args {
     dg_ws_layout wl;
     dg_params prm;
     int dim, n_pairs, pts_in_lds;
+    int dev_knob;                    /* development: one integer for A/B experiments (mi_degensac_dev_set_knob); 0 = defaults.  Sits in padding */
     double *resids_out;              /* optional diagnostics: the reference's per-LO residual dump (exp_ranF.c:1503-1511, :776-779,
                                         :670-672, :729-730; exp_ranH.c likewise), [offsets[pair] * resid_runs * 62 + (run * 62 + row) * n + j];
                                         rows the reference never writes for a run are NaN; null = off                        */

@@ -968,7 +968,8 @@ __device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, doub
     /* batch size: the candidates behind the first one that beats m_i are thrown away (the loop restarts behind it), and records are
      * front-loaded — with m_i = 4 nearly every candidate beats it, later ones rarely do.  So batches start small and double while
      * they bring no hit: the first hits cost a handful of scored candidates each instead of a full batch */
-    int Bcap = 4 * DG_NW < DG_CHUNK ? 4 * DG_NW : DG_CHUNK;
+    int Bcap = 2 * DG_NW < DG_CHUNK ? 2 * DG_NW : DG_CHUNK;       /* measured on C2 x 4096: 2 .. 16 equal within the noise, 32 and more slower */
+    if (c.A->dev_knob > 0) { Bcap = c.A->dev_knob & 0xffff; if (Bcap > DG_CHUNK) Bcap = DG_CHUNK; }
     while (no_sam < 2*max_sam) {
         int B = (int)(2*max_sam - no_sam); if (B > Bcap) B = Bcap;
         __syncthreads();
