@@ -256,7 +256,11 @@ __device__ __forceinline__ dg_score dg_inHranic(CTX &c, int kind, int ninl, doub
  * the same order; a repetition the reference would have cut short is simply computed further than needed. */
 #define DG_HLT 640                /* doubles of LDS per wave: the long-list fit's table (dg_lsq_seq_par), the 12-point fit's design matrix */
 struct dg_hrep_sc { double *Z, *V, *D, *A1, *A2; dg_eig_ws &ews; };     /* scratch view with the member names the solvers use */
-__device__ __forceinline__ size_t dg_hrep_logs_bytes() { return ((size_t)DG_RAN_REP * sizeof(dg_hrep_log) + 255) & ~(size_t)255; }
+/* behind the ten records: the published inlier sets of a local optimisation's repetitions (dg_hpub_*): per repetition eight 8-byte words */
+#define DG_HPUB_OFF   (((size_t)DG_RAN_REP * sizeof(dg_hrep_log) + 127) & ~(size_t)127)
+#define DG_HPUB_BYTES ((size_t)DG_RAN_REP * 8 * sizeof(unsigned long long))
+#define DG_HREP_HDR_BYTES ((DG_HPUB_OFF + DG_HPUB_BYTES + 255) & ~(size_t)255)
+__device__ __forceinline__ size_t dg_hrep_logs_bytes() { return DG_HREP_HDR_BYTES; }
 __device__ __forceinline__ size_t dg_hrep_wave_bytes(int n_max) { return ((size_t)n_max * (2 * sizeof(int) + sizeof(double) + 2 * sizeof(dg_pt)) + 255) & ~(size_t)255; }
 
 #define DG_AS1(T) __attribute__((address_space(1))) T
@@ -509,9 +513,61 @@ __device__ __noinline__ dg_pass_res dg_hm_wpass(const dg_pt *P, int n, int kind,
     return out;
 }
 
-/* one repetition (sample lg->ids), by one wave; writes the rest of *lg */
+/* ---- what the repetitions of ONE local optimisation tell each other while they run ------------------------------------
+ * In the reference a repetition stops at the first inlier set that an earlier repetition (or an earlier local optimisation)
+ * has put into the hash table: with ten repetitions running side by side nobody sees the others' sets, and every one of
+ * them runs its four long-list fits where the reference runs 1.2 on average (C3 data: 25.6 passes per local optimisation
+ * against 60).  So every repetition PUBLISHES the (hash, I) of each iteration as one 8-byte word in the owner's workspace
+ * (one self-contained agent-scope store: no fence, readable from any XCD), and a status word when it ends.  A repetition j
+ * may stop at a set X as soon as X is certainly in the reference's table at that point: the sets INSERTED by repetitions
+ * k < j.  What a repetition inserts depends on the lower ones, so that is only known for the leading run of FINISHED
+ * repetitions 0 .. p - 1 — their words are final, a replay of them in order gives their inserts exactly — and for
+ * repetition p itself as far as it has got (everything below it is final).  Repetition 0 is always in that set, and the
+ * others converge to the sets it visits.  Stopping early never changes a result: the owner's replay finds the same set in
+ * the real table at that iteration (or cuts the repetition earlier still); a repetition that misses a word that is
+ * published a moment later just runs one iteration more, as before.
+ * word: bit 63 valid, bit 62 "this set was already in the table of the earlier local optimisations" (not an insert; the
+ * repetition ended there), bits 32-61 I, bits 0-31 hash; word 7 of a repetition: bit 63 finished, low bits = its iterations */
+#define DG_HPUB_VALID (1ull << 63)
+#define DG_HPUB_KNOWN (1ull << 62)
+__device__ __forceinline__ void dg_hpub_store(unsigned long long *w, unsigned long long v)
+{
+    __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+/* all 64 lanes of one wave, j >= 1: is the set (hash, I) among the inserts of the repetitions below j that are certain? */
+__device__ __forceinline__ bool dg_hpub_seen(unsigned long long *pub, int j, unsigned hash, int I, int lane)
+{
+    /* lane 6 r + e holds word e of repetition r (e = 0..3: iterations, e = 5: status) */
+    const int r = lane / 6, e = lane - 6 * r;
+    unsigned long long v = 0;
+    if (r < j && r < DG_RAN_REP && (e < DG_ILSQ_ITERS || e == 5)) v = __hip_atomic_load(pub + 8 * r + (e == 5 ? 7 : e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    /* p = the leading finished repetitions */
+    const unsigned long long finm = __ballot(e == 5 && (v & DG_HPUB_VALID) != 0ull);
+    int p = 0; while (p < j && ((finm >> (6 * p + 5)) & 1ull)) p++;
+    const int top = p < j ? p : j - 1;                      /* repetitions 0 .. top count */
+    const unsigned long long key = v & ~(DG_HPUB_VALID | DG_HPUB_KNOWN);
+    bool inserted = false;
+    for (int k = 0; k <= top; k++) {
+        /* a finished repetition's iteration count is in its status word; the unfinished one (k == p) counts as far as its words go */
+        for (int i = 0; i < DG_ILSQ_ITERS; i++) {
+            const int src = 6 * k + i;
+            const unsigned long long w = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), src) << 32) | (unsigned)__builtin_amdgcn_readlane((int)v, src);
+            if (!(w & DG_HPUB_VALID)) break;                                    /* not (yet) reached */
+            const unsigned long long kk = w & ~(DG_HPUB_VALID | DG_HPUB_KNOWN);
+            if (w & DG_HPUB_KNOWN) break;                                       /* ended at a set of an earlier local optimisation */
+            if (__ballot(inserted && r != k && key == kk) != 0ull) break;       /* cut by a lower repetition's set: it inserts nothing from here on */
+            if (lane == src) inserted = true;                                   /* (a set it visited itself before is in the table already: marking it twice is harmless) */
+        }
+    }
+    const unsigned long long mine = ((unsigned long long)(unsigned)I << 32) | hash;
+    return __ballot(inserted && key == mine) != 0ull;
+}
+
+/* one repetition (sample lg->ids), by one wave; writes the rest of *lg.  pub: the published sets of this local optimisation
+ * (dg_hpub_seen), rep: this repetition's number */
 template <int LDSPTS>
-__device__ __noinline__ void dg_hrep_wave(CTX &c, int kind, dg_hrep_log *lg, int ssiz, double th, double *lt, char *wb, int lane, int wave)
+__device__ __noinline__ void dg_hrep_wave(CTX &c, int kind, dg_hrep_log *lg, int ssiz, double th, double *lt, char *wb, int lane, int wave,
+                                         unsigned long long *pub, int rep)
 {
     dg_f_shared *S = c.S; const int n = c.n, nm = c.K->n_max; const dg_pt *P = c.P;
     dg_wave_ws *w = &S->ww[wave];
@@ -525,7 +581,11 @@ __device__ __noinline__ void dg_hrep_wave(CTX &c, int kind, dg_hrep_log *lg, int
     const dg_pass_res r0 = dg_hm_wpass<LDSPTS>(P, n, kind, h, z18, th, lb, th * DG_MWM, (int *)0, 0.0, lt, lane);
     DG_HW(0);
     if (lane == 0) { lg->I0 = (int)r0.I; lg->J0 = r0.J; lg->nit = 0; lg->last_short = 0; lg->has_fin = 0; }
-    if (r0.I < 4) return;
+    /* the status word goes out when the repetition ends, behind its iteration words (the wave's stores are drained first) */
+    auto finish = [&](int nit_) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) dg_hpub_store(pub + 8 * rep + 7, DG_HPUB_VALID | (unsigned long long)nit_); };
+    /* the real table takes at most DG_HT_CAP entries and drops the rest: near that limit "inserted" is no longer certain */
+    const bool share = *c.ht.count + 4 * DG_RAN_REP * DG_ILSQ_ITERS < DG_HT_CAP;
+    if (r0.I < 4) { finish(0); return; }
     dg_u2h_wave<LDSPTS>(c, w, lt, lb, (int)r0.nL, stage, hl, lane);
     DG_HW(1);
     double ths = DG_TC * th; const double dth = (ths - th) / DG_ILSQ_ITERS;
@@ -539,8 +599,13 @@ __device__ __noinline__ void dg_hrep_wave(CTX &c, int kind, dg_hrep_log *lg, int
         if (lane == 0) { lg->it[it].J = r1.J; lg->it[it].hash = hash; lg->it[it].I = (int)r1.I; lg->nit = it + 1; }
         /* a set some EARLIER local optimisation already inserted ends the repetition here at the latest, whatever the other
          * repetitions of this one do (the table is not written before the replay) */
-        { int known = 0; if (lane == 0) known = dg_ht_contains(c.ht, hash, (int)r1.I, -1) != -1; if (__builtin_amdgcn_readfirstlane(known)) return; }
-        if (r1.nL2 < 4) { if (lane == 0) lg->last_short = 1; return; }
+        { int known = 0; if (lane == 0) known = dg_ht_contains(c.ht, hash, (int)r1.I, -1) != -1;
+          known = __builtin_amdgcn_readfirstlane(known);
+          if (lane == 0) dg_hpub_store(pub + 8 * rep + it, DG_HPUB_VALID | (known ? DG_HPUB_KNOWN : 0ull) | ((unsigned long long)(unsigned)r1.I << 32) | hash);
+          if (known) { finish(it + 1); return; } }
+        /* ... and so does a set that a repetition below this one has certainly inserted by now */
+        if (share && rep > 0 && dg_hpub_seen(pub, rep, hash, (int)r1.I, lane)) { finish(it + 1); return; }
+        if (r1.nL2 < 4) { if (lane == 0) lg->last_short = 1; finish(it + 1); return; }
         dg_u2h_wave<LDSPTS>(c, w, lt, lb, (int)r1.nL2, stage, hl, lane);
         DG_HW(1);
         ths -= dth;
@@ -549,6 +614,7 @@ __device__ __noinline__ void dg_hrep_wave(CTX &c, int kind, dg_hrep_log *lg, int
     DG_HW(0);
     if (lane < 9) lg->hf[lane] = hl[lane];
     if (lane == 0) { lg->If = (int)rf.I; lg->Jf = rf.J; lg->has_fin = 1; }
+    finish(DG_ILSQ_ITERS);
 }
 
 /* ---- repetitions as claimable jobs (dg_hjob_cb) -------------------------------------------------------------------- */
@@ -579,7 +645,7 @@ __device__ __forceinline__ void dg_hjob_work(CTX &c, dg_hjob_cb *cb, int g, int 
     for (;;) {
         const int r = dg_hjob_claim(cb, g, lds_next, lane);
         if (r < 0) break;
-        dg_hrep_wave<LDSPTS>(c, kind, &logs[r], ssiz, th, c.hlt + (size_t)DG_HLT * wave, wb, lane, wave);
+        dg_hrep_wave<LDSPTS>(c, kind, &logs[r], ssiz, th, c.hlt + (size_t)DG_HLT * wave, wb, lane, wave, (unsigned long long *)((char *)logs + DG_HPUB_OFF), r);
         if (cb) {
             /* the record is in the owner's workspace: visible before the count goes up */
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -613,6 +679,9 @@ __device__ __forceinline__ dg_score dg_inHranic_waves(CTX &c, int kind, int ninl
         }
     }
     if (tid == 0) S->itmp[20] = 0;
+    /* no word of the previous local optimisation survives (plain stores: the job's release below, or this barrier for the
+     * workgroup's own waves, puts them in front of every reader) */
+    if (tid < (int)(DG_HPUB_BYTES / sizeof(unsigned long long))) ((unsigned long long *)((char *)logs + DG_HPUB_OFF))[tid] = 0ull;
     __syncthreads();
     int g = 0;
     if (cb) {
