@@ -785,7 +785,8 @@ __device__ __noinline__ unsigned dg_u2Fit_wave(dg_wave_ws *w, const dg_pt *P, in
         } else {
             for (int j = lane; j < (int)cnt; j += 64) stage[j] = dg_ldpt<LDSPTS>(P, list[j]);
             DG_WSYNC();
-            if (stage_cap >= 2 * (int)cnt) dg_lsq_seq_par(w, stage, (int)cnt, lane, 64, 0, w->A1, w->A2, [] { DG_WSYNC(); });
+            /* the normal matrix from shared design-matrix entries, twelve points per fill of this wave's Z (idle in the long form) */
+            if (stage_cap >= 2 * (int)cnt) dg_lsq_seq_par(w, stage, (int)cnt, lane, 64, 0, w->A1, w->A2, [] { DG_WSYNC(); }, w->Z, 12);
             else dg_lsq_seq_core(w, stage, (int)cnt, lane, 0, w->A1, w->A2);
             DG_WSYNC();
             dg_eig_sym_wave(w->V, w->D, lane, &w->ews);

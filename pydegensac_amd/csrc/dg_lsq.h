@@ -322,7 +322,8 @@ __device__ __forceinline__ void dg_lsq_seq_core(SC *s, const dg_pt *stage, int l
  * runs the serial parts. */
 template <class SC, class Sync>
 __device__ __forceinline__ void dg_lsq_seq_par(SC *s, dg_pt *stage, int len, int tid, int nthr, int rows2, double *A1o, double *A2o, Sync sync,
-                                               double *ltab = (double *)0 /* optional LDS scratch, 640 doubles, used by wave 0 only */)
+                                               double *ltab = (double *)0 /* optional LDS scratch, 10 doubles per point of a fill, used by wave 0 only */,
+                                               const int ltab_pts = 64 /* points per fill of ltab (<= 64) */)
 {
     /* [4][len] coordinates, then [2][len] centroid distances; stored and loaded as global memory (not flat) */
     __attribute__((address_space(1))) double *aux = (__attribute__((address_space(1))) double *)(double *)(stage + len);
@@ -379,8 +380,8 @@ __device__ __forceinline__ void dg_lsq_seq_par(SC *s, dg_pt *stage, int len, int
         const int x0 = !rows2 ? ie : (li == 0 ? ki : li == 1 ? 9 : 3 + ki), y0 = !rows2 ? je : (lj == 0 ? kj : lj == 1 ? 9 : 3 + kj);
         const int x1 = li == 0 ? 9 : li == 1 ? ki : 6 + ki, y1 = lj == 0 ? 9 : lj == 1 ? kj : 6 + kj;
         double val = 0;
-        for (int base = 0; base < len; base += 64) {
-            const int cnt = len - base < 64 ? len - base : 64;
+        for (int base = 0; base < len; base += ltab_pts) {
+            const int cnt = len - base < ltab_pts ? len - base : ltab_pts;
             if (lane < cnt) {
                 const dg_pt q = stage[base + lane]; double *t = ltab + 10 * lane;
                 if (!rows2) {
