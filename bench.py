@@ -225,14 +225,19 @@ def parity_against_cpu_leg(records, lo, models, masks, stats):
     """Every pair the all-cores CPU leg ran through the UNMODIFIED reference (oracle/_ref) against the same pair of the timed GPU
     batch: sample / LO / scored-model counters and inlier count equal, mask bit for bit, model within 1e-6 relative Frobenius
     (north_star's tolerance).  Any mismatch ends the bench (SystemExit).  Returns (pairs checked, of them set-aside pairs)."""
-    P = models.shape[0]; n_ok = 0; n_aside = 0
+    P = models.shape[0]; n_ok = 0; n_aside = 0; soft = []
     for pid, samples, lo_runs, I, n_models, mbits, M in records:
         p = pid - lo
         if p < 0 or p >= P:
             continue
         st = stats[p]
-        if (int(st[0]), int(st[1]), int(st[3]), int(st[4])) != (samples, lo_runs, I, n_models):
+        if (int(st[0]), int(st[1]), int(st[3])) != (samples, lo_runs, I):
             raise SystemExit(f"parity check failed (reference leg): pair {pid} counters {[int(x) for x in st[:5]]} vs reference {(samples, lo_runs, I, n_models)}")
+        if int(st[4]) != n_models:
+            # the reference's OWN count of scoring passes is not stable: four consecutive calls of oracle/_ref on C3 pair 463 in one process
+            # gave 138 / 140 / 138 / 138, a fresh process 131, the restatement and the kernel 130 — with identical samples, LO runs,
+            # inlier count, mask and model every time.  So this counter is compared and listed, not fatal; mask and model below are.
+            soft.append((pid, int(st[4]), n_models))
         na, nb = np.linalg.norm(models[p]), np.linalg.norm(M)
         if nb == 0 or not np.isfinite(M).all():
             if na != 0:
@@ -244,7 +249,7 @@ def parity_against_cpu_leg(records, lo, models, masks, stats):
             if na == 0 or np.linalg.norm(models[p].ravel() / na - M / nb) > 1e-6:
                 raise SystemExit(f"parity check failed (reference leg): pair {pid} model differs")
         n_ok += 1; n_aside += int((st[15] >> 8) & 1)
-    return n_ok, n_aside
+    return n_ok, n_aside, soft
 
 
 def models_by_arithmetic(screen, models, ex_passes):
@@ -525,13 +530,16 @@ def main():
                 out["cpu_baseline_all_cores"] = allc
                 if recs:
                     # the whole CPU leg doubles as the parity sample: every pair it ran, against the timed GPU batch
-                    n_ref, n_ref_aside = parity_against_cpu_leg(recs, r["lo"], r["host_models"], r["host_masks"], local_st)
+                    n_ref, n_ref_aside, soft = parity_against_cpu_leg(recs, r["lo"], r["host_models"], r["host_masks"], local_st)
                     out["parity_checked_vs_restatement"] = out["parity_checked"]
                     out["parity_checked"] = out["parity_checked"] + n_ref
                     out["parity_checked_set_aside"] = out["parity_checked_set_aside"] + n_ref_aside
                     out["parity_checked_vs_reference"] = {"pairs": n_ref, "set_aside": n_ref_aside,
+                        "scored_model_count_differs": [list(x) for x in soft[:8]], "scored_model_count_differs_n": len(soft),
                         "what": "every pair of the all-cores CPU leg (the unmodified reference, oracle/_ref) against the same pair of the timed GPU "
-                                "batch: samples, LO runs, inlier count, scored-model count equal; mask bit-exact; model <= 1e-6 relative Frobenius"}
+                                "batch: samples, LO runs, inlier count equal, mask bit-exact, model <= 1e-6 relative Frobenius (any mismatch ends the "
+                                "bench); the scored-model count is compared too and its differences are listed (pair, GPU, reference): the reference's own "
+                                "count varies from call to call on some homography pairs (same mask, model and trajectory), see bench.py"}
         if world == 1 and not args.no_secondary and args.config == "c2":
             # the other BASELINE configurations, short runs inside the same driver-timed process (about a minute together)
             sec = {}
