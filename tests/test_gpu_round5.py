@@ -175,3 +175,27 @@ def test_h2el_no_model_means_no_inliers():
         assert not np.asarray(m).any()
     Hr, mr = pd.ransacH2el(u10, 4.0, 0.99, 500, seed=1, raw=True)          # the driver's own arrays are returned untouched
     assert np.asarray(mr).shape == np.asarray(m).shape
+
+
+def test_laf_rows_in_batches_set_aside_and_streamed(oracle_port):
+    """[N, 6] rows with the LAF check through the BATCH paths: a ragged batch on a capped grid with pairs set aside and resumed, the
+    same batch with producers (stream mode) forced on, and over a device list — every pair against the restatement."""
+    A, B = [], []
+    for i in range(14):
+        n = [2000, 600, 1500, 300, 1000][i % 5]
+        p1, p2, _, _ = syn.two_view_fundamental(n, 0.4, 0.1, seed=700 + i, plane_fraction=0.7 if i % 3 == 1 else 0.0, laf=True, laf_bad=0.5 if i % 2 else 0.25)
+        A.append(p1); B.append(p2)
+    seeds = [5 + 11 * i for i in range(14)]
+    ora = [oracle_port.find_fundamental(A[p], B[p], 0.5, 0.9999, 20000, 0, True, 2.0, True, seed=seeds[p]) for p in range(14)]
+    assert sum(o[2]["rejected"] for o in ora) > 0
+    runs = [("set aside on 4 workgroups", dict(tuning=_lib.TUNE_THROUGHPUT | _lib.TUNE_GRID_CAP(4) | _lib.TUNE_SET_ASIDE(2))),
+            ("producers", dict(flags=_lib.FLAG_STREAM_ON | _lib.FLAG_STREAM_TEST(2))),
+            ("device list", dict(devices=[0, 0, 0]))]
+    for tag, kw in runs:
+        F, m = pd.findFundamentalMatrixBatch(A, B, 0.5, 0.9999, 20000, 2.0, seeds=seeds, **kw); st = pd.last_stats()
+        for p, (Fo, mo, so) in enumerate(ora):
+            assert (st[p]["samples"], st[p]["lo_runs"], st[p]["rejected"], st[p]["I"]) == (so["samples"], so["lo_runs"], so["rejected"], so["I"]), (tag, p)
+            assert np.array_equal(np.asarray(m[p]), mo), (tag, p)
+            assert np.linalg.norm(np.asarray(F[p]).ravel() - Fo.ravel()) <= 1e-9 * np.linalg.norm(Fo), (tag, p)
+        if tag.startswith("set aside"):
+            assert sum(s_["set_aside"] for s_ in st) >= 3

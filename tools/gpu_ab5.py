@@ -2,6 +2,9 @@
 usage: gpu_ab5.py P[,P2...] name=flags:tuning[:lo_width[:knob]] ...      e.g.  gpu_ab5.py 4096 base=0:0 stream=8:0 t128=0:3
 Results of every configuration are compared with the first one's (must be identical)."""
 import sys, os, time, ctypes as C
+# the lo_width / knob fields need the development build (make -C pydegensac_amd/csrc dev); flags and tuning work on the product library
+if any(a.count(":") >= 2 for a in sys.argv[2:]):
+    os.environ.setdefault("MI_DEGENSAC_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmi_degensac_dev.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from pydegensac_amd import synthetic as syn, _lib, parallel
