@@ -298,6 +298,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         DG_PH(3);
         DG_PH(0);
         int Mtot = 0, nxt = cur, cn2 = 0;
+        double tau_scored = 0.0;      /* the bound this chunk's models were screened against: a model whose candidate count did not exceed it has J = 0 */
       int full = 1;                   /* the chunk's 7-point solves and scoring run in this workgroup */
       if (strm == 2) {
         /* ================= the chunk comes from the producer's ring ================= */
@@ -354,6 +355,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             }
             __syncthreads();
             c.n_fds += Mtot;
+            tau_scored = tau_used;
         }
       }
       if (full) {
@@ -404,6 +406,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             tau_c = S->dtmp[31];
             __syncthreads();
         }
+        tau_scored = tau_c;
         const bool coop_screen = th != 0 && tau_c >= 4.0;
         int coop_units = 0;
         if (LDSPTS == 0 && coopK > 0) {
@@ -724,6 +727,39 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                             if (new_max) maxS.J = rj.J;
                             if (track && dphys == p4) { __syncthreads(); if (tid < 9) e4F[tid] = S->f[tid]; e4kind = mk_full; __syncthreads(); }
                             ++degen_cnt;
+                            {
+                                /* exp_ranF.c:1478-1480 can LOWER maxS.J (the recount is the MSAC sum of the plane-and-parallax model, whatever
+                                 * the sample's own model scored).  The rest of this chunk was screened against the bound of the chunk's start: a
+                                 * later model whose J lies between the new bound and that one may carry J = 0 although the reference would
+                                 * now look at it (found by the LAF-rejection counter of the fuzz sweep: same results, 3 rejections against the
+                                 * reference's 10).  Rare (a DEGENSAC completion inside the chunk that also made a new best): score the chunk's
+                                 * models again against the new bound, all waves; a ring chunk that only carried the producer's few candidates
+                                 * gets its models solved again first. */
+                                const double tau_new = maxS.J < maxSs.J ? maxS.J : maxSs.J;
+                                if (tau_new < tau_scored && !A.hist_out && th != 0) {
+                                    __syncthreads();
+                                    if (strm == 2 && !full) {
+                                        if (tid >= k && tid < chunk) {
+                                            unsigned rixp = 0;
+                                            const int r_ = dg_solve7_lane(P, c.draws[tid], c.K->gmodels + (size_t)tid * 27, &rixp, (double *)&S->ww[wave]);
+                                            const int nvv = r_ < 0 ? 0 : r_;
+                                            S->nsolv[tid] = (unsigned char)((rixp >> 8) & 3u);
+                                            for (int q = 0; q < nvv; q++) S->ridx[tid][q] = (unsigned char)((rixp >> (2*q)) & 3u);
+                                        }
+                                        __syncthreads();
+                                    }
+                                    if (LDSPTS == 0 && coopK > 0 && tid == 0)        /* the helpers' bound of this pair follows (only this workgroup writes it) */
+                                        __hip_atomic_store(&cb->tau_bits, (unsigned long long)__double_as_longlong(tau_new < 0 ? 0.0 : tau_new), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    {
+                                        const int capr = (int)((sizeof(dg_lsq_scratch) / DG_NW) & ~(size_t)15);
+                                        dg_score_chunk_F<LDSPTS>(P, n, c.K->gmodels, S->mslot, Mtot, wave, DG_NW, mk_full, th, tau_new, S->ext,
+                                                                 (char *)&S->lsq + (size_t)wave * capr, capr,
+                                                                 (double *)(c.K->wstage + (size_t)wave * c.K->n_max), c.K->res_I, c.K->res_J, lane, S->scnt);
+                                    }
+                                    __syncthreads();
+                                    tau_scored = tau_new;
+                                }
+                            }
                         }
                         DG_PH(5);
                     } else {

@@ -199,3 +199,27 @@ def test_laf_rows_in_batches_set_aside_and_streamed(oracle_port):
             assert np.linalg.norm(np.asarray(F[p]).ravel() - Fo.ravel()) <= 1e-9 * np.linalg.norm(Fo), (tag, p)
         if tag.startswith("set aside"):
             assert sum(s_["set_aside"] for s_ in st) >= 3
+
+
+def test_bound_that_falls_inside_a_chunk(oracle_port):
+    """exp_ranF.c:1478-1480: after a plane-and-parallax completion `maxS.J` becomes the MSAC sum of THAT model and may fall below the
+    bound the current chunk was screened against; models of later samples of the chunk between the two must be looked at again.  The
+    case the fuzz sweep found through the LAF-rejection counter (sweep seed 21, case 1771: 3 rejections counted against the
+    reference's 10, results equal): every workgroup size and placement, own sample stream and producer ring."""
+    p1, p2, _, _ = syn.two_view_fundamental(150, 0.7889425968606831, 0.1, seed=1771, plane_fraction=0.9, laf=True, laf_bad=0.5, laf_sigma=0.05)
+    seed = 1847496781
+    Fo, mo, so = oracle_port.find_fundamental(p1, p2, 2.0, 0.9999, 20000, 1, False, 2.0, True, seed=seed)
+    assert so["rejected"] == 10 and so["degen"] == 3
+    for variant in (1, 2, 3):
+        for mode in (1, 2, 3):
+            for flags in (_lib.FLAG_NO_STREAM, _lib.FLAG_STREAM_ON | _lib.FLAG_STREAM_TEST(2)):
+                F, m = pd.findFundamentalMatrix_(p1, p2, 2.0, 0.9999, 20000, 1, False, 2.0, True, seed=seed, flags=flags, tuning=variant | (mode << 2)); st = pd.last_stats()
+                assert (st["samples"], st["lo_runs"], st["degen"], st["rejected"], st["I"]) == (so["samples"], so["lo_runs"], so["degen"], so["rejected"], so["I"]), (variant, mode, flags, st)
+                assert np.array_equal(np.asarray(m), mo) and np.linalg.norm(np.asarray(F).ravel() - Fo.ravel()) <= 1e-9 * np.linalg.norm(Fo)
+    # the same scene without the LAF check: the candidates the LAF check turned down are now ACCEPTED by the reference
+    Fo, mo, so = oracle_port.find_fundamental(p1[:, :2].copy(), p2[:, :2].copy(), 2.0, 0.9999, 20000, 1, False, 0.0, True, seed=seed)
+    for variant in (1, 2, 3):
+        for flags in (_lib.FLAG_NO_STREAM, _lib.FLAG_STREAM_ON | _lib.FLAG_STREAM_TEST(2)):
+            F, m = pd.findFundamentalMatrix_(p1[:, :2].copy(), p2[:, :2].copy(), 2.0, 0.9999, 20000, 1, False, 0.0, True, seed=seed, flags=flags, tuning=variant); st = pd.last_stats()
+            assert (st["samples"], st["lo_runs"], st["degen"], st["I"]) == (so["samples"], so["lo_runs"], so["degen"], so["I"]), (variant, flags)
+            assert np.array_equal(np.asarray(m), mo)

@@ -15,6 +15,8 @@ def run(N, rng_seed, verbose=True):
     rng = np.random.default_rng(rng_seed)
     bad = 0; bad_res = 0
     if True:
+        only = os.environ.get("FUZZ_ONLY")                      # debugging: run only these case numbers (the random stream still advances)
+        only = set(int(x) for x in only.split(",")) if only else None
         for case in range(N):
             variant = int(rng.choice([512, 256, 128])); mode = int(rng.choice([0, 1, 2]))
             tn = {512: 1, 256: 2, 128: 3}[variant] | ((mode + 1) << 2)          # params.tuning: variant, placement (include/mi_degensac.h)
@@ -27,16 +29,19 @@ def run(N, rng_seed, verbose=True):
                 # final LAF filter (MI_DEGENSAC_FLAG_FINAL_LAF_FILTER, :1724-1739) in half of those
                 laf = bool(rng.random() < 0.4); lc = float(rng.choice([1.0, 2.0, 3.0])) if laf else 0.0
                 lbad = float(rng.choice([0.1, 0.25, 0.5])); fin = int(laf and rng.random() < 0.5)
-                p1, p2, _, _ = syn.two_view_fundamental(n, ir, sg, seed=case, plane_fraction=pf, laf=laf, laf_bad=lbad, laf_sigma=float(rng.choice([0.05, 0.5])))
+                lsig = float(rng.choice([0.05, 0.5]))
+                if only is not None and case not in only: continue
+                p1, p2, _, _ = syn.two_view_fundamental(n, ir, sg, seed=case, plane_fraction=pf, laf=laf, laf_bad=lbad, laf_sigma=lsig)
                 Mg, mg = pd.findFundamentalMatrix_(p1, p2, th, 0.9999, mi, et, sym, lc, dg, seed=seed, flags=fin, tuning=tn); sg_ = pd.last_stats()
                 Mo, mo, so = port.find_fundamental(p1, p2, th, 0.9999, mi, et, sym, lc, dg, seed=seed, final_laf_filter=bool(fin))
-                tag = f"F n={n} ir={ir:.2f} sig={sg} pf={pf} et={et} sym={sym} dg={dg} th={th} mi={mi} laf={lc} bad={lbad} fin={fin} laf_rej={so['rejected']}"
+                tag = f"F case={case} n={n} ir={ir:.2f} sig={sg} pf={pf} et={et} sym={sym} dg={dg} th={th} mi={mi} laf={lc} bad={lbad} lsig={lsig} fin={fin} laf_rej={so['rejected']} gpu_laf_rej={sg_['rejected']}"
                 if sg_["rejected"] != so["rejected"]: sg_ = dict(sg_, samples=-1)      # the LAF check's rejections are part of the trajectory
                 LAF_STATS[0] += laf; LAF_STATS[1] += so["rejected"] > 0
             else:
                 if n < 8: n = 8
                 ir = float(rng.uniform(0.15, 0.8)); sg = float(rng.choice([0.2, 0.5, 1.0])); laf = bool(rng.random() < 0.5)
                 et = int(rng.integers(0, 5)); sym = bool(rng.random() < 0.7); th = float(rng.choice([1.0, 2.0, 4.0])); lc = 3.0 if laf else 0.0
+                if only is not None and case not in only: continue
                 p1, p2, _, _ = syn.homography_pairs(n, ir, sg, seed=case, laf=laf)
                 Mg, mg = pd.findHomography_(p1, p2, th, 0.999, mi, et, sym, lc, seed=seed, tuning=tn); sg_ = pd.last_stats()
                 Mo, mo, so = port.find_homography(p1, p2, th, 0.999, mi, et, sym, lc, seed=seed)
