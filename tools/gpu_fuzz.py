@@ -50,7 +50,10 @@ def run(N, rng_seed, verbose=True):
             rel = np.linalg.norm(Mg - Mo) / max(np.linalg.norm(Mo), 1e-300) if np.abs(Mo).sum() else float(np.abs(Mg).sum())
             nomodel = np.abs(Mo).sum() == 0                      # the reference leaves the mask undefined then
             res_ok = (nomodel and np.abs(Mg).sum() == 0) or (np.array_equal(np.asarray(mg, dtype=bool), np.asarray(mo, dtype=bool)) and rel < 1e-9)
-            traj_ok = sg_["samples"] == so["samples"] and sg_["lo_runs"] == so["lo_runs"]
+            # every counter the two sides share: a path that diverges without changing the result (a skipped check, a pass more or less) shows here
+            keys = ["samples", "lo_runs", "rejected", "I", "models", "best_sample"] + (["degen", "Ih", "full_passes", "ex_passes"] if "degen" in so else [])
+            traj_ok = all(sg_[k_] == so[k_] for k_ in keys if k_ in so and k_ in sg_)
+            if not traj_ok and verbose: print("   counters", {k_: (sg_[k_], so[k_]) for k_ in keys if k_ in so and k_ in sg_ and sg_[k_] != so[k_]})
             if not res_ok: bad_res += 1
             if not (res_ok and traj_ok):
                 bad += 1
