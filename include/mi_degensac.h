@@ -355,7 +355,10 @@ int mi_degensac_solve7(const double *pts1, const double *pts2, int n, int dim,
  * order; in 9, out 9 + 3), op 2 = Hdetect (DegUtils.c:84-161; in F (9) + seven correspondences x1 y1 x2 y2 (28) + the
  * triplet as three doubles, out 9).  op 3 = the 9x9 symmetric eigen-solver (LAPACK dsyev as lap_eig calls it,
  * degensac/lapwrap.c:67-96), one problem per wave: in 81, out 9 eigenvalues (smallest first, the rest as the QL/QR
- * iteration left them) + 81 (column-major vectors, column 0 = the one of the smallest eigenvalue), flag = info. */
+ * iteration left them) + 81 (column-major vectors, column 0 = the one of the smallest eigenvalue), flag = info.
+ * op 4 = the real roots of a cubic as the 7-point solver takes them (Ftools.c:251-298; in 4 coefficients, out 3, flag =
+ * the number of roots): the one routine of the path that calls the math library (pow / acos / cos), so the one place
+ * where the device can differ from a host run of the reference in the last bits. */
 int mi_degensac_mat3(int op, const double *in, int count, int device, double *out, int32_t *flag);
 /* the screening counts of the scoring phase (dg_score_tiles.h) for given fundamental-matrix models over a point set:
  * c1[m] = level-1 count (single precision, loosest denominator, rounding-widened threshold), c2[m] = level-2 count

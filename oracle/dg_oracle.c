@@ -816,15 +816,19 @@ static int exp_ransacFcustomLAF(dg_ctx *c, const double *u, const double *u_1, c
 
             if (scoreLess(maxSs, S)) {
                 maxSs = S;
+                TRACE2(30, S.I, S.J);
                 if (enable_degen_check && checksample(f, u7, 3*th, H)) {
                     HDs(u, H, HDsv, len); c->n_hds++;            /* dHDs, :1430 */
                     I = 0;
                     for (j = 0; j < len; ++j) if (HDsv[j] < th*3) ++I;
+                    TRACE2(31, I, no_sam);
                     if (I < 8) break;
                     I = innerH(c, H, u, len, 16*th, 10, inl);
+                    TRACE2(32, I, 0);
                     if ((int)I > Ihmax) Ihmax = (int)I;
                     if (I > 6) {
                         I = rFtH(c, u, inl, th, H, len, f);
+                        TRACE2(33, I, maxS.I);
                         if (I > maxS.I) {
                             FDS1(u, f, errs[3], len); c->n_fds++; TRACE(0, f);
                             maxS.I = I;

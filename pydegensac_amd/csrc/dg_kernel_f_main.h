@@ -683,6 +683,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                 }
                 if (maxSs.J < Sc.J) {
                     maxSs = Sc;
+                    DG_TRACE(c, 30, Sc.I, Sc.J);
                     int degenerate = 0;
                     if (pr.degen) {
                         __syncthreads();
@@ -706,11 +707,14 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                         dg_pass_cfg ch = dg_cfg0(n); ch.flags = c.K->Fl[1]; ch.thF = th*3;
                         dg_pass_res rh = dg_h_pass(c, S->H, ch); c.n_hds++;
                         unsigned I = rh.nF;
+                        DG_TRACE(c, 31, I, no_sam);
                         if (I < 8) { DG_FLAST(S->f); brk = 1; c.n_fds -= (nvk - 1 - r); if (A.hist_out) { __syncthreads(); if (tid == 0) S->nv[k] = (unsigned char)(r + 1); __syncthreads(); } break; }   /* exp_ranF.c:1437-1439: later roots are never scored */
                         { long long ti0 = DG_CLK(); I = dg_innerH(c, S->H, 16*th, 10, c.K->Fl[0]); DG_DEVT(if (tid == 0) S->dbg[0] += DG_CLK() - ti0); (void)ti0; }
+                        DG_TRACE(c, 32, I, 0);
                         if ((int)I > Ihmax) Ihmax = (int)I;
                         if (I > 6) {
                             I = dg_rFtH(c, c.K->Fl[0], th, S->H, S->f);
+                            DG_TRACE(c, 33, I, maxS.I);
                             if (ri == (int)S->nsolv[k] - 1) DG_FLAST(S->f);      /* no later root overwrites f (exp_ranF.c:1365-1368) */
                             int dphys;
                             if (I > maxS.I) {

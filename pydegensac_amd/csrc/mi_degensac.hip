@@ -294,6 +294,12 @@ __global__ void dg_mat3_kernel(int op, const double *in, int count, double *out,
         for (int i = 0; i < 9; i++) out[(size_t)t * 12 + i] = v[i];
         for (int i = 0; i < 3; i++) out[(size_t)t * 12 + 9 + i] = d[i];
         flag[t] = 0;
+    } else if (op == 4) {
+        /* the cubic's real roots as the 7-point solver takes them (Ftools.c:251-298): the one place where the device's math
+         * library (pow / acos / cos) stands in for the host's */
+        double po[4], r[3] = {0, 0, 0}; for (int i = 0; i < 4; i++) po[i] = in[(size_t)t * 4 + i];
+        flag[t] = dg_rroots3(po, r);
+        for (int i = 0; i < 3; i++) out[(size_t)t * 3 + i] = r[i];
     } else {
         /* in: F (9), seven correspondences x1 y1 x2 y2 (28), triplet (3, as doubles) */
         double F[9], u7[7][4]; unsigned char ids[3];
@@ -327,8 +333,8 @@ __global__ void dg_eig9_kernel(const double *in, int count, double *out, int *fl
 extern "C" int mi_degensac_mat3(int op, const double *in, int count, int device, double *out, int32_t *flag)
 {
     DG_UNIT_ENTER(device);
-    if (op < 0 || op > 3 || count < 0) { set_err("bad op"); return MI_DEGENSAC_EINVAL; }
-    const size_t ni = op == 3 ? 81 : op == 2 ? 40 : 9, no = op == 3 ? 90 : op == 1 ? 12 : 9;
+    if (op < 0 || op > 4 || count < 0) { set_err("bad op"); return MI_DEGENSAC_EINVAL; }
+    const size_t ni = op == 4 ? 4 : op == 3 ? 81 : op == 2 ? 40 : 9, no = op == 4 ? 3 : op == 3 ? 90 : op == 1 ? 12 : 9;
     DevBuf<double> di, dout; DevBuf<int> df;
     if (di.alloc(count * ni) || dout.alloc(count * no) || df.alloc(count)) { set_err("device allocation failed"); return MI_DEGENSAC_ENOMEM; }
     HIPCHK(hipMemcpy(di.p, in, count * ni * 8, hipMemcpyHostToDevice));

@@ -10,6 +10,33 @@ from oracle import port
 LAF_STATS = [0, 0]          # F cases run with the LAF check on; of those, cases in which it turned a candidate down
 
 
+class _Trace:
+    """FUZZ_TRACE=1 (with FUZZ_ONLY=<case> and MI_DEGENSAC_LIB=tools/libmi_degensac_dev.so): the driver's checkpoints (tag, I, J) of
+    one fundamental-matrix case on both sides -- tags 1, 2 around the least squares before an LO, 10-15 inside it, 30 a new best
+    sample model (exp_ranF.c:1421), 31 the plane's support (:1430-1436), 32 after innerH, 33 after rFtH -- and the first that differs."""
+    def __init__(self):
+        import ctypes as C
+        from pydegensac_amd import _lib
+        self.C = C; self.L = _lib.lib(); self.P = port.lib(); self.o = []; self.cap = 20000
+        self.CB = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_double); self.cb = self.CB(lambda t, i, j: self.o.append((t, i, j)))
+        self.L.mi_degensac_debug_trace(self.cap, None)
+    def gpu_done(self):
+        C = self.C; buf = np.zeros(1 + 4 * self.cap, np.int32); self.L.mi_degensac_debug_trace(0, buf.ctypes.data_as(C.POINTER(C.c_int)))
+        rec = buf[1:1 + 4 * buf[0]].reshape(-1, 4)
+        self.g = [(int(r[0]), int(r[1]), float(np.array([(int(r[2]) & 0xffffffff) | (int(r[3]) << 32)], dtype=np.int64).view(np.float64)[0])) for r in rec]
+        self.P.dg_oracle_set_trace2(self.cb)
+    def report(self):
+        self.P.dg_oracle_set_trace2(self.CB(0))
+        keep = lambda tr: [x for x in tr if x[0] in (1, 2, 12, 30, 31, 32, 33)]
+        o, g = keep(self.o), keep(self.g)
+        for i, (a, b) in enumerate(zip(o, g)):
+            if a != b:
+                print(f"   trace: first difference at event {i} of {len(o)} / {len(g)}  (tag, I, J)")
+                for j in range(max(0, i - 3), min(len(o), len(g), i + 4)): print("     oracle", o[j], " gpu", g[j])
+                return
+        print(f"   trace: {len(o)} / {len(g)} events, equal over the common prefix")
+
+
 def run(N, rng_seed, verbose=True):
     """Returns (cases with different results, cases where only sample / LO counters differ)."""
     rng = np.random.default_rng(rng_seed)
@@ -20,6 +47,8 @@ def run(N, rng_seed, verbose=True):
         for case in range(N):
             variant = int(rng.choice([512, 256, 128])); mode = int(rng.choice([0, 1, 2]))
             tn = {512: 1, 256: 2, 128: 3}[variant] | ((mode + 1) << 2)          # params.tuning: variant, placement (include/mi_degensac.h)
+            if os.environ.get("FUZZ_TUNING"):                   # debugging: this kernel variant / placement instead of the drawn one
+                variant, mode = (int(x) for x in os.environ["FUZZ_TUNING"].split(",")); tn = {512: 1, 256: 2, 128: 3}[variant] | ((mode + 1) << 2)
             seed = int(rng.integers(1, 2**31 - 1)); n = int(rng.choice([8, 20, 64, 150, 400, 1000, 2000, 3000]))
             mi = int(rng.choice([500, 3000, 20000]))
             if rng.random() < 0.6:
@@ -32,8 +61,11 @@ def run(N, rng_seed, verbose=True):
                 lsig = float(rng.choice([0.05, 0.5]))
                 if only is not None and case not in only: continue
                 p1, p2, _, _ = syn.two_view_fundamental(n, ir, sg, seed=case, plane_fraction=pf, laf=laf, laf_bad=lbad, laf_sigma=lsig)
+                tr = _Trace() if os.environ.get("FUZZ_TRACE") else None
                 Mg, mg = pd.findFundamentalMatrix_(p1, p2, th, 0.9999, mi, et, sym, lc, dg, seed=seed, flags=fin, tuning=tn); sg_ = pd.last_stats()
+                if tr: tr.gpu_done()
                 Mo, mo, so = port.find_fundamental(p1, p2, th, 0.9999, mi, et, sym, lc, dg, seed=seed, final_laf_filter=bool(fin))
+                if tr: tr.report()
                 tag = f"F case={case} n={n} ir={ir:.2f} sig={sg} pf={pf} et={et} sym={sym} dg={dg} th={th} mi={mi} laf={lc} bad={lbad} lsig={lsig} fin={fin} laf_rej={so['rejected']} gpu_laf_rej={sg_['rejected']}"
                 if sg_["rejected"] != so["rejected"]: sg_ = dict(sg_, samples=-1)      # the LAF check's rejections are part of the trajectory
                 LAF_STATS[0] += laf; LAF_STATS[1] += so["rejected"] > 0
@@ -89,7 +121,65 @@ def run_set_aside(N, rng_seed):
     return bad
 
 
+def run_batches(N, rng_seed):
+    """Random BATCHES through the batch entry points against the oracle, pair by pair: 2 ... 200 ragged pairs (8 ... 3000 correspondences,
+    [N, 2] or [N, 6] with the LAF check), F or H, a random kernel variant / placement / resident-grid cap / set-aside threshold, and the
+    per-call scheduling flags (producers on / off / with their test bits, homography helpers on / off).  Every result and every shared
+    counter of every pair must be the oracle's; no pair may carry the discarded / re-run bits."""
+    from pydegensac_amd import api, _lib
+    rng = np.random.default_rng(rng_seed); t0 = time.time()
+    bad_res = bad_traj = pairs = 0; seen = {"set_aside": 0, "streamed": 0, "F": 0, "H": 0}
+    for case in range(N):
+        isF = rng.random() < 0.6
+        P = int(rng.choice([2, 9, 30, 80, 200], p=[0.2, 0.3, 0.25, 0.15, 0.1])); mi = int(rng.choice([500, 3000, 20000], p=[0.3, 0.4, 0.3]))
+        laf = bool(rng.random() < 0.35); sym = bool(rng.random() < 0.7)
+        variant = int(rng.choice([0, 1, 2, 3])); place = int(rng.choice([0, 1, 2, 3])); tn = variant | (place << 2)
+        ns = [int(x) for x in rng.choice([8, 20, 64, 150, 400, 1000, 2000, 3000], P, p=[0.1, 0.1, 0.15, 0.2, 0.2, 0.15, 0.07, 0.03])]
+        seeds = [int(x) for x in rng.integers(1, 2**31 - 1, P)]; A = []; B = []
+        if isF:
+            et = int(rng.choice([0, 1])); dg = bool(rng.random() < 0.7); th = float(rng.choice([0.5, 1.0, 2.0])); lc = float(rng.choice([1.0, 2.0, 3.0])) if laf else 0.0
+            fin = int(laf and rng.random() < 0.5)
+            cap = int(rng.choice([0, 0, 3, 8, 31])); sa = int(rng.choice([0, 0, 255, int(rng.integers(1, 12))]))
+            tn |= (cap << 24) | (sa << 16) | ((int(rng.integers(0, 6)) << 29) if 0 < sa < 255 else 0)
+            fl = int(rng.choice([0, _lib.FLAG_NO_STREAM, _lib.FLAG_STREAM_ON, _lib.FLAG_STREAM_ON | _lib.FLAG_STREAM_TEST(int(rng.integers(1, 4)))])) | fin
+            for i in range(P):
+                p1, p2, _, _ = syn.two_view_fundamental(ns[i], float(rng.uniform(0.1, 0.8)), float(rng.choice([0.05, 0.1, 0.5, 1.0])), seed=100000 + 1000 * case + i,
+                                                        plane_fraction=float(rng.choice([0.0, 0.0, 0.6, 0.9])), laf=laf, laf_bad=float(rng.choice([0.1, 0.25, 0.5])), laf_sigma=float(rng.choice([0.05, 0.5])))
+                A.append(p1); B.append(p2)
+            M, masks = api._batch("F", A, B, th, 0.9999, mi, et, sym, lc, dg, seeds, 0, tn, fl); st = pd.last_stats()
+            ref = [port.find_fundamental(A[i], B[i], th, 0.9999, mi, et, sym, lc, dg, seed=seeds[i], final_laf_filter=bool(fin)) for i in range(P)]
+            keys = ["samples", "lo_runs", "rejected", "I", "models", "best_sample", "degen", "Ih", "full_passes", "ex_passes"]
+        else:
+            et = int(rng.integers(0, 5)); th = float(rng.choice([1.0, 2.0, 4.0])); lc = 3.0 if laf else 0.0
+            fl = int(rng.choice([0, _lib.FLAG_NO_HJOB]))
+            for i in range(P):
+                p1, p2, _, _ = syn.homography_pairs(max(ns[i], 12), float(rng.uniform(0.15, 0.8)), float(rng.choice([0.2, 0.5, 1.0])), seed=100000 + 1000 * case + i, laf=laf)
+                A.append(p1); B.append(p2)
+            M, masks = api._batch("H", A, B, th, 0.999, mi, et, sym, lc, True, seeds, 0, tn, fl); st = pd.last_stats()
+            ref = [port.find_homography(A[i], B[i], th, 0.999, mi, et, sym, lc, seed=seeds[i]) for i in range(P)]
+            keys = ["samples", "lo_runs", "rejected", "I", "models", "best_sample"]
+        seen["F" if isF else "H"] += 1
+        for i in range(P):
+            Mo, mo, so = ref[i]; Mg = np.asarray(M[i], float).ravel(); Mo = np.asarray(Mo, float).ravel(); pairs += 1
+            seen["set_aside"] += st[i].get("set_aside", 0); seen["streamed"] += st[i].get("streamed", 0)
+            nomodel = np.abs(Mo).sum() == 0
+            rel = np.linalg.norm(Mg - Mo) / max(np.linalg.norm(Mo), 1e-300) if not nomodel else float(np.abs(Mg).sum())
+            res_ok = (nomodel and np.abs(Mg).sum() == 0) or (np.array_equal(masks[i], np.asarray(mo, bool)) and rel < 1e-9)
+            diff = {k_: (st[i][k_], so[k_]) for k_ in keys if k_ in so and k_ in st[i] and st[i][k_] != so[k_]}
+            if st[i].get("discarded") or st[i].get("rerun"): diff["discarded/rerun"] = (st[i].get("discarded"), st[i].get("rerun"))
+            if not res_ok or diff:
+                bad_res += not res_ok; bad_traj += bool(res_ok)
+                print("MISMATCH" if not res_ok else "trajectory-only", "batch", case, "F" if isF else "H", "pair", i, "of", P, "n", ns[i], "mi", mi, "et", et, "sym", sym,
+                      "laf", lc, "th", th, "tuning", hex(tn), "flags", hex(fl), "seed", seeds[i], "rel", rel, diff)
+    print(f"batches: {N} ({seen['F']} F, {seen['H']} H), {pairs} pairs: results differ in {bad_res}, trajectory counters only in {bad_traj}; "
+          f"{seen['set_aside']} pairs were set aside, {seen['streamed']} fed by a producer; {time.time() - t0:.0f} s")
+    return bad_res, bad_traj
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "batches":
+        br, bt = run_batches(int(sys.argv[2]) if len(sys.argv) > 2 else 40, int(sys.argv[3]) if len(sys.argv) > 3 else 0)
+        sys.exit(1 if br else 0)
     if len(sys.argv) > 1 and sys.argv[1] == "set-aside":
         sys.exit(1 if run_set_aside(int(sys.argv[2]) if len(sys.argv) > 2 else 40, int(sys.argv[3]) if len(sys.argv) > 3 else 0) else 0)
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
