@@ -357,7 +357,8 @@ int mi_degensac_solve7(const double *pts1, const double *pts2, int n, int dim,
  * degensac/lapwrap.c:67-96), one problem per wave: in 81, out 9 eigenvalues (smallest first, the rest as the QL/QR
  * iteration left them) + 81 (column-major vectors, column 0 = the one of the smallest eigenvalue), flag = info.
  * op 4 = the real roots of a cubic as the 7-point solver takes them (Ftools.c:251-298; in 4 coefficients, out 3, flag =
- * the number of roots): the one routine of the path that calls the math library (pow / acos / cos), so the one place
+ * the number of roots): the one routine of the path that calls the math library (pow / acos / cos).  The device takes their
+ * correctly rounded values (dg_crmath.h), which the host's libm returns in all but ~0.1-0.2 % of its calls: the one place
  * where the device can differ from a host run of the reference in the last bits. */
 int mi_degensac_mat3(int op, const double *in, int count, int device, double *out, int32_t *flag);
 /* the screening counts of the scoring phase (dg_score_tiles.h) for given fundamental-matrix models over a point set:

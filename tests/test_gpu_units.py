@@ -51,16 +51,18 @@ def test_solve7_matches_oracle_nullspace_cubic_and_orientation(oracle_port):
         assert nsol[t] == len(want), (t, nsol[t], len(want))
         polys[t] = (poly.copy(), nr, roots.copy()); want_all[t] = want
         for k, (i, f) in enumerate(want):
-            # the three-real-roots branch of rroots3 goes through acos / cos (Ftools.c:283-292): the device math
-            # library and glibc agree to a few ulp there (amplified by cancellation in the model entries), everything else is the same IEEE operation sequence
+            # rroots3 goes through pow / acos / cos (Ftools.c:251-298): the device takes their correctly rounded values
+            # (dg_crmath.h), the host's libm returns those in all but ~0.1-0.2 % of its calls; a root that differs in its last bit
+            # is amplified by cancellation in the model entries.  Everything else is the same IEEE operation sequence
             got = models[t, 9 * k:9 * k + 9]
             assert ridx[t, k] == i and np.abs(got - f).max() <= 1e-10 * np.abs(f).max(), (t, k)
             n_exact += int(np.array_equal(got, f))
         n_models += len(want)
-    assert n_models > 200 and (nsol == -1).any() and n_exact > 0.5 * n_models, (n_models, n_exact)
+    assert n_models > 200 and (nsol == -1).any() and n_exact > 0.98 * n_models, (n_models, n_exact)
     # where do the inexact ones come from?  The cubic's roots on the device (mi_degensac_mat3 op 4 = the solver's own rroots3)
-    # against the host's: wherever a root has the same bits, so has its model -- the math library's pow / acos / cos are the
-    # only operations of the solver that are not the reference's IEEE sequence
+    # against the host's: wherever a root has the same bits, so has its model -- pow / acos / cos are the only operations of
+    # the solver that are not the reference's IEEE sequence, and with their correctly rounded values (dg_crmath.h) more than
+    # 99 % of the roots carry the host's bits (96.6 % with the device library's own functions)
     ts = sorted(polys); PO = np.ascontiguousarray(np.stack([polys[t][0] for t in ts]))
     R = np.zeros((len(ts), 3)); nrd = np.zeros(len(ts), np.int32)
     _lib.check(L.mi_degensac_mat3(4, _lib.dptr(PO), len(ts), 0, _lib.dptr(R), nrd.ctypes.data_as(C.POINTER(C.c_int32))))
@@ -75,7 +77,7 @@ def test_solve7_matches_oracle_nullspace_cubic_and_orientation(oracle_port):
             if R[a, i] == roots[i]:
                 n_same_roots += 1
                 assert np.array_equal(models[t, 9 * k:9 * k + 9], f), (t, k)
-    assert n_same_roots > 100 and n_roots_same > 0.5 * n_roots and worst < 1e-14, (n_same_roots, n_roots_same, n_roots, worst)
+    assert n_same_roots > 100 and n_roots_same > 0.99 * n_roots and worst < 1e-14, (n_same_roots, n_roots_same, n_roots, worst)
     print(f"rroots3: {n_roots_same}/{n_roots} roots with the host's bits, worst difference {worst:.1e} of the scale; "
           f"{n_exact}/{n_models} models bit-equal, all {n_same_roots} with a bit-equal root among them")
 
