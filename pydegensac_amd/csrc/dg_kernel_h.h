@@ -841,9 +841,21 @@ __device__ __noinline__ int dg_h_lo(CTX &c, int kind, const double *e4, double t
     const int B0 = B.pe[0];                                   /* d = errs[0] */
     dg_resid_begin(c, lo_run); __syncthreads();
     DG_DEVT(if (tid == 0) S->dbg[7] = DG_CLK());
-    dg_dump_resid(c, 0, e4, 10 + kind);                                   /* errs[4], exp_ranH.c:679 / :794 */
     dg_pass_cfg ca = dg_cfg0(n); ca.list = c.K->L[0]; ca.thL = DG_TC * th * DG_MWM;
-    dg_pass_res ra = dg_hm_pass(c, kind, e4, ca);
+    dg_pass_res ra;
+    if (e4) {
+        dg_dump_resid(c, 0, e4, 10 + kind);                               /* errs[4], exp_ranH.c:679 / :794 */
+        ra = dg_hm_pass(c, kind, e4, ca);
+    } else {
+        /* the run after the loop with errs[4] still where it started (exp_ranH.c:531: errs[4] = errs[3], never written because no
+         * sample ever beat the running best -- all rejected, or no sample with an inlier): the reference reads its uninitialised
+         * allocation there.  As the oracle: a zero-filled buffer (what a fresh allocation of this size holds), i.e. every point is
+         * within the threshold and the least squares runs over ALL points. */
+        if (c.rrun) for (int j = tid; j < n; j += DG_T) c.rrun[j] = 0.0;
+        for (int j = tid; j < n; j += DG_T) c.K->L[0][j] = j;
+        __syncthreads();
+        ra = dg_pass_res(); ra.nL = (unsigned)n;
+    }
     DG_HT(0);
     DG_TRACE(c, 1, ra.nL, no_sam);
     if (c.hlt && c.K->hrep && (int)ra.nL > 12) {
@@ -1205,7 +1217,7 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
         __syncthreads();
         iter_cnt++;
         DG_PHH(2);
-        if (dg_h_lo(c, kind, e4, th, maxS, &iterID, &p1_inliers, no_sam, iter_cnt - 1)) { accepted = 1; best_sample = no_sam; t_best = wall_clock64(); }
+        if (dg_h_lo(c, kind, maxSs.J > 0 ? e4 : (const double *)0 /* errs[4] never written */, th, maxS, &iterID, &p1_inliers, no_sam, iter_cnt - 1)) { accepted = 1; best_sample = no_sam; t_best = wall_clock64(); }
         DG_PHH(3);
     }
 

@@ -242,12 +242,20 @@ __device__ __forceinline__ dg_score dg_h2_inHrani(CTX &c, int ninl, double th, d
 /* the local-optimisation block of the driver (ranH2el.c:128-151 and :165-187): h = S->Hx (the driver's `h`, in/out).
  * Returns 1 when it set a new maximum. */
 template <int LDSPTS>
-__device__ __noinline__ int dg_h2_lo(CTX &c, double th, unsigned inlLimit, dg_score &maxS, dg_h2bufs &B)
+__device__ __noinline__ int dg_h2_lo(CTX &c, double th, unsigned inlLimit, dg_score &maxS, dg_h2bufs &B, const bool e4_written = true)
 {
     dg_f_shared *S = c.S; const int n = c.n, tid = c.tid;
     const int pd = B.pe[0];                                                       /* d = errs[0] */
     dg_pass_cfg ca = dg_cfg0(n); ca.list = c.K->L[0]; ca.thL = DG_TC * th * DG_H2_TAU;
-    dg_pass_res ra = dg_h_pass(c, S->bufF[B.pe[4]], ca);
+    dg_pass_res ra;
+    if (e4_written) ra = dg_h_pass(c, S->bufF[B.pe[4]], ca);
+    else {
+        /* errs[4] never written (no sample beat the running best before the run after the loop, ranH2el.c:163-171): the reference
+         * reads its uninitialised allocation; as the oracle, a zero-filled buffer = every point within the threshold */
+        for (int j = tid; j < n; j += DG_T) c.K->L[0][j] = j;
+        __syncthreads();
+        ra = dg_pass_res(); ra.nL = (unsigned)n;
+    }
     if (ra.nL >= 4) dg_u2h_list(c, c.K->L[0], (int)ra.nL, S->Hx);                 /* u2h leaves h alone below 4 ids (Htools.c:106) */
     DG_H2SET(S, pd, S->Hx); c.n_hds++;                                            /* HDs(h) -> d */
     dg_pass_cfg cb = dg_cfg0(n); cb.list = c.K->L[0]; cb.thL = th;
@@ -366,7 +374,7 @@ __device__ __forceinline__ void dg_h2_pair(const dg_args &A, dg_f_shared *S, con
     }
     if (do_lo && !iter_cnt) {
         iter_cnt++;
-        if (dg_h2_lo(c, th, inlLimit, maxS, B)) { best_sample = no_sam; t_best = wall_clock64(); }
+        if (dg_h2_lo(c, th, inlLimit, maxS, B, maxSs.J > 0)) { best_sample = no_sam; t_best = wall_clock64(); }
     }
     /* inl[j] = errs[3][j] <= th */
     __syncthreads();

@@ -223,3 +223,31 @@ def test_bound_that_falls_inside_a_chunk(oracle_port):
             F, m = pd.findFundamentalMatrix_(p1[:, :2].copy(), p2[:, :2].copy(), 2.0, 0.9999, 20000, 1, False, 0.0, True, seed=seed, flags=flags, tuning=variant); st = pd.last_stats()
             assert (st["samples"], st["lo_runs"], st["degen"], st["I"]) == (so["samples"], so["lo_runs"], so["degen"], so["I"]), (variant, flags)
             assert np.array_equal(np.asarray(m), mo)
+
+
+@pytest.mark.gpu
+def test_run_after_the_loop_when_no_sample_ever_beat_the_running_best(oracle_port):
+    """exp_ranH.c:759-862 / ranH2el.c:163-187: with no local optimisation so far the drivers run one after the loop from errs[4] —
+    which still is the buffer it started as (errs[4] = errs[3], exp_ranH.c:531) when every sample was rejected or none had an inlier.
+    The reference reads its uninitialised allocation there; the oracle and the device take a zero-filled one (every point within the
+    threshold: the least squares runs over ALL points).  Found by `tools/gpu_fuzz.py edges` (sample budgets of 1-7): the device used
+    to score the all-zero model instead (NaN residuals: no point, or every point, depending on the metric)."""
+    hit = 0
+    for seed in range(60):
+        mi = 1 + seed % 3; et = seed % 5
+        p1, p2, _, _ = syn.homography_pairs(64, 0.5, 0.1, seed=1400 + seed)
+        for tn in (1, 2, 3):
+            Hg, mg = pd.findHomography_(p1, p2, 10.0, 0.9, mi, et, True, 0.0, seed=345625506 + seed, tuning=tn); sg = pd.last_stats()
+            Ho, mo, so = oracle_port.find_homography(p1, p2, 10.0, 0.9, mi, et, True, 0.0, seed=345625506 + seed)
+            assert (sg["samples"], sg["lo_runs"], sg["rejected"], sg["I"], sg["models"], sg["best_sample"]) == \
+                   (so["samples"], so["lo_runs"], so["rejected"], so["I"], so["models"], so["best_sample"]), (seed, tn)
+            assert np.array_equal(np.asarray(mg, bool), np.asarray(mo, bool)) and np.allclose(np.asarray(Hg).ravel(), np.asarray(Ho).ravel(), rtol=1e-9, atol=0), (seed, tn)
+        hit += so["rejected"] == so["samples"]                # every sample turned down before scoring: errs[4] never written
+    assert hit >= 3, hit
+    # ransacH2el: a threshold no sample meets
+    u10 = syn.ellipse_pairs(100, 0.4, 1.0, 5)[0]
+    for mi in (1, 3, 60):
+        H, m = pd.ransacH2el_batch([u10], 1e-6, 0.99, mi, True, 0, seeds=[11], raw=True); st = pd.last_stats()[0]
+        Ho, mo, so = oracle_port.ransacH2el(u10, 1e-6, 0.99, mi, True, 0, 11)
+        assert (st["samples"], st["lo_runs"], st["I"], st["models"]) == (so["samples"], so["lo_runs"], so["I"], so["models"]), mi
+        assert np.allclose(np.asarray(H[0]).ravel(), np.asarray(Ho).ravel(), rtol=1e-9, atol=0)

@@ -176,7 +176,82 @@ def run_batches(N, rng_seed):
     return bad_res, bad_traj
 
 
+def _compare(tag, Mg, mg, sg_, Mo, mo, so, keys):
+    Mg = np.asarray(Mg, dtype=float).ravel(); Mo = np.asarray(Mo, dtype=float).ravel()
+    nomodel = np.abs(Mo).sum() == 0
+    rel = np.linalg.norm(Mg - Mo) / max(np.linalg.norm(Mo), 1e-300) if not nomodel else float(np.abs(Mg).sum())
+    res_ok = (nomodel and np.abs(Mg).sum() == 0) or (np.array_equal(np.asarray(mg, dtype=bool), np.asarray(mo, dtype=bool)) and rel < 1e-9)
+    diff = {k_: (sg_[k_], so[k_]) for k_ in keys if k_ in so and k_ in sg_ and sg_[k_] != so[k_]}
+    if not res_ok or diff: print("MISMATCH" if not res_ok else "trajectory-only", tag, "rel", rel, diff, flush=True)
+    return res_ok, not diff
+
+
+def run_edges(N, rng_seed):
+    """The corners the main sweep does not visit: 8 ... 200 correspondences, sample budgets of 1 ... 600 (around the 50-sample rule of the
+    first local optimisation, exp_ranF.c:1497-1500, and the 256-sample chunk), confidences 0.5 ... 0.999999, thresholds 0.05 ... 100 px,
+    noise-free and pixel-quantised coordinates (exact ties and zeros), repeated correspondences (rank-deficient samples), all-inlier sets."""
+    rng = np.random.default_rng(rng_seed); t0 = time.time(); bad_res = bad_traj = 0
+    only = os.environ.get("FUZZ_ONLY"); only = set(int(x) for x in only.split(",")) if only else None
+    for case in range(N):
+        isF = rng.random() < 0.6; variant = int(rng.choice([512, 256, 128])); mode = int(rng.choice([0, 1, 2]))
+        tn = {512: 1, 256: 2, 128: 3}[variant] | ((mode + 1) << 2)
+        n = int(rng.choice([8, 9, 10, 11, 12, 16, 30, 64, 200])); mi = int(rng.choice([1, 2, 7, 49, 50, 51, 52, 100, 255, 256, 257, 600]))
+        conf = float(rng.choice([0.5, 0.9, 0.99, 0.9999, 0.999999])); th = float(rng.choice([0.05, 0.5, 2.0, 10.0, 100.0]))
+        ir = float(rng.choice([0.2, 0.5, 0.8, 1.0])); sg = float(rng.choice([0.0, 0.1, 1.0])); seed = int(rng.integers(1, 2**31 - 1))
+        quant = bool(rng.random() < 0.3); dup = bool(rng.random() < 0.25); laf = bool(rng.random() < 0.3); sym = bool(rng.random() < 0.7)
+        et = int(rng.integers(0, 2 if isF else 5)); dg = bool(rng.random() < 0.7); pf = float(rng.choice([0.0, 0.6, 1.0]))
+        kdup = int(rng.integers(2, max(3, n // 2))); lafc = float(rng.choice([1.0, 3.0]))
+        if only is not None and case not in only: continue
+        if isF: p1, p2, _, _ = syn.two_view_fundamental(n, ir, sg, seed=case, plane_fraction=pf, laf=laf)
+        else:
+            n = max(n, 11)                                   # <= 10: the reference's 4-point u2h path reads uninitialised memory (DESIGN.md 4)
+            p1, p2, _, _ = syn.homography_pairs(n, ir, sg, seed=case, laf=laf)
+        if quant: p1[:, :2] = np.round(p1[:, :2]); p2[:, :2] = np.round(p2[:, :2])
+        if dup: p1[1:kdup] = p1[0]; p2[1:kdup] = p2[0]
+        lc = lafc if laf else 0.0
+        tag = f"edge case={case} {'F' if isF else 'H'} n={n} mi={mi} conf={conf} th={th} ir={ir} sig={sg} quant={quant} dup={dup} laf={lc} sym={sym} et={et} dg={dg} pf={pf} seed={seed} variant={variant} mode={mode}"
+        if isF:
+            Mg, mg = pd.findFundamentalMatrix_(p1, p2, th, conf, mi, et, sym, lc, dg, seed=seed, tuning=tn); sg_ = pd.last_stats()
+            Mo, mo, so = port.find_fundamental(p1, p2, th, conf, mi, et, sym, lc, dg, seed=seed)
+            keys = ["samples", "lo_runs", "rejected", "I", "models", "best_sample", "degen", "Ih", "full_passes", "ex_passes"]
+        else:
+            Mg, mg = pd.findHomography_(p1, p2, th, conf, mi, et, sym, lc, seed=seed, tuning=tn); sg_ = pd.last_stats()
+            Mo, mo, so = port.find_homography(p1, p2, th, conf, mi, et, sym, lc, seed=seed)
+            keys = ["samples", "lo_runs", "rejected", "I", "models", "best_sample"]
+        r, t = _compare(tag, Mg, mg, sg_, Mo, mo, so, keys); bad_res += not r; bad_traj += (r and not t)
+    print(f"edges: {N} cases: results differ in {bad_res}, trajectory counters only in {bad_traj}; {time.time() - t0:.0f} s")
+    return bad_res, bad_traj
+
+
+def run_large(N, rng_seed):
+    """5 000 ... 50 000 correspondences, up to 100 000 samples: the cooperative multi-workgroup mode (n >= 8192), long inlier lists in the
+    local optimisations (random subsets beyond inlLimit), the hash table at its capacity."""
+    rng = np.random.default_rng(rng_seed); t0 = time.time(); bad_res = bad_traj = 0
+    for case in range(N):
+        isF = rng.random() < 0.65; n = int(rng.choice([5000, 9000, 20000, 50000], p=[0.3, 0.3, 0.25, 0.15])); mi = int(rng.choice([3000, 20000, 100000], p=[0.4, 0.4, 0.2]))
+        ir = float(rng.uniform(0.08, 0.7)); sg = float(rng.choice([0.1, 0.5, 1.0])); seed = int(rng.integers(1, 2**31 - 1)); sym = bool(rng.random() < 0.7)
+        laf = bool(rng.random() < 0.3); et = int(rng.integers(0, 2 if isF else 5)); th = float(rng.choice([0.5, 1.0, 2.0])); lc = 3.0 if laf else 0.0
+        tag = f"large case={case} {'F' if isF else 'H'} n={n} mi={mi} ir={ir:.3f} sig={sg} laf={lc} sym={sym} et={et} th={th} seed={seed}"
+        if isF:
+            pf = float(rng.choice([0.0, 0.0, 0.6])); dg = bool(rng.random() < 0.7)
+            p1, p2, _, _ = syn.two_view_fundamental(n, ir, sg, seed=5000 + case, plane_fraction=pf, laf=laf)
+            Mg, mg = pd.findFundamentalMatrix_(p1, p2, th, 0.9999, mi, et, sym, lc, dg, seed=seed); sg_ = pd.last_stats()
+            Mo, mo, so = port.find_fundamental(p1, p2, th, 0.9999, mi, et, sym, lc, dg, seed=seed)
+            keys = ["samples", "lo_runs", "rejected", "I", "models", "best_sample", "degen", "Ih", "full_passes", "ex_passes"]; tag += f" pf={pf} dg={dg}"
+        else:
+            p1, p2, _, _ = syn.homography_pairs(n, ir, sg, seed=5000 + case, laf=laf)
+            Mg, mg = pd.findHomography_(p1, p2, th, 0.999, mi, et, sym, lc, seed=seed); sg_ = pd.last_stats()
+            Mo, mo, so = port.find_homography(p1, p2, th, 0.999, mi, et, sym, lc, seed=seed)
+            keys = ["samples", "lo_runs", "rejected", "I", "models", "best_sample"]
+        r, t = _compare(tag + f" threads={sg_.get('threads')} placement={sg_.get('placement')}", Mg, mg, sg_, Mo, mo, so, keys); bad_res += not r; bad_traj += (r and not t)
+    print(f"large: {N} cases: results differ in {bad_res}, trajectory counters only in {bad_traj}; {time.time() - t0:.0f} s")
+    return bad_res, bad_traj
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] in ("edges", "large"):
+        br, bt = (run_edges if sys.argv[1] == "edges" else run_large)(int(sys.argv[2]) if len(sys.argv) > 2 else 40, int(sys.argv[3]) if len(sys.argv) > 3 else 0)
+        sys.exit(1 if br else 0)
     if len(sys.argv) > 1 and sys.argv[1] == "batches":
         br, bt = run_batches(int(sys.argv[2]) if len(sys.argv) > 2 else 40, int(sys.argv[3]) if len(sys.argv) > 3 else 0)
         sys.exit(1 if br else 0)
