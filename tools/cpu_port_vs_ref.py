@@ -59,8 +59,8 @@ def run_edges(N, rng_seed):
     rng = np.random.default_rng(rng_seed); bad = 0; nomodel = 0; lapack = 0
     for case in range(N):
         isF = rng.random() < 0.6; variant = int(rng.choice([512, 256, 128])); mode = int(rng.choice([0, 1, 2]))
-        n = int(rng.choice([8, 9, 10, 11, 12, 16, 30, 64, 200])); mi = int(rng.choice([1, 2, 7, 49, 50, 51, 52, 100, 255, 256, 257, 600]))
-        conf = float(rng.choice([0.5, 0.9, 0.99, 0.9999, 0.999999])); th = float(rng.choice([0.05, 0.5, 2.0, 10.0, 100.0]))
+        n = int(rng.choice([8, 9, 10, 11, 12, 16, 30, 64, 200])); mi = int(rng.choice([0, 1, 2, 7, 49, 50, 51, 52, 100, 255, 256, 257, 600]))
+        conf = float(rng.choice([0.0, 0.5, 0.9, 0.99, 0.9999, 0.999999, 1.0])); th = float(rng.choice([0.0, 0.05, 0.5, 2.0, 10.0, 100.0]))
         ir = float(rng.choice([0.2, 0.5, 0.8, 1.0])); sg = float(rng.choice([0.0, 0.1, 1.0])); seed = int(rng.integers(1, 2**31 - 1))
         quant = bool(rng.random() < 0.3); dup = bool(rng.random() < 0.25); laf = bool(rng.random() < 0.3); sym = bool(rng.random() < 0.7)
         et = int(rng.integers(0, 2 if isF else 5)); dg = bool(rng.random() < 0.7); pf = float(rng.choice([0.0, 0.6, 1.0]))
@@ -100,11 +100,15 @@ def run_edges(N, rng_seed):
                 same = sk["samples"] == sr["samples"] and sk["lo_runs"] == sr["lo_runs"] and np.array_equal(np.asarray(mk, bool), np.asarray(mr, bool)) and np.linalg.norm(Mk - Mr) <= 1e-6 * max(np.linalg.norm(Mr), 1e-300)
                 extra = " | reference on MKL vs reference on OpenBLAS: " + ("same" if same else "DIFFERENT")
             lapack += 1; print("lapack-dependent", tag, extra, flush=True); continue
+        if not ok and not isF and min(sp["I"], sr["I"]) <= 9:
+            # eight or nine inliers: the local optimisation's samples have FOUR points and u2h takes its null-space path, which reads
+            # uninitialised memory in the reference (Htools.c:108-114; the restatement zero-fills: DESIGN.md 4)
+            lapack += 1; print("u2h-4-point-path", tag, flush=True); continue
         if not ok:
             bad += 1; print("MISMATCH", tag, "port", sp["samples"], sp["lo_runs"], sp["I"], "ref", sr["samples"], sr["lo_runs"], sr["I"],
                             "model rel", float(np.linalg.norm(Mp - Mr) / max(np.linalg.norm(Mr), 1e-300)), "mask bits that differ", int((np.asarray(mp, bool) != np.asarray(mr, bool)).sum()), flush=True)
     print(f"edges: {N - bad - lapack}/{N} identical ({nomodel} without a model: counters only); {lapack} differ on inputs whose answer depends "
-          f"on the reference's LAPACK build (repeated correspondences / noise-free data); {bad} other mismatches")
+          f"on the reference's LAPACK build (repeated correspondences / noise-free data) or on its uninitialised 4-point u2h path; {bad} other mismatches")
     return bad
 
 

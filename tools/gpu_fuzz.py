@@ -195,8 +195,8 @@ def run_edges(N, rng_seed):
     for case in range(N):
         isF = rng.random() < 0.6; variant = int(rng.choice([512, 256, 128])); mode = int(rng.choice([0, 1, 2]))
         tn = {512: 1, 256: 2, 128: 3}[variant] | ((mode + 1) << 2)
-        n = int(rng.choice([8, 9, 10, 11, 12, 16, 30, 64, 200])); mi = int(rng.choice([1, 2, 7, 49, 50, 51, 52, 100, 255, 256, 257, 600]))
-        conf = float(rng.choice([0.5, 0.9, 0.99, 0.9999, 0.999999])); th = float(rng.choice([0.05, 0.5, 2.0, 10.0, 100.0]))
+        n = int(rng.choice([8, 9, 10, 11, 12, 16, 30, 64, 200])); mi = int(rng.choice([0, 1, 2, 7, 49, 50, 51, 52, 100, 255, 256, 257, 600]))
+        conf = float(rng.choice([0.0, 0.5, 0.9, 0.99, 0.9999, 0.999999, 1.0])); th = float(rng.choice([0.0, 0.05, 0.5, 2.0, 10.0, 100.0]))
         ir = float(rng.choice([0.2, 0.5, 0.8, 1.0])); sg = float(rng.choice([0.0, 0.1, 1.0])); seed = int(rng.integers(1, 2**31 - 1))
         quant = bool(rng.random() < 0.3); dup = bool(rng.random() < 0.25); laf = bool(rng.random() < 0.3); sym = bool(rng.random() < 0.7)
         et = int(rng.integers(0, 2 if isF else 5)); dg = bool(rng.random() < 0.7); pf = float(rng.choice([0.0, 0.6, 1.0]))
@@ -220,6 +220,25 @@ def run_edges(N, rng_seed):
             keys = ["samples", "lo_runs", "rejected", "I", "models", "best_sample"]
         r, t = _compare(tag, Mg, mg, sg_, Mo, mo, so, keys); bad_res += not r; bad_traj += (r and not t)
     print(f"edges: {N} cases: results differ in {bad_res}, trajectory counters only in {bad_traj}; {time.time() - t0:.0f} s")
+    return bad_res, bad_traj
+
+
+def run_legacy(N, rng_seed):
+    """The reference's older fundamental-matrix drivers (exp_ransacF / exp_ransacFcustom, MI_DEGENSAC_FLAG_LEGACY_F): main-sweep sizes and
+    corner budgets, with and without exp_ransacFcustom's own symmetric check."""
+    from pydegensac_amd import _lib
+    rng = np.random.default_rng(rng_seed); t0 = time.time(); bad_res = bad_traj = 0
+    for case in range(N):
+        variant = int(rng.choice([512, 256, 128])); mode = int(rng.choice([0, 1, 2])); tn = {512: 1, 256: 2, 128: 3}[variant] | ((mode + 1) << 2)
+        n = int(rng.choice([8, 12, 30, 64, 150, 400, 1000, 2000, 3000])); mi = int(rng.choice([1, 7, 49, 50, 51, 257, 500, 3000, 20000]))
+        ir = float(rng.uniform(0.1, 0.9)); sg = float(rng.choice([0.05, 0.1, 0.5, 1.0])); pf = float(rng.choice([0.0, 0.0, 0.6, 0.9])); seed = int(rng.integers(1, 2**31 - 1))
+        et = int(rng.choice([0, 1])); sym = bool(rng.random() < 0.5); th = float(rng.choice([0.5, 1.0, 2.0])); conf = float(rng.choice([0.9, 0.9999]))
+        p1, p2, _, _ = syn.two_view_fundamental(n, ir, sg, seed=20000 + case, plane_fraction=pf)
+        Mg, mg = pd.findFundamentalMatrix_(p1, p2, th, conf, mi, et, sym, 0.0, True, seed=seed, flags=_lib.FLAG_LEGACY_F, tuning=tn); sg_ = pd.last_stats()
+        Mo, mo, so = port.find_fundamental(p1, p2, th, conf, mi, et, sym, 0.0, True, seed=seed, legacy=True)
+        tag = f"legacy case={case} n={n} mi={mi} ir={ir:.3f} sig={sg} pf={pf} et={et} sym={sym} th={th} conf={conf} seed={seed} variant={variant} mode={mode}"
+        r, t = _compare(tag, Mg, mg, sg_, Mo, mo, so, ["samples", "lo_runs", "I", "models", "best_sample", "degen", "Ih", "full_passes", "ex_passes"]); bad_res += not r; bad_traj += (r and not t)
+    print(f"legacy: {N} cases: results differ in {bad_res}, trajectory counters only in {bad_traj}; {time.time() - t0:.0f} s")
     return bad_res, bad_traj
 
 
@@ -249,8 +268,8 @@ def run_large(N, rng_seed):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("edges", "large"):
-        br, bt = (run_edges if sys.argv[1] == "edges" else run_large)(int(sys.argv[2]) if len(sys.argv) > 2 else 40, int(sys.argv[3]) if len(sys.argv) > 3 else 0)
+    if len(sys.argv) > 1 and sys.argv[1] in ("edges", "large", "legacy"):
+        br, bt = {"edges": run_edges, "large": run_large, "legacy": run_legacy}[sys.argv[1]](int(sys.argv[2]) if len(sys.argv) > 2 else 40, int(sys.argv[3]) if len(sys.argv) > 3 else 0)
         sys.exit(1 if br else 0)
     if len(sys.argv) > 1 and sys.argv[1] == "batches":
         br, bt = run_batches(int(sys.argv[2]) if len(sys.argv) > 2 else 40, int(sys.argv[3]) if len(sys.argv) > 3 else 0)
