@@ -25,11 +25,12 @@ def work(tid, rounds, log):
         else:
             ids = r.integers(0, len(E), min(P, 64)); pd.ransacH2el_batch([E[i] for i in ids], 4.0, 0.99, 1000, True, 0, seeds=list(range(len(ids))))
         if tid == 0 and it % 25 == 0: log.append((it, free()))
-f0 = free(); log = []
-ts = [threading.Thread(target=work, args=(t, R, log)) for t in range(2)]
-[t.start() for t in ts]; [t.join() for t in ts]
-torch.cuda.synchronize()
-print("free MiB before", round(f0), "samples", [(i, round(v)) for i, v in log], "after", round(free()))
-# workspaces grow with a 600-pair launch and shrink again after eight small ones, so free memory moves by 1-2 GiB; a leak is a TREND
-k = max(1, len(log) // 3); first = min(v for _, v in log[:k]); last = min(v for _, v in log[-k:])
-print("OK: no downward trend" if last >= first - 256 else "LEAK?", "lowest free MiB in the first third", round(first), "in the last third", round(last))
+f0 = free(); log = []; ends = []
+for phase in range(3):                                   # the SAME sequence of launches three times: the caches end each phase in the same state
+    ts = [threading.Thread(target=work, args=(t, R, log)) for t in range(2)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    torch.cuda.synchronize(); ends.append(free())
+print("free MiB before", round(f0), "while running", sorted(set(round(v) for _, v in log)), "after each of three identical phases", [round(v) for v in ends])
+# workspaces grow with a 600-pair launch and shrink again after eight small ones, so free memory moves by 1-2 GiB WITHIN a phase; a leak shows
+# as less free memory at the end of a later phase
+print("OK: nothing leaks" if ends[2] >= ends[0] - 64 and ends[1] >= ends[0] - 64 else "LEAK?", "2 x", R, "launches per phase")
