@@ -769,6 +769,13 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                     } else {
                         do_iterate = (no_sam > DG_ITER_SAM);
                         p4 = phys;                                  /* errs[4] = d */
+                        /* ... and d's buffer can be written again BEFORE this sample's local optimisation reads errs[4]: when this root was
+                         * also accepted as the best model, d is errs[3] now; a later root of the same sample that is accepted takes that
+                         * buffer as its errs[i] (exp_ranF.c:1409-1410) and, if it turns out degenerate, the plane-and-parallax model's
+                         * residuals land in it (:1463-1466).  Past sample 50 the bookkeeping of errs[4]'s buffer is otherwise off (every
+                         * use is preceded by an assignment): switch it on for the rest of this sample.  (`tools/gpu_fuzz.py 6000 202`,
+                         * case 3465: three roots of one sample, the first sets errs[4], the third is accepted and degenerate.) */
+                        track = 1;
                         __syncthreads();
                         if (tid < 9) { e4F[tid] = S->f[tid]; S->FBest[tid] = S->f[tid]; }
                         if (tid < 7) S->samidxBest[tid] = c.draws[k][6 - tid];

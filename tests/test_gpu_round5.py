@@ -251,3 +251,20 @@ def test_run_after_the_loop_when_no_sample_ever_beat_the_running_best(oracle_por
         Ho, mo, so = oracle_port.ransacH2el(u10, 1e-6, 0.99, mi, True, 0, 11)
         assert (st["samples"], st["lo_runs"], st["I"], st["models"]) == (so["samples"], so["lo_runs"], so["I"], so["models"]), mi
         assert np.allclose(np.asarray(H[0]).ravel(), np.asarray(Ho).ravel(), rtol=1e-9, atol=0)
+
+
+def test_errs4_buffer_written_again_inside_the_sample_that_set_it(oracle_port):
+    """Three models of ONE sample past sample 50 (exp_ranF.c:1365-1495): the first beats the best sample score, is accepted as the best
+    model (its residual buffer becomes errs[3]) and sets errs[4]; the third is accepted too — errs[3]'s old buffer becomes ITS errs[i]
+    (:1409-1410) — and is degenerate, so the plane-and-parallax model's residuals are written there (:1463-1466): the local
+    optimisation at the end of the sample reads THOSE through errs[4].  The device used to take the first model's (the bookkeeping of
+    errs[4]'s buffer was off past sample 50): `tools/gpu_fuzz.py 6000 202`, case 3465 — 208 samples / 41 inliers against the
+    reference's 209 / 42."""
+    p1, p2, _, _ = syn.two_view_fundamental(64, 0.6202637445729403, 0.5, seed=3465, plane_fraction=0.9)
+    Fo, mo, so = oracle_port.find_fundamental(p1, p2, 2.0, 0.9999, 3000, 0, True, 0.0, True, seed=106905411)
+    assert (so["samples"], so["lo_runs"], so["I"], so["degen"]) == (209, 3, 42, 6), so          # = the unmodified reference's run
+    for tn in (1 | (3 << 2), 1 | (1 << 2), 2 | (3 << 2), 3 | (1 << 2)):
+        for fl in (0, _lib.FLAG_STREAM_ON | _lib.FLAG_STREAM_TEST(2)):
+            Fg, mg = pd.findFundamentalMatrix_(p1, p2, 2.0, 0.9999, 3000, 0, True, 0.0, True, seed=106905411, tuning=tn, flags=fl); sg = pd.last_stats()
+            assert [sg[k] for k in ("samples", "lo_runs", "I", "models", "best_sample", "degen")] == [so[k] for k in ("samples", "lo_runs", "I", "models", "best_sample", "degen")], (tn, fl)
+            assert np.array_equal(np.asarray(mg, bool), mo) and np.allclose(np.asarray(Fg).ravel(), np.asarray(Fo).ravel(), rtol=1e-9, atol=0), (tn, fl)

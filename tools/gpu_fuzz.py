@@ -32,7 +32,8 @@ class _Trace:
         for i, (a, b) in enumerate(zip(o, g)):
             if a != b:
                 print(f"   trace: first difference at event {i} of {len(o)} / {len(g)}  (tag, I, J)")
-                for j in range(max(0, i - 3), min(len(o), len(g), i + 4)): print("     oracle", o[j], " gpu", g[j])
+                lo_ = 0 if os.environ.get("FUZZ_TRACE") == "all" else max(0, i - 3)
+                for j in range(lo_, min(len(o), len(g), i + 4)): print("     oracle", o[j], " gpu", g[j])
                 return
         print(f"   trace: {len(o)} / {len(g)} events, equal over the common prefix")
 
