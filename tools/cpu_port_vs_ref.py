@@ -8,6 +8,7 @@ from oracle import port, ref
 from pydegensac_amd import synthetic as syn
 
 
+FLIPS = [0]               # cases whose model is the reference's with the opposite sign
 LAF_STATS = [0, 0]          # F cases with the LAF check on; of those, cases in which it turned a candidate down
 
 
@@ -41,6 +42,9 @@ def run(N, rng_seed, verbose=True):
             ok = sp["samples"] == sr["samples"] and sp["lo_runs"] == sr["lo_runs"]; skipped += 1
         else:
             rel = np.linalg.norm(Mp - Mr) / max(np.linalg.norm(Mr), 1e-300)
+            if np.linalg.norm(Mp + Mr) < np.linalg.norm(Mp - Mr):
+                # the same matrix with the opposite sign (an eigenvector's sign is LAPACK's choice; F and -F are one fundamental matrix)
+                rel = np.linalg.norm(Mp + Mr) / max(np.linalg.norm(Mr), 1e-300); FLIPS[0] += 1
             ok = np.array_equal(np.asarray(mp, bool), np.asarray(mr, bool)) and sp["samples"] == sr["samples"] and sp["lo_runs"] == sr["lo_runs"]
             if ok and rel >= 1e-9:
                 # same trajectory and mask, model off by more than rounding: an ill-conditioned final LSQ (plane-dominated
@@ -118,5 +122,5 @@ if __name__ == "__main__":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     t0 = time.time()
     bad, loose, worst, skipped = run(N, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-    print(f"{N - bad}/{N} identical masks and counters ({skipped} without a model: counters only); model beyond 1e-9 in {loose} "
+    print(f"{N - bad}/{N} identical masks and counters ({skipped} without a model: counters only); {FLIPS[0]} with the opposite sign; model beyond 1e-9 in {loose} "
           f"(worst {worst:.2e}) in {time.time() - t0:.0f} s; F + LAF cases {LAF_STATS[0]}, with LAF rejections {LAF_STATS[1]}")
