@@ -116,7 +116,40 @@ def run_edges(N, rng_seed):
     return bad
 
 
+def run_legacy(N, rng_seed):
+    """`tools/gpu_fuzz.py legacy`'s distribution (main-sweep sizes and corner budgets), the restatement's legacy rule against the reference's
+    exp_ransacFcustom (either metric, with / without its symmetric check) and exp_ransacF (Sampson, no check)."""
+    rng = np.random.default_rng(rng_seed); bad = 0; nomodel = 0; undef = 0
+    for case in range(N):
+        variant = int(rng.choice([512, 256, 128])); mode = int(rng.choice([0, 1, 2]))
+        n = int(rng.choice([8, 12, 30, 64, 150, 400, 1000, 2000, 3000])); mi = int(rng.choice([1, 7, 49, 50, 51, 257, 500, 3000, 20000]))
+        ir = float(rng.uniform(0.1, 0.9)); sg = float(rng.choice([0.05, 0.1, 0.5, 1.0])); pf = float(rng.choice([0.0, 0.0, 0.6, 0.9])); seed = int(rng.integers(1, 2**31 - 1))
+        et = int(rng.choice([0, 1])); sym = bool(rng.random() < 0.5); th = float(rng.choice([0.5, 1.0, 2.0])); conf = float(rng.choice([0.9, 0.9999]))
+        p1, p2, _, _ = syn.two_view_fundamental(n, ir, sg, seed=20000 + case, plane_fraction=pf)
+        Mp, mp, sp = port.find_fundamental(p1, p2, th, conf, mi, et, sym, 0.0, True, seed=seed, legacy=True)
+        which = 1 if (et == 0 and not sym and case % 2) else 0          # exp_ransacF where it applies, every other case
+        Mr, mr, sr = ref.find_fundamental_legacy(which, p1, p2, th, conf, mi, et, sym, seed=seed)
+        Mp = np.asarray(Mp, float).ravel(); Mr = np.asarray(Mr, float).ravel()
+        cnt = sp["samples"] == sr["samples"] and sp["lo_runs"] == sr["lo_runs"]
+        if not np.isfinite(Mr).all() or np.abs(Mr).sum() == 0 or sr["I"] == 0 or np.abs(Mp).sum() == 0: ok = cnt; nomodel += 1
+        else:
+            rel = min(np.linalg.norm(Mp - Mr), np.linalg.norm(Mp + Mr)) / max(np.linalg.norm(Mr), 1e-300)
+            ok = cnt and np.array_equal(np.asarray(mp, bool), np.asarray(mr, bool)) and rel < 1e-6
+        if not ok and cnt and min(sp["I"], sr["I"]) < 8:
+            # fewer than eight inliers: the local optimisation's u2f runs on < 8 points, where the reference reads uninitialised memory
+            # (DESIGN.md 4) -- its own mask changes from call to call on these inputs
+            undef += 1; continue
+        if not ok:
+            bad += 1; print("MISMATCH legacy", "exp_ransacF" if which else "exp_ransacFcustom", f"case={case} n={n} mi={mi} ir={ir:.3f} sig={sg} pf={pf} et={et} sym={sym} th={th} conf={conf} seed={seed}",
+                            "port", sp["samples"], sp["lo_runs"], sp["I"], "ref", sr["samples"], sr["lo_runs"], sr["I"], flush=True)
+    print(f"legacy: {N - bad - undef}/{N} identical ({nomodel} without a model: counters only); {undef} with fewer than 8 inliers, where the "
+          f"reference's own mask varies from call to call (u2f on < 8 points reads uninitialised memory); {bad} other mismatches")
+    return bad
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "legacy":
+        sys.exit(1 if run_legacy(int(sys.argv[2]) if len(sys.argv) > 2 else 300, int(sys.argv[3]) if len(sys.argv) > 3 else 0) else 0)
     if len(sys.argv) > 1 and sys.argv[1] == "edges":
         sys.exit(1 if run_edges(int(sys.argv[2]) if len(sys.argv) > 2 else 300, int(sys.argv[3]) if len(sys.argv) > 3 else 0) else 0)
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
