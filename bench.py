@@ -11,7 +11,11 @@ one pair and ~9 % of C2 pairs run all 100 000 samples, so a batch needs many pai
 are resident in HBM before the timed region; the per-pair results are gathered over RCCL inside it.
 
   python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (no WORLD_SIZE in the environment: re-executes itself under
+                                                        torch.distributed.run with N ranks, one per GPU; fails loudly when
+                                                        fewer than N devices are visible)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --single-process             (ONE process, the C-ABI's device-list mode *_batch_multi, no collective)
 
 Prints ONE JSON line on rank 0 (contract of the driver) with `roofline` and `cpu_baseline` (the reference on one host
 core, the north-star denominator) plus `cpu_baseline_all_cores` (one reference process per host core).
@@ -174,20 +178,40 @@ def pmc_traffic(cfg_name, pairs_per_gpu):
     tools/pmc_summary.py writes next to the rocprofv3 CSVs together with the hash of the kernel sources it was measured
     on and the batch size; any mismatch with this build / this batch gives null instead of a stale number."""
     path = None
-    for rnd in ("r5", "r4", "r3"):
+    for rnd in ("r6", "r5", "r4", "r3"):
         cand = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{cfg_name}.json")
         if os.path.exists(cand):
             path = cand
             break
     if path is None:
-        return None
+        return None, "none: no committed PMC pass for this configuration"
+    rel = os.path.relpath(path, ROOT)
     try:
         m = json.load(open(path))
-        if m.get("source_id") != source_id() or int(m.get("pairs_per_gpu", -1)) != pairs_per_gpu:
-            return None
-        return (2.0 * float(m["FETCH_SIZE_KiB"]) + float(m["WRITE_SIZE_KiB"])) * 1024.0
-    except Exception:
-        return None
+        if m.get("source_id") != source_id():
+            return None, f"none: {rel} was measured on other kernel sources (stamp {m.get('source_id')}, this build {source_id()})"
+        if int(m.get("pairs_per_gpu", -1)) != pairs_per_gpu:
+            return None, f"none: {rel} was measured on {m.get('pairs_per_gpu')} pairs per GPU"
+        return ((2.0 * float(m["FETCH_SIZE_KiB"]) + float(m["WRITE_SIZE_KiB"])) * 1024.0,
+                f"committed rocprofv3 PMC passes of this command ({rel}: 2 x FETCH_SIZE + WRITE_SIZE, stamped with the hash of the kernel "
+                f"sources = this build's {source_id()}); NOT measured inside this run (counters cannot be read from inside the process)")
+    except Exception as e:
+        return None, f"none: {rel} unreadable ({str(e)[:80]})"
+
+
+def model_rel(a, b):
+    """relative Frobenius distance of two homogeneous 3x3 models UP TO SIGN: (distance, sign_flipped).  F and H are defined up to
+    scale; the sign of the returned vector is the sign LAPACK's dsyev gives the eigenvector, which differs between LAPACK builds on
+    about one input in 7000 (profiles/r5_cpu_port_vs_ref.log: reference on MKL vs reference on OpenBLAS) — same model, same mask."""
+    a = np.asarray(a, float).ravel(); b = np.asarray(b, float).ravel()
+    na, nb = np.linalg.norm(a), np.linalg.norm(b)
+    if na == 0 or nb == 0:
+        return (0.0 if na == nb else 1.0), False
+    d_same, d_flip = np.linalg.norm(a / na - b / nb), np.linalg.norm(a / na + b / nb)
+    return (d_flip, True) if d_flip < d_same else (d_same, False)
+
+
+SIGN_FLIPS = []        # (pair id, against what): models equal up to sign only — listed in the line, never fatal
 
 
 def parity_check(which, cfg_pairs, n_check, lo, models, masks, stats):
@@ -214,10 +238,11 @@ def parity_check(which, cfg_pairs, n_check, lo, models, masks, stats):
             raise SystemExit(f"parity check failed: pair {lo + p} counters {int(st[0])},{int(st[1])} vs oracle {so['samples']},{so['lo_runs']}")
         if not np.array_equal(masks[p].astype(bool), mo):
             raise SystemExit(f"parity check failed: pair {lo + p} mask differs in {(masks[p].astype(bool) != mo).sum()} bits")
-        a = models[p].ravel(); b = np.asarray(Mo).ravel()
-        na, nb = np.linalg.norm(a), np.linalg.norm(b)
-        if (na == 0) != (nb == 0) or (nb and np.linalg.norm(a / na - b / nb) > 1e-6):
-            raise SystemExit(f"parity check failed: pair {lo + p} model differs")
+        d_, flipped = model_rel(models[p], Mo)
+        if d_ > 1e-6:
+            raise SystemExit(f"parity check failed: pair {lo + p} model differs (relative Frobenius distance {d_:.3g})")
+        if flipped:
+            SIGN_FLIPS.append([int(lo + p), "restatement"])
     return len(pick), n_aside_checked
 
 
@@ -246,8 +271,11 @@ def parity_against_cpu_leg(records, lo, models, masks, stats):
             mo = np.unpackbits(mbits)[:masks.shape[1]].astype(bool)
             if not np.array_equal(masks[p].astype(bool), mo):
                 raise SystemExit(f"parity check failed (reference leg): pair {pid} mask differs in {(masks[p].astype(bool) != mo).sum()} bits")
-            if na == 0 or np.linalg.norm(models[p].ravel() / na - M / nb) > 1e-6:
-                raise SystemExit(f"parity check failed (reference leg): pair {pid} model differs")
+            d_, flipped = model_rel(models[p], M)
+            if na == 0 or d_ > 1e-6:
+                raise SystemExit(f"parity check failed (reference leg): pair {pid} model differs (relative Frobenius distance {d_:.3g})")
+            if flipped:
+                SIGN_FLIPS.append([int(pid), "reference"])
         n_ok += 1; n_aside += int((st[15] >> 8) & 1)
     return n_ok, n_aside, soft
 
@@ -272,18 +300,32 @@ def models_by_arithmetic(screen, models, ex_passes):
 
 def single_call_ms(reps=7):
     """wall time of ONE call through the host-pointer API (pageable numpy arrays in, numpy out: staging over PCIe, one
-    pair on one CU, sync): the reference's own use case.  Median over `reps` seeds after one warm-up call."""
+    pair on one CU, sync): the reference's own use case.  Median over `reps` seeds after one warm-up call, with the library's own
+    account of where each call's time went (mi_degensac_last_call_timing: host clocks + HIP events on the context's stream)."""
     import pydegensac_amd as pd
+    from pydegensac_amd import _lib
     p1, p2 = make_pair(0)
-    ts = []
-    for r in range(reps + 1):
-        t = time.perf_counter()
-        if CFG["which"] == "F":
-            pd.findFundamentalMatrix_(p1, p2, PRM["px_th"], PRM["conf"], PRM["max_iters"], PRM["error_type"], PRM["sym"], PRM["laf"], PRM["degen"], seed=r + 1)
-        else:
-            pd.findHomography_(p1, p2, PRM["px_th"], PRM["conf"], PRM["max_iters"], PRM["error_type"], PRM["sym"], PRM["laf"], seed=r + 1)
-        ts.append((time.perf_counter() - t) * 1e3)
+    ts = []; parts = []
+    prev = _lib.set_call_timing(1)
+    try:
+        for r in range(reps + 1):
+            t = time.perf_counter()
+            if CFG["which"] == "F":
+                pd.findFundamentalMatrix_(p1, p2, PRM["px_th"], PRM["conf"], PRM["max_iters"], PRM["error_type"], PRM["sym"], PRM["laf"], PRM["degen"], seed=r + 1)
+            else:
+                pd.findHomography_(p1, p2, PRM["px_th"], PRM["conf"], PRM["max_iters"], PRM["error_type"], PRM["sym"], PRM["laf"], seed=r + 1)
+            ts.append((time.perf_counter() - t) * 1e3)
+            tm = _lib.last_call_timing(); tm["python_ms"] = ts[-1] - tm["call_ms"]
+            tm["host_overhead_ms"] = ts[-1] - tm["dev_kernel_ms"]
+            parts.append(tm)
+    finally:
+        _lib.set_call_timing(prev)
+    med = {k: float(np.median([q[k] for q in parts[1:]])) for k in parts[0]}
     return {"median": float(np.median(ts[1:])), "min": float(min(ts[1:])), "max": float(max(ts[1:])),
+            "breakdown": dict(med, note="medians over the same calls (seeds 2.. of one pair): call_ms = the C entry point, of it pack / enqueue (H2D, scratch "
+                                        "set-up, launch, D2H) / wait (stream sync) / unpack on the host clock; dev_* = HIP events on the call's stream "
+                                        "(dev_kernel_ms = header memsets + the kernel); python_ms = wall - call_ms (ctypes + numpy marshalling); "
+                                        "host_overhead_ms = wall - dev_kernel_ms"),
             "note": "host-pointer API, PCIe staging included, 1 pair = 1 workgroup; never used as `value`"}
 
 
@@ -418,6 +460,100 @@ def h2el_line(pairs=64, n=5000, reps=3, n_check=8):
         return {"workload": "ransacH2el", "error": str(e)[:300]}
 
 
+def relaunch_argv(n_gpus, argv, port=None):
+    """The command line `bench.py --gpus N` (N > 1, no launcher in the environment) re-executes itself with: one rank per GPU
+    under torch.distributed.run on 127.0.0.1 (the container's hostname may not resolve), the driver's own launch form."""
+    if port is None:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def visible_gpus():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def resolve_world(gpus, single_process, env, n_visible):
+    """What `--gpus N` means in this environment (pure function: tests/test_host_cpu.py).  Returns ("run", world) to measure in this
+    process, ("exec", N) to re-execute under torch.distributed.run; raises SystemExit with a message for every inconsistent case — a
+    request for N GPUs never silently becomes a one-GPU run labelled n_gpus 1."""
+    if gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    launched = "WORLD_SIZE" in env
+    world = int(env.get("WORLD_SIZE", "1"))
+    if launched:
+        if single_process:
+            raise SystemExit("bench.py: --single-process drives all GPUs from ONE process; do not start it under torch.distributed.run")
+        if world != gpus:
+            raise SystemExit(f"bench.py: --gpus {gpus} but the launcher started WORLD_SIZE={world} ranks; the two must agree")
+        if int(env.get("LOCAL_RANK", "0")) >= n_visible:
+            raise SystemExit(f"bench.py: LOCAL_RANK {env.get('LOCAL_RANK')} but only {n_visible} GPU(s) are visible on this node")
+        return "run", world
+    if n_visible < gpus:
+        raise SystemExit(f"bench.py: --gpus {gpus} requested but only {n_visible} GPU(s) are visible on this node; refusing to print a "
+                         f"{n_visible}-GPU measurement under an n_gpus={gpus} request")
+    if gpus > 1 and not single_process:
+        return "exec", gpus
+    return "run", 1
+
+
+def measure_single_process(n_dev, pairs_per_gpu, steps, warmup, parity_pairs):
+    """--single-process: ONE process drives `n_dev` GPUs through the C-ABI's device-list mode (mi_degensac_find_*_batch_multi: one host
+    thread per device, contiguous blocks of pairs, NO collective; SURVEY 8e "no collective at all in single-process multi-device
+    mode (host gathers D2H)").  The boundary takes HOST buffers here, so PCIe staging of inputs and results is inside the timed
+    region — the line says so, and this mode is never the default."""
+    from pydegensac_amd import parallel, _lib
+    P = pairs_per_gpu * n_dev
+    DIM = CFG["dim"]; homography = CFG["which"] == "H"
+    a = np.empty((P * N_CORR, DIM)); b = np.empty((P * N_CORR, DIM))
+    for pid in range(P):
+        p1, p2 = make_pair(pid)
+        a[pid * N_CORR:(pid + 1) * N_CORR] = p1; b[pid * N_CORR:(pid + 1) * N_CORR] = p2
+    offs = np.arange(P + 1, dtype=np.int64) * N_CORR
+    seeds = parallel.pair_seeds(0, P)
+    M = np.zeros((P, 9)); mask = np.zeros(P * N_CORR, np.uint8); st = np.zeros((P, 16), np.int32)
+    devs = (C.c_int32 * n_dev)(*range(n_dev))
+    prm = _lib.make_params(PRM["px_th"], PRM["conf"], PRM["max_iters"], PRM["error_type"], PRM["sym"], PRM["laf"], PRM["degen"])
+    L = _lib.lib()
+    fn = L.mi_degensac_find_homography_batch_multi if homography else L.mi_degensac_find_fundamental_batch_multi
+
+    def step():
+        _lib.check(fn(_lib.dptr(a), _lib.dptr(b), offs.ctypes.data_as(C.POINTER(C.c_int64)), P, DIM, C.byref(prm),
+                      seeds.ctypes.data_as(C.POINTER(C.c_uint32)), devs, n_dev, _lib.dptr(M), mask.ctypes.data_as(C.POINTER(C.c_uint8)),
+                      st.ctypes.data_as(C.POINTER(C.c_int32))))
+    for _ in range(warmup):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    n_checked = n_aside = 0
+    if parity_pairs > 0:
+        n_checked, n_aside = parity_check(CFG["which"], P, parity_pairs, 0, M, mask.reshape(P, N_CORR), st)
+    return dict(dt=dt, st=st, P=P, n_checked=n_checked, n_aside_checked=n_aside, masks=mask.reshape(P, N_CORR))
+
+
+def single_process_line(args, n_dev):
+    r = measure_single_process(n_dev, args.pairs_per_gpu, args.steps, args.warmup, args.parity_pairs)
+    st, dt = r["st"], r["dt"]
+    models_step = int(st[:, 4].sum())
+    return {"metric": "models/sec, findFundamentalMatrix @2000 corrs (LO-RANSAC + DEGENSAC, batched pairs)" if args.config == "c2" else f"models/sec, config {args.config}",
+            "value": models_step * args.steps / dt, "unit": "models/s", "n_gpus": n_dev, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.config.upper()} x {args.pairs_per_gpu} pairs per GPU, {N_CORR} correspondences", "pairs_total": r["P"],
+                       "pairs_per_gpu": args.pairs_per_gpu, "n_corr": N_CORR,
+                       "parallelism": f"ONE process, device list [0..{n_dev - 1}] through mi_degensac_find_*_batch_multi (one host thread per device), no collective",
+                       "collective": "none (the host gathers D2H)", "process_group": None,
+                       "inputs": "HOST buffers: PCIe staging of inputs and results is INSIDE the timed region (the default multi-rank mode keeps inputs resident in HBM)"},
+            "pairs_per_s": r["P"] * args.steps / dt, "models_per_pair": models_step / r["P"], "mean_inliers": float(r["masks"].sum(1).mean()),
+            "roofline": None, "cpu_baseline": None,
+            "parity_checked": r["n_checked"], "parity_checked_set_aside": r["n_aside_checked"], "sign_flips": SIGN_FLIPS[:8],
+            "devices_used": sorted(set(int(x) for x in range(n_dev)))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -429,6 +565,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the short C2 x 512 / C3 / C5 measurements of the `secondary` object")
     ap.add_argument("--parity-pairs", type=int, default=16, help="pairs of the timed batch checked against the oracle afterwards")
     ap.add_argument("--dump-results", default="", help="rank 0 writes the gathered per-pair results of the last timed step to this .npz (tests)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="drive the N GPUs from ONE process through the device-list entry points (*_batch_multi, no collective, host buffers)")
     ap.add_argument("--dist-always", action="store_true",
                     help="initialise the RCCL process group and run the result all-gather even with one rank (tests the N > 1 code path on one GPU)")
     args = ap.parse_args()
@@ -439,11 +577,20 @@ def main():
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # --gpus N is a REQUEST for N GPUs: N ranks from a launcher (WORLD_SIZE must agree), or this process starts them itself
+    action, world = resolve_world(args.gpus, args.single_process, os.environ, visible_gpus())
+    if action == "exec":
+        cmd = relaunch_argv(args.gpus, sys.argv[1:])
+        print("bench.py: --gpus %d without a launcher: re-executing as  %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+        env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execve(sys.executable, cmd, env)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if args.single_process:
+        print(json.dumps(single_process_line(args, args.gpus)))
+        return
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or (args.dist_always and "MASTER_ADDR" in os.environ)
@@ -466,6 +613,21 @@ def main():
               "pairs_per_gpu": 4096 // world, "ms_per_step": r4["dt"] / 3 * 1e3, "kernel_ms_rank0": r4["kms"], "models_per_s": m4 * 3 / r4["dt"],
               "pairs_per_s": 4096 * 3 / r4["dt"], "parity_checked_rank0": r4["n_checked"]}
 
+    # ... and the same literal C4 batch driven from ONE process over the same N GPUs (device-list mode, no collective): rank 0 measures
+    # it while the other ranks wait at a barrier with their GPUs idle
+    sp = None
+    if c4 is not None:
+        dist.barrier()
+        if rank == 0:
+            try:
+                r1 = measure_single_process(world, 4096 // world, 3, 1, 4)
+                sp = {"workload": f"C4 literal through ONE process: mi_degensac_find_fundamental_batch_multi, devices [0..{world - 1}], host buffers (PCIe staging timed), no collective",
+                      "n_gpus": world, "pairs_per_gpu": 4096 // world, "ms_per_step": r1["dt"] / 3 * 1e3, "models_per_s": int(r1["st"][:, 4].sum()) * 3 / r1["dt"],
+                      "pairs_per_s": 4096 * 3 / r1["dt"], "parity_checked": r1["n_checked"]}
+            except Exception as e:        # a parity mismatch is a SystemExit and still ends the bench
+                sp = {"workload": "C4 literal through one process", "error": str(e)[:300]}
+        dist.barrier()
+
     if rank == 0 and args.dump_results:
         np.savez(args.dump_results, models=r["gm"].cpu().numpy(), stats=st, masks=gmask.cpu().numpy())
     if rank == 0:
@@ -479,13 +641,14 @@ def main():
                      "px_th 2, conf 0.999, max_iters 50000, sampson error, laf_consistensy_coef 3, symmetric check on, LO on"),
               "c5": (f"C5 x {P} pairs per GPU: findFundamentalMatrix, {N_CORR} correspondences, 10% inliers, sigma 0.1 px, px_th 0.5, "
                      "conf 0.9999, max_iters 200000, sampson error, symmetric check on, degeneracy check on")}[args.config]
+        traffic, traffic_src = pmc_traffic(args.config, P)
         out = {
             "metric": ("models/sec, findFundamentalMatrix @2000 corrs (LO-RANSAC + DEGENSAC, batched pairs)" if args.config == "c2" else
                        "models/sec, findHomography @5000 corrs with LAFs (LO-RANSAC, LAF + symmetric checks, batched pairs)" if homography else
                        "models/sec, findFundamentalMatrix @50000 corrs (LO-RANSAC + DEGENSAC)"),
             "value": models_step * args.steps / dt,
             "unit": "models/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": (dist.get_world_size() if use_dist else 1), "steps": args.steps, "warmup": args.warmup,   # the ranks the process group (RCCL) actually has
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
@@ -503,7 +666,10 @@ def main():
             "pair_latency_ms": {"mean": float(ticks.mean() * 1e3), "p50": float(np.median(ticks) * 1e3), "max": float(ticks.max() * 1e3),
                                 "note": "device clock, time the pair was being worked on; the time a pair waits in the set-aside queues of a batch is excluded (as in time_to_best_ms)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.config, P),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "hbm_frac": (traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "hbm_frac_note": "measured HBM bytes per launch (traffic) / kernel time / peak: the share of the HBM bandwidth the kernel "
+                                          "really uses; `frac` above is the reference-equivalent (algorithmic) rate, not bandwidth use",
                          "kernel": r["kernel"], "kernel_ms": kms,
                          "models_by_arithmetic": models_by_arithmetic(r.get("screen"), int(local_st[:, 4].sum()), int(local_st[:, 9].sum())),
                          "algorithmic_bytes_per_launch": alg_bytes,
@@ -553,6 +719,11 @@ def main():
             out["secondary"] = sec
         if c4 is not None:
             out.setdefault("secondary", {})["c4_literal"] = c4
+        if sp is not None:
+            out.setdefault("secondary", {})["c4_literal_single_process"] = sp
+        out["sign_flips"] = {"pairs": SIGN_FLIPS[:16], "n": len(SIGN_FLIPS),
+                             "what": "pairs whose model equals the CPU side's only up to SIGN (same mask and counters): F and H are homogeneous, and the sign "
+                                     "is the one LAPACK's dsyev gives the eigenvector, which differs between LAPACK builds on about one input in 7000; never fatal"}
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

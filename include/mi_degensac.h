@@ -165,11 +165,16 @@ int mi_degensac_set_stream_mode(int mode);      /* any mode > 0 turns the mode o
  * MI_DEGENSAC_HJOB); a call switches them off for itself with MI_DEGENSAC_FLAG_NO_HJOB in params.flags. */
 int mi_degensac_set_hjob_mode(int mode);        /* default of the calls that do not set MI_DEGENSAC_FLAG_NO_HJOB */
 /* Hand-overs between workgroups (stream mode, homography helpers, the cooperative large-n mode) never wait for a workgroup that
- * may not have been dispatched; a wait for a RUNNING workgroup gives up after 4 s of device wall clock.  The launch then raises
- * its error word, every pair that ends afterwards discards its results (MI_ST_PLACEMENT bit 10), and the host-pointer entry
- * points run those pairs again in a second launch without producers / helpers (bit 11) instead of failing the call.  Test hook:
- * the limit of the stream mode's data waits in 100 MHz ticks (0 = fault injection: every data wait fails at once; < 0 restores the
- * default); returns the previous limit. */
+ * may not have been dispatched.  Every wait for a RUNNING workgroup — the stream mode's data waits, the owner's wait for the
+ * repetitions its homography helpers claimed, the cooperative mode's waits for claimed units — gives up after the same limit, 4 s of
+ * device wall clock (dg_wait_count / dg_stream_wait).  The launch then raises its error word, every pair that ends afterwards
+ * discards its results (MI_ST_PLACEMENT bit 10: zero model, all-zero mask, I = 0), and the host-pointer entry points run those pairs
+ * again in a second launch without producers / helpers (bit 11) instead of failing the call.  The asynchronous *_dev entry points
+ * cannot do that: their ONLY report of a discarded pair is bit 10 of its stats block, so a caller that wants to tell "discarded" from
+ * "no model found" must pass d_stats (with d_stats = NULL both read as a zero model).  (One wait is not a hand-over and has no limit:
+ * an idle helper workgroup of the cooperative mode sleeping until its owner publishes the next stage or retires the slot.)
+ * Test hook: the limit in 100 MHz ticks (0 = fault injection: every such wait fails at once; < 0 restores the default); returns the
+ * previous limit. */
 long long mi_degensac_set_wait_ticks(long long ticks);
 /* Memory: the library caches one scratch buffer per (device, stream): one workspace per resident workgroup (about 0.65 MB at
  * n = 2000) plus, for fundamental-matrix batches larger than the resident grid, one spare workspace per queued pair (within half
@@ -276,7 +281,9 @@ int mi_degensac_release_scratch(int device, void *stream_or_null);
 typedef struct mi_degensac_diag {
     double  *d_resids;        /* device buffer of total_points * resid_runs * 62 doubles, or NULL              */
     int32_t  resid_runs;      /* LO runs per pair the buffer has room for                                     */
-    int32_t  reserved;
+    int32_t  struct_size;     /* sizeof(mi_degensac_diag) of the caller's header.  0 (what callers built against the first layout
+                                 pass in this field, then called `reserved`) = the layout that ends at d_hist: d_screen is NOT read.
+                                 Fields added later are only read when struct_size covers them.                                */
     int32_t *d_hist;          /* fundamental matrix only: the drivers' `data_out` (exp_ranF.c:1495, :1758-1759; allocated and freed at
                                  bindings.cpp:412, :459): per pair n + 3 ints at d_hist[offsets[pair] + 3 * pair]: [0] samples drawn,
                                  [1] LO runs, [2 + I] number of samples whose best model had I inliers.  Device buffer of
@@ -379,6 +386,15 @@ int mi_degensac_screen_counts_h(const double *pts1, const double *pts2, int n, i
  * outputs per step as three interleaved prefix sums): out[i] = the (skip + i + 1)-th rand() after srand(seed), generated `block`
  * (1..31) values at a time.  Must equal libc's sequence. */
 int mi_degensac_rng_wave(uint32_t seed, int skip, int block, int count, int device, int32_t *out);
+
+/* Where the time of ONE host-pointer call goes (the single-call latency of bench.py's `single_call_ms.breakdown`).  With timing on,
+ * every host-pointer call of the calling thread leaves, in milliseconds: [0] the whole call (host clock), [1] packing the inputs into
+ * the pinned block, [2] enqueueing (H2D copy, scratch set-up, launch, D2H copy), [3] waiting for the stream, [4] unpacking the
+ * results; and from HIP events on the context's stream: [5] the H2D copy, [6] header memsets + kernel + error-word copy, [7] the
+ * D2H copy.  Process-wide switch (returns the previous value), per-thread result; off by default (it costs four events per call). */
+#define MI_DEGENSAC_TIMING_LEN 8
+int mi_degensac_set_call_timing(int on);
+int mi_degensac_last_call_timing(double *out /*[MI_DEGENSAC_TIMING_LEN]*/);
 
 /* ---- misc -------------------------------------------------------------------------------------- */
 int         mi_degensac_device_count(void);

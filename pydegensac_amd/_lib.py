@@ -40,8 +40,12 @@ class Params(C.Structure):
 
 
 class Diag(C.Structure):
-    """mi_degensac_diag (include/mi_degensac.h): optional device buffers of the *_batch_dev_ex entry points"""
-    _fields_ = [("d_resids", C.c_void_p), ("resid_runs", C.c_int32), ("reserved", C.c_int32), ("d_hist", C.c_void_p), ("d_screen", C.c_void_p)]
+    """mi_degensac_diag (include/mi_degensac.h): optional device buffers of the *_batch_dev_ex entry points.  struct_size is filled
+    in here (the library reads fields added after the first layout only when the stated size covers them)."""
+    _fields_ = [("d_resids", C.c_void_p), ("resid_runs", C.c_int32), ("struct_size", C.c_int32), ("d_hist", C.c_void_p), ("d_screen", C.c_void_p)]
+
+    def __init__(self, d_resids=None, resid_runs=0, struct_size=0, d_hist=None, d_screen=None):
+        super().__init__(d_resids, int(resid_runs), int(struct_size) or C.sizeof(Diag), d_hist, d_screen)
 
 
 class H2elParams(C.Structure):
@@ -161,6 +165,10 @@ def lib():
         l.mi_degensac_screen_counts_h.argtypes = [dp, dp, C.c_int, C.c_int, dp, C.c_int, C.c_double, C.c_int, up, bp]
         l.mi_degensac_rng_wave.restype = C.c_int
         l.mi_degensac_rng_wave.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, ip]
+        l.mi_degensac_set_call_timing.restype = C.c_int
+        l.mi_degensac_set_call_timing.argtypes = [C.c_int]
+        l.mi_degensac_last_call_timing.restype = C.c_int
+        l.mi_degensac_last_call_timing.argtypes = [dp]
         l.mi_degensac_last_error.restype = C.c_char_p
         l.mi_degensac_version.restype = C.c_char_p
         l.mi_degensac_kernel_name.restype = C.c_char_p
@@ -204,6 +212,21 @@ def set_wait_ticks(ticks):
     """test hook: limit of the stream mode's data waits in 100 MHz device ticks (0: every data wait fails at once; < 0: the default
     4 s); returns the previous limit"""
     return int(lib().mi_degensac_set_wait_ticks(int(ticks)))
+
+
+TIMING_NAMES = ["call_ms", "pack_ms", "enqueue_ms", "wait_ms", "unpack_ms", "dev_h2d_ms", "dev_kernel_ms", "dev_d2h_ms"]
+
+
+def set_call_timing(on):
+    """per-call timing of the host-pointer entry points (include/mi_degensac.h); returns the previous switch"""
+    return int(lib().mi_degensac_set_call_timing(int(bool(on))))
+
+
+def last_call_timing():
+    """the calling thread's last timed host-pointer call: dict of TIMING_NAMES (milliseconds)"""
+    out = (C.c_double * len(TIMING_NAMES))()
+    check(lib().mi_degensac_last_call_timing(out))
+    return {k: float(v) for k, v in zip(TIMING_NAMES, out)}
 
 
 def stats_dict(st):

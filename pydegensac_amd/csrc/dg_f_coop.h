@@ -404,7 +404,7 @@ __device__ __noinline__ dg_pass_res dg_coop_pass(CTX &c, const double *Fm /* LDS
     dg_coop_publish(cb, *c.coop_gen, 3, n_units, 0, n, kind, slice, 0, cfg.thJ, S->ext, 0.0);
     dg_coop_work<DG_T>(A, c.coop_slot, S, v, cb, *c.coop_gen, (double *)(A.ws + (size_t)c.coop_slot * A.wl.stride + A.wl.off_hjbuf), &S->itmp[28], tid);
     if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
-        while (__hip_atomic_load(&cb->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_units) __builtin_amdgcn_s_sleep(2);
+        dg_wait_count(A, &cb->done, n_units, 4, 2);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
@@ -441,7 +441,7 @@ __device__ __forceinline__ void dg_lo_round_coop(CTX &c, int nr, int ssiz, doubl
     dg_coop_publish(cb, *c.coop_gen, 4, nr, 0, c.n, mk_full, 0, 0, th, S->ext, 0.0);
     dg_coop_work<DG_T>(A, c.coop_slot, S, v, cb, *c.coop_gen, (double *)(A.ws + (size_t)c.coop_slot * A.wl.stride + A.wl.off_hjbuf), &S->itmp[28], tid);
     if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
-        while (__hip_atomic_load(&cb->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nr) __builtin_amdgcn_s_sleep(8);
+        dg_wait_count(A, &cb->done, nr, 4, 8);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();

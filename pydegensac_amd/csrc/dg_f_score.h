@@ -17,11 +17,13 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
                                              int Mtot, int ws, int NS, int kind, double th, double tauJ, const double *ext /* LDS[4] */,
                                              char *tab /* LDS, this wave's */, int tab_bytes,
                                              double *jbuf /* this wave's scratch, >= n doubles */, unsigned *res_I, double *res_J, int lane,
-                                             unsigned *scnt /* LDS[4]: dg_f_shared::scnt */)
+                                             unsigned *scnt /* LDS[4]: dg_f_shared::scnt; null = do not count (a second scoring of the same chunk) */,
+                                             int m_first = 0 /* only the models mi >= m_first (the commit's re-scoring of the rest of a chunk) */)
 {
     /* workgroup-uniform arguments arrive in vector registers (separate function): make the loop control scalar again */
     n = __builtin_amdgcn_readfirstlane(n); Mtot = __builtin_amdgcn_readfirstlane(Mtot); ws = __builtin_amdgcn_readfirstlane(ws);
     NS = __builtin_amdgcn_readfirstlane(NS); kind = __builtin_amdgcn_readfirstlane(kind); tab_bytes = __builtin_amdgcn_readfirstlane(tab_bytes);
+    m_first = __builtin_amdgcn_readfirstlane(m_first);
     const double t94 = th * 9 / 4, t94b = t94 * (1.0 + 1e-6);
     const bool use_bound = th != 0 && kind != DG_K_EXFSYM && tauJ >= 4.0;
     const bool use_l1 = use_bound && tauJ >= 64.0;
@@ -32,8 +34,9 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     for (int j0 = 0; j0 < nm; j0 += 64) {
         const int nb = nm - j0 < 64 ? nm - j0 : 64;
-        const bool have = lane < nb;
         const int mi = ws + (j0 + lane) * NS;                       /* this lane's model (have) */
+        const bool have = lane < nb && mi >= m_first;
+        if (__ballot(have) == 0ull) continue;
         double F[9];
         {
             const double *gp = gmodels + (size_t)mslot[have ? mi : ws] * 9;
@@ -89,7 +92,7 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
             if (mine && !keep) { res_I[mi] = 0; res_J[mi] = 0; }
             surv = __ballot(keep);
         }
-        if (lane == 0) {                 /* four LDS adds per batch of up to 64 models */
+        if (lane == 0 && scnt) {         /* four LDS adds per batch of up to 64 models */
             __hip_atomic_fetch_add(&scnt[0], n_l1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(&scnt[1], n_l2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(&scnt[2], (unsigned)__popcll(surv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -243,6 +243,25 @@ struct dg_args {
     long long *phase_out;            /* debug: [n_pairs][8] 100 MHz ticks per phase (sample, solve, score, commit+events, LO, degen, tail, total) */
 };
 
+/* ONE wave, uniform control flow: wait until the agent-scope counter *cnt reaches `target`, for at most A.wait_ticks of the 100 MHz clock
+ * (4 s; mi_degensac_set_wait_ticks).  Every wait of an owner for units / repetitions that RUNNING workgroups have claimed goes through
+ * here (cooperative large-n mode, homography helpers): a wait that long is a bug or a stuck device — raise the launch's error word
+ * (`code`), give up and go on; every pair that ends afterwards discards its results and the host-pointer entry points run it again
+ * without helpers.  wait_ticks == 0 is the test hook's fault injection: the wait fails at once.  Returns false on a time-out. */
+__device__ __forceinline__ bool dg_wait_count(const dg_args &A, int *cnt, int target, int code, int sleep_ticks)
+{
+    const long long t0 = wall_clock64(), limit = (long long)A.wait_ticks;
+    for (;;) {
+        const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (v >= target && limit != 0) return true;
+        if (wall_clock64() - t0 > limit || limit == 0) {
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(A.err_flag, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        if (sleep_ticks >= 8) __builtin_amdgcn_s_sleep(8); else if (sleep_ticks >= 4) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(2);
+    }
+}
+
 /* ---- glibc TYPE_3 fast path ----------------------------------------------------------------------
  * After srandom(seed) the k-th output is ((sum_j C[k][j] * r_j) mod 2^32) >> 1 with r_0 = seed,
  * r_j = 16807 * r_{j-1} mod (2^31-1): the 310 discarded steps of r[i] = r[i-31] + r[i-3] are linear

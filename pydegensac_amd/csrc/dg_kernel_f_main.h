@@ -542,7 +542,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             for (int st = coop_screen ? 1 : 2; st <= 2; st++) {
                 dg_coop_work<T>(A, slot, S, cv, cb, coop_gen, jb0, &S->itmp[28], tid);          /* (starts with a workgroup barrier) */
                 if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
-                    while (__hip_atomic_load(&cb->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < units) __builtin_amdgcn_s_sleep(2);
+                    dg_wait_count(A, &cb->done, units, 4, 2);
                     /* stage 1 leaves device counters that are read with agent-scope atomic loads below; only stage 2 leaves plain data */
                     if (st == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
@@ -756,9 +756,13 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                                         __hip_atomic_store(&cb->tau_bits, (unsigned long long)__double_as_longlong(tau_new < 0 ? 0.0 : tau_new), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                     {
                                         const int capr = (int)((sizeof(dg_lsq_scratch) / DG_NW) & ~(size_t)15);
+                                        /* only what the commit has not consumed yet: this sample's remaining roots and the later samples (the slots of
+                                         * earlier samples may hold event models or leftovers of earlier chunks, and their scores are final); the second
+                                         * look at these models is not counted in scnt */
                                         dg_score_chunk_F<LDSPTS>(P, n, c.K->gmodels, S->mslot, Mtot, wave, DG_NW, mk_full, th, tau_new, S->ext,
                                                                  (char *)&S->lsq + (size_t)wave * capr, capr,
-                                                                 (double *)(c.K->wstage + (size_t)wave * c.K->n_max), c.K->res_I, c.K->res_J, lane, S->scnt);
+                                                                 (double *)(c.K->wstage + (size_t)wave * c.K->n_max), c.K->res_I, c.K->res_J, lane, (unsigned *)0,
+                                                                 (int)S->moff[k] + r + 1);
                                     }
                                     __syncthreads();
                                     tau_scored = tau_new;
@@ -1140,6 +1144,9 @@ __global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_fundamental_kernel(dg_a
         __hip_atomic_store(&As.coop[slot].gen, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     /* development build: when this workgroup ran out of work (tools/gpu_sched.py: the tail of a launch) */
     DG_DEVT(if (As.phase_out && threadIdx.x == 0) As.phase_out[((size_t)As.n_pairs + blockIdx.x) * 16] = DG_CLK());
+    /* ... and where its waves sit: HW_ID | XCC_ID << 32 per wave (tools/gpu_simd.py: which SIMDs the serial waves of co-resident workgroups share) */
+    DG_DEVT(if (As.phase_out && (threadIdx.x & 63) == 0) As.phase_out[((size_t)As.n_pairs + blockIdx.x) * 16 + 1 + (threadIdx.x >> 6)] =
+                (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32));
 
 }
 

@@ -540,7 +540,15 @@ __device__ __forceinline__ bool dg_hpub_seen(unsigned long long *pub, int j, uns
     /* lane 6 r + e holds word e of repetition r (e = 0..3: iterations, e = 5: status) */
     const int r = lane / 6, e = lane - 6 * r;
     unsigned long long v = 0;
-    if (r < j && r < DG_RAN_REP && (e < DG_ILSQ_ITERS || e == 5)) v = __hip_atomic_load(pub + 8 * r + (e == 5 ? 7 : e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    /* ONE consistent snapshot per repetition: its status word FIRST, then (behind an agent-scope acquire, which also waits for the
+     * status loads) its iteration words.  The writer stores the iteration words, drains its stores and then stores the status word
+     * (`finish` in dg_hrep_wave), so a repetition that is seen finished here is seen with all of its iteration words; an unfinished
+     * one counts as far as its words go, and any prefix of them is a valid state.  (Loading all six words of a repetition at once,
+     * unordered, could pair "finished" with a stale iteration word and undercount that repetition's inserts.) */
+    const bool mine_r = r < j && r < DG_RAN_REP;
+    if (mine_r && e == 5) v = __hip_atomic_load(pub + 8 * r + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (mine_r && e < DG_ILSQ_ITERS) v = __hip_atomic_load(pub + 8 * r + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     /* p = the leading finished repetitions */
     const unsigned long long finm = __ballot(e == 5 && (v & DG_HPUB_VALID) != 0ull);
     int p = 0; while (p < j && ((finm >> (6 * p + 5)) & 1ull)) p++;
@@ -705,11 +713,7 @@ __device__ __forceinline__ dg_score dg_inHranic_waves(CTX &c, int kind, int ninl
     if (cb) {
         /* repetitions that helpers claimed may still run */
         if (__builtin_amdgcn_readfirstlane(wave) == 0) {
-            const long long t0 = wall_clock64();
-            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&cb->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < DG_RAN_REP) {
-                if (wall_clock64() - t0 > 400000000ll) { if (lane == 0) __hip_atomic_store(c.A->err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                __builtin_amdgcn_s_sleep(4);
-            }
+            dg_wait_count(*c.A, &cb->done, DG_RAN_REP, 2, 4);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (lane == 0) { __hip_atomic_store(&cb->gen, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_fetch_add(c.A->done_pairs + 2, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         }
@@ -735,6 +739,14 @@ __device__ __forceinline__ dg_score dg_inHranic_waves(CTX &c, int kind, int ninl
                     if (ret != -1 && ret != id) { dead = true; break; }
                     if (mlJ < q->J) { mlI = (unsigned)q->I; mlJ = q->J; const int t = pe0; pe1 = t; pe0 = pd; pd = pe1; hres = q->hl; }
                     if (it == g_->nit - 1 && g_->last_short) fin = true;
+                }
+                if (!dead && !fin && !g_->has_fin) {
+                    /* The repetition stopped early because it took a set for certainly inserted (dg_hpub_seen) — and the real table
+                     * does not hold it here.  Its final pass was never made (hf / If / Jf are not this repetition's): never consume
+                     * them.  Raise the launch's error word: the pair's results are discarded and the host-pointer entry points run
+                     * it again (include/mi_degensac.h, MI_ST_PLACEMENT bit 10 / 11). */
+                    __hip_atomic_store(c.A->err_flag, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    dead = true;
                 }
                 if (!dead && !fin) {
                     nh++;

@@ -148,8 +148,8 @@ __device__ __noinline__ int dg_h2_A2toRH(const double *ua, const double *ub, dou
 
 /* errs[] bookkeeping of the driver: pe[i] = physical buffer behind errs[i] (i = 0..4), S->bufF[b] = the model whose
  * residuals buffer b holds */
-struct dg_h2bufs { int pe[5]; };
-#define DG_H2SET(S, b, src) do { __syncthreads(); if (tid < 9) (S)->bufF[(b)][tid] = (src)[tid]; __syncthreads(); } while (0)
+struct dg_h2bufs { int pe[5]; unsigned wr; /* bit b: buffer b has been written (a model stands behind it) */ };
+#define DG_H2SET(S, b, src) do { __syncthreads(); if (tid < 9) (S)->bufF[(b)][tid] = (src)[tid]; B.wr |= 1u << (b); __syncthreads(); } while (0)
 
 /* ranH.c:18-86 iterH.  h (LDS) = in/out parameter H; errs[4]'s model is bufF[B.pe[4]] */
 template <int LDSPTS>
@@ -309,7 +309,7 @@ __device__ __forceinline__ void dg_h2_pair(const dg_args &A, dg_f_shared *S, con
     const unsigned inlLimit = pr.h2_inl_limit == 0 ? 0x7fffffffu : (unsigned)pr.h2_inl_limit;
     const int do_lo = pr.h2_do_lo;
     dg_score maxS = {0, 0, 0, 0}, maxSs = {0, 0, 0, 0};
-    dg_h2bufs B; B.pe[0] = 0; B.pe[1] = 1; B.pe[2] = 2; B.pe[3] = 3; B.pe[4] = 3;
+    dg_h2bufs B; B.pe[0] = 0; B.pe[1] = 1; B.pe[2] = 2; B.pe[3] = 3; B.pe[4] = 3; B.wr = 0;
     int no_sam = 0, max_sam = pr.max_iters, iter_cnt = 0, best_sample = 0; long long t_best = t_start;
     if (tid < 64) { dg_srand_wave(&S->rng, A.seeds[pair], tid); const int v_ = dg_rand_block(&S->rng, 1, tid); if (tid == 0) S->itmp[31] = v_; }
     __syncthreads();
@@ -383,7 +383,16 @@ __device__ __forceinline__ void dg_h2_pair(const dg_args &A, dg_f_shared *S, con
 #pragma unroll
         for (int i = 0; i < 9; i++) H[i] = S->bufF[B.pe[3]][i];
         unsigned char *mask = A.mask_out + off;
-        for (int j = tid; j < n; j += DG_T) { const dg_pt p = Pw[j]; mask[j] = dg_HDs(H, p.x1, p.y1, p.x2, p.y2) <= th ? 1 : 0; }
+        if ((B.wr >> B.pe[3]) & 1u)
+            for (int j = tid; j < n; j += DG_T) { const dg_pt p = Pw[j]; mask[j] = dg_HDs(H, p.x1, p.y1, p.x2, p.y2) <= th ? 1 : 0; }
+        else {
+            /* errs[3] was never written: no sample's model and no local optimisation ever became the best (budgets of a few samples,
+             * thresholds nothing meets).  The reference reads the buffer as its malloc left it (ranH2el.c:189-198); oracle and device take the
+             * zero-filled buffer of a fresh allocation, as for errs[4]: every residual 0, so inl[j] = (0 <= th).  The model stays
+             * zero; pydegensac_amd.ransacH2el turns "zero H" into an all-false mask for its callers (raw=True returns this one). */
+            const unsigned char v0 = 0.0 <= th ? 1 : 0;
+            for (int j = tid; j < n; j += DG_T) mask[j] = v0;
+        }
     }
     if (tid < 9) A.model_out[(size_t)pair * 9 + tid] = S->F[tid];
     if (A.stats_out && tid == 0) {

@@ -4,7 +4,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stddef.h>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <string>

@@ -1,0 +1,140 @@
+"""GPU: round 6 — every hand-over wait is bounded and fault-injectable (homography helpers, cooperative large-n mode), ransacH2el's
+no-model mask equals the oracle's, the versioned diagnostics struct, per-call timing of the host-pointer path, bench.py's launch modes."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import pydegensac_amd as pd
+from pydegensac_amd import _lib, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_homography_helper_time_out_is_discarded_and_rerun(oracle_port):
+    """Fault injection on the homography path (wait limit 0): the owner's wait for the repetitions its helper workgroups claimed fails at
+    once (dg_wait_count), the launch raises its error word, the pairs are discarded and run again without helpers — the host-pointer
+    entry point still returns the oracle's results (stats bit 11)."""
+    sets = [syn.homography_pairs(3000, 0.4, 0.5, seed=40 + i, laf=True)[:2] for i in range(3)]
+    A = [s_[0] for s_ in sets]; B = [s_[1] for s_ in sets]; seeds = [3, 4, 5]
+    ora = [oracle_port.find_homography(A[p], B[p], 2.0, 0.999, 20000, 0, True, 3.0, seed=seeds[p]) for p in range(3)]
+    prev = _lib.set_wait_ticks(0)
+    try:
+        H, k = pd.findHomographyBatch(A, B, 2.0, 0.999, 20000, 3.0, seeds=seeds, tuning=_lib.TUNE_LATENCY | _lib.TUNE_PLACE_POOL_LDS); st = pd.last_stats()
+        assert sum(s_["rerun"] for s_ in st) >= 1, "with helpers on, the zero limit must have tripped a wait"
+        assert sum(s_["discarded"] for s_ in st) == 0
+        for p, (Ho, mo, so) in enumerate(ora):
+            assert (st[p]["samples"], st[p]["lo_runs"], st[p]["I"]) == (so["samples"], so["lo_runs"], so["I"]), p
+            assert np.array_equal(np.asarray(k[p]), mo), p
+    finally:
+        _lib.set_wait_ticks(prev)
+    H2, k2 = pd.findHomographyBatch(A, B, 2.0, 0.999, 20000, 3.0, seeds=seeds, tuning=_lib.TUNE_LATENCY | _lib.TUNE_PLACE_POOL_LDS); st2 = pd.last_stats()
+    assert sum(s_["rerun"] + s_["discarded"] for s_ in st2) == 0                    # with the default limit nothing trips
+    assert np.array_equal(np.asarray(H), np.asarray(H2)) and all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(k, k2))
+
+
+def test_cooperative_mode_time_out_is_discarded_and_rerun(oracle_port):
+    """The same for the cooperative large-n mode (fundamental matrix, 9000 correspondences, helper workgroups forced on): the owner's
+    waits for claimed units give up at once, the pair is discarded and run again with the helpers off."""
+    p1, p2, _, _ = syn.two_view_fundamental(9000, 0.3, 0.1, seed=77)
+    Fo, mo, so = oracle_port.find_fundamental(p1, p2, 0.5, 0.9999, 3000, seed=9)
+    tun = _lib.TUNE_LATENCY | _lib.TUNE_PLACE_HBM | _lib.TUNE_HELPERS(3)
+    prev = _lib.set_wait_ticks(0)
+    try:
+        F, m = pd.findFundamentalMatrixBatch([p1], [p2], max_iters=3000, seeds=[9], tuning=tun); st = pd.last_stats()
+        assert st[0]["rerun"] == 1 and st[0]["discarded"] == 0
+        assert (st[0]["samples"], st[0]["lo_runs"], st[0]["I"]) == (so["samples"], so["lo_runs"], so["I"])
+        assert np.array_equal(np.asarray(m[0]), mo)
+        assert np.linalg.norm(np.asarray(F[0]).ravel() - Fo.ravel()) <= 1e-9 * np.linalg.norm(Fo)
+    finally:
+        _lib.set_wait_ticks(prev)
+    F2, m2 = pd.findFundamentalMatrixBatch([p1], [p2], max_iters=3000, seeds=[9], tuning=tun); st2 = pd.last_stats()
+    assert st2[0]["rerun"] == 0 and st2[0]["discarded"] == 0 and np.array_equal(np.asarray(m2[0]), mo)
+
+
+def test_h2el_no_model_mask_equals_the_oracle(oracle_port):
+    """ransacH2el when NOTHING ever becomes the best model (a threshold nothing meets, budgets of one or a few samples, with and without
+    the run after the loop): errs[3] is the buffer as allocated.  Oracle and device take a zero-filled one: the raw mask
+    is (0 <= th) for every point, the model stays zero — compared unconditionally, mask included — and the user-facing call turns
+    the zero model into an all-false mask (findHomography's convention, utils.py:104-107)."""
+    u10, _ = syn.ellipse_pairs(300, 0.0, 1.0, 301, 0.05)
+    n_zero = 0
+    for th, iters, lo in ((1e-12, 1, False), (1e-12, 1, True), (1e-12, 7, False), (1e-12, 60, True), (4.0, 1, False), (4.0, 3, True)):
+        for seed in (1, 2, 3):
+            Hr, mr = pd.ransacH2el(u10, th, 0.99, iters, lo, 0, seed=seed, raw=True); st = pd.last_stats()
+            Ho, mo, so = oracle_port.ransacH2el(u10, th, 0.99, iters, lo, 0, seed)
+            assert (st["samples"], st["lo_runs"], st["I"]) == (so["samples"], so["lo_runs"], so["I"]), (th, iters, lo, seed)
+            assert np.array_equal(np.asarray(mr).astype(bool), mo), (th, iters, lo, seed, int(np.asarray(mr).sum()), int(mo.sum()))
+            assert np.array_equal(np.asarray(Hr).ravel() == 0, Ho.ravel() == 0), (th, iters, lo, seed)
+            if not Ho.any():
+                n_zero += 1
+                H, m = pd.ransacH2el(u10, th, 0.99, iters, lo, 0, seed=seed)
+                assert not np.asarray(H).any() and not np.asarray(m).any()
+    assert n_zero >= 3, "the sweep must contain runs that end without a model"
+
+
+def test_diag_struct_is_versioned():
+    """mi_degensac_diag.struct_size: a caller built against the first layout passes 0 in that field (it was `reserved`) and a struct
+    that ends at d_hist — the library must not read d_screen then (here: a poisoned pointer that would fault if it were written through)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    p1, p2, _, _ = syn.two_view_fundamental(600, 0.5, 0.1, seed=2)
+    offs = np.array([0, 600], np.int64)
+    d_a = torch.from_numpy(p1).to(dev); d_b = torch.from_numpy(p2).to(dev); d_off = torch.from_numpy(offs).to(dev)
+    d_seeds = torch.tensor([5], dtype=torch.int32, device=dev)
+    prm = _lib.make_params(0.5, 0.9999, 5000, 0, True, 0.0, True)
+    L = _lib.lib(); stream = torch.cuda.current_stream(dev)
+    outs = []
+    for size, scr in ((0, 0xdead0000), (None, None)):
+        d_F = torch.zeros((1, 9), dtype=torch.float64, device=dev); d_mask = torch.zeros(600, dtype=torch.uint8, device=dev); d_st = torch.zeros((1, 16), dtype=torch.int32, device=dev)
+        d_scr = torch.zeros((1, 4), dtype=torch.int32, device=dev)
+        diag = _lib.Diag(None, 0, 0, None, scr if scr is not None else d_scr.data_ptr())
+        if size is not None:
+            diag.struct_size = size
+        _lib.check(L.mi_degensac_find_fundamental_batch_dev_ex(d_a.data_ptr(), d_b.data_ptr(), d_off.data_ptr(), offs.ctypes.data_as(C.POINTER(C.c_int64)), 1, 2,
+                                                               C.byref(prm), d_seeds.data_ptr(), 0, C.c_void_p(stream.cuda_stream), d_F.data_ptr(), d_mask.data_ptr(),
+                                                               d_st.data_ptr(), C.byref(diag)))
+        torch.cuda.synchronize(dev)
+        outs.append((d_F.cpu().numpy(), d_mask.cpu().numpy(), d_scr.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert not outs[0][2].any() and outs[1][2][0, 3] > 0          # only the caller that states its size gets the screening counters
+
+
+def test_call_timing_adds_up():
+    """mi_degensac_set_call_timing / _last_call_timing: the phases of one host-pointer call sum to the call, the kernel lies inside the wait."""
+    p1, p2, _, _ = syn.two_view_fundamental(2000, 0.4, 0.1, seed=0)
+    prev = _lib.set_call_timing(1)
+    try:
+        pd.findFundamentalMatrix_(p1, p2, 0.5, 0.9999, 100000, 0, True, 0.0, True, seed=1)
+        pd.findFundamentalMatrix_(p1, p2, 0.5, 0.9999, 100000, 0, True, 0.0, True, seed=2)
+        t = _lib.last_call_timing()
+    finally:
+        _lib.set_call_timing(prev)
+    parts = t["pack_ms"] + t["enqueue_ms"] + t["wait_ms"] + t["unpack_ms"]
+    assert t["call_ms"] > 0 and abs(parts - t["call_ms"]) < 0.2 + 0.05 * t["call_ms"], t
+    assert 0 < t["dev_kernel_ms"] <= t["call_ms"], t
+    assert t["dev_h2d_ms"] >= 0 and t["dev_d2h_ms"] >= 0
+
+
+def test_bench_gpus_flag_is_a_request_not_a_label():
+    """bench.py --gpus 2 on a box with fewer GPUs must fail loudly instead of printing a one-GPU line; --single-process runs the
+    device-list mode and reports the devices it used; a launcher whose WORLD_SIZE disagrees with --gpus is an error."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    n_vis = torch.cuda.device_count()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n_vis + 1), "--steps", "1", "--warmup", "0"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and "visible" in out.stderr and not out.stdout.strip(), (out.returncode, out.stderr[-400:])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and "must agree" in out.stderr
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--single-process", "--pairs-per-gpu", "64", "--steps", "1", "--warmup", "1",
+                          "--parity-pairs", "3"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-800:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["process_group"] is None and line["parity_checked"] >= 3 and line["value"] > 0

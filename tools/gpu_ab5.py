@@ -1,5 +1,6 @@
 """A/B timing inside ONE process on ONE box: C2 batches, every configuration in turn, `reps` launches each (best and mean).
-usage: gpu_ab5.py P[,P2...] name=flags:tuning[:lo_width[:knob]] ...      e.g.  gpu_ab5.py 4096 base=0:0 stream=8:0 t128=0:3
+usage: gpu_ab5.py P[,P2...] name=flags:tuning[:lo_width[:knob[:per_cu]]] ...      e.g.  gpu_ab5.py 4096 base=0:0 stream=8:0 t128=0:3 t128x2=0:3:-1:0:2
+(per_cu caps the resident workgroups per CU: development build)
 Results of every configuration are compared with the first one's (must be identical)."""
 import sys, os, time, ctypes as C
 # the lo_width / knob fields need the development build (make -C pydegensac_amd/csrc dev); flags and tuning work on the product library
@@ -13,7 +14,7 @@ Ps = [int(x) for x in sys.argv[1].split(",")]
 cfgs = []
 for a in sys.argv[2:]:
     name, rest = a.split("=", 1); parts = rest.split(":")
-    cfgs.append((name, int(parts[0], 0), int(parts[1], 0) if len(parts) > 1 else 0, int(parts[2]) if len(parts) > 2 else -1, int(parts[3], 0) if len(parts) > 3 else 0))
+    cfgs.append((name, int(parts[0], 0), int(parts[1], 0) if len(parts) > 1 else 0, int(parts[2]) if len(parts) > 2 else -1, int(parts[3], 0) if len(parts) > 3 else 0, int(parts[4]) if len(parts) > 4 else 0))
 N = 2000
 dev = torch.device('cuda', 0)
 def data(P):
@@ -40,11 +41,12 @@ def run(P, d, flags, tuning, reps=3):
 for P in Ps:
     d = data(P); ref = None
     for rnd in range(2):                                  # every configuration twice, interleaved (drift of the box shows)
-        for name, flags, tuning, low, knob in cfgs:
+        for name, flags, tuning, low, knob, percu in cfgs:
+            if hasattr(L, "mi_degensac_dev_set_per_cu"): L.mi_degensac_dev_set_per_cu(percu)
             if hasattr(L, "mi_degensac_dev_set_lo_width"): L.mi_degensac_dev_set_lo_width(low)
             if hasattr(L, "mi_degensac_dev_set_knob"): L.mi_degensac_dev_set_knob(knob)
             best, mean, streamed, longest, busy, F, m, st = run(P, d, flags, tuning)
             same = ""
             if ref is not None: same = " identical: %s" % (np.array_equal(ref[0], F) and np.array_equal(ref[1], m) and np.array_equal(ref[2][:, :12], st[:, :12]))
             else: ref = (F, m, st)
-            print(f"P={P:5d} {name:12s} best {best:7.2f} ms  mean {mean:7.2f} ms  streamed {streamed:4d}  longest pair {longest:6.1f} ms  sum of pair times {busy:9.1f} ms ({busy / 512:6.1f} per 512 slots){same}", flush=True)
+            print(f"P={P:5d} {name:12s} best {best:7.2f} ms  mean {mean:7.2f} ms  streamed {streamed:4d}  longest pair {longest:6.1f} ms  sum of pair times {busy:9.1f} ms ({busy / 512:6.1f} per 512 slots; mean pair {busy / P:6.2f} ms){same}", flush=True)

@@ -6,7 +6,8 @@ import sys, os, ctypes as C, numpy as np, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pydegensac_amd import _lib
 L = _lib.lib()
-grid, threads, dyn = 512, int(sys.argv[1]) if len(sys.argv) > 1 else 256, int(sys.argv[2]) if len(sys.argv) > 2 else 61440
+threads, dyn = int(sys.argv[1]) if len(sys.argv) > 1 else 256, int(sys.argv[2]) if len(sys.argv) > 2 else 61440
+grid = int(sys.argv[3]) if len(sys.argv) > 3 else 512
 nw = threads // 64
 o = np.zeros(grid * nw, np.int64)
 rc = L.mi_degensac_hwid_probe(grid, threads, dyn, o.ctypes.data_as(C.POINTER(C.c_longlong)))

@@ -47,4 +47,5 @@ for name, col in (("samples left", 0), ("LO runs so far", 1), ("degen so far", 2
     print("  corr(remaining busy, %s) = %.3f" % (name, np.corrcoef(X[:, col], y)[0, 1]))
 w, *_ = np.linalg.lstsq(X, y, rcond=None); pred = X @ w
 print("  linear fit on all five: corr %.3f; weights" % np.corrcoef(pred, y)[0, 1], np.round(w, 4))
+os.makedirs(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "tail"), exist_ok=True)
 np.save(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "tail", "park.npy"), np.concatenate([pk, busy_all[:, None], st[:, :6].astype(np.float64)], 1))
