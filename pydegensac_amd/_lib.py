@@ -12,7 +12,7 @@ STAT_NAMES = ["samples", "lo_runs", "rejected", "I", "models", "degen", "Ih", "b
 FLAG_FINAL_LAF_FILTER = 1
 FLAG_LEGACY_F = 2            # exp_ransacF / exp_ransacFcustom sample-budget rule (include/mi_degensac.h)
 # per-call scheduling switches (results never depend on them; they win over set_stream_mode / set_hjob_mode)
-FLAG_NO_STREAM, FLAG_STREAM_ON, FLAG_NO_HJOB = 4, 8, 16
+FLAG_NO_STREAM, FLAG_STREAM_ON, FLAG_NO_HJOB, FLAG_NO_MIX = 4, 8, 16, 32
 
 
 def FLAG_STREAM_TEST(b): return (int(b) & 3) << 8        # noqa: E704  with FLAG_STREAM_ON: bit 0 = owner re-scores, bit 1 = ask at once

@@ -233,6 +233,10 @@ struct dg_args {
     int *done_pairs;                 /* [0] pairs finished (header): workgroups without work leave when it reaches n_pairs; [1] open producer requests
                                         (stream mode); [2] open local-optimisation jobs (homography helpers) */
     dg_hjob_cb *hjob;                /* homography: [n_res] job control blocks, or null (no helper workgroups) */
+    int *xq;                         /* mixed-width launches (dg_f_sched.h, "cross queue"): the block both launches share, or null */
+    int xq_role;                     /* 0 = none; 1 = this launch TAKES pairs from the cross queue (the wide one); 2 = it PUSHES its long pairs there (the narrow one) */
+    int xq_cap;                      /* entries of the cross queue (= n_pairs) */
+    int xq_rule;                     /* wide side: how many unstarted pairs it may take (dg_xq_may_take): bits 0-7 = a x 256, 8-15 = b x 16, 16-23 = A0 / 16; 0 = defaults */
     int *err_flag;                   /* set when a hand-over wait times out: every pair that ends afterwards discards its results (zero model, zero mask,
                                         bit 10 of stats[15]) and the host-pointer entry points run those pairs again without helpers (dg_discard_if_failed) */
     int *trace;                      /* debug: [0] = count, then (tag, I, J lo, J hi) records; null = off */

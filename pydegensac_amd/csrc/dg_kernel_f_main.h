@@ -77,6 +77,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     unsigned &seed = D.seed;
     int &cur = D.cur, (&chunk_s)[3] = D.chunk_s, &chunk_base = D.chunk_base;
     int park_on = (A.park_sam > 0 && !resume) ? 1 : 0;
+    /* mixed-width launch, narrow side (dg_f_sched.h, cross queue): this pair's discovery round is still open */
+    int disc_open = (A.xq_role == 2 && !resume) ? 1 : 0;
 
   if (!resume) {
     t_start = wall_clock64();
@@ -255,6 +257,14 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                 } else if (act == 2) strm = 2;
             }
         }
+        if (disc_open && no_sam >= (A.park_sam > 0 ? A.park_sam : 1024)) {
+            /* narrow side of a mixed-width launch, end of the pair's discovery round: a pair with many samples left goes to the wide
+             * launch, which runs it again from its first sample on four waves (what was computed here is dropped: a result does not
+             * depend on who computes it); everything else stays (and may be set aside below) */
+            disc_open = 0;
+            if (max_sam - no_sam >= (A.park_long > 0 ? A.park_long : 8192) && dg_xq_push(A, pair, &S->itmp[30])) { dg_xq_discovered(A); return -2; }
+            dg_xq_discovered(A);
+        }
         if (park_on && no_sam >= A.park_sam) {
             /* still running after park_sam samples: set the pair aside if unstarted pairs remain and a spare workspace is left */
             park_on = 0;
@@ -307,16 +317,32 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             if (h_ < 0) { done = 1; break; }
             head_seen = h_;          /* everything below it is visible after this one acquire */
         }
+        DG_PH(0);                    /* development build: phase 0 = waiting for the producer's ring */
         const dg_stream_ent *e_ = dg_stream_entry(A, oslot, seq);
+        __syncthreads();
+        if (tid == 0) { S->itmp[24] = e_->cn; S->itmp[25] = e_->Mtot; S->itmp[26] = e_->n_ev; S->itmp[27] = e_->overflow; S->dtmp[31] = e_->tau_used; }
+        __syncthreads();
+        const int cn_ = S->itmp[24], n_ev = S->itmp[26], ovf = S->itmp[27];
+        const double tau_used = S->dtmp[31], tau_now = A.hist_out ? 0.0 : (maxS.J < maxSs.J ? maxS.J : maxSs.J);
+        /* An uneventful chunk: the producer found no model above a bound that is still at most the pair's (so none is above the pair's
+         * bound now), the samples before it are past the point where every sample has side effects (DG_ITER_SAM) and the budget does
+         * not end inside it.  The commit would skip all of its samples in one step (the event search finds nothing): do exactly that,
+         * without staging its seeds, ids and tables — a long pair's owner spent ~64 us per such chunk, 25 of its 40-50 ms (round 6).  The last
+         * chunk of the budget always takes the ordinary path: what runs after the loop reads its seeds. */
+        if (n_ev == 0 && !ovf && !(tau_used > tau_now) && !(A.stream_test & 1) && no_sam >= DG_ITER_SAM && cn_ > 0 && no_sam + cn_ < max_sam) {
+            const int Mt_ = S->itmp[25];
+            __syncthreads();                                /* (the header words are read; the next iteration rewrites them) */
+            track = 0;
+            no_sam += cn_; c.n_fds += Mt_;
+            DG_DEVT(if (tid == 0) S->dbg[5] += 100000);      /* development build: chunks taken this way (tools/gpu_phases.py: "draws" of a streamed pair, x 1e5) */
+            continue;
+        }
         for (int i = tid; i < DG_CHUNK; i += DG_T) {
             S->seeds3[cur][i] = e_->seeds[i];
 #pragma unroll
             for (int q = 0; q < 8; q++) S->draws3[cur][i][q] = e_->draws[i][q];
         }
-        if (tid == 0) { S->itmp[24] = e_->cn; S->itmp[25] = e_->Mtot; S->itmp[26] = e_->n_ev; S->itmp[27] = e_->overflow; S->dtmp[31] = e_->tau_used; }
         __syncthreads();
-        const int cn_ = S->itmp[24], n_ev = S->itmp[26], ovf = S->itmp[27];
-        const double tau_used = S->dtmp[31], tau_now = A.hist_out ? 0.0 : (maxS.J < maxSs.J ? maxS.J : maxSs.J);
         chunk = cn_ < max_sam - no_sam ? cn_ : max_sam - no_sam;
         /* more models above the producer's bound than an entry holds (the first chunks of a pair), or the bound has fallen since
          * the producer screened this chunk (a DEGENSAC completion can lower maxS.J: its screens are no superset any more):
@@ -1051,6 +1077,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         }
     }
     if (A.done_pairs && tid == 0) __hip_atomic_fetch_add(A.done_pairs, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (disc_open) dg_xq_discovered(A);            /* (the pair ended inside its discovery round) */
     DG_PH(6);
 #ifdef DG_LO_PROF
     if (A.phase_out && tid == 0) { for (int i = 0; i < 16; i++) A.phase_out[(size_t)pair * 16 + i] = S->lt[i]; }
@@ -1067,7 +1094,12 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
 __device__ __forceinline__ int dg_next_pair(const dg_args &A, int *bc /* LDS */)
 {
     __syncthreads();
-    if (threadIdx.x == 0) *bc = atomicAdd(A.ticket, 1);
+    if (threadIdx.x == 0) {
+        const int t_ = atomicAdd(A.ticket, 1);
+        *bc = t_;
+        /* mixed-width launch, wide side: the tickets this launch took (the narrow side counts the pairs it has discovered) */
+        if (A.xq_role == 1 && t_ < A.n_pairs) __hip_atomic_fetch_add(A.xq + DG_XQ_WTICK, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     const int t = *bc;
     if (t >= A.n_pairs) return -1;
@@ -1107,6 +1139,8 @@ __global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_fundamental_kernel(dg_a
     if (threadIdx.x == 0) As = A;
     __syncthreads();
     int slot = (int)blockIdx.x, coop_gen = 0;
+    /* development build: when this workgroup started, and which half of a mixed-width launch it belongs to (the narrow half's records sit 1024 rows up) */
+    DG_DEVT(if (As.phase_out && threadIdx.x == 0) { long long *o_ = As.phase_out + ((size_t)As.n_pairs + blockIdx.x + (As.xq_role == 2 ? 1024 : 0)) * 16; o_[10] = DG_CLK(); o_[11] = As.xq_role; });
     if (LDSPTS == 0 && As.coop_k > 0) {
         /* cooperative large-n mode: block b = owner of slot b / (k+1) when b % (k+1) == 0, else one of its helpers */
         slot = (int)blockIdx.x / (As.coop_k + 1);
@@ -1122,12 +1156,19 @@ __global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_fundamental_kernel(dg_a
          * (The queues can look empty one after the other while another workgroup queues a pair in between: that workgroup
          * takes it itself on its next round.) */
         int resume = 0;
-        int pair = dg_next_pair(As, &next_pair);
+        /* mixed-width launch, wide side: the long pairs the narrow launch has discovered come first (they run longest) */
+        int pair = As.xq_role == 1 ? dg_xq_take(As, &next_pair, 0) : -1;
+        if (pair < 0 && (As.xq_role != 1 || dg_xq_may_take(As, &next_pair))) pair = dg_next_pair(As, &next_pair);
         if (pair < 0 && As.park_sam > 0) {
             long long e = dg_park_take(As, &next_parked, 1);
             if (e < 0) e = dg_park_take(As, &next_parked, 0);
             if (e < 0) e = dg_park_take(As, &next_parked, 1);
             if (e >= 0) { pair = (int)(e >> 32); wsid = (int)(e & 0xffffffffll); resume = 1; }   /* the image lives in the pair's own workspace */
+        }
+        /* ... and with nothing else left, wait for them as long as narrow workgroups are still in discovery rounds */
+        if (pair < 0 && As.xq_role == 1) {
+            pair = dg_xq_take(As, &next_pair, 1);
+            if (pair == -3) { pair = dg_next_pair(As, &next_pair); if (pair < 0) continue; }       /* (idle with unstarted pairs left: take one) */
         }
         int img_wsid = wsid, oslot = slot;
         if (pair < 0 && As.stream_on) {
@@ -1138,14 +1179,14 @@ __global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_fundamental_kernel(dg_a
         if (pair < 0) break;
         const int spare = dg_f_pair<T, LDSPTS>(As, &Sh, dyn_smem, pair, slot, img_wsid, resume, coop_gen, wsid, oslot);
         if (spare >= 0) wsid = spare;                /* the pair was set aside with its workspace */
-        else if (resume != 2) dg_discard_if_failed(As, pair, &next_pair);
+        else if (spare == -1 && resume != 2) dg_discard_if_failed(As, pair, &next_pair);      /* (-2: the pair went to the wide launch of a mixed-width batch) */
     }
     if (LDSPTS == 0 && As.coop_k > 0 && threadIdx.x == 0)          /* retire the slot: its helpers leave */
         __hip_atomic_store(&As.coop[slot].gen, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     /* development build: when this workgroup ran out of work (tools/gpu_sched.py: the tail of a launch) */
-    DG_DEVT(if (As.phase_out && threadIdx.x == 0) As.phase_out[((size_t)As.n_pairs + blockIdx.x) * 16] = DG_CLK());
+    DG_DEVT(if (As.phase_out && threadIdx.x == 0) As.phase_out[((size_t)As.n_pairs + blockIdx.x + (As.xq_role == 2 ? 1024 : 0)) * 16] = DG_CLK());
     /* ... and where its waves sit: HW_ID | XCC_ID << 32 per wave (tools/gpu_simd.py: which SIMDs the serial waves of co-resident workgroups share) */
-    DG_DEVT(if (As.phase_out && (threadIdx.x & 63) == 0) As.phase_out[((size_t)As.n_pairs + blockIdx.x) * 16 + 1 + (threadIdx.x >> 6)] =
+    DG_DEVT(if (As.phase_out && (threadIdx.x & 63) == 0) As.phase_out[((size_t)As.n_pairs + blockIdx.x + (As.xq_role == 2 ? 1024 : 0)) * 16 + 1 + (threadIdx.x >> 6)] =
                 (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32));
 
 }

@@ -14,7 +14,8 @@ Ps = [int(x) for x in sys.argv[1].split(",")]
 cfgs = []
 for a in sys.argv[2:]:
     name, rest = a.split("=", 1); parts = rest.split(":")
-    cfgs.append((name, int(parts[0], 0), int(parts[1], 0) if len(parts) > 1 else 0, int(parts[2]) if len(parts) > 2 else -1, int(parts[3], 0) if len(parts) > 3 else 0, int(parts[4]) if len(parts) > 4 else 0))
+    cfgs.append((name, int(parts[0], 0), int(parts[1], 0) if len(parts) > 1 else 0, int(parts[2]) if len(parts) > 2 else -1, int(parts[3], 0) if len(parts) > 3 else 0, int(parts[4]) if len(parts) > 4 else 0,
+                 int(parts[5], 0) if len(parts) > 5 else 0, int(parts[6]) if len(parts) > 6 else 1, int(parts[7]) if len(parts) > 7 else 2))      # mixed-width: rule word, wide / narrow workgroups per CU
 N = 2000
 dev = torch.device('cuda', 0)
 def data(P):
@@ -41,7 +42,8 @@ def run(P, d, flags, tuning, reps=3):
 for P in Ps:
     d = data(P); ref = None
     for rnd in range(2):                                  # every configuration twice, interleaved (drift of the box shows)
-        for name, flags, tuning, low, knob, percu in cfgs:
+        for name, flags, tuning, low, knob, percu, rule, mw, mn in cfgs:
+            if hasattr(L, "mi_degensac_dev_set_mix"): L.mi_degensac_dev_set_mix(-1 if (mw != 1 or mn != 2 or rule or name.startswith("mix")) else 0, -rule, mw, mn)      # mixed-width launches are off by default
             if hasattr(L, "mi_degensac_dev_set_per_cu"): L.mi_degensac_dev_set_per_cu(percu)
             if hasattr(L, "mi_degensac_dev_set_lo_width"): L.mi_degensac_dev_set_lo_width(low)
             if hasattr(L, "mi_degensac_dev_set_knob"): L.mi_degensac_dev_set_knob(knob)
@@ -49,4 +51,9 @@ for P in Ps:
             same = ""
             if ref is not None: same = " identical: %s" % (np.array_equal(ref[0], F) and np.array_equal(ref[1], m) and np.array_equal(ref[2][:, :12], st[:, :12]))
             else: ref = (F, m, st)
+            thr = st[:, 14]
+            if len(set(thr.tolist())) > 1:          # a mixed-width launch: who ran what
+                for t_ in sorted(set(thr.tolist())):
+                    m_ = thr == t_; b_ = st[m_, 13].astype(np.float64) / 1e5; full_ = st[m_, 0] >= 99999
+                    print(f"        {t_:4d} threads: pairs {int(m_.sum()):5d}  sum {b_.sum():9.1f} ms  mean {b_.mean():6.2f}  longest {b_.max():6.1f}  pairs with the whole budget {int(full_.sum())}  set aside {int(((st[m_, 15] >> 8) & 1).sum())}", flush=True)
             print(f"P={P:5d} {name:12s} best {best:7.2f} ms  mean {mean:7.2f} ms  streamed {streamed:4d}  longest pair {longest:6.1f} ms  sum of pair times {busy:9.1f} ms ({busy / 512:6.1f} per 512 slots; mean pair {busy / P:6.2f} ms){same}", flush=True)
