@@ -1,0 +1,152 @@
+/* Fan mode of the fundamental-matrix kernel (dg_args::fan_k; one pair of many thousand correspondences on an otherwise idle device: C5).
+ * The cooperative large-n mode hands every chunk of 256 samples to its helper workgroups in two stages (screening counts over point
+ * slices, then exact scoring of the survivors) and waits for each: two hand-overs per chunk, 80 us per chunk against the 34 us the
+ * seed chain needs.  Here nothing waits per chunk: the OWNER draws the sample stream chunk after chunk (seed chain,
+ * draws, pool swaps: outcome-independent, exp_ranF.c:1337-1342) and writes each chunk's seeds and drawn ids into the entry of the
+ * stream mode's ring; WORKER workgroups (fan_k per owner) claim entries as they appear, solve the chunk's 7-point problems, screen and
+ * score its models against the owner's points with the owner's current bound, and complete the entry exactly as a stream-mode
+ * producer would (models per sample, the few models above the bound); the owner commits the completed entries in order, some tens
+ * of chunks behind its sampler — an entry without a model above the bound is one addition (dg_f_pair, "uneventful chunk").  The
+ * cooperative helpers stay for what does need the whole device at once: the passes and repetitions of the local optimisations, and the
+ * chunks the owner has to score itself (the first one; a chunk whose bound has fallen).
+ * Hand-over: plain payload, one agent-scope release, then a relaxed agent-scope word on its own 128-byte line (scb->head for "ids
+ * published", fan_flags[] for "entry complete"); nobody waits for a workgroup that may not be running: a worker waits for ids only
+ * while its owner has opened the pair (and for at most wait_ticks), the owner waits for an entry a running worker has claimed.
+ * Part of the fundamental-matrix kernel: included by dg_kernel_f_main.h after dg_f_sched.h. */
+#ifndef DG_F_FAN_H
+#define DG_F_FAN_H
+
+__device__ __forceinline__ int *dg_fan_flag(const dg_args &A, int oslot, int seq)
+{
+    return A.fan_flags + ((size_t)oslot * A.stream_depth + (size_t)(seq % A.stream_depth)) * 32;
+}
+
+/* worker `widx` of owner slot `oslot`, on workspace `wsid`: serves the one pair its owner opens, then leaves */
+template <int T>
+__device__ __noinline__ void dg_f_fan_worker(const dg_args &A, dg_f_shared *S, const int oslot, const int wsid, int *bc /* LDS */)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    dg_stream_cb *const scb = A.scb + oslot;
+    /* the owner opens its pair (state ATTACHED) or the launch ends without one for this slot */
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(wave) == 0) {
+        int res = 0;
+        const long long t0 = wall_clock64();
+        for (;;) {
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&scb->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == DG_ST_ATTACHED) { res = 1; break; }
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&scb->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(A.done_pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= A.n_pairs) break;
+            if (wall_clock64() - t0 > 4 * (long long)A.wait_ticks + 1000000ll) break;             /* (an owner that never starts: leave) */
+            __builtin_amdgcn_s_sleep(32);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *bc = res;
+    }
+    __syncthreads();
+    if (!*bc) return;
+    __syncthreads();
+    const int pair = scb->pair, kind = scb->fan_kind;
+    const double th = scb->fan_th;
+    const long long off = A.offsets[pair];
+    const int n = (int)(A.offsets[pair + 1] - off);
+    char *const ws = A.ws + (size_t)wsid * A.wl.stride;
+    const dg_pt *P = (const dg_pt *)(A.ws + (size_t)scb->wsid * A.wl.stride + A.wl.off_pts);          /* the owner's staged correspondences */
+    if (tid == 0) dg_fill_views(&S->K, ws, A.wl);
+    if (tid < 4) S->ext[tid] = scb->fan_ext[tid];
+    __syncthreads();
+    const __attribute__((address_space(3))) dg_f_cshared *K = (const __attribute__((address_space(3))) dg_f_cshared *)&S->K;
+    for (;;) {
+        /* claim the next chunk whose ids are in the ring */
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(wave) == 0) {
+            int seq = -1;
+            const long long t0 = wall_clock64();
+            for (;;) {
+                if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&scb->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
+                const int cl = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&scb->claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                const int ms = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&scb->max_sam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if ((long long)cl * DG_CHUNK >= (long long)ms) break;                              /* the owner's budget ends before that chunk */
+                const int hd = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&scb->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (cl < hd) {
+                    int ok = 0;
+                    if (lane == 0) { int e = cl; ok = __hip_atomic_compare_exchange_strong(&scb->claim, &e, cl + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0; }
+                    if (__builtin_amdgcn_readfirstlane(ok)) { seq = cl; break; }
+                    continue;
+                }
+                if (wall_clock64() - t0 > 4 * (long long)A.wait_ticks + 1000000ll) break;         /* (the owner is a running workgroup: it publishes or stops) */
+                __builtin_amdgcn_s_sleep(8);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            *bc = seq;
+        }
+        __syncthreads();
+        const int seq = *bc;
+        __syncthreads();
+        if (seq < 0) break;
+        dg_stream_ent *ent = dg_stream_entry(A, oslot, seq);
+        const int chunk = ent->cn;
+        const double tau_c = __longlong_as_double((long long)__hip_atomic_load(&scb->tau_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        /* solve: one 7-point problem per lane; ordered model slots by an exclusive scan (as the owner's own solve phase) */
+        int nvalid = 0, nullbad = 0; unsigned rixp = 0;
+        if (tid < chunk) {
+            const int r_ = dg_solve7_lane(P, ent->draws[tid], K->gmodels + (size_t)tid * 27, &rixp, (double *)&S->ww[wave]);
+            if (r_ < 0) nullbad = 1; else nvalid = r_;
+        }
+        {
+            unsigned v = (unsigned)nvalid, incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            if (lane == 63) S->wave_cnt[wave] = incl;
+            __syncthreads();
+            unsigned wbase = 0;
+            for (int w = 0; w < wave; w++) wbase += S->wave_cnt[w];
+            const unsigned excl = wbase + incl - v;
+            if (tid < chunk) {
+                S->moff[tid] = (unsigned short)excl;
+                S->nv[tid] = nullbad ? 255 : (unsigned char)nvalid;
+                S->nsolv[tid] = (unsigned char)((rixp >> 8) & 3u);
+                for (int r = 0; r < nvalid; r++) { S->ridx[tid][r] = (unsigned char)((rixp >> (2*r)) & 3u); S->mslot[excl + r] = (unsigned short)(tid * 3 + r); }
+            }
+            if (tid == T - 1) S->moff[DG_CHUNK] = (unsigned short)(excl + v);
+            __syncthreads();
+        }
+        const int Mtot = __builtin_amdgcn_readfirstlane((int)S->moff[DG_CHUNK]);
+        {
+            const int capr = (int)((sizeof(dg_lsq_scratch) / DG_NW) & ~(size_t)15);
+            dg_score_chunk_F<0>(P, n, K->gmodels, S->mslot, Mtot, wave, DG_NW, kind, th, tau_c, S->ext, (char *)&S->lsq + (size_t)wave * capr, capr,
+                                (double *)(K->wstage + (size_t)wave * K->n_max), K->res_I, K->res_J, lane, (unsigned *)0, 0, n < 8192);
+        }
+        __syncthreads();
+        /* complete the entry: models per sample, the models above the bound (only such a model can be an event of the owner's commit) */
+        if (tid == 0) S->itmp[24] = 0;
+        __syncthreads();
+        if (tid < DG_CHUNK) {
+            const unsigned char nvb = tid < chunk ? S->nv[tid] : (unsigned char)0;
+            ent->nv[tid] = nvb;
+            if (tid < chunk && nvb != 255)
+                for (int r = 0; r < (int)nvb; r++) {
+                    const int mi = (int)S->moff[tid] + r;
+                    const double J_ = K->res_J[mi];
+                    if (J_ > tau_c) {
+                        const int sl = atomicAdd(&S->itmp[24], 1);
+                        if (sl < DG_STREAM_EV_MAX) {
+                            dg_stream_ev *ev = &ent->ev[sl];
+                            ev->J = J_; ev->I = K->res_I[mi]; ev->k = (short)tid; ev->r = (unsigned char)r; ev->pad = 0;
+#pragma unroll
+                            for (int j = 0; j < 9; j++) ev->model[j] = K->gmodels[(size_t)S->mslot[mi] * 9 + j];
+#pragma unroll
+                            for (int q = 0; q < 4; q++) ev->ridx[q] = S->ridx[tid][q];
+                        }
+                    }
+                }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int ne = S->itmp[24];
+            ent->Mtot = Mtot; ent->n_ev = ne < DG_STREAM_EV_MAX ? ne : DG_STREAM_EV_MAX; ent->overflow = ne > DG_STREAM_EV_MAX ? 1 : 0; ent->tau_used = tau_c;
+        }
+        dg_stream_publish(dg_fan_flag(A, oslot, seq), seq + 1);
+    }
+}
+
+#endif /* DG_F_FAN_H */

@@ -18,7 +18,9 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
                                              char *tab /* LDS, this wave's */, int tab_bytes,
                                              double *jbuf /* this wave's scratch, >= n doubles */, unsigned *res_I, double *res_J, int lane,
                                              unsigned *scnt /* LDS[4]: dg_f_shared::scnt; null = do not count (a second scoring of the same chunk) */,
-                                             int m_first = 0 /* only the models mi >= m_first (the commit's re-scoring of the rest of a chunk) */)
+                                             int m_first = 0 /* only the models mi >= m_first (the commit's re-scoring of the rest of a chunk) */,
+                                             bool allow_l1 = true /* false: level 2 only (large point sets with few inliers: random models have far more
+                                                                     points inside the looser level-1 band than the bound to beat) */)
 {
     /* workgroup-uniform arguments arrive in vector registers (separate function): make the loop control scalar again */
     n = __builtin_amdgcn_readfirstlane(n); Mtot = __builtin_amdgcn_readfirstlane(Mtot); ws = __builtin_amdgcn_readfirstlane(ws);
@@ -26,7 +28,7 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
     m_first = __builtin_amdgcn_readfirstlane(m_first);
     const double t94 = th * 9 / 4, t94b = t94 * (1.0 + 1e-6);
     const bool use_bound = th != 0 && kind != DG_K_EXFSYM && tauJ >= 4.0;
-    const bool use_l1 = use_bound && tauJ >= 64.0;
+    const bool use_l1 = use_bound && allow_l1 && tauJ >= 64.0;
     const int nm = Mtot > ws ? (Mtot - ws + NS - 1) / NS : 0;
     int B1 = tab_bytes / (DG_L1_ENTRY_FLOATS * (int)sizeof(float)), B2 = tab_bytes / (DG_L2_ENTRY_DOUBLES * (int)sizeof(double));
     B1 = B1 > 64 ? 64 : B1; B2 = B2 > 64 ? 64 : B2;

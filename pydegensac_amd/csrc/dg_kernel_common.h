@@ -151,9 +151,12 @@ struct dg_stream_cb {
     int owner_sam;            /* since when the pair has been worked on (wall_clock64 >> 10): producers take the oldest of the requests with the most samples left */
     int max_sam;              /* the owner's current sample budget */
     unsigned long long tau_bits;   /* the owner's current bound min(maxS.J, maxSs.J), as the bits of a double */
-    int fpad[24];
+    int claim;                /* fan mode: next chunk (sequence number) a worker may claim; head = chunks whose drawn ids are in the ring */
+    int fpad[23];
     /* second line: written by the owner before the release that opens the request */
-    int pair, wsid, img_sam, ppad[29];
+    int pair, wsid, img_sam, fan_kind;        /* fan mode: the metric of the main loop's scoring (DG_K_*) */
+    double fan_th, fan_ext[4];                /* fan mode: threshold and coordinate extents of the pair (the screens' bounds) */
+    int ppad[18];
 };
 static_assert(sizeof(dg_stream_cb) == 256, "stream control block = two 128-byte lines");
 
@@ -233,6 +236,12 @@ struct dg_args {
     int *done_pairs;                 /* [0] pairs finished (header): workgroups without work leave when it reaches n_pairs; [1] open producer requests
                                         (stream mode); [2] open local-optimisation jobs (homography helpers) */
     dg_hjob_cb *hjob;                /* homography: [n_res] job control blocks, or null (no helper workgroups) */
+    /* Fan mode (fundamental matrix, one large pair per owner, everything in the HBM workspace; dg_f_fan.h): the owner draws the sample stream
+     * and commits; fan_k WORKER workgroups per owner claim whole chunks of drawn ids from the owner's ring, solve and score them against the
+     * owner's points and leave the stream mode's chunk entries; the cooperative helpers keep the local optimisations' stages. */
+    int fan_k;                       /* worker workgroups per owner; 0 = off */
+    int fan_ws0;                     /* workspace index of the first worker (worker w of owner o: fan_ws0 + o * fan_k + w) */
+    int *fan_flags;                  /* [n_res][stream_depth] "entry done" words, one 128-byte line each (agent-scope atomics only): seq + 1 */
     int *xq;                         /* mixed-width launches (dg_f_sched.h, "cross queue"): the block both launches share, or null */
     int xq_role;                     /* 0 = none; 1 = this launch TAKES pairs from the cross queue (the wide one); 2 = it PUSHES its long pairs there (the narrow one) */
     int xq_cap;                      /* entries of the cross queue (= n_pairs) */

@@ -11,6 +11,7 @@
 #include "dg_f_sampler.h"
 #include "dg_f_score.h"
 #include "dg_f_sched.h"
+#include "dg_f_fan.h"
 #include "dg_f_coop.h"
 
 /* the whole driver for ONE pair, run by one workgroup on workspace `wsid` (a resident workgroup starts on the workspace
@@ -24,7 +25,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                                          const int resume, int &coop_gen, const int own_wsid, const int oslot)
 {
     const int producer = resume == 2;
-    dg_stream_cb *const scb = A.stream_on ? A.scb + oslot : (dg_stream_cb *)0;
+    dg_stream_cb *const scb = (A.stream_on || A.fan_k > 0) ? A.scb + oslot : (dg_stream_cb *)0;
     int head_seen = 0;               /* owner: ring entries below this sequence number are known to be visible */
     int gpar = 0, pend_draws = 0;    /* deep pipeline: the seed buffer this iteration's chain writes; the chunk in slot nx2 still needs its draws (its seeds are in the other buffer) */
     int mtab = 0, presolved = 0;     /* cooperative mode: the model table of the current chunk; samples of the current chunk that were solved during the previous chunk's scoring */
@@ -34,7 +35,11 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     /* cooperative mode with eight waves: the sampler runs one chunk further ahead (pool swaps of chunk c + 2, seed chain of chunk c + 3),
      * so that the 7-point problems of chunk c + 1 can be solved from the start of the phase in which the helpers score chunk c */
-    const bool deep = DG_NW >= 8 && LDSPTS == 0 && coopK > 0 && !A.hist_out;
+    /* fan mode (dg_f_fan.h): this workgroup draws the sample stream into the ring, worker workgroups solve and score the chunks, the
+     * commit below takes the completed entries in order (the stream mode's consumer path, strm == 2, from the first chunk on) */
+    const bool fan = LDSPTS == 0 && A.fan_k > 0 && coopK > 0 && !resume && !(A.prm.legacy && A.prm.sym_th > 0);
+    int f_cur = 0, f_pub = 0, f_sam = 0, f_ch[3] = {0, 0, 0};     /* fan sampler: ring slot of the next chunk to publish, chunks / samples published, chunk sizes per slot */
+    const bool deep = DG_NW >= 8 && LDSPTS == 0 && coopK > 0 && !A.hist_out && !fan;
     const long long off = A.offsets[pair];
     const int n = (int)(A.offsets[pair + 1] - off);
     const dg_params &pr = A.prm;
@@ -151,6 +156,22 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         if (deep) { int cn2_ = max_sam - no_sam - cn0 - cn1; if (cn2_ > DG_CHUNK) cn2_ = DG_CHUNK; if (cn2_ < 0) cn2_ = 0; chunk_s[2] = cn2_; }
         __syncthreads();
         seed = (unsigned)S->itmp[31];
+        if (fan) {
+            /* open the pair for this slot's workers: parameters, counters, one release, then the state word */
+            f_ch[0] = cn0; f_ch[1] = cn1; f_ch[2] = 0;
+            if (tid == 0) {
+                scb->pair = pair; scb->wsid = wsid; scb->img_sam = 0; scb->fan_kind = mk_full; scb->fan_th = th;
+                for (int i = 0; i < 4; i++) scb->fan_ext[i] = S->ext[i];
+                __hip_atomic_store(&scb->tau_bits, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&scb->max_sam, max_sam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&scb->tail, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&scb->head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&scb->claim, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&scb->stop, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            dg_stream_publish(&scb->state, DG_ST_ATTACHED);
+            strm = 2;
+        }
     }
   } else {
     /* continue a pair that was set aside: its LDS image, then the driver state the image carries */
@@ -180,7 +201,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         int coop_no_ev = 0;          /* cooperative mode: the screen left no survivor: no model of this chunk can be an event of the commit */
         int pre_cnt = 0, cn3 = 0;    /* cooperative mode: samples of the next chunk solved during this one's scoring; size of the chunk whose seed chain runs in this iteration (deep pipeline) */
         int ff = 0, tail_p = 0;      /* producer: the owner is already past this chunk: sampler stages only; the owner's position */
-        const int seq = no_sam / DG_CHUNK;
+        int seq = no_sam / DG_CHUNK;
         dg_stream_ent *ent = (dg_stream_ent *)0;
         if (producer) {
             /* what the owner says: done?  its budget, its position, its bound */
@@ -257,6 +278,99 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                 } else if (act == 2) strm = 2;
             }
         }
+        if (fan) {
+            /* fan mode: one step of the sampler (the chunk in slot f_cur has its drawn ids: into the ring with it; pool swaps of the next
+             * chunk on wave 0, seed chain of the one behind on wave 1, its draws afterwards), then the commit of entry `seq` if a worker
+             * has completed it; without either, wait for that entry */
+            bool ready = false;
+            DG_PH(3);
+            for (;;) {
+                const bool can = f_ch[f_cur] > 0 && f_sam < max_sam && f_pub - seq < A.stream_depth - 1;
+                if (can) {
+                    const int fnxt = f_cur == 2 ? 0 : f_cur + 1, fnx2 = fnxt == 2 ? 0 : fnxt + 1;
+                    int fc2 = max_sam - (f_sam + f_ch[f_cur] + f_ch[fnxt]); if (fc2 > DG_CHUNK) fc2 = DG_CHUNK; if (fc2 < 0) fc2 = 0;
+                    dg_stream_ent *fe = dg_stream_entry(A, oslot, f_pub);
+                    if (DG_NW >= 8) {
+                        /* eight waves, one phase: 0 = pool swaps of the next chunk, 1 = seed chain of the one behind, 2-5 = its draws, one block of
+                         * 64 samples each, as soon as the chain has stored the block's seeds (LDS progress word), 6 = this chunk's seeds and ids
+                         * into its ring entry, 7 = the scout: how many of the next entries are complete and uneventful (dg_f_pair, "uneventful
+                         * chunk"), so that the workgroup takes them in one step behind the phase */
+                        const double tau_now = maxS.J < maxSs.J ? maxS.J : maxSs.J;
+                        __syncthreads();
+                        if (tid == 0) { S->itmp[23] = 0; S->itmp[20] = 0; S->itmp[21] = no_sam; S->itmp[22] = 0; }
+                        __syncthreads();
+                        if (wave == 0) { if (f_ch[fnxt] > 0) dg_sample_pool<7, LDSPTS>(f_ch[fnxt], n, pool, S->draws3[fnxt], S->alm3[fnxt], pscr, lane, S->dbg); }
+                        else if (wave == 1) { if (fc2 > 0) { const unsigned sd = dg_sample_chain<7>(seed, fc2, S->seeds3[fnx2], lane, S->dbg, &S->itmp[23]); if (lane == 0) S->itmp[31] = (int)sd; } }
+                        else if (wave < 2 + DG_CHUNK / 64) {
+                            const int rd = wave - 2;
+                            if (rd * 64 < fc2) {
+                                const int need = (rd + 1) * 64 < fc2 ? (rd + 1) * 64 : fc2;
+                                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&S->itmp[23], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(24);      /* (a poll every ~0.6 us: the chain wave shares its SIMD with one of these) */
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                                dg_sample_draws_round<7>(rd, fc2, n, S->seeds3[fnx2], S->draws3[fnx2], S->alm3[fnx2], lane, S->dbg);
+                            }
+                        } else if (wave == 6) {
+                            for (int i = lane; i < DG_CHUNK; i += 64) {
+                                fe->seeds[i] = S->seeds3[f_cur][i];
+#pragma unroll
+                                for (int q = 0; q < 8; q++) fe->draws[i][q] = S->draws3[f_cur][i][q];
+                            }
+                            if (lane == 0) fe->cn = f_ch[f_cur];
+                        } else {
+                            int cnt = 0, ns = no_sam, msum = 0;
+                            for (int s_ = seq; cnt < 32 && s_ < f_pub; s_++) {
+                                if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(dg_fan_flag(A, oslot, s_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != s_ + 1) break;
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                                const dg_stream_ent *q_ = dg_stream_entry(A, oslot, s_);
+                                const int cn_ = __builtin_amdgcn_readfirstlane(q_->cn), mt_ = __builtin_amdgcn_readfirstlane(q_->Mtot);
+                                const int ne_ = __builtin_amdgcn_readfirstlane(q_->n_ev), ov_ = __builtin_amdgcn_readfirstlane(q_->overflow);
+                                const double tu_ = q_->tau_used;
+                                const bool quiet = ne_ == 0 && !ov_ && !(tu_ > tau_now) && !(A.stream_test & 1) && ns >= DG_ITER_SAM && cn_ > 0 && ns + cn_ < max_sam;
+                                if (!__builtin_amdgcn_readfirstlane(quiet ? 1 : 0)) break;
+                                ns += cn_; msum += mt_; cnt++;
+                            }
+                            if (lane == 0) { S->itmp[20] = cnt; S->itmp[21] = ns; S->itmp[22] = msum; }
+                        }
+                        __syncthreads();
+                        if (fc2 > 0) seed = (unsigned)S->itmp[31];
+                        if (S->itmp[20] > 0) {
+                            DG_DEVT(if (tid == 0) S->dbg[5] += 100000ll * S->itmp[20]);
+                            no_sam = S->itmp[21]; c.n_fds += S->itmp[22]; track = 0;
+                            seq = no_sam / DG_CHUNK;
+                        }
+                    } else {
+                        __syncthreads();
+                        if (wave == 0) { if (f_ch[fnxt] > 0) dg_sample_pool<7, LDSPTS>(f_ch[fnxt], n, pool, S->draws3[fnxt], S->alm3[fnxt], pscr, lane, S->dbg); }
+                        else if (wave == 1 % DG_NW) { if (fc2 > 0) { const unsigned sd = dg_sample_chain<7>(seed, fc2, S->seeds3[fnx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; } }
+                        __syncthreads();
+                        if (fc2 > 0) seed = (unsigned)S->itmp[31];
+                        for (int i = tid; i < DG_CHUNK; i += DG_T) {
+                            fe->seeds[i] = S->seeds3[f_cur][i];
+#pragma unroll
+                            for (int q = 0; q < 8; q++) fe->draws[i][q] = S->draws3[f_cur][i][q];
+                        }
+                        if (tid == 0) fe->cn = f_ch[f_cur];
+                        if (fc2 > 0 && wave < DG_CHUNK / 64)
+                            for (int rd = wave; rd < DG_CHUNK / 64; rd += DG_NW) dg_sample_draws_round<7>(rd, fc2, n, S->seeds3[fnx2], S->draws3[fnx2], S->alm3[fnx2], lane, S->dbg);
+                    }
+                    dg_stream_publish(&scb->head, f_pub + 1);
+                    f_sam += f_ch[f_cur]; f_pub++; f_ch[f_cur] = 0; f_ch[fnx2] = fc2; f_cur = fnxt;
+                }
+                __syncthreads();
+                if (tid == 0) S->itmp[30] = (seq < f_pub && __hip_atomic_load(dg_fan_flag(A, oslot, seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq + 1) ? 1 : 0;
+                __syncthreads();
+                ready = S->itmp[30] != 0;
+                __syncthreads();
+                if (ready || !can) break;
+            }
+            DG_PH(2);                    /* development build: phase 2 = the sampler steps of the fan mode, phase 0 = waiting for a worker's entry */
+            if (!ready) {
+                const int want = seq + 1;
+                if (dg_stream_wait(A, dg_fan_flag(A, oslot, seq), (int *)0, [=](int v) { return v == want; }, &S->itmp[28], A.wait_ticks) < 0) { done = 1; break; }
+            } else if (__builtin_amdgcn_readfirstlane(wave) == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __syncthreads();
+            DG_PH(0);
+        }
         if (disc_open && no_sam >= (A.park_sam > 0 ? A.park_sam : 1024)) {
             /* narrow side of a mixed-width launch, end of the pair's discovery round: a pair with many samples left goes to the wide
              * launch, which runs it again from its first sample on four waves (what was computed here is dropped: a result does not
@@ -312,7 +426,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
       int full = 1;                   /* the chunk's 7-point solves and scoring run in this workgroup */
       if (strm == 2) {
         /* ================= the chunk comes from the producer's ring ================= */
-        if (seq >= head_seen) {
+        if (!fan && seq >= head_seen) {
             const int h_ = dg_stream_wait(A, &scb->head, (int *)0, [=](int h) { return h > seq; }, &S->itmp[28], A.wait_ticks);
             if (h_ < 0) { done = 1; break; }
             head_seen = h_;          /* everything below it is visible after this one acquire */
@@ -337,10 +451,15 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             DG_DEVT(if (tid == 0) S->dbg[5] += 100000);      /* development build: chunks taken this way (tools/gpu_phases.py: "draws" of a streamed pair, x 1e5) */
             continue;
         }
-        for (int i = tid; i < DG_CHUNK; i += DG_T) {
-            S->seeds3[cur][i] = e_->seeds[i];
+        if (fan) {
+            /* the three LDS slots belong to this workgroup's own sampler: the commit reads the chunk's seeds and ids where they are */
+            c.seeds = (unsigned *)e_->seeds; c.draws = (int (*)[8])e_->draws;
+        } else {
+            for (int i = tid; i < DG_CHUNK; i += DG_T) {
+                S->seeds3[cur][i] = e_->seeds[i];
 #pragma unroll
-            for (int q = 0; q < 8; q++) S->draws3[cur][i][q] = e_->draws[i][q];
+                for (int q = 0; q < 8; q++) S->draws3[cur][i][q] = e_->draws[i][q];
+            }
         }
         __syncthreads();
         chunk = cn_ < max_sam - no_sam ? cn_ : max_sam - no_sam;
@@ -1055,7 +1174,9 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         st[10] = c.n_hds; st[11] = c.n_aux; st[12] = (int)(t_best - t_start); st[13] = (int)(t_end - t_start);
         st[14] = A.variant_threads; st[15] = A.mode | (resume ? 256 : 0) | (strm == 2 ? 512 : 0);      /* bit 8: the pair was set aside and resumed; bit 9: its chunks came from a producer workgroup */
     }
-    if (scb && strm >= 1) {
+    if (fan) {
+        if (tid == 0) __hip_atomic_store(&scb->stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       /* the workers leave: nothing of theirs is read any more */
+    } else if (scb && strm >= 1) {
         /* take the request back, or tell the producer to stop and wait until it has left */
         __syncthreads();
         int gone = 0;
@@ -1138,6 +1259,15 @@ __global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_fundamental_kernel(dg_a
     __shared__ dg_args As;
     if (threadIdx.x == 0) As = A;
     __syncthreads();
+    if (LDSPTS == 0 && As.fan_k > 0) {
+        /* fan mode: the blocks behind the owners and their helpers are the owners' workers */
+        const int base = As.n_res * (As.coop_k + 1);
+        if ((int)blockIdx.x >= base) {
+            const int w = (int)blockIdx.x - base;
+            dg_f_fan_worker<T>(As, &Sh, w / As.fan_k, As.fan_ws0 + w, &next_pair);
+            return;
+        }
+    }
     int slot = (int)blockIdx.x, coop_gen = 0;
     /* development build: when this workgroup started, and which half of a mixed-width launch it belongs to (the narrow half's records sit 1024 rows up) */
     DG_DEVT(if (As.phase_out && threadIdx.x == 0) { long long *o_ = As.phase_out + ((size_t)As.n_pairs + blockIdx.x + (As.xq_role == 2 ? 1024 : 0)) * 16; o_[10] = DG_CLK(); o_[11] = As.xq_role; });

@@ -156,6 +156,7 @@ for i in range(P):
     n = 160 + 8 * (i %% 7)
     p1, p2, _, _ = syn.two_view_fundamental(n, 0.22 if i %% 3 == 0 else 0.5, 0.1, seed=3000 + i, plane_fraction=0.7 if i %% 11 == 0 else 0.0); A.append(p1); B.append(p2)
 seeds = [11 + 7 * i for i in range(P)]
+pd.findFundamentalMatrixBatch(A, B, max_iters=20000, seeds=seeds)        # (first use of the narrow kernel: its code object loads while the wide launch already runs)
 F, m = pd.findFundamentalMatrixBatch(A, B, max_iters=20000, seeds=seeds); st = pd.last_stats()
 F0, m0 = pd.findFundamentalMatrixBatch(A, B, max_iters=20000, seeds=seeds, flags=_lib.FLAG_NO_MIX); s0 = pd.last_stats()
 key = lambda s: [(x["samples"], x["lo_runs"], x["models"], x["degen"], x["I"], x["best_sample"]) for x in s]
@@ -181,3 +182,38 @@ print("ok", thr.count(128), thr.count(256), sorted(thr0))
             Fo, mo, so = oracle_port.find_fundamental(p1, p2, 0.5, 0.9999, 20000, seed=11 + 7 * p)
             assert int(z["samples"][p]) == so["samples"], p
             assert np.array_equal(z["masks"][z["offs"][p]:z["offs"][p + 1]].astype(bool), mo), p
+
+
+def test_fan_mode_equals_the_cooperative_mode_and_the_oracle(oracle_port):
+    """Fan mode (dg_f_fan.h; automatic for one large pair per owner on an idle device): the owner draws the sample stream into the ring, worker
+    workgroups solve and score the chunks, the owner commits the completed entries in order.  Same results as the cooperative mode alone
+    (MI_DEGENSAC_FLAG_NO_STREAM switches the workers off) and as the oracle, for two pairs at once, a budget that ends inside a chunk, a
+    symmetric-epipolar metric and a plane-dominated scene (DEGENSAC branch: a bound that can fall); a worker that never answers
+    (wait limit 0) ends in discard + re-run, not in wrong numbers."""
+    cases = [dict(n=9000, ir=0.3, iters=6000, et="sampson", plane=0.0), dict(n=12000, ir=0.15, iters=10001, et="sampson", plane=0.0),
+             dict(n=8500, ir=0.35, iters=4000, et="symm_epipolar", plane=0.0), dict(n=9000, ir=0.4, iters=5000, et="sampson", plane=0.7)]
+    for cs in cases:
+        A, B = [], []
+        for i in range(2):
+            p1, p2, _, _ = syn.two_view_fundamental(cs["n"], cs["ir"], 0.1, seed=900 + i, plane_fraction=cs["plane"]); A.append(p1); B.append(p2)
+        seeds = [5, 6]
+        tun = _lib.TUNE_LATENCY | _lib.TUNE_PLACE_HBM          # (below ~19 000 correspondences the sampler pool would stay in LDS: no cooperative mode, no fan)
+        F, m = pd.findFundamentalMatrixBatch(A, B, 0.5, 0.9999, cs["iters"], error_type=cs["et"], seeds=seeds, tuning=tun); st = pd.last_stats()
+        F0, m0 = pd.findFundamentalMatrixBatch(A, B, 0.5, 0.9999, cs["iters"], error_type=cs["et"], seeds=seeds, tuning=tun, flags=_lib.FLAG_NO_STREAM); s0 = pd.last_stats()
+        assert sum(s_["streamed"] for s_ in st) == 2 and sum(s_["streamed"] for s_ in s0) == 0, cs        # stats bit 9: the chunks came from the ring
+        key = lambda s: [(x["samples"], x["lo_runs"], x["models"], x["degen"], x["I"], x["best_sample"]) for x in s]
+        assert np.array_equal(np.asarray(F), np.asarray(F0)) and all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(m, m0)) and key(st) == key(s0), cs
+        et = 1 if cs["et"] == "symm_epipolar" else 0
+        for p in range(2):
+            Fo, mo, so = oracle_port.find_fundamental(A[p], B[p], 0.5, 0.9999, cs["iters"], et, True, 0.0, True, seed=seeds[p])
+            assert (st[p]["samples"], st[p]["lo_runs"], st[p]["I"], st[p]["degen"]) == (so["samples"], so["lo_runs"], so["I"], so["degen"]), (cs, p)
+            assert np.array_equal(np.asarray(m[p]), mo), (cs, p)
+            assert np.linalg.norm(np.asarray(F[p]).ravel() - Fo.ravel()) <= 1e-9 * np.linalg.norm(Fo), (cs, p)
+    prev = _lib.set_wait_ticks(0)
+    try:
+        p1, p2, _, _ = syn.two_view_fundamental(9000, 0.3, 0.1, seed=900)
+        F, m = pd.findFundamentalMatrixBatch([p1], [p2], 0.5, 0.9999, 6000, seeds=[5], tuning=_lib.TUNE_LATENCY | _lib.TUNE_PLACE_HBM); st = pd.last_stats()
+        Fo, mo, so = oracle_port.find_fundamental(p1, p2, 0.5, 0.9999, 6000, seed=5)
+        assert st[0]["discarded"] == 0 and st[0]["rerun"] == 1 and np.array_equal(np.asarray(m[0]), mo) and st[0]["samples"] == so["samples"]
+    finally:
+        _lib.set_wait_ticks(prev)
