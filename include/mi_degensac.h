@@ -72,6 +72,8 @@ extern "C" {
 #define MI_DEGENSAC_FLAG_STREAM_ON   8u       /* fundamental matrix: stream mode on whatever the batch size                            */
 #define MI_DEGENSAC_FLAG_STREAM_TEST(b) (((uint32_t)(b) & 3u) << 8)   /* with STREAM_ON: bit 0 = the owner scores every chunk it takes from
                                                  the producer again, bit 1 = pairs ask for a producer even while unstarted pairs remain */
+#define MI_DEGENSAC_FLAG_STREAM_AUTO 64u      /* fundamental matrix: the library's automatic choice for this call, whatever the process-wide default says        */
+#define MI_DEGENSAC_FLAG_HJOB_ON     128u     /* homography: helper workgroups on for this call, whatever the process-wide default says                          */
 #define MI_DEGENSAC_FLAG_NO_MIX      32u      /* fundamental matrix: never split this call's batch into a wide and a narrow launch (see "Mixed-width launches" below) */
 #define MI_DEGENSAC_FLAG_NO_HJOB     16u      /* homography: no helper workgroups for the local optimisations of this call             */
 
@@ -160,7 +162,9 @@ enum {
  * DEFAULT (returns the previous one; environment: MI_DEGENSAC_STREAM); a call chooses for itself with MI_DEGENSAC_FLAG_NO_STREAM /
  * MI_DEGENSAC_FLAG_STREAM_ON in params.flags. */
 int mi_degensac_set_stream_mode(int mode);      /* any mode > 0 turns the mode on; its test bits are (mode >> 1).  Default of the calls that
-                                                   set neither MI_DEGENSAC_FLAG_NO_STREAM nor MI_DEGENSAC_FLAG_STREAM_ON */
+                                                   set none of MI_DEGENSAC_FLAG_NO_STREAM / _STREAM_ON / _STREAM_AUTO and run on a context
+                                                   without its own setting (mi_degensac_ctx_set_scheduling): process-wide, kept for the
+                                                   entry points that take no context */
 /* Homography: workgroups that have run out of pairs take whole repetitions of the local optimisations of the pairs that still
  * run (results never depend on it).  1 = on (default), 0 = off.  Process-wide DEFAULT (returns the previous one; environment:
  * MI_DEGENSAC_HJOB); a call switches them off for itself with MI_DEGENSAC_FLAG_NO_HJOB in params.flags. */
@@ -189,6 +193,11 @@ int  mi_degensac_ctx_create(int device, mi_degensac_ctx **out);
 void mi_degensac_ctx_destroy(mi_degensac_ctx *ctx);
 /* the context's stream (hipStream_t), e.g. to order other work after a call */
 void *mi_degensac_ctx_stream(mi_degensac_ctx *ctx);
+/* Scheduling defaults of ONE context (results never depend on them): every call on `ctx` whose params.flags say nothing about the stream
+ * mode / the homography helpers takes these instead of the process-wide defaults of mi_degensac_set_stream_mode / _set_hjob_mode (which
+ * remain for the entry points without a context).  stream_mode: -2 = inherit the process-wide default (initial), -1 = automatic,
+ * 0 = off, > 0 = on with test bits in (mode >> 1).  hjob_mode: -2 = inherit (initial), 0 = off, 1 = on.  Returns 0 or MI_DEGENSAC_EINVAL. */
+int mi_degensac_ctx_set_scheduling(mi_degensac_ctx *ctx, int stream_mode, int hjob_mode);
 
 /* ---- host-pointer entry points (mirror the pybind signatures) -------------------------------- */
 /* pts1, pts2: [n, dim] row-major float64, dim in {2, 6}; F/H: 9 doubles row-major as the reference's C

@@ -217,3 +217,31 @@ def test_fan_mode_equals_the_cooperative_mode_and_the_oracle(oracle_port):
         assert st[0]["discarded"] == 0 and st[0]["rerun"] == 1 and np.array_equal(np.asarray(m[0]), mo) and st[0]["samples"] == so["samples"]
     finally:
         _lib.set_wait_ticks(prev)
+
+
+def test_scheduling_defaults_belong_to_a_context():
+    """mi_degensac_ctx_set_scheduling: the stream mode / helper choice of ONE context; other contexts and the process-wide defaults are
+    untouched, per-call flags still win, results are the same either way."""
+    L = _lib.lib()
+    p1, p2, _, _ = syn.two_view_fundamental(2000, 0.4, 0.1, seed=0)
+    off = np.array([0, 2000], np.int64); seeds = np.array([3], np.uint32)
+
+    def run(ctx, flags=0):
+        F = np.zeros(9); m = np.zeros(2000, np.uint8); st = np.zeros(16, np.int32)
+        prm = _lib.make_params(0.5, 0.9999, 100000, 0, True, 0.0, True, flags)
+        _lib.check(L.mi_degensac_ctx_find_fundamental_batch(ctx, _lib.dptr(p1), _lib.dptr(p2), off.ctypes.data_as(C.POINTER(C.c_int64)), 1, 2, C.byref(prm),
+                                                            seeds.ctypes.data_as(C.POINTER(C.c_uint32)), _lib.dptr(F), m.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                            st.ctypes.data_as(C.POINTER(C.c_int32))))
+        return F, m, (int(st[15]) >> 9) & 1, tuple(int(x) for x in st[:8])
+    a = C.c_void_p(); b = C.c_void_p()
+    _lib.check(L.mi_degensac_ctx_create(0, C.byref(a))); _lib.check(L.mi_degensac_ctx_create(0, C.byref(b)))
+    try:
+        assert L.mi_degensac_ctx_set_scheduling(a, 0, -2) == 0                       # context a: stream mode off
+        assert L.mi_degensac_ctx_set_scheduling(b, 1 | (2 << 1), -2) == 0            # context b: on, pairs ask at once
+        Fa, ma, sa, ka = run(a); Fb, mb, sb, kb = run(b)
+        assert sa == 0 and sb == 1
+        assert np.array_equal(Fa, Fb) and np.array_equal(ma, mb) and ka == kb
+        assert run(a, _lib.FLAG_STREAM_ON | _lib.FLAG_STREAM_TEST(2))[2] == 1 and run(b, _lib.FLAG_NO_STREAM)[2] == 0     # the call's own flags win
+        assert L.mi_degensac_ctx_set_scheduling(a, -3, 0) != 0
+    finally:
+        L.mi_degensac_ctx_destroy(a); L.mi_degensac_ctx_destroy(b)
