@@ -74,7 +74,6 @@ extern "C" {
                                                  the producer again, bit 1 = pairs ask for a producer even while unstarted pairs remain */
 #define MI_DEGENSAC_FLAG_STREAM_AUTO 64u      /* fundamental matrix: the library's automatic choice for this call, whatever the process-wide default says        */
 #define MI_DEGENSAC_FLAG_HJOB_ON     128u     /* homography: helper workgroups on for this call, whatever the process-wide default says                          */
-#define MI_DEGENSAC_FLAG_NO_MIX      32u      /* fundamental matrix: never split this call's batch into a wide and a narrow launch (see "Mixed-width launches" below) */
 #define MI_DEGENSAC_FLAG_NO_HJOB     16u      /* homography: no helper workgroups for the local optimisations of this call             */
 
 /* tuning word (0 = let the library decide; results never depend on it, only speed does):

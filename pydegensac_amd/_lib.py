@@ -12,7 +12,7 @@ STAT_NAMES = ["samples", "lo_runs", "rejected", "I", "models", "degen", "Ih", "b
 FLAG_FINAL_LAF_FILTER = 1
 FLAG_LEGACY_F = 2            # exp_ransacF / exp_ransacFcustom sample-budget rule (include/mi_degensac.h)
 # per-call scheduling switches (results never depend on them; they win over set_stream_mode / set_hjob_mode)
-FLAG_NO_STREAM, FLAG_STREAM_ON, FLAG_NO_HJOB, FLAG_NO_MIX, FLAG_STREAM_AUTO, FLAG_HJOB_ON = 4, 8, 16, 32, 64, 128
+FLAG_NO_STREAM, FLAG_STREAM_ON, FLAG_NO_HJOB, FLAG_STREAM_AUTO, FLAG_HJOB_ON = 4, 8, 16, 64, 128
 
 
 def FLAG_STREAM_TEST(b): return (int(b) & 3) << 8        # noqa: E704  with FLAG_STREAM_ON: bit 0 = owner re-scores, bit 1 = ask at once
@@ -128,8 +128,9 @@ def lib():
         l.mi_degensac_ctx_destroy.argtypes = [C.c_void_p]
         l.mi_degensac_ctx_stream.restype = C.c_void_p
         l.mi_degensac_ctx_stream.argtypes = [C.c_void_p]
-        l.mi_degensac_ctx_set_scheduling.restype = C.c_int
-        l.mi_degensac_ctx_set_scheduling.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        if hasattr(l, "mi_degensac_ctx_set_scheduling"):          # (absent from older builds loaded through MI_DEGENSAC_LIB for A/B runs)
+            l.mi_degensac_ctx_set_scheduling.restype = C.c_int
+            l.mi_degensac_ctx_set_scheduling.argtypes = [C.c_void_p, C.c_int, C.c_int]
         l.mi_degensac_release_scratch.restype = C.c_int
         l.mi_degensac_release_scratch.argtypes = [C.c_int, C.c_void_p]
         l.mi_degensac_pool_stage_parallel.restype = C.c_int
@@ -167,10 +168,11 @@ def lib():
         l.mi_degensac_screen_counts_h.argtypes = [dp, dp, C.c_int, C.c_int, dp, C.c_int, C.c_double, C.c_int, up, bp]
         l.mi_degensac_rng_wave.restype = C.c_int
         l.mi_degensac_rng_wave.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, ip]
-        l.mi_degensac_set_call_timing.restype = C.c_int
-        l.mi_degensac_set_call_timing.argtypes = [C.c_int]
-        l.mi_degensac_last_call_timing.restype = C.c_int
-        l.mi_degensac_last_call_timing.argtypes = [dp]
+        if hasattr(l, "mi_degensac_set_call_timing"):
+            l.mi_degensac_set_call_timing.restype = C.c_int
+            l.mi_degensac_set_call_timing.argtypes = [C.c_int]
+            l.mi_degensac_last_call_timing.restype = C.c_int
+            l.mi_degensac_last_call_timing.argtypes = [dp]
         l.mi_degensac_last_error.restype = C.c_char_p
         l.mi_degensac_version.restype = C.c_char_p
         l.mi_degensac_kernel_name.restype = C.c_char_p

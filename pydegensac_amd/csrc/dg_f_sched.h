@@ -64,136 +64,6 @@ __device__ __forceinline__ long long dg_park_take(const dg_args &A, long long *b
     return *bc;
 }
 
-/* ---- mixed-width launches: the cross queue (dg_args::xq) ---------------------------------------------------------------
- * One batch, TWO persistent kernels side by side on the device (two streams): a NARROW one (128-thread workgroups, two per CU)
- * and a WIDE one (256-thread workgroups, one per CU), pulling unstarted pairs from ONE ticket counter.  Two waves per pair waste the
- * least on the speculated repetitions of a local optimisation, so the many short pairs cost least there (per CU: 4 / 17.9 ms against
- * 2 / 11.2 ms); a pair that runs its whole sample budget needs four waves for its main loop (60-75 ms against 130-150) and would end
- * a narrow launch alone.  Which pairs are long is known after the discovery round (park_sam samples): a narrow workgroup whose
- * pair then has park_long or more samples left PUSHES the pair's index here and drops the work done so far; a wide workgroup TAKES
- * it and runs the pair from its first sample — a pair's result does not depend on who computes it, and nothing but the index
- * crosses over (the two kernels' LDS images differ).  Nobody waits for a workgroup that may not have been dispatched: the narrow
- * side never waits; a wide workgroup without work waits for entries only while the counters below say that pairs are still in
- * their discovery round on RUNNING narrow workgroups (every ticket that was handed out is accounted for by one of the two
- * counters), for at most wait_ticks; giving up CLOSES the queue, after which the narrow side keeps its long pairs.
- * Layout (ints; one 128-byte line per counter): */
-#define DG_XQ_STATE  0       /* bit 30: closed; low bits: entries pushed */
-#define DG_XQ_TAKEN  32      /* entries taken */
-#define DG_XQ_WTICK  64      /* unstarted pairs (tickets) the wide launch took */
-#define DG_XQ_NDONE  96      /* pairs whose discovery round is over at the narrow launch (finished, set aside, pushed, or kept) */
-#define DG_XQ_ENT    128     /* entries[xq_cap]: pair index, -1 until published */
-#define DG_XQ_CLOSED (1 << 30)
-/* narrow side, whole workgroup: push `pair`; false = the queue is closed (keep the pair) */
-__device__ __forceinline__ bool dg_xq_push(const dg_args &A, int pair, int *bc /* LDS */)
-{
-    __syncthreads();
-    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
-        int res = -1;
-        for (;;) {
-            const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(A.xq + DG_XQ_STATE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if ((v & DG_XQ_CLOSED) || (v & (DG_XQ_CLOSED - 1)) >= A.xq_cap) break;
-            int ok = 0;
-            if (threadIdx.x == 0) { int e = v; ok = __hip_atomic_compare_exchange_strong(A.xq + DG_XQ_STATE, &e, v + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0; }
-            if (__builtin_amdgcn_readfirstlane(ok)) { res = v & (DG_XQ_CLOSED - 1); break; }
-        }
-        if (res >= 0 && threadIdx.x == 0) __hip_atomic_store(A.xq + DG_XQ_ENT + res, pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *bc = res;                                                           /* every lane stores the same value */
-    }
-    __syncthreads();
-    const bool ok = *bc >= 0;
-    __syncthreads();
-    return ok;
-}
-/* narrow side, one thread's worth of work done by the whole first wave: one more pair's discovery round is over (every push of
- * this workgroup is visible before the count goes up) */
-__device__ __forceinline__ void dg_xq_discovered(const dg_args &A)
-{
-    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(A.xq + DG_XQ_NDONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-/* wide side, first wave only (uniform): claim the next entry; -1 = none at the moment */
-__device__ __forceinline__ int dg_xq_take_w0(const dg_args &A)
-{
-    int t;
-    for (;;) {
-        t = __builtin_amdgcn_readfirstlane(__hip_atomic_load(A.xq + DG_XQ_TAKEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        const int p = __builtin_amdgcn_readfirstlane(__hip_atomic_load(A.xq + DG_XQ_STATE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & (DG_XQ_CLOSED - 1);
-        if (t >= p) return -1;
-        int ok = 0;
-        if (threadIdx.x == 0) { int e = t; ok = __hip_atomic_compare_exchange_strong(A.xq + DG_XQ_TAKEN, &e, t + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0; }
-        if (__builtin_amdgcn_readfirstlane(ok)) break;
-    }
-    /* the pusher is a running workgroup between its compare-and-swap and its store: a few cycles */
-    int pair;
-    const long long t0 = wall_clock64();
-    for (;;) {
-        pair = __builtin_amdgcn_readfirstlane(__hip_atomic_load(A.xq + DG_XQ_ENT + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (pair >= 0) break;
-        if (wall_clock64() - t0 > (long long)A.wait_ticks) { if (threadIdx.x == 0) __hip_atomic_store(A.err_flag, 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        __builtin_amdgcn_s_sleep(2);
-    }
-    return pair;
-}
-/* wide side, whole workgroup: may this launch start another unstarted pair?  Every pair a launch starts stays with it (the images of the
- * two kernels differ), and the two launches should end together.  The wide launch runs the long pairs of the whole batch (each worth
- * about b short ones), so it may hold   A0 + a x (tickets handed out so far) - b x (long pairs known so far)   tickets: a = its share of a
- * batch without long pairs (its 256 four-wave slots against the narrow launch's 512 two-wave slots: 0.48 on C2 data), A0 = one generation
- * of its workgroups for the start of the launch, when nothing else is known.  (Only speed depends on the constants: dg_args::xq_rule.) */
-__device__ __forceinline__ bool dg_xq_may_take(const dg_args &A, int *bc /* LDS */)
-{
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int rule = A.xq_rule;
-        const int a256 = (rule & 255) ? (rule & 255) : 123, b16 = ((rule >> 8) & 255) ? ((rule >> 8) & 255) : 64, a0 = ((rule >> 16) & 255) ? ((rule >> 16) & 255) * 16 : 256;
-        int t = __hip_atomic_load(A.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (t > A.n_pairs) t = A.n_pairs;
-        const int L = (__hip_atomic_load(A.xq + DG_XQ_STATE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (DG_XQ_CLOSED - 1))
-                    + (A.park_sam > 0 ? __hip_atomic_load(A.park_ctl + DG_PARK_CLAIMED + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
-        const int wt = __hip_atomic_load(A.xq + DG_XQ_WTICK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *bc = (long long)wt * 256 * 16 < (long long)a0 * 256 * 16 + (long long)a256 * 16 * t - (long long)b16 * 256 * L ? 1 : 0;
-    }
-    __syncthreads();
-    const bool r = *bc != 0;
-    __syncthreads();
-    return r;
-}
-/* wide side, whole workgroup: the next pair of the cross queue or -1.  wait = 0: do not wait.  wait = 1 (this workgroup has nothing
- * else to do): wait for entries while pairs are still in their discovery round on the narrow side. */
-__device__ __forceinline__ int dg_xq_take(const dg_args &A, int *bc /* LDS */, const int wait)
-{
-    __syncthreads();
-    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
-        int pair = -1;
-        const long long t0 = wall_clock64();
-        for (;;) {
-            pair = dg_xq_take_w0(A);
-            if (pair >= 0 || !wait) break;
-            /* every ticket handed out is a pair the wide launch took itself or one whose discovery round the narrow launch has finished:
-             * nothing more can arrive once the two counts cover the batch (the counts only grow; read before the last look at the queue) */
-            const int acc = __builtin_amdgcn_readfirstlane(__hip_atomic_load(A.xq + DG_XQ_WTICK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                          + __builtin_amdgcn_readfirstlane(__hip_atomic_load(A.xq + DG_XQ_NDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (acc >= A.n_pairs) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); pair = dg_xq_take_w0(A); break; }
-            /* unstarted pairs remain that this launch held back from (dg_xq_may_take): an idle workgroup takes one after all, a little later */
-            if (wall_clock64() - t0 > 30000ll && __builtin_amdgcn_readfirstlane(__hip_atomic_load(A.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < A.n_pairs) { pair = -3; break; }
-            if (wall_clock64() - t0 > (long long)A.wait_ticks) {
-                /* give up: close the queue (the narrow side keeps its long pairs from now on), take what was pushed before that */
-                if (threadIdx.x == 0) __hip_atomic_fetch_or(A.xq + DG_XQ_STATE, DG_XQ_CLOSED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                pair = dg_xq_take_w0(A);
-                break;
-            }
-            for (int q = 0; q < 4; q++) __builtin_amdgcn_s_sleep(127);
-        }
-        *bc = pair;                                                          /* every lane stores the same value */
-    }
-    __syncthreads();
-    const int r = *bc;
-    __syncthreads();
-    return r;
-}
-
 /* ---- stream mode (dg_stream_cb, dg_stream_ent) -------------------------------------------------------------------- */
 #define DG_STREAM_TIMEOUT 400000000ll         /* 4 s of the 100 MHz clock: a wait that long is a bug; flag it and go on instead of hanging */
 __device__ __forceinline__ dg_stream_ent *dg_stream_entry(const dg_args &A, int oslot, int seq)

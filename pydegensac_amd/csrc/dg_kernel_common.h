@@ -242,10 +242,6 @@ struct dg_args {
     int fan_k;                       /* worker workgroups per owner; 0 = off */
     int fan_ws0;                     /* workspace index of the first worker (worker w of owner o: fan_ws0 + o * fan_k + w) */
     int *fan_flags;                  /* [n_res][stream_depth] "entry done" words, one 128-byte line each (agent-scope atomics only): seq + 1 */
-    int *xq;                         /* mixed-width launches (dg_f_sched.h, "cross queue"): the block both launches share, or null */
-    int xq_role;                     /* 0 = none; 1 = this launch TAKES pairs from the cross queue (the wide one); 2 = it PUSHES its long pairs there (the narrow one) */
-    int xq_cap;                      /* entries of the cross queue (= n_pairs) */
-    int xq_rule;                     /* wide side: how many unstarted pairs it may take (dg_xq_may_take): bits 0-7 = a x 256, 8-15 = b x 16, 16-23 = A0 / 16; 0 = defaults */
     int *err_flag;                   /* set when a hand-over wait times out: every pair that ends afterwards discards its results (zero model, zero mask,
                                         bit 10 of stats[15]) and the host-pointer entry points run those pairs again without helpers (dg_discard_if_failed) */
     int *trace;                      /* debug: [0] = count, then (tag, I, J lo, J hi) records; null = off */

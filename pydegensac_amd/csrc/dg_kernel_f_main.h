@@ -82,8 +82,6 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     unsigned &seed = D.seed;
     int &cur = D.cur, (&chunk_s)[3] = D.chunk_s, &chunk_base = D.chunk_base;
     int park_on = (A.park_sam > 0 && !resume) ? 1 : 0;
-    /* mixed-width launch, narrow side (dg_f_sched.h, cross queue): this pair's discovery round is still open */
-    int disc_open = (A.xq_role == 2 && !resume) ? 1 : 0;
 
   if (!resume) {
     t_start = wall_clock64();
@@ -370,14 +368,6 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             } else if (__builtin_amdgcn_readfirstlane(wave) == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             __syncthreads();
             DG_PH(0);
-        }
-        if (disc_open && no_sam >= (A.park_sam > 0 ? A.park_sam : 1024)) {
-            /* narrow side of a mixed-width launch, end of the pair's discovery round: a pair with many samples left goes to the wide
-             * launch, which runs it again from its first sample on four waves (what was computed here is dropped: a result does not
-             * depend on who computes it); everything else stays (and may be set aside below) */
-            disc_open = 0;
-            if (max_sam - no_sam >= (A.park_long > 0 ? A.park_long : 8192) && dg_xq_push(A, pair, &S->itmp[30])) { dg_xq_discovered(A); return -2; }
-            dg_xq_discovered(A);
         }
         if (park_on && no_sam >= A.park_sam) {
             /* still running after park_sam samples: set the pair aside if unstarted pairs remain and a spare workspace is left */
@@ -1198,7 +1188,6 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         }
     }
     if (A.done_pairs && tid == 0) __hip_atomic_fetch_add(A.done_pairs, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (disc_open) dg_xq_discovered(A);            /* (the pair ended inside its discovery round) */
     DG_PH(6);
 #ifdef DG_LO_PROF
     if (A.phase_out && tid == 0) { for (int i = 0; i < 16; i++) A.phase_out[(size_t)pair * 16 + i] = S->lt[i]; }
@@ -1215,12 +1204,7 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
 __device__ __forceinline__ int dg_next_pair(const dg_args &A, int *bc /* LDS */)
 {
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int t_ = atomicAdd(A.ticket, 1);
-        *bc = t_;
-        /* mixed-width launch, wide side: the tickets this launch took (the narrow side counts the pairs it has discovered) */
-        if (A.xq_role == 1 && t_ < A.n_pairs) __hip_atomic_fetch_add(A.xq + DG_XQ_WTICK, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x == 0) *bc = atomicAdd(A.ticket, 1);
     __syncthreads();
     const int t = *bc;
     if (t >= A.n_pairs) return -1;
@@ -1269,8 +1253,8 @@ __global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_fundamental_kernel(dg_a
         }
     }
     int slot = (int)blockIdx.x, coop_gen = 0;
-    /* development build: when this workgroup started, and which half of a mixed-width launch it belongs to (the narrow half's records sit 1024 rows up) */
-    DG_DEVT(if (As.phase_out && threadIdx.x == 0) { long long *o_ = As.phase_out + ((size_t)As.n_pairs + blockIdx.x + (As.xq_role == 2 ? 1024 : 0)) * 16; o_[10] = DG_CLK(); o_[11] = As.xq_role; });
+    /* development build: when this workgroup started */
+    DG_DEVT(if (As.phase_out && threadIdx.x == 0) { long long *o_ = As.phase_out + ((size_t)As.n_pairs + blockIdx.x) * 16; o_[10] = DG_CLK(); o_[11] = 0; });
     if (LDSPTS == 0 && As.coop_k > 0) {
         /* cooperative large-n mode: block b = owner of slot b / (k+1) when b % (k+1) == 0, else one of its helpers */
         slot = (int)blockIdx.x / (As.coop_k + 1);
@@ -1286,19 +1270,12 @@ __global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_fundamental_kernel(dg_a
          * (The queues can look empty one after the other while another workgroup queues a pair in between: that workgroup
          * takes it itself on its next round.) */
         int resume = 0;
-        /* mixed-width launch, wide side: the long pairs the narrow launch has discovered come first (they run longest) */
-        int pair = As.xq_role == 1 ? dg_xq_take(As, &next_pair, 0) : -1;
-        if (pair < 0 && (As.xq_role != 1 || dg_xq_may_take(As, &next_pair))) pair = dg_next_pair(As, &next_pair);
+        int pair = dg_next_pair(As, &next_pair);
         if (pair < 0 && As.park_sam > 0) {
             long long e = dg_park_take(As, &next_parked, 1);
             if (e < 0) e = dg_park_take(As, &next_parked, 0);
             if (e < 0) e = dg_park_take(As, &next_parked, 1);
             if (e >= 0) { pair = (int)(e >> 32); wsid = (int)(e & 0xffffffffll); resume = 1; }   /* the image lives in the pair's own workspace */
-        }
-        /* ... and with nothing else left, wait for them as long as narrow workgroups are still in discovery rounds */
-        if (pair < 0 && As.xq_role == 1) {
-            pair = dg_xq_take(As, &next_pair, 1);
-            if (pair == -3) { pair = dg_next_pair(As, &next_pair); if (pair < 0) continue; }       /* (idle with unstarted pairs left: take one) */
         }
         int img_wsid = wsid, oslot = slot;
         if (pair < 0 && As.stream_on) {
@@ -1309,14 +1286,14 @@ __global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_fundamental_kernel(dg_a
         if (pair < 0) break;
         const int spare = dg_f_pair<T, LDSPTS>(As, &Sh, dyn_smem, pair, slot, img_wsid, resume, coop_gen, wsid, oslot);
         if (spare >= 0) wsid = spare;                /* the pair was set aside with its workspace */
-        else if (spare == -1 && resume != 2) dg_discard_if_failed(As, pair, &next_pair);      /* (-2: the pair went to the wide launch of a mixed-width batch) */
+        else if (resume != 2) dg_discard_if_failed(As, pair, &next_pair);
     }
     if (LDSPTS == 0 && As.coop_k > 0 && threadIdx.x == 0)          /* retire the slot: its helpers leave */
         __hip_atomic_store(&As.coop[slot].gen, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     /* development build: when this workgroup ran out of work (tools/gpu_sched.py: the tail of a launch) */
-    DG_DEVT(if (As.phase_out && threadIdx.x == 0) As.phase_out[((size_t)As.n_pairs + blockIdx.x + (As.xq_role == 2 ? 1024 : 0)) * 16] = DG_CLK());
+    DG_DEVT(if (As.phase_out && threadIdx.x == 0) As.phase_out[((size_t)As.n_pairs + blockIdx.x) * 16] = DG_CLK());
     /* ... and where its waves sit: HW_ID | XCC_ID << 32 per wave (tools/gpu_simd.py: which SIMDs the serial waves of co-resident workgroups share) */
-    DG_DEVT(if (As.phase_out && (threadIdx.x & 63) == 0) As.phase_out[((size_t)As.n_pairs + blockIdx.x + (As.xq_role == 2 ? 1024 : 0)) * 16 + 1 + (threadIdx.x >> 6)] =
+    DG_DEVT(if (As.phase_out && (threadIdx.x & 63) == 0) As.phase_out[((size_t)As.n_pairs + blockIdx.x) * 16 + 1 + (threadIdx.x >> 6)] =
                 (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32));
 
 }

@@ -140,50 +140,6 @@ def test_bench_gpus_flag_is_a_request_not_a_label():
     assert line["n_gpus"] == 1 and line["config"]["process_group"] is None and line["parity_checked"] >= 3 and line["value"] > 0
 
 
-def test_mixed_width_launch_equals_one_launch(oracle_port):
-    """MI_DEGENSAC_MIX=1: one batch as a wide (256-thread) and a narrow (128-thread) launch side by side sharing the ticket counter, with
-    the narrow launch's long pairs handed to the wide one through the cross queue (dg_f_sched.h).  Off by default (measured slower,
-    profiles/r6_ab_mixed_width.log); results must not depend on it: every pair equals the one-launch run bit for bit, pairs ran on both
-    widths, long pairs ended up on 256 threads, and a sample of pairs equals the oracle."""
-    code = r'''
-import sys, numpy as np
-sys.path.insert(0, %r)
-import pydegensac_amd as pd
-from pydegensac_amd import synthetic as syn, _lib
-P = 900
-A, B = [], []
-for i in range(P):
-    n = 160 + 8 * (i %% 7)
-    p1, p2, _, _ = syn.two_view_fundamental(n, 0.22 if i %% 3 == 0 else 0.5, 0.1, seed=3000 + i, plane_fraction=0.7 if i %% 11 == 0 else 0.0); A.append(p1); B.append(p2)
-seeds = [11 + 7 * i for i in range(P)]
-pd.findFundamentalMatrixBatch(A, B, max_iters=20000, seeds=seeds)        # (first use of the narrow kernel: its code object loads while the wide launch already runs)
-F, m = pd.findFundamentalMatrixBatch(A, B, max_iters=20000, seeds=seeds); st = pd.last_stats()
-F0, m0 = pd.findFundamentalMatrixBatch(A, B, max_iters=20000, seeds=seeds, flags=_lib.FLAG_NO_MIX); s0 = pd.last_stats()
-key = lambda s: [(x["samples"], x["lo_runs"], x["models"], x["degen"], x["I"], x["best_sample"]) for x in s]
-assert np.array_equal(np.asarray(F), np.asarray(F0)) and all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(m, m0)) and key(st) == key(s0)
-thr = [x["threads"] for x in st]; thr0 = set(x["threads"] for x in s0)
-long_on_narrow = sum(1 for x in st if x["threads"] == 128 and x["samples"] >= 20000 and x["best_sample"] < 1024)
-np.savez(sys.argv[1], F=np.asarray(F), samples=[x["samples"] for x in st], n128=thr.count(128), n256=thr.count(256), one=sorted(thr0),
-         masks=np.concatenate([np.asarray(x) for x in m]), offs=np.cumsum([0] + [len(x) for x in m]))
-print("ok", thr.count(128), thr.count(256), sorted(thr0))
-''' % ROOT
-    import tempfile
-    with tempfile.TemporaryDirectory() as td:
-        out_npz = os.path.join(td, "r.npz")
-        env = dict(os.environ, MI_DEGENSAC_MIX="1")
-        out = subprocess.run([sys.executable, "-c", code, out_npz], env=env, capture_output=True, text=True, timeout=900)
-        assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-300:], out.stderr[-1200:])
-        z = np.load(out_npz)
-        assert int(z["n128"]) > 100 and int(z["n256"]) > 100, (int(z["n128"]), int(z["n256"]))          # both launches took pairs
-        assert list(z["one"]) in ([256], [128], [512])                                                  # FLAG_NO_MIX: one launch
-        for p in (0, 3, 11, 450, 899):
-            n = 160 + 8 * (p % 7)
-            p1, p2, _, _ = syn.two_view_fundamental(n, 0.22 if p % 3 == 0 else 0.5, 0.1, seed=3000 + p, plane_fraction=0.7 if p % 11 == 0 else 0.0)
-            Fo, mo, so = oracle_port.find_fundamental(p1, p2, 0.5, 0.9999, 20000, seed=11 + 7 * p)
-            assert int(z["samples"][p]) == so["samples"], p
-            assert np.array_equal(z["masks"][z["offs"][p]:z["offs"][p + 1]].astype(bool), mo), p
-
-
 def test_fan_mode_equals_the_cooperative_mode_and_the_oracle(oracle_port):
     """Fan mode (dg_f_fan.h; automatic for one large pair per owner on an idle device): the owner draws the sample stream into the ring, worker
     workgroups solve and score the chunks, the owner commits the completed entries in order.  Same results as the cooperative mode alone

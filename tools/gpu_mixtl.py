@@ -1,4 +1,5 @@
-"""Timeline of a mixed-width launch (development build): when do the pairs of each kernel end, when do the long pairs start?
+"""(Needs the library of commit d779705: the mixed-width launch was measured slower and removed again, profiles/r6_ab_mixed_width.log.)
+Timeline of a mixed-width launch (development build): when do the pairs of each kernel end, when do the long pairs start?
 usage: gpu_mixtl.py [pairs] [wide grid or per-CU] [narrow grid or per-CU] [rule]"""
 import os as _os
 _os.environ.setdefault("MI_DEGENSAC_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "libmi_degensac_dev.so"))
