@@ -1,17 +1,22 @@
 /* Fan mode of the fundamental-matrix kernel (dg_args::fan_k; one pair of many thousand correspondences on an otherwise idle device: C5).
  * The cooperative large-n mode hands every chunk of 256 samples to its helper workgroups in two stages (screening counts over point
- * slices, then exact scoring of the survivors) and waits for each: two hand-overs per chunk, 80 us per chunk against the 34 us the
- * seed chain needs.  Here nothing waits per chunk: the OWNER draws the sample stream chunk after chunk (seed chain,
- * draws, pool swaps: outcome-independent, exp_ranF.c:1337-1342) and writes each chunk's seeds and drawn ids into the entry of the
- * stream mode's ring; WORKER workgroups (fan_k per owner) claim entries as they appear, solve the chunk's 7-point problems, screen and
- * score its models against the owner's points with the owner's current bound, and complete the entry exactly as a stream-mode
- * producer would (models per sample, the few models above the bound); the owner commits the completed entries in order, some tens
- * of chunks behind its sampler — an entry without a model above the bound is one addition (dg_f_pair, "uneventful chunk").  The
- * cooperative helpers stay for what does need the whole device at once: the passes and repetitions of the local optimisations, and the
- * chunks the owner has to score itself (the first one; a chunk whose bound has fallen).
+ * slices, then exact scoring of the survivors) and waits for each: two hand-overs per chunk, 80 us per chunk against the 25-34 us the
+ * seed chain needs.  Here nothing waits per chunk.  Three kinds of workgroup serve one pair:
+ *   - the SAMPLER (dg_f_fan_sampler) draws the pair's sample stream chunk after chunk (seed chain, draws, pool swaps: outcome-independent,
+ *     exp_ranF.c:1337-1342) and writes each chunk's seeds and drawn ids into an entry of the stream mode's ring;
+ *   - WORKERS (dg_f_fan_worker, fan_k - 1 per pair) claim entries as they appear, solve the chunk's 7-point problems, screen and score
+ *     its models against the owner's points with the owner's current bound, and complete the entry exactly as a stream-mode producer
+ *     would (models per sample, the few models above the bound);
+ *   - the OWNER commits the completed entries in order (dg_f_pair, strm == 2 from the first chunk): an entry without a model above the
+ *     bound is one addition ("uneventful chunk"; a scout wave takes up to 64 of them per step), the others go through the ordinary ring
+ *     path; its local optimisations run while the sampler keeps drawing.
+ * The cooperative helpers stay for what does need many workgroups at once: the passes and repetitions of the local optimisations, and
+ * the chunks the owner has to score itself (the first one; a chunk whose bound has fallen).
  * Hand-over: plain payload, one agent-scope release, then a relaxed agent-scope word on its own 128-byte line (scb->head for "ids
- * published", fan_flags[] for "entry complete"); nobody waits for a workgroup that may not be running: a worker waits for ids only
- * while its owner has opened the pair (and for at most wait_ticks), the owner waits for an entry a running worker has claimed.
+ * published", fan_flags[] for "entry complete", scb->tail for "entry committed: its slot is free").  Nobody waits for a workgroup that
+ * may not be running: sampler and workers wait only once their owner has opened the pair (state ATTACHED), with a limit; the owner
+ * waits (wait_ticks) for an entry that a running worker has claimed or will claim — a time-out raises the launch's error word:
+ * discard and re-run without the mode.  C5: 61.3 -> 30.1 ms (profiles/r6_phases_c5.log).
  * Part of the fundamental-matrix kernel: included by dg_kernel_f_main.h after dg_f_sched.h. */
 #ifndef DG_F_FAN_H
 #define DG_F_FAN_H
@@ -146,6 +151,104 @@ __device__ __noinline__ void dg_f_fan_worker(const dg_args &A, dg_f_shared *S, c
             ent->Mtot = Mtot; ent->n_ev = ne < DG_STREAM_EV_MAX ? ne : DG_STREAM_EV_MAX; ent->overflow = ne > DG_STREAM_EV_MAX ? 1 : 0; ent->tau_used = tau_c;
         }
         dg_stream_publish(dg_fan_flag(A, oslot, seq), seq + 1);
+    }
+}
+
+/* The SAMPLER of owner slot `oslot` (worker 0 of the slot), on workspace `wsid`: the pair's whole sample stream — what the owner's own
+ * sampler stages would draw (same seed, same pool, same chunking) — chunk after chunk into the ring, nothing else; the owner only
+ * commits, so its local optimisations run while this workgroup keeps drawing.  The stream depends on nothing but the pair's seed and
+ * its size (exp_ranF.c:1277, :1337-1342), so the sampler starts from scratch: no state crosses over.  It follows the owner's budget
+ * (scb->max_sam only shrinks; what is drawn past the final budget is dropped) and its position (scb->tail: an entry is reused once
+ * the owner has committed it). */
+template <int T>
+__device__ __noinline__ void dg_f_fan_sampler(const dg_args &A, dg_f_shared *S, const int oslot, const int wsid, int *bc /* LDS */)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    dg_stream_cb *const scb = A.scb + oslot;
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(wave) == 0) {
+        int res = 0;
+        const long long t0 = wall_clock64();
+        for (;;) {
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&scb->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == DG_ST_ATTACHED) { res = 1; break; }
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&scb->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(A.done_pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= A.n_pairs) break;
+            if (wall_clock64() - t0 > 4 * (long long)A.wait_ticks + 1000000ll) break;
+            __builtin_amdgcn_s_sleep(32);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *bc = res;
+    }
+    __syncthreads();
+    if (!*bc) return;
+    __syncthreads();
+    const int pair = scb->pair;
+    const int n = (int)(A.offsets[pair + 1] - A.offsets[pair]);
+    int *pool = (int *)(A.ws + (size_t)wsid * A.wl.stride + A.wl.off_pool);
+    int *const pscr = A.pool_seq ? (int *)0 : (int *)S->ww;
+    for (int i = tid; i < n; i += T) pool[i] = i;
+    int max_sam = __hip_atomic_load(&scb->max_sam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    /* srand(seed0); seed = rand(); then the first two chunks as the owner's prologue draws them */
+    if (__builtin_amdgcn_readfirstlane(wave) == 0) { dg_srand_wave(&S->rng, A.seeds[pair], lane); const int v_ = dg_rand_block(&S->rng, 1, lane); if (lane == 0) S->itmp[31] = v_; }
+    __syncthreads();
+    unsigned seed = (unsigned)S->itmp[31];
+    int f_ch[3] = {0, 0, 0}, f_cur = 0, f_pub = 0, f_sam = 0;
+    { int c0 = max_sam < DG_CHUNK ? max_sam : DG_CHUNK; if (c0 < 0) c0 = 0; int c1 = max_sam - c0; if (c1 > DG_CHUNK) c1 = DG_CHUNK; if (c1 < 0) c1 = 0; f_ch[0] = c0; f_ch[1] = c1; }
+    __syncthreads();
+    if (wave == 0) {
+        unsigned sd = seed;
+        if (f_ch[0] > 0) sd = dg_sample_chunk<7, 0>(sd, f_ch[0], n, pool, S->seeds3[0], S->draws3[0], S->alm3[0], pscr, lane);
+        if (f_ch[1] > 0) sd = dg_sample_draws<7>(sd, f_ch[1], n, S->seeds3[1], S->draws3[1], S->alm3[1], lane);
+        if (lane == 0) S->itmp[31] = (int)sd;
+    }
+    __syncthreads();
+    seed = (unsigned)S->itmp[31];
+    while (f_ch[f_cur] > 0 && f_sam < max_sam) {
+        /* the owner's word: stop?  its budget, its position (the ring's free room) */
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(wave) == 0) {
+            int go = 1;
+            const long long t0 = wall_clock64();
+            for (;;) {
+                if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&scb->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { go = 0; break; }
+                const int tl = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&scb->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (f_pub - tl < A.stream_depth - 1) break;
+                if (wall_clock64() - t0 > 4 * (long long)A.wait_ticks + 1000000ll) { go = 0; break; }
+                __builtin_amdgcn_s_sleep(16);
+            }
+            if (lane == 0) { S->itmp[24] = go; S->itmp[26] = __hip_atomic_load(&scb->max_sam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); S->itmp[23] = 0; }
+        }
+        __syncthreads();
+        if (!S->itmp[24]) break;
+        if (S->itmp[26] < max_sam) max_sam = S->itmp[26];
+        if (f_sam >= max_sam) break;
+        const int fnxt = f_cur == 2 ? 0 : f_cur + 1, fnx2 = fnxt == 2 ? 0 : fnxt + 1;
+        int fc2 = max_sam - (f_sam + f_ch[f_cur] + f_ch[fnxt]); if (fc2 > DG_CHUNK) fc2 = DG_CHUNK; if (fc2 < 0) fc2 = 0;
+        dg_stream_ent *fe = dg_stream_entry(A, oslot, f_pub);
+        __syncthreads();
+        /* one phase: wave 0 = pool swaps of the next chunk, 1 = seed chain of the one behind, 2.. = its draws block by block behind the chain
+         * (LDS progress word), the last wave = this chunk's seeds and ids into its ring entry */
+        if (wave == 0) { if (f_ch[fnxt] > 0) dg_sample_pool<7, 0>(f_ch[fnxt], n, pool, S->draws3[fnxt], S->alm3[fnxt], pscr, lane); }
+        else if (wave == 1) { if (fc2 > 0) { const unsigned sd = dg_sample_chain<7>(seed, fc2, S->seeds3[fnx2], lane, (long long *)0, &S->itmp[23]); if (lane == 0) S->itmp[31] = (int)sd; } }
+        else if (wave == DG_NW - 1) {
+            for (int i = lane; i < DG_CHUNK; i += 64) {
+                fe->seeds[i] = S->seeds3[f_cur][i];
+#pragma unroll
+                for (int q = 0; q < 8; q++) fe->draws[i][q] = S->draws3[f_cur][i][q];
+            }
+            if (lane == 0) fe->cn = f_ch[f_cur];
+        } else {
+            for (int rd = wave - 2; rd * 64 < fc2; rd += DG_NW - 3) {
+                const int need = (rd + 1) * 64 < fc2 ? (rd + 1) * 64 : fc2;
+                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&S->itmp[23], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(24);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                dg_sample_draws_round<7>(rd, fc2, n, S->seeds3[fnx2], S->draws3[fnx2], S->alm3[fnx2], lane);
+            }
+        }
+        __syncthreads();
+        if (fc2 > 0) seed = (unsigned)S->itmp[31];
+        dg_stream_publish(&scb->head, f_pub + 1);
+        f_sam += f_ch[f_cur]; f_pub++; f_ch[f_cur] = 0; f_ch[fnx2] = fc2; f_cur = fnxt;
     }
 }
 

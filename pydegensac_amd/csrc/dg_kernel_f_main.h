@@ -38,7 +38,6 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     /* fan mode (dg_f_fan.h): this workgroup draws the sample stream into the ring, worker workgroups solve and score the chunks, the
      * commit below takes the completed entries in order (the stream mode's consumer path, strm == 2, from the first chunk on) */
     const bool fan = LDSPTS == 0 && A.fan_k > 0 && coopK > 0 && !resume && !(A.prm.legacy && A.prm.sym_th > 0);
-    int f_cur = 0, f_pub = 0, f_sam = 0, f_ch[3] = {0, 0, 0};     /* fan sampler: ring slot of the next chunk to publish, chunks / samples published, chunk sizes per slot */
     const bool deep = DG_NW >= 8 && LDSPTS == 0 && coopK > 0 && !A.hist_out && !fan;
     const long long off = A.offsets[pair];
     const int n = (int)(A.offsets[pair + 1] - off);
@@ -156,7 +155,6 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         seed = (unsigned)S->itmp[31];
         if (fan) {
             /* open the pair for this slot's workers: parameters, counters, one release, then the state word */
-            f_ch[0] = cn0; f_ch[1] = cn1; f_ch[2] = 0;
             if (tid == 0) {
                 scb->pair = pair; scb->wsid = wsid; scb->img_sam = 0; scb->fan_kind = mk_full; scb->fan_th = th;
                 for (int i = 0; i < 4; i++) scb->fan_ext[i] = S->ext[i];
@@ -277,97 +275,46 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             }
         }
         if (fan) {
-            /* fan mode: one step of the sampler (the chunk in slot f_cur has its drawn ids: into the ring with it; pool swaps of the next
-             * chunk on wave 0, seed chain of the one behind on wave 1, its draws afterwards), then the commit of entry `seq` if a worker
-             * has completed it; without either, wait for that entry */
-            bool ready = false;
+            /* fan mode: the slot's sampler workgroup draws the stream, the workers complete the entries; here only the commit.  First the
+             * scout (one wave): how many of the next entries are complete and uneventful ("uneventful chunk" below) — they are taken in one
+             * step; then entry `seq` itself, which the ordinary ring path below commits: wait for it if it is not complete yet. */
             DG_PH(3);
-            for (;;) {
-                const bool can = f_ch[f_cur] > 0 && f_sam < max_sam && f_pub - seq < A.stream_depth - 1;
-                if (can) {
-                    const int fnxt = f_cur == 2 ? 0 : f_cur + 1, fnx2 = fnxt == 2 ? 0 : fnxt + 1;
-                    int fc2 = max_sam - (f_sam + f_ch[f_cur] + f_ch[fnxt]); if (fc2 > DG_CHUNK) fc2 = DG_CHUNK; if (fc2 < 0) fc2 = 0;
-                    dg_stream_ent *fe = dg_stream_entry(A, oslot, f_pub);
-                    if (DG_NW >= 8) {
-                        /* eight waves, one phase: 0 = pool swaps of the next chunk, 1 = seed chain of the one behind, 2-5 = its draws, one block of
-                         * 64 samples each, as soon as the chain has stored the block's seeds (LDS progress word), 6 = this chunk's seeds and ids
-                         * into its ring entry, 7 = the scout: how many of the next entries are complete and uneventful (dg_f_pair, "uneventful
-                         * chunk"), so that the workgroup takes them in one step behind the phase */
-                        const double tau_now = maxS.J < maxSs.J ? maxS.J : maxSs.J;
-                        __syncthreads();
-                        if (tid == 0) { S->itmp[23] = 0; S->itmp[20] = 0; S->itmp[21] = no_sam; S->itmp[22] = 0; }
-                        __syncthreads();
-                        if (wave == 0) { if (f_ch[fnxt] > 0) dg_sample_pool<7, LDSPTS>(f_ch[fnxt], n, pool, S->draws3[fnxt], S->alm3[fnxt], pscr, lane, S->dbg); }
-                        else if (wave == 1) { if (fc2 > 0) { const unsigned sd = dg_sample_chain<7>(seed, fc2, S->seeds3[fnx2], lane, S->dbg, &S->itmp[23]); if (lane == 0) S->itmp[31] = (int)sd; } }
-                        else if (wave < 2 + DG_CHUNK / 64) {
-                            const int rd = wave - 2;
-                            if (rd * 64 < fc2) {
-                                const int need = (rd + 1) * 64 < fc2 ? (rd + 1) * 64 : fc2;
-                                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&S->itmp[23], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(24);      /* (a poll every ~0.6 us: the chain wave shares its SIMD with one of these) */
-                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                                dg_sample_draws_round<7>(rd, fc2, n, S->seeds3[fnx2], S->draws3[fnx2], S->alm3[fnx2], lane, S->dbg);
-                            }
-                        } else if (wave == 6) {
-                            for (int i = lane; i < DG_CHUNK; i += 64) {
-                                fe->seeds[i] = S->seeds3[f_cur][i];
-#pragma unroll
-                                for (int q = 0; q < 8; q++) fe->draws[i][q] = S->draws3[f_cur][i][q];
-                            }
-                            if (lane == 0) fe->cn = f_ch[f_cur];
-                        } else {
-                            int cnt = 0, ns = no_sam, msum = 0;
-                            for (int s_ = seq; cnt < 32 && s_ < f_pub; s_++) {
-                                if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(dg_fan_flag(A, oslot, s_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != s_ + 1) break;
-                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                                const dg_stream_ent *q_ = dg_stream_entry(A, oslot, s_);
-                                const int cn_ = __builtin_amdgcn_readfirstlane(q_->cn), mt_ = __builtin_amdgcn_readfirstlane(q_->Mtot);
-                                const int ne_ = __builtin_amdgcn_readfirstlane(q_->n_ev), ov_ = __builtin_amdgcn_readfirstlane(q_->overflow);
-                                const double tu_ = q_->tau_used;
-                                const bool quiet = ne_ == 0 && !ov_ && !(tu_ > tau_now) && !(A.stream_test & 1) && ns >= DG_ITER_SAM && cn_ > 0 && ns + cn_ < max_sam;
-                                if (!__builtin_amdgcn_readfirstlane(quiet ? 1 : 0)) break;
-                                ns += cn_; msum += mt_; cnt++;
-                            }
-                            if (lane == 0) { S->itmp[20] = cnt; S->itmp[21] = ns; S->itmp[22] = msum; }
-                        }
-                        __syncthreads();
-                        if (fc2 > 0) seed = (unsigned)S->itmp[31];
-                        if (S->itmp[20] > 0) {
-                            DG_DEVT(if (tid == 0) S->dbg[5] += 100000ll * S->itmp[20]);
-                            no_sam = S->itmp[21]; c.n_fds += S->itmp[22]; track = 0;
-                            seq = no_sam / DG_CHUNK;
-                        }
-                    } else {
-                        __syncthreads();
-                        if (wave == 0) { if (f_ch[fnxt] > 0) dg_sample_pool<7, LDSPTS>(f_ch[fnxt], n, pool, S->draws3[fnxt], S->alm3[fnxt], pscr, lane, S->dbg); }
-                        else if (wave == 1 % DG_NW) { if (fc2 > 0) { const unsigned sd = dg_sample_chain<7>(seed, fc2, S->seeds3[fnx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; } }
-                        __syncthreads();
-                        if (fc2 > 0) seed = (unsigned)S->itmp[31];
-                        for (int i = tid; i < DG_CHUNK; i += DG_T) {
-                            fe->seeds[i] = S->seeds3[f_cur][i];
-#pragma unroll
-                            for (int q = 0; q < 8; q++) fe->draws[i][q] = S->draws3[f_cur][i][q];
-                        }
-                        if (tid == 0) fe->cn = f_ch[f_cur];
-                        if (fc2 > 0 && wave < DG_CHUNK / 64)
-                            for (int rd = wave; rd < DG_CHUNK / 64; rd += DG_NW) dg_sample_draws_round<7>(rd, fc2, n, S->seeds3[fnx2], S->draws3[fnx2], S->alm3[fnx2], lane, S->dbg);
+            {
+                const double tau_now = maxS.J < maxSs.J ? maxS.J : maxSs.J;
+                __syncthreads();
+                if (__builtin_amdgcn_readfirstlane(wave) == 0) {
+                    int cnt = 0, ns = no_sam, msum = 0;
+                    /* lane l looks at the flag of entry seq + l: the leading run of complete entries, then ONE acquire for all of them */
+                    const bool fl_ = __hip_atomic_load(dg_fan_flag(A, oslot, seq + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq + lane + 1;
+                    const unsigned long long nb_ = ~__ballot(fl_);
+                    const int nready = nb_ ? __ffsll((long long)nb_) - 1 : 64;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    for (int s_ = seq; cnt < nready; s_++) {
+                        const dg_stream_ent *q_ = dg_stream_entry(A, oslot, s_);
+                        const int cn_ = __builtin_amdgcn_readfirstlane(q_->cn), mt_ = __builtin_amdgcn_readfirstlane(q_->Mtot);
+                        const int ne_ = __builtin_amdgcn_readfirstlane(q_->n_ev), ov_ = __builtin_amdgcn_readfirstlane(q_->overflow);
+                        const double tu_ = q_->tau_used;
+                        const bool quiet = ne_ == 0 && !ov_ && !(tu_ > tau_now) && !(A.stream_test & 1) && ns >= DG_ITER_SAM && cn_ > 0 && ns + cn_ < max_sam;
+                        if (!__builtin_amdgcn_readfirstlane(quiet ? 1 : 0)) break;
+                        ns += cn_; msum += mt_; cnt++;
                     }
-                    dg_stream_publish(&scb->head, f_pub + 1);
-                    f_sam += f_ch[f_cur]; f_pub++; f_ch[f_cur] = 0; f_ch[fnx2] = fc2; f_cur = fnxt;
+                    if (lane == 0) { S->itmp[20] = cnt; S->itmp[21] = ns; S->itmp[22] = msum; }
                 }
                 __syncthreads();
-                if (tid == 0) S->itmp[30] = (seq < f_pub && __hip_atomic_load(dg_fan_flag(A, oslot, seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq + 1) ? 1 : 0;
+                if (S->itmp[20] > 0) {
+                    DG_DEVT(if (tid == 0) S->dbg[5] += 100000ll * S->itmp[20]);
+                    no_sam = S->itmp[21]; c.n_fds += S->itmp[22]; track = 0;
+                    seq = no_sam / DG_CHUNK;
+                    if (tid == 0) __hip_atomic_store(&scb->tail, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 __syncthreads();
-                ready = S->itmp[30] != 0;
-                __syncthreads();
-                if (ready || !can) break;
             }
-            DG_PH(2);                    /* development build: phase 2 = the sampler steps of the fan mode, phase 0 = waiting for a worker's entry */
-            if (!ready) {
+            DG_PH(2);
+            {
                 const int want = seq + 1;
                 if (dg_stream_wait(A, dg_fan_flag(A, oslot, seq), (int *)0, [=](int v) { return v == want; }, &S->itmp[28], A.wait_ticks) < 0) { done = 1; break; }
-            } else if (__builtin_amdgcn_readfirstlane(wave) == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __syncthreads();
-            DG_PH(0);
+            }
+            DG_PH(0);                    /* development build: phase 2 = the scout, phase 0 = waiting for a worker's entry */
         }
         if (park_on && no_sam >= A.park_sam) {
             /* still running after park_sam samples: set the pair aside if unstarted pairs remain and a spare workspace is left */
@@ -1248,7 +1195,8 @@ __global__ __launch_bounds__(DG_T, DG_MINW) void dg_find_fundamental_kernel(dg_a
         const int base = As.n_res * (As.coop_k + 1);
         if ((int)blockIdx.x >= base) {
             const int w = (int)blockIdx.x - base;
-            dg_f_fan_worker<T>(As, &Sh, w / As.fan_k, As.fan_ws0 + w, &next_pair);
+            if (w % As.fan_k == 0) dg_f_fan_sampler<T>(As, &Sh, w / As.fan_k, As.fan_ws0 + w, &next_pair);       /* the slot's sampler ... */
+            else dg_f_fan_worker<T>(As, &Sh, w / As.fan_k, As.fan_ws0 + w, &next_pair);                         /* ... and its workers */
             return;
         }
     }
