@@ -192,64 +192,76 @@ __device__ __noinline__ void dg_f_fan_sampler(const dg_args &A, dg_f_shared *S, 
     if (__builtin_amdgcn_readfirstlane(wave) == 0) { dg_srand_wave(&S->rng, A.seeds[pair], lane); const int v_ = dg_rand_block(&S->rng, 1, lane); if (lane == 0) S->itmp[31] = v_; }
     __syncthreads();
     unsigned seed = (unsigned)S->itmp[31];
-    int f_ch[3] = {0, 0, 0}, f_cur = 0, f_pub = 0, f_sam = 0;
-    { int c0 = max_sam < DG_CHUNK ? max_sam : DG_CHUNK; if (c0 < 0) c0 = 0; int c1 = max_sam - c0; if (c1 > DG_CHUNK) c1 = DG_CHUNK; if (c1 < 0) c1 = 0; f_ch[0] = c0; f_ch[1] = c1; }
+    /* Pipeline, four chunks in flight: chunk i (slot f_cur: drawn ids) goes into the ring, chunk i + 1 gets its pool swaps (wave 0), chunk
+     * i + 2 — whose seeds the previous step chained into sx[par] — its draws (four waves, one block of 64 samples each), chunk i + 3 its
+     * seed chain (wave 1, into sx[par ^ 1]).  The chain is the long stage (one dependent step per sample): nobody polls it, and the wave
+     * that shares its SIMD (wave 5: waves w and w + 4 sit on one SIMD) stays idle. */
+    static_assert(sizeof(dg_lsq_scratch) >= 2 * DG_CHUNK * sizeof(unsigned), "the seed buffers of the fan sampler do not fit the least-squares scratch");
+    unsigned (*sx)[DG_CHUNK] = (unsigned (*)[DG_CHUNK])&S->lsq;
+    int f_ch[3] = {0, 0, 0}, f_cur = 0, f_pub = 0, f_sam = 0, cX = 0, par = 0;
+    {
+        int c0 = max_sam < DG_CHUNK ? max_sam : DG_CHUNK; if (c0 < 0) c0 = 0;
+        int c1 = max_sam - c0; if (c1 > DG_CHUNK) c1 = DG_CHUNK; if (c1 < 0) c1 = 0;
+        int c2 = max_sam - c0 - c1; if (c2 > DG_CHUNK) c2 = DG_CHUNK; if (c2 < 0) c2 = 0;
+        f_ch[0] = c0; f_ch[1] = c1; cX = c2;
+    }
     __syncthreads();
     if (wave == 0) {
         unsigned sd = seed;
         if (f_ch[0] > 0) sd = dg_sample_chunk<7, 0>(sd, f_ch[0], n, pool, S->seeds3[0], S->draws3[0], S->alm3[0], pscr, lane);
         if (f_ch[1] > 0) sd = dg_sample_draws<7>(sd, f_ch[1], n, S->seeds3[1], S->draws3[1], S->alm3[1], lane);
+        if (cX > 0) sd = dg_sample_chain<7>(sd, cX, sx[0], lane);
         if (lane == 0) S->itmp[31] = (int)sd;
     }
     __syncthreads();
     seed = (unsigned)S->itmp[31];
     while (f_ch[f_cur] > 0 && f_sam < max_sam) {
-        /* the owner's word: stop?  its budget, its position (the ring's free room) */
+        /* the owner's word: stop?  its budget, its position (the ring's free room): every fourth chunk (four chunks of slack in the window test) */
         __syncthreads();
-        if (__builtin_amdgcn_readfirstlane(wave) == 0) {
+        if ((f_pub & 3) != 0) { if (tid == 0) { S->itmp[24] = 1; S->itmp[26] = max_sam; } }
+        else if (__builtin_amdgcn_readfirstlane(wave) == 0) {
             int go = 1;
             const long long t0 = wall_clock64();
             for (;;) {
                 if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&scb->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { go = 0; break; }
                 const int tl = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&scb->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                if (f_pub - tl < A.stream_depth - 1) break;
+                if (f_pub - tl < A.stream_depth - 5) break;
                 if (wall_clock64() - t0 > 4 * (long long)A.wait_ticks + 1000000ll) { go = 0; break; }
                 __builtin_amdgcn_s_sleep(16);
             }
-            if (lane == 0) { S->itmp[24] = go; S->itmp[26] = __hip_atomic_load(&scb->max_sam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); S->itmp[23] = 0; }
+            if (lane == 0) { S->itmp[24] = go; S->itmp[26] = __hip_atomic_load(&scb->max_sam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         }
         __syncthreads();
         if (!S->itmp[24]) break;
         if (S->itmp[26] < max_sam) max_sam = S->itmp[26];
         if (f_sam >= max_sam) break;
         const int fnxt = f_cur == 2 ? 0 : f_cur + 1, fnx2 = fnxt == 2 ? 0 : fnxt + 1;
-        int fc2 = max_sam - (f_sam + f_ch[f_cur] + f_ch[fnxt]); if (fc2 > DG_CHUNK) fc2 = DG_CHUNK; if (fc2 < 0) fc2 = 0;
+        int cY = max_sam - (f_sam + f_ch[f_cur] + f_ch[fnxt] + cX); if (cY > DG_CHUNK) cY = DG_CHUNK; if (cY < 0) cY = 0;
         dg_stream_ent *fe = dg_stream_entry(A, oslot, f_pub);
         __syncthreads();
-        /* one phase: wave 0 = pool swaps of the next chunk, 1 = seed chain of the one behind, 2.. = its draws block by block behind the chain
-         * (LDS progress word), the last wave = this chunk's seeds and ids into its ring entry */
         if (wave == 0) { if (f_ch[fnxt] > 0) dg_sample_pool<7, 0>(f_ch[fnxt], n, pool, S->draws3[fnxt], S->alm3[fnxt], pscr, lane); }
-        else if (wave == 1) { if (fc2 > 0) { const unsigned sd = dg_sample_chain<7>(seed, fc2, S->seeds3[fnx2], lane, (long long *)0, &S->itmp[23]); if (lane == 0) S->itmp[31] = (int)sd; } }
-        else if (wave == DG_NW - 1) {
+        else if (wave == 1) { if (cY > 0) { const unsigned sd = dg_sample_chain<7>(seed, cY, sx[par ^ 1], lane); if (lane == 0) S->itmp[31] = (int)sd; } }
+        else if (wave == 4 % DG_NW) {
             for (int i = lane; i < DG_CHUNK; i += 64) {
                 fe->seeds[i] = S->seeds3[f_cur][i];
 #pragma unroll
                 for (int q = 0; q < 8; q++) fe->draws[i][q] = S->draws3[f_cur][i][q];
             }
             if (lane == 0) fe->cn = f_ch[f_cur];
-        } else {
-            for (int rd = wave - 2; rd * 64 < fc2; rd += DG_NW - 3) {
-                const int need = (rd + 1) * 64 < fc2 ? (rd + 1) * 64 : fc2;
-                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&S->itmp[23], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(24);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                dg_sample_draws_round<7>(rd, fc2, n, S->seeds3[fnx2], S->draws3[fnx2], S->alm3[fnx2], lane);
+        } else if (wave != 5) {
+            const int rd = wave == 2 ? 0 : wave == 3 ? 1 : wave == 6 ? 2 : 3;                 /* (DG_NW == 8: the host only takes this mode at 512 threads) */
+            if (rd * 64 < cX) {
+                dg_sample_draws_round<7>(rd, cX, n, sx[par], S->draws3[fnx2], S->alm3[fnx2], lane);
+                const int k_ = rd * 64 + lane; if (k_ < cX) S->seeds3[fnx2][k_] = sx[par][k_];
             }
         }
         __syncthreads();
-        if (fc2 > 0) seed = (unsigned)S->itmp[31];
-        dg_stream_publish(&scb->head, f_pub + 1);
-        f_sam += f_ch[f_cur]; f_pub++; f_ch[f_cur] = 0; f_ch[fnx2] = fc2; f_cur = fnxt;
+        if (cY > 0) seed = (unsigned)S->itmp[31];
+        f_sam += f_ch[f_cur]; f_pub++; f_ch[f_cur] = 0; f_ch[fnx2] = cX; cX = cY; par ^= 1; f_cur = fnxt;
+        /* one release (a write-back of this XCD's L2) per four chunks, and for the first ones and the last one at once */
+        if ((f_pub & 3) == 0 || f_pub <= 8 || !(f_ch[f_cur] > 0 && f_sam < max_sam)) dg_stream_publish(&scb->head, f_pub);
     }
+    dg_stream_publish(&scb->head, f_pub);
 }
 
 #endif /* DG_F_FAN_H */

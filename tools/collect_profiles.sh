@@ -1,5 +1,5 @@
-# Copies the newest summaries of gpurun_out/r5p (merged back from `gpurun -- bash tools/profile_round.sh`) into profiles/.
-R=r5; O=gpurun_out/${R}p
+# Copies the newest summaries of gpurun_out/r6p (merged back from `gpurun -- bash tools/profile_round.sh`) into profiles/.
+R=r6; O=gpurun_out/${R}p
 new() { ls -t $1 | head -1; }
 cp $(new "$O/stats/*/*_kernel_stats.csv") profiles/${R}_bench_kernel_stats.csv
 cp $(new "$O/stats_c3/*/*_kernel_stats.csv") profiles/${R}_bench_c3_kernel_stats.csv
@@ -25,10 +25,10 @@ import json
 out = {}
 for p in (8192, 16384):
     try:
-        j = json.loads(open(f"gpurun_out/r5p/bench_line_{p}.json").read().strip().splitlines()[-1])
+        j = json.loads(open(f"gpurun_out/r6p/bench_line_{p}.json").read().strip().splitlines()[-1])
         out[str(p)] = {k: j[k] for k in ("value", "ms_per_step", "pairs_set_aside")} | {"frac": j["roofline"]["frac"], "kernel_ms": j["roofline"]["kernel_ms"]}
     except Exception as e:
         out[str(p)] = {"error": str(e)}
-json.dump(out, open("profiles/r5_bench_batch_sizes.json", "w"), indent=1)
+json.dump(out, open("profiles/r6_bench_batch_sizes.json", "w"), indent=1)
 PY
 python -c "import bench; print('sources', bench.source_id(), 'traffic', bench.pmc_traffic('c2', 4096))"

@@ -1,5 +1,5 @@
 """Summarise the two rocprofv3 PMC passes of bench.py (FETCH_SIZE, WRITE_SIZE; separate passes, --kernel-trace only) into
-profiles/r5_pmc_<config>.json, stamped with the hash of the kernel sources and the batch size, so bench.py's
+profiles/r6_pmc_<config>.json, stamped with the hash of the kernel sources and the batch size, so bench.py's
 `roofline.traffic` can never quote a pass measured on another build.
     python tools/pmc_summary.py <config> <pairs_per_gpu> <fetch_dir> <write_dir> [out_dir]"""
 import csv, glob, json, os, sys
@@ -34,6 +34,6 @@ if __name__ == "__main__":
            "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "dispatches": [nf, nw],
            "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
            "note": "per launch; 2 x FETCH_SIZE + WRITE_SIZE KiB (MI355X_MICROARCH.md gfx950 correction)"}
-    path = os.path.join(out_dir, f"r5_pmc_{cfg}.json")
+    path = os.path.join(out_dir, f"r6_pmc_{cfg}.json")
     json.dump(out, open(path, "w"), indent=1)
     print(path, json.dumps(out))

@@ -1,7 +1,7 @@
 # Round profile: kernel-trace stats, the PMC passes (separate runs, --kernel-trace only) of C2 / C3 / C5, the bench lines.
-# Run on the GPU box:   gpurun -- bash tools/profile_round.sh   -> gpurun_out/r5p/ ; then here: bash tools/collect_profiles.sh
+# Run on the GPU box:   gpurun -- bash tools/profile_round.sh   -> gpurun_out/r6p/ ; then here: bash tools/collect_profiles.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-R=r5; O=gpurun_out/${R}p; rm -rf $O; mkdir -p $O
+R=r6; O=gpurun_out/${R}p; rm -rf $O; mkdir -p $O
 B="--no-cpu-baseline --no-secondary"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --steps 3 --warmup 1 $B > $O/bench_profiled.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --steps 1 --warmup 0 $B --parity-pairs 0 > $O/pmc_fetch.log 2>&1
