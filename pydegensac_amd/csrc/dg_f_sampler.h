@@ -11,36 +11,37 @@
 /* Sampler stage 1 (one wave): the seed chain of a chunk and the raw draws of every sample.
  * Returns the seed that follows the chunk; almask[] (LDS) receives the per-sample alias flags. */
 template <int NDRAW>
-__device__ __noinline__ unsigned dg_sample_chain(unsigned seed, int cn, unsigned *seeds, int lane, long long *dbg = 0,
-                                                 int *prog = 0 /* LDS, optional: receives the number of seeds stored so far, in blocks of 64 (the draws of a block can start behind it) */)
+__device__ __noinline__ unsigned dg_sample_chain(unsigned seed, int cn, unsigned *seeds, int lane, long long *dbg = 0)
 {
     long long ts0 = DG_CLK();
     __builtin_amdgcn_s_setprio(3);                        /* the serial waves must not queue behind the scoring waves */
     /* seed chain: lane j < 31 carries the term C[NDRAW][j] * r_j, r_j = seed * 16807^j mod (2^31-1).  One step is one dependent chain
      * (121 ns in round 5: the floor of a pair that draws its whole budget): the seed stays on the scalar unit, the loop control is
      * scalar, the modular product is 32-bit arithmetic behind ONE 64-bit multiply, lane 0's own term is a select (no divergent
-     * branch), and only the two rows that carry terms are read back. */
+     * branch), only the two rows that carry terms are read back, and the seeds leave in blocks of 64 (lane j of a register keeps the
+     * seed of step j: one compare-and-select per step instead of a store under a one-lane branch). */
     cn = __builtin_amdgcn_readfirstlane(cn);
     const unsigned gk = lane < 31 ? dg_rng_G[lane] : 0u, ck = lane < 31 ? dg_rng_C[NDRAW][lane] : 0u;
     unsigned sd = (unsigned)__builtin_amdgcn_readfirstlane((int)seed);
-    for (int k = 0; k < cn; k++) {
-        if (lane == 0) seeds[k] = sd;
-        const unsigned s1 = sd ? sd : 1u;                        /* rand() outputs are < 2^31: Schrage == exact mulmod */
-        const unsigned long long x = (unsigned long long)s1 * gk;                           /* < 2^62 */
-        unsigned t = ((unsigned)x & 0x7fffffffu) + (unsigned)(x >> 31);                     /* < 2^32, congruent mod 2^31 - 1 */
-        t = (t & 0x7fffffffu) + (t >> 31);                                                  /* <= 2^31 */
-        { const unsigned t2 = t - 0x7fffffffu; t = t2 < t ? t2 : t; }                       /* t >= p: t - p (the difference of a smaller t wraps to a huge value) */
-        const unsigned rj = lane == 0 ? s1 : t;
-        unsigned v = ck * rj;
-        v += (unsigned)dg_dpp<DG_DPP_ROR(8)>((int)v);
-        v += (unsigned)dg_dpp<DG_DPP_ROR(4)>((int)v);
-        v += (unsigned)dg_dpp<DG_DPP_ROR(2)>((int)v);
-        v += (unsigned)dg_dpp<DG_DPP_ROR(1)>((int)v);
-        sd = ((unsigned)__builtin_amdgcn_readlane((int)v, 0) + (unsigned)__builtin_amdgcn_readlane((int)v, 16)) >> 1;      /* lanes 32.. carry zeros */
-        if (prog && ((k & 63) == 63 || k == cn - 1)) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) __hip_atomic_store(prog, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int k0 = 0; k0 < cn; k0 += 64) {
+        const int m = cn - k0 < 64 ? cn - k0 : 64;
+        int keep = 0;
+        for (int j = 0; j < m; j++) {
+            keep = lane == j ? (int)sd : keep;
+            const unsigned s1 = sd ? sd : 1u;                        /* rand() outputs are < 2^31: Schrage == exact mulmod */
+            const unsigned long long x = (unsigned long long)s1 * gk;                           /* < 2^62 */
+            unsigned t = ((unsigned)x & 0x7fffffffu) + (unsigned)(x >> 31);                     /* < 2^32, congruent mod 2^31 - 1 */
+            t = (t & 0x7fffffffu) + (t >> 31);                                                  /* <= 2^31 */
+            { const unsigned t2 = t - 0x7fffffffu; t = t2 < t ? t2 : t; }                       /* t >= p: t - p (the difference of a smaller t wraps to a huge value) */
+            const unsigned rj = lane == 0 ? s1 : t;
+            unsigned v = ck * rj;
+            v += (unsigned)dg_dpp<DG_DPP_ROR(8)>((int)v);
+            v += (unsigned)dg_dpp<DG_DPP_ROR(4)>((int)v);
+            v += (unsigned)dg_dpp<DG_DPP_ROR(2)>((int)v);
+            v += (unsigned)dg_dpp<DG_DPP_ROR(1)>((int)v);
+            sd = ((unsigned)__builtin_amdgcn_readlane((int)v, 0) + (unsigned)__builtin_amdgcn_readlane((int)v, 16)) >> 1;      /* lanes 32.. carry zeros */
         }
+        if (lane < m) seeds[k0 + lane] = (unsigned)keep;
     }
     DG_WSYNC();
     __builtin_amdgcn_s_setprio(0);
