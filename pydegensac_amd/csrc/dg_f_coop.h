@@ -82,7 +82,8 @@ __device__ __forceinline__ int dg_coop_claim(dg_coop_cb *cb, int G, int *bc /* L
                 const int rem = v & 0xfff;
                 if (rem == 0) break;
                 int ok = 0;
-                if (threadIdx.x == 0) { int e = v; ok = __hip_atomic_compare_exchange_strong(&cb->next, &e, v - 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0; }
+                if (threadIdx.x == 0) { int e = v;
+                    ok = __hip_atomic_compare_exchange_strong(&cb->next, &e, v - 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0; }
                 if (__builtin_amdgcn_readfirstlane(ok)) { res = rem - 1; break; }
             } else if (d < (DG_COOP_GEN_MASK + 1) / 2) break;             /* a newer stage is up: this one is over */
             else __builtin_amdgcn_s_sleep(1);                            /* the counter still carries an older tag: not visible yet */
@@ -437,7 +438,8 @@ __device__ __forceinline__ void dg_lo_round_coop(CTX &c, int nr, int ssiz, doubl
 {
     dg_f_shared *S = c.S; const dg_args &A = *c.A; dg_coop_cb *cb = c.cb; const int tid = c.tid;
     const dg_coop_ws v = dg_coop_views(A, c.coop_slot);
-    if (tid == 0) { dg_lo_job *job = (dg_lo_job *)dg_coop_lojob(A, c.coop_slot); job->n = c.n; job->ssiz = ssiz; job->mk_full = mk_full; job->mk_ex = mk_ex; job->th = th; }
+    if (tid == 0) { dg_lo_job *job = (dg_lo_job *)dg_coop_lojob(A, c.coop_slot); job->n = c.n; job->ssiz = ssiz; job->mk_full = mk_full; job->mk_ex = mk_ex;
+        job->th = th; }
     dg_coop_publish(cb, *c.coop_gen, 4, nr, 0, c.n, mk_full, 0, 0, th, S->ext, 0.0);
     dg_coop_work<DG_T>(A, c.coop_slot, S, v, cb, *c.coop_gen, (double *)(A.ws + (size_t)c.coop_slot * A.wl.stride + A.wl.off_hjbuf), &S->itmp[28], tid);
     if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {

@@ -38,7 +38,8 @@ __device__ __noinline__ void dg_f_fan_worker(const dg_args &A, dg_f_shared *S, c
         int res = 0;
         const long long t0 = wall_clock64();
         for (;;) {
-            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&scb->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == DG_ST_ATTACHED) { res = 1; break; }
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&scb->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == DG_ST_ATTACHED) { res = 1; break;
+                }
             if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&scb->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
             if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(A.done_pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= A.n_pairs) break;
             if (wall_clock64() - t0 > 4 * (long long)A.wait_ticks + 1000000ll) break;             /* (an owner that never starts: leave) */
@@ -74,11 +75,13 @@ __device__ __noinline__ void dg_f_fan_worker(const dg_args &A, dg_f_shared *S, c
                 const int hd = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&scb->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 if (cl < hd) {
                     int ok = 0;
-                    if (lane == 0) { int e = cl; ok = __hip_atomic_compare_exchange_strong(&scb->claim, &e, cl + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0; }
+                    if (lane == 0) { int e = cl;
+                        ok = __hip_atomic_compare_exchange_strong(&scb->claim, &e, cl + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0; }
                     if (__builtin_amdgcn_readfirstlane(ok)) { seq = cl; break; }
                     continue;
                 }
-                if (wall_clock64() - t0 > 4 * (long long)A.wait_ticks + 1000000ll) break;         /* (the owner is a running workgroup: it publishes or stops) */
+                /* (the owner is a running workgroup: it publishes or stops) */
+                if (wall_clock64() - t0 > 4 * (long long)A.wait_ticks + 1000000ll) break;
                 __builtin_amdgcn_s_sleep(8);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -110,7 +113,8 @@ __device__ __noinline__ void dg_f_fan_worker(const dg_args &A, dg_f_shared *S, c
                 S->moff[tid] = (unsigned short)excl;
                 S->nv[tid] = nullbad ? 255 : (unsigned char)nvalid;
                 S->nsolv[tid] = (unsigned char)((rixp >> 8) & 3u);
-                for (int r = 0; r < nvalid; r++) { S->ridx[tid][r] = (unsigned char)((rixp >> (2*r)) & 3u); S->mslot[excl + r] = (unsigned short)(tid * 3 + r); }
+                for (int r = 0; r < nvalid; r++) { S->ridx[tid][r] = (unsigned char)((rixp >> (2*r)) & 3u); S->mslot[excl + r] = (unsigned short)(tid * 3 + r);
+                    }
             }
             if (tid == T - 1) S->moff[DG_CHUNK] = (unsigned short)(excl + v);
             __syncthreads();
@@ -170,7 +174,8 @@ __device__ __noinline__ void dg_f_fan_sampler(const dg_args &A, dg_f_shared *S, 
         int res = 0;
         const long long t0 = wall_clock64();
         for (;;) {
-            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&scb->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == DG_ST_ATTACHED) { res = 1; break; }
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&scb->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == DG_ST_ATTACHED) { res = 1; break;
+                }
             if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&scb->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
             if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(A.done_pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= A.n_pairs) break;
             if (wall_clock64() - t0 > 4 * (long long)A.wait_ticks + 1000000ll) break;
@@ -189,7 +194,8 @@ __device__ __noinline__ void dg_f_fan_sampler(const dg_args &A, dg_f_shared *S, 
     for (int i = tid; i < n; i += T) pool[i] = i;
     int max_sam = __hip_atomic_load(&scb->max_sam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     /* srand(seed0); seed = rand(); then the first two chunks as the owner's prologue draws them */
-    if (__builtin_amdgcn_readfirstlane(wave) == 0) { dg_srand_wave(&S->rng, A.seeds[pair], lane); const int v_ = dg_rand_block(&S->rng, 1, lane); if (lane == 0) S->itmp[31] = v_; }
+    if (__builtin_amdgcn_readfirstlane(wave) == 0) { dg_srand_wave(&S->rng, A.seeds[pair], lane); const int v_ = dg_rand_block(&S->rng, 1, lane);
+        if (lane == 0) S->itmp[31] = v_; }
     __syncthreads();
     unsigned seed = (unsigned)S->itmp[31];
     /* Pipeline, four chunks in flight: chunk i (slot f_cur: drawn ids) goes into the ring, chunk i + 1 gets its pool swaps (wave 0), chunk

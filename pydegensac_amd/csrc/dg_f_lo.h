@@ -175,7 +175,8 @@ __device__ __noinline__ dg_score dg_inFrani_serial(CTX &c, int ninl, double th, 
     dg_score maxS = {0, 0, 0, 0};
     *kindBest = mk_full;
     if (ninl < 16) {
-        if (c.rrun) { for (size_t j = tid; j < (size_t)(DG_RESIDS_M - 2) * c.n; j += DG_T) c.rrun[2 * (size_t)c.n + j] = 0.; __syncthreads(); }   /* exp_ranF.c:761 */
+        /* exp_ranF.c:761 */
+        if (c.rrun) { for (size_t j = tid; j < (size_t)(DG_RESIDS_M - 2) * c.n; j += DG_T) c.rrun[2 * (size_t)c.n + j] = 0.; __syncthreads(); }
         return maxS;
     }
     int ssiz = ninl / 2; if (ssiz > 14) ssiz = 14;
@@ -306,7 +307,8 @@ __device__ __noinline__ void dg_lo_rep_wave(CTX &c, dg_lo_log *lg, int ssiz, dou
 #endif
     auto stale = [&]() {
         int bad = 0;
-        if (lane < wave) { const int d = __hip_atomic_load(&S->lo[lane].pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); bad = d >= 0 && d != DG_LO_ASSUMED_DRAWS; }
+        if (lane < wave) { const int d = __hip_atomic_load(&S->lo[lane].pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            bad = d >= 0 && d != DG_LO_ASSUMED_DRAWS; }
         return __ballot(bad) != 0ull;
     };
     int drawn = 0;
@@ -321,7 +323,8 @@ __device__ __noinline__ void dg_lo_rep_wave(CTX &c, dg_lo_log *lg, int ssiz, dou
     DG_RW(9);
     unsigned mI = r0.I; double mJ = r0.J; int kind0 = mk_full;
     if (lane == 0) { lg->I0 = (int)r0.I; lg->drew0 = 0; lg->nit = 0; lg->has_fin = 0; }
-    if (mI < 8) { if (lane == 0) { lg->I = 0; lg->J = 0; lg->kind0 = mk_full; __hip_atomic_store(&lg->pub, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } DG_WSYNC(); return; }
+    if (mI < 8) { if (lane == 0) { lg->I = 0; lg->J = 0; lg->kind0 = mk_full; __hip_atomic_store(&lg->pub, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } DG_WSYNC(); return; }
     /* the first 8-point model */
     {
         const int cnt = (int)r0.nL; int id;
@@ -350,7 +353,8 @@ __device__ __noinline__ void dg_lo_rep_wave(CTX &c, dg_lo_log *lg, int ssiz, dou
         if (lane == 0) { lg->it[it].hash = hash; lg->it[it].I = (int)r1.I; lg->it[it].drew = 0; lg->nit = it + 1; }
         /* a set an EARLIER round or local optimisation inserted ends the repetition here whatever the others of this round do
          * (the table is not written before the replay) */
-        { int known = 0; if (lane == 0) known = dg_ht_contains(c.ht, hash, (int)r1.I, -1) != -1; DG_RW(11); if (__builtin_amdgcn_readfirstlane(known)) { ended = 2; break; } }
+        { int known = 0; if (lane == 0) known = dg_ht_contains(c.ht, hash, (int)r1.I, -1) != -1; DG_RW(11);
+            if (__builtin_amdgcn_readfirstlane(known)) { ended = 2; break; } }
         if (fit) {
             const int cnt = (int)nL2; int id;
             if (8 < cnt) {
@@ -436,7 +440,8 @@ __device__ __noinline__ dg_score dg_inFrani_waves(CTX &c, int ninl, double th, d
                 int id = 0;
                 dg_randsubset_wave_ahead(&S->lo_work, inliers, ninl, ssiz, lane, &id, g->upos, g->uval);
                 if (lane < ssiz) g->ids[lane] = id;
-                if (lane < 2 * ssiz && g->upos[lane] >= 0) { const int old = inliers[g->upos[lane]]; inliers[g->upos[lane]] = g->uval[lane]; g->uval[lane] = old; }
+                if (lane < 2 * ssiz && g->upos[lane] >= 0) { const int old = inliers[g->upos[lane]]; inliers[g->upos[lane]] = g->uval[lane];
+                    g->uval[lane] = old; }
                 if (lane == 0) { g->g = S->lo_work; g->g0 = S->lo_work; g->pub = -1; g->aborted = 0; }
                 DG_WSYNC();
                 dg_rand_skip(&S->lo_work, assumed, lane);

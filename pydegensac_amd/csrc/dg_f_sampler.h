@@ -32,7 +32,8 @@ __device__ __noinline__ unsigned dg_sample_chain(unsigned seed, int cn, unsigned
             const unsigned long long x = (unsigned long long)s1 * gk;                           /* < 2^62 */
             unsigned t = ((unsigned)x & 0x7fffffffu) + (unsigned)(x >> 31);                     /* < 2^32, congruent mod 2^31 - 1 */
             t = (t & 0x7fffffffu) + (t >> 31);                                                  /* <= 2^31 */
-            { const unsigned t2 = t - 0x7fffffffu; t = t2 < t ? t2 : t; }                       /* t >= p: t - p (the difference of a smaller t wraps to a huge value) */
+            /* t >= p: t - p (the difference of a smaller t wraps to a huge value) */
+            { const unsigned t2 = t - 0x7fffffffu; t = t2 < t ? t2 : t; }
             const unsigned rj = lane == 0 ? s1 : t;
             unsigned v = ck * rj;
             v += (unsigned)dg_dpp<DG_DPP_ROR(8)>((int)v);
@@ -229,7 +230,8 @@ __device__ __noinline__ void dg_sample_pool_par(int cn, int n, int *vp_generic, 
 #pragma unroll
         for (int q = 0; q < 8; q++) { const int tau = t0 + 64 * q; val[q] = tau < cn * NDRAW ? ptr[2 * tau] : 0; }
 #pragma unroll
-        for (int q = 0; q < 8; q++) { const int tau = t0 + 64 * q; if (tau < cn * NDRAW) { const int k = tau / NDRAW, i = tau - k * NDRAW; draws[k][i] = -1 - val[q]; } }
+        for (int q = 0; q < 8; q++) { const int tau = t0 + 64 * q; if (tau < cn * NDRAW) { const int k = tau / NDRAW, i = tau - k * NDRAW;
+            draws[k][i] = -1 - val[q]; } }
     }
     DG_WSYNC();
     __builtin_amdgcn_s_setprio(0);
@@ -318,7 +320,8 @@ __device__ __noinline__ void dg_sample_pool_grp(int cn, int n, int *vp_, int (*d
         if (!al) {
             const unsigned key = ((unsigned)s << 6) | (unsigned)lane;
             const unsigned h1 = (unsigned)s % DG_PGT, h2 = ((unsigned)s * 40503u >> 7) % DG_PGT;
-            if (active) { __hip_atomic_fetch_max(tab + h1, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_max(tab + DG_PGT + h2, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            if (active) { __hip_atomic_fetch_max(tab + h1, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_max(tab + DG_PGT + h2, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
             DG_WSYNC();
             if (active) {
                 const unsigned e1 = tab[h1], e2 = tab[DG_PGT + h2];

@@ -83,7 +83,8 @@ __device__ __forceinline__ int dg_stream_wait(const dg_args &A, int *flag, int *
             v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (pred(v) && limit != 0) break;                        /* limit 0 = fault injection (tests): every data wait fails at once */
             if (stop && __builtin_amdgcn_readfirstlane(__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { v = -1; break; }
-            if (wall_clock64() - t0 > limit) { if (threadIdx.x == 0) __hip_atomic_store(A.err_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = -1; break; }
+            if (wall_clock64() - t0 > limit) { if (threadIdx.x == 0) __hip_atomic_store(A.err_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = -1;
+                break; }
             __builtin_amdgcn_s_sleep(8);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -138,7 +139,8 @@ __device__ __forceinline__ int dg_stream_find(const dg_args &A, int *bc /* LDS *
                     const int j = __builtin_amdgcn_readfirstlane((int)(key & 0xffffll));
                     int ok = 0;
                     if (threadIdx.x == 0) {
-                        int e = DG_ST_REQ; ok = __hip_atomic_compare_exchange_strong(&A.scb[j].state, &e, DG_ST_ATTACHED, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+                        int e = DG_ST_REQ;
+                            ok = __hip_atomic_compare_exchange_strong(&A.scb[j].state, &e, DG_ST_ATTACHED, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
                         if (ok) __hip_atomic_fetch_add(A.done_pairs + 1, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     if (__builtin_amdgcn_readfirstlane(ok)) { res = j; __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }

@@ -144,11 +144,13 @@ struct dg_coop_rec { unsigned I, nL, nL2, nJ; };
  * behind the usual release / acquire pair (MI355X_MICROARCH.md, inter-workgroup visibility). */
 enum { DG_ST_IDLE = 0, DG_ST_REQ = 1, DG_ST_BUSY = 2, DG_ST_ATTACHED = 3, DG_ST_RELEASED = 4 };
 struct dg_stream_cb {
-    int state;                /* DG_ST_*: IDLE -> REQ (image valid) -> ATTACHED (a producer took it) -> RELEASED (producer gone) -> IDLE; BUSY = the owner rewrites the image */
+    /* DG_ST_*: IDLE -> REQ (image valid) -> ATTACHED (a producer took it) -> RELEASED (producer gone) -> IDLE; BUSY = the owner rewrites the image */
+    int state;
     int head;                 /* chunks the producer has published: sequence numbers < head are in the ring */
     int tail;                 /* chunks the owner has consumed */
     int stop;                 /* the owner is done with the pair */
-    int owner_sam;            /* since when the pair has been worked on (wall_clock64 >> 10): producers take the oldest of the requests with the most samples left */
+    /* since when the pair has been worked on (wall_clock64 >> 10): producers take the oldest of the requests with the most samples left */
+    int owner_sam;
     int max_sam;              /* the owner's current sample budget */
     unsigned long long tau_bits;   /* the owner's current bound min(maxS.J, maxSs.J), as the bits of a double */
     int claim;                /* fan mode: next chunk (sequence number) a worker may claim; head = chunks whose drawn ids are in the ring */
@@ -221,7 +223,8 @@ struct dg_args {
     int park_long;                   /* a pair set aside with at least this many samples left goes to queue 1    */
     int lo_serial;                   /* homography: 1 = run the repetitions of a local optimisation one after the other on the whole workgroup */
     int pool_seq;                    /* 1 = always use the sequential pool-swap stage (LDS exchange-order self-check failed, or forced) */
-    int innerh_serial;               /* fundamental matrix: 1 = the repetitions of innerH and of the local optimisation one after the other on the whole workgroup (tests) */
+    /* fundamental matrix: 1 = the repetitions of innerH and of the local optimisation one after the other on the whole workgroup (tests) */
+    int innerh_serial;
     int variant_threads, mode;       /* reported in the stats block */
     /* stream mode (dg_stream_cb): */
     int stream_on;                   /* 0 = off */
@@ -279,7 +282,8 @@ __device__ __forceinline__ bool dg_wait_count(const dg_args &A, int *cnt, int ta
 static __constant__ unsigned dg_rng_C[8][32];
 static __constant__ unsigned dg_rng_Ct[32][8];     /* transposed copy: one 32-byte scalar load per term j */
 static __constant__ unsigned dg_rng_G[32];
-static __constant__ unsigned dg_rng_T[31][32];     /* [j][p]: coefficient (mod 2^32) of the initial word r_j in ring word p after srandom's 310 discarded steps */
+/* [j][p]: coefficient (mod 2^32) of the initial word r_j in ring word p after srandom's 310 discarded steps */
+static __constant__ unsigned dg_rng_T[31][32];
 
 __device__ __forceinline__ unsigned dg_mulmod31(unsigned a, unsigned b)
 {

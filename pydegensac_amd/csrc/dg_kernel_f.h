@@ -69,13 +69,16 @@ struct dg_ih_log { dg_rng g; double h[9]; double itJ; int ids[12]; int passes, d
 struct dg_lo_it { unsigned hash; int I; int drew; };
 struct dg_lo_log {
     dg_rng g, g0;                         /* g0: the generator right behind the sample's draws (g moves on with the repetition's own draws) */
-    int upos[28], uval[28];               /* the list slots the sample's draws stored, with the values they replaced (-1: none): undone when the repetition is not committed */
+    /* the list slots the sample's draws stored, with the values they replaced (-1: none): undone when the repetition is not committed */
+    int upos[28], uval[28];
     int ids[14];
-    int I0, drew0, nit, has_fin;          /* r0.I (< 8: the repetition ends at once), draws of the first 8-subset, iterations that hashed their set, final pass made */
+    /* r0.I (< 8: the repetition ends at once), draws of the first 8-subset, iterations that hashed their set, final pass made */
+    int I0, drew0, nit, has_fin;
     dg_lo_it it[DG_ILSQ_ITERS];
     double f[9], J; int I, kind0;         /* result when no iteration is cut short by the replay: model, score, metric variant of errs[0] */
     int cut, draws, n_ex, n_fd;           /* filled by the replay: cut short by an earlier repetition's set, 8-subset draws really consumed, passes to count */
-    int pub, aborted;                     /* pub: -1 while the repetition runs, then the draws it made (the later repetitions of the round watch it); aborted: stopped as stale */
+    /* pub: -1 while the repetition runs, then the draws it made (the later repetitions of the round watch it); aborted: stopped as stale */
+    int pub, aborted;
 };
 /* cooperative large-n mode: the repetitions of a round are units of stage 4, one claiming workgroup each; their records live in
  * the owner's workspace (DG_LOJOB_BYTES at the end of the stage-3 staging): a header, then one record per repetition on its own
@@ -165,7 +168,8 @@ struct dg_f_ctx {
     dg_coop_cb *cb; int *coop_gen; int coop_slot;   /* cooperative large-n mode: this owner's control block (null = off) */
     double *hlt;             /* homography kernel: [DG_NW][DG_HLT] doubles of LDS, one block per wave (one-repetition-per-wave LO) */
     int hjob_gen;            /* homography kernel: generation of this slot's last local-optimisation job (dg_hjob_cb) */
-    int lo_assumed, lo_prev; /* cooperative large-n mode: 8-subset draws the last committed repetition of a local optimisation consumed (the start states of the next ones assume it) */
+    int lo_assumed, lo_prev;
+        /* cooperative large-n mode: 8-subset draws the last committed repetition of a local optimisation consumed (the start states of the next ones assume it) */
 
     __device__ __forceinline__ dg_pt pt(int i) const { return P[i]; }
     /* LAF point sets u_1 (which=1: +a12,+a22) and u_2 (which=2: +a11,+a21): bindings.cpp:337-409 */
@@ -261,7 +265,8 @@ __device__ __forceinline__ dg_pass_res dg_h_pass(CTX &c, const double *Hm /* LDS
 }
 __device__ __forceinline__ dg_pass_cfg dg_cfg0(int n)
 {
-    dg_pass_cfg c; c.n = n; c.src = 0; c.p0 = 0; c.wantJ = 0; c.thJ = 0; c.jbuf = 0; c.jl = 0; c.jl_cap = 0; c.wantC = 0; c.thC = 0; c.list = 0; c.thL = 0; c.listStrict = 0; c.list2 = 0; c.thL2 = 0; c.flags = 0; c.thF = 0;
+    dg_pass_cfg c; c.n = n; c.src = 0; c.p0 = 0; c.wantJ = 0; c.thJ = 0; c.jbuf = 0; c.jl = 0; c.jl_cap = 0; c.wantC = 0; c.thC = 0; c.list = 0; c.thL = 0;
+        c.listStrict = 0; c.list2 = 0; c.thL2 = 0; c.flags = 0; c.thF = 0;
     return c;
 }
 
@@ -348,8 +353,10 @@ __device__ __noinline__ int dg_checksample(CTX &c, const double *F /* LDS */, co
             for (int j = 0; j < 7; j++) { w->Ds[j] = dg_HDs(w->H, u7[j][0], u7[j][1], u7[j][2], u7[j][3]); w->sDs[j] = w->Ds[j]; w->idx[j] = j; }
             for (int a = 0; a < 7; ++a)                                  /* sortDs, DegUtils.c:164-183 */
                 for (int b = a + 1; b < 7; ++b)
-                    if (w->sDs[b] < w->sDs[a]) { double t = w->sDs[b]; w->sDs[b] = w->sDs[a]; w->sDs[a] = t; int ti = w->idx[b]; w->idx[b] = w->idx[a]; w->idx[a] = ti; }
-            for (int j = 0; j < 5; ++j) { const double *q = u7[w->idx[j]]; w->cpx[4*j] = q[0]; w->cpx[4*j+1] = q[1]; w->cpx[4*j+2] = q[2]; w->cpx[4*j+3] = q[3]; }
+                    if (w->sDs[b] < w->sDs[a]) { double t = w->sDs[b]; w->sDs[b] = w->sDs[a]; w->sDs[a] = t; int ti = w->idx[b]; w->idx[b] = w->idx[a];
+                        w->idx[a] = ti; }
+            for (int j = 0; j < 5; ++j) { const double *q = u7[w->idx[j]]; w->cpx[4*j] = q[0]; w->cpx[4*j+1] = q[1]; w->cpx[4*j+2] = q[2]; w->cpx[4*j+3] = q[3];
+                }
         }
         DG_WSYNC();
         dg_u2h_norm_w(w, w->cpx, 5, w->H, lane);
@@ -404,7 +411,8 @@ __device__ __noinline__ unsigned dg_innerH_serial(CTX &c, double *H /* LDS, in/o
                     __syncthreads();
                     if (tid < 64) {
                         int cnt = (int)mI > (int)inlLimit ? (int)inlLimit : (int)mI;
-                        { int id; if (mI > inlLimit) dg_randsubset_wave(&S->rng, intbuff, (int)mI, (int)inlLimit, tid, &id); else id = tid < cnt ? intbuff[tid] : 0; dg_gather_wave(c, id, cnt, S->lsq.px, tid); }
+                        { int id; if (mI > inlLimit) dg_randsubset_wave(&S->rng, intbuff, (int)mI, (int)inlLimit, tid, &id);
+                            else id = tid < cnt ? intbuff[tid] : 0; dg_gather_wave(c, id, cnt, S->lsq.px, tid); }
                         DG_WSYNC();
                         dg_u2h_small_w(&S->lsq, S->lsq.px, cnt, hl, tid);
                     }
@@ -418,7 +426,8 @@ __device__ __noinline__ unsigned dg_innerH_serial(CTX &c, double *H /* LDS, in/o
                         __syncthreads();
                         if (tid < 64) {
                             int cnt = r2.nL > inlLimit ? (int)inlLimit : (int)r2.nL;
-                            { int id; if (r2.nL > inlLimit) dg_randsubset_wave(&S->rng, intbuff, (int)r2.nL, (int)inlLimit, tid, &id); else id = tid < cnt ? intbuff[tid] : 0; dg_gather_wave(c, id, cnt, S->lsq.px, tid); }
+                            { int id; if (r2.nL > inlLimit) dg_randsubset_wave(&S->rng, intbuff, (int)r2.nL, (int)inlLimit, tid, &id);
+                                else id = tid < cnt ? intbuff[tid] : 0; dg_gather_wave(c, id, cnt, S->lsq.px, tid); }
                             DG_WSYNC();
                             dg_u2h_small_w(&S->lsq, S->lsq.px, cnt, hl, tid);
                         }
@@ -630,7 +639,8 @@ __device__ __noinline__ void dg_innerH_rep_wave(CTX &c, dg_ih_log *lg, int ssiz,
     }
     DG_WSYNC();
     if (lane < 9) lg->h[lane] = h[lane];
-    if (lane == 0) { lg->itJ = itJ; lg->passes = passes; lg->draws = draws; __hip_atomic_store(&lg->pub, draws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    if (lane == 0) { lg->itJ = itJ; lg->passes = passes; lg->draws = draws; __hip_atomic_store(&lg->pub, draws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     DG_WSYNC();
 }
 
@@ -771,12 +781,15 @@ __device__ __noinline__ unsigned dg_u2Fit_wave(dg_wave_ws *w, const dg_pt *P, in
         if (cnt < 8) { *thf = ths; return cnt; }
         DG_WSYNC();
         if (cnt <= 14) {
-            if (lane < (int)cnt) { dg_pt q = dg_ldpt<LDSPTS>(P, list[lane]); w->px[4*lane] = q.x1; w->px[4*lane+1] = q.y1; w->px[4*lane+2] = q.x2; w->px[4*lane+3] = q.y2; }
+            if (lane < (int)cnt) { dg_pt q = dg_ldpt<LDSPTS>(P, list[lane]); w->px[4*lane] = q.x1; w->px[4*lane+1] = q.y1; w->px[4*lane+2] = q.x2;
+                w->px[4*lane+3] = q.y2; }
             DG_WSYNC();
             if (cnt > 8) dg_u2f_norm_w(w, w->px, (const double *)0, (int)cnt, F, lane);
             else {
                 /* exactly 8: the svduv path of u2f (Ftools.c:371-384) */
-                if (lane == 0) { for (int i = 0; i < 72; i++) w->Z[i] = 0.; for (int i = 0; i < 8; i++) { double a[3] = {w->px[4*i], w->px[4*i+1], 1.0}, b[3] = {w->px[4*i+2], w->px[4*i+3], 1.0}; for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) w->Z[(k*3+l)*8 + i] = b[k] * a[l]; } }
+                if (lane == 0) { for (int i = 0; i < 72; i++) w->Z[i] = 0.;
+                    for (int i = 0; i < 8; i++) { double a[3] = {w->px[4*i], w->px[4*i+1], 1.0}, b[3] = {w->px[4*i+2], w->px[4*i+3], 1.0};
+                    for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) w->Z[(k*3+l)*8 + i] = b[k] * a[l]; } }
                 DG_WSYNC();
                 dg_svd_lastcol_9x8_wave(w->Z, w->V, lane);
                 if (lane == 0) { for (int i = 0; i < 9; i++) F[i] = w->V[i]; dg_singulF(F); }
@@ -864,7 +877,8 @@ __device__ __noinline__ void dg_innerFH(CTX &c, const int *idxH, unsigned lenH, 
     /* 10-point model + its consensus, one wave per repetition */
     for (unsigned rep = wave; rep < repCount; rep += DG_NW) {
         dg_wave_ws *w = &S->ww[wave];
-        if (lane < 10) { dg_pt q = dg_ldpt<LDSPTS>(P, S->fhIds[rep][lane]); w->px[4*lane] = q.x1; w->px[4*lane+1] = q.y1; w->px[4*lane+2] = q.x2; w->px[4*lane+3] = q.y2; }
+        if (lane < 10) { dg_pt q = dg_ldpt<LDSPTS>(P, S->fhIds[rep][lane]); w->px[4*lane] = q.x1; w->px[4*lane+1] = q.y1; w->px[4*lane+2] = q.x2;
+            w->px[4*lane+3] = q.y2; }
         DG_WSYNC();
         dg_u2f_norm_w(w, w->px, (const double *)0, 10, S->fhF[rep], lane);
         double Fr[9];
@@ -878,7 +892,8 @@ __device__ __noinline__ void dg_innerFH(CTX &c, const int *idxH, unsigned lenH, 
     __syncthreads();
     /* repetitions that set a new record of the pre-refinement count get u2Fit (DegUtils.c:562-566) */
     int nfit = 0, fitrep[16];
-    { unsigned max_s = 0; for (unsigned rep = 0; rep < repCount; ++rep) if ((unsigned)S->fhCnt[rep] > max_s) { max_s = (unsigned)S->fhCnt[rep]; fitrep[nfit++] = (int)rep; } }
+    { unsigned max_s = 0; for (unsigned rep = 0; rep < repCount; ++rep) if ((unsigned)S->fhCnt[rep] > max_s) { max_s = (unsigned)S->fhCnt[rep];
+        fitrep[nfit++] = (int)rep; } }
     int aux_local = 0;
     for (int q = wave; q < nfit; q += DG_NW) {
         const int rep = fitrep[q];

@@ -27,8 +27,10 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     const int producer = resume == 2;
     dg_stream_cb *const scb = (A.stream_on || A.fan_k > 0) ? A.scb + oslot : (dg_stream_cb *)0;
     int head_seen = 0;               /* owner: ring entries below this sequence number are known to be visible */
-    int gpar = 0, pend_draws = 0;    /* deep pipeline: the seed buffer this iteration's chain writes; the chunk in slot nx2 still needs its draws (its seeds are in the other buffer) */
-    int mtab = 0, presolved = 0;     /* cooperative mode: the model table of the current chunk; samples of the current chunk that were solved during the previous chunk's scoring */
+    /* deep pipeline: the seed buffer this iteration's chain writes; the chunk in slot nx2 still needs its draws (its seeds are in the other buffer) */
+    int gpar = 0, pend_draws = 0;
+    /* cooperative mode: the model table of the current chunk; samples of the current chunk that were solved during the previous chunk's scoring */
+    int mtab = 0, presolved = 0;
     int strm = 0, img_sam = 0;       /* owner: 0 = own sample stream, 1 = asked for a producer (image written), 2 = takes its chunks from the ring */
     const int coopK = LDSPTS == 0 ? A.coop_k : 0;
     dg_coop_cb *const cb = coopK > 0 ? A.coop + slot : (dg_coop_cb *)0;
@@ -119,7 +121,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     if (coopK > 0 && tid == 0) __hip_atomic_store(&cb->tau_bits, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     /* srand(seed0); seed = rand() */
-    if (__builtin_amdgcn_readfirstlane(wave) == 0) { dg_srand_wave(&S->rng, A.seeds[pair], lane); const int v_ = dg_rand_block(&S->rng, 1, lane); if (lane == 0) S->itmp[31] = v_; }
+    if (__builtin_amdgcn_readfirstlane(wave) == 0) { dg_srand_wave(&S->rng, A.seeds[pair], lane); const int v_ = dg_rand_block(&S->rng, 1, lane);
+        if (lane == 0) S->itmp[31] = v_; }
     __syncthreads();
     seed = (unsigned)S->itmp[31];
     __syncthreads();
@@ -177,7 +180,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     __syncthreads();
     if (tid == 0) dg_fill_views(&S->K, wsown, A.wl);      /* the image carries the views of the workspace it was written from */
     D = S->park;
-    { const long long waited = wall_clock64() - D.t_parked; D.t_start += waited; D.t_best += waited; }   /* reported times = time the pair was being worked on */
+    /* reported times = time the pair was being worked on */
+    { const long long waited = wall_clock64() - D.t_parked; D.t_start += waited; D.t_best += waited; }
     c.n_fds = D.n_fds; c.n_exfds = D.n_exfds; c.n_hds = D.n_hds; c.n_aux = D.n_aux;
     DG_DEVT(if (tid == 0) S->tq = DG_CLK());
     __syncthreads();
@@ -195,7 +199,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     };
     while (!done && no_sam < max_sam) {
         int coop_no_ev = 0;          /* cooperative mode: the screen left no survivor: no model of this chunk can be an event of the commit */
-        int pre_cnt = 0, cn3 = 0;    /* cooperative mode: samples of the next chunk solved during this one's scoring; size of the chunk whose seed chain runs in this iteration (deep pipeline) */
+        /* cooperative mode: samples of the next chunk solved during this one's scoring; size of the chunk whose seed chain runs in this iteration (deep pipeline) */
+        int pre_cnt = 0, cn3 = 0;
         int ff = 0, tail_p = 0;      /* producer: the owner is already past this chunk: sampler stages only; the owner's position */
         int seq = no_sam / DG_CHUNK;
         dg_stream_ent *ent = (dg_stream_ent *)0;
@@ -265,7 +270,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                         __hip_atomic_store(&scb->tail, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(&scb->head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(&scb->stop, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&scb->owner_sam, (int)(t_start >> 10), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* since when the pair runs (10 us units) */
+                        /* since when the pair runs (10 us units) */
+                        __hip_atomic_store(&scb->owner_sam, (int)(t_start >> 10), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     write_image();
                     dg_stream_publish(&scb->state, DG_ST_REQ);
@@ -312,7 +318,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             DG_PH(2);
             {
                 const int want = seq + 1;
-                if (dg_stream_wait(A, dg_fan_flag(A, oslot, seq), (int *)0, [=](int v) { return v == want; }, &S->itmp[28], A.wait_ticks) < 0) { done = 1; break; }
+                if (dg_stream_wait(A, dg_fan_flag(A, oslot, seq), (int *)0, [=](int v) { return v == want; }, &S->itmp[28], A.wait_ticks) < 0) { done = 1;
+                    break; }
             }
             DG_PH(0);                    /* development build: phase 2 = the scout, phase 0 = waiting for a worker's entry */
         }
@@ -385,7 +392,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             __syncthreads();                                /* (the header words are read; the next iteration rewrites them) */
             track = 0;
             no_sam += cn_; c.n_fds += Mt_;
-            DG_DEVT(if (tid == 0) S->dbg[5] += 100000);      /* development build: chunks taken this way (tools/gpu_phases.py: "draws" of a streamed pair, x 1e5) */
+            /* development build: chunks taken this way (tools/gpu_phases.py: "draws" of a streamed pair, x 1e5) */
+            DG_DEVT(if (tid == 0) S->dbg[5] += 100000);
             continue;
         }
         if (fan) {
@@ -408,7 +416,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         if (!full) {
             /* the commit's tables from the entry: models per sample -> slots, every score 0 except the entry's models */
             const unsigned char nvb = tid < DG_CHUNK ? e_->nv[tid] : (unsigned char)0;
-            const unsigned v = (tid < chunk && nvb != 255) ? (unsigned)nvb : 0u;     /* only the samples this pair still draws count (its budget may end inside the chunk) */
+            /* only the samples this pair still draws count (its budget may end inside the chunk) */
+            const unsigned v = (tid < chunk && nvb != 255) ? (unsigned)nvb : 0u;
             unsigned incl = v;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
@@ -449,7 +458,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         int nvalid = 0, nullbad = 0; unsigned rixp = 0;
         if (presolved >= chunk && chunk > 0) {
             /* cooperative mode: this chunk's 7-point problems were solved while the helpers scored the previous chunk */
-            if (tid < chunk) { const int *pre = (const int *)(ws + A.wl.off_models + 2 * DG_MTAB_BYTES) + 2 * tid; const int a_ = pre[0]; nvalid = a_ & 0xff; nullbad = (a_ >> 8) & 1; rixp = (unsigned)pre[1]; }
+            if (tid < chunk) { const int *pre = (const int *)(ws + A.wl.off_models + 2 * DG_MTAB_BYTES) + 2 * tid; const int a_ = pre[0]; nvalid = a_ & 0xff;
+                nullbad = (a_ >> 8) & 1; rixp = (unsigned)pre[1]; }
         } else
         if (!fuse && !ff && tid < chunk) {
             int r_ = dg_solve7_lane(P, c.draws[tid], c.K->gmodels + (size_t)tid * 27, &rixp, (double *)&S->ww[wave]);
@@ -554,7 +564,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                 if (lane == 0) __hip_atomic_fetch_add(&S->itmp[23], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else if (wave == 1) {
                 if (cn3 > 0) { unsigned sd = dg_sample_chain<7>(seed, cn3, gseedT, lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }
-                else if (cn2 > 0) { unsigned sd = dg_sample_chain<7>(seed, cn2, S->seeds3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }   /* its draws: after the barrier, one wave per 64 samples */
+                /* its draws: after the barrier, one wave per 64 samples */
+                else if (cn2 > 0) { unsigned sd = dg_sample_chain<7>(seed, cn2, S->seeds3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }
             }
             /* cooperative mode: the helpers score every group (a whole workgroup per group); the owner's waves only sample.
              * Otherwise: waves 2.. score while waves 0 and 1 run their sampler stages (the critical path); with two
@@ -693,7 +704,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                 __syncthreads();
                 if (tid == 0) {
                     const int ne = S->itmp[24];
-                    ent->cn = chunk; ent->Mtot = Mtot; ent->n_ev = ne < DG_STREAM_EV_MAX ? ne : DG_STREAM_EV_MAX; ent->overflow = ne > DG_STREAM_EV_MAX ? 1 : 0; ent->tau_used = tau_c;
+                    ent->cn = chunk; ent->Mtot = Mtot; ent->n_ev = ne < DG_STREAM_EV_MAX ? ne : DG_STREAM_EV_MAX; ent->overflow = ne > DG_STREAM_EV_MAX ? 1 : 0;
+                        ent->tau_used = tau_c;
                 }
             }
             /* one release (a write-back of this XCD's L2) per batch of chunks while the producer is far ahead of the owner */
@@ -740,7 +752,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                 const int phys = perm[ri];
                 const bool ev1 = maxS.J < Sc.J, ev2 = maxSs.J < Sc.J;
                 if (!(ev1 || ev2)) {
-                    if (track && phys == p4) { __syncthreads(); if (tid < 9) e4F[tid] = c.K->gmodels[(size_t)S->mslot[mi]*9 + tid]; e4kind = mk_full; __syncthreads(); }
+                    if (track && phys == p4) { __syncthreads(); if (tid < 9) e4F[tid] = c.K->gmodels[(size_t)S->mslot[mi]*9 + tid]; e4kind = mk_full;
+                        __syncthreads(); }
                     continue;
                 }
                 __syncthreads();
@@ -790,8 +803,11 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                         dg_pass_res rh = dg_h_pass(c, S->H, ch); c.n_hds++;
                         unsigned I = rh.nF;
                         DG_TRACE(c, 31, I, no_sam);
-                        if (I < 8) { DG_FLAST(S->f); brk = 1; c.n_fds -= (nvk - 1 - r); if (A.hist_out) { __syncthreads(); if (tid == 0) S->nv[k] = (unsigned char)(r + 1); __syncthreads(); } break; }   /* exp_ranF.c:1437-1439: later roots are never scored */
-                        { long long ti0 = DG_CLK(); I = dg_innerH(c, S->H, 16*th, 10, c.K->Fl[0]); DG_DEVT(if (tid == 0) S->dbg[0] += DG_CLK() - ti0); (void)ti0; }
+                        /* exp_ranF.c:1437-1439: later roots are never scored */
+                        if (I < 8) { DG_FLAST(S->f); brk = 1; c.n_fds -= (nvk - 1 - r); if (A.hist_out) { __syncthreads();
+                            if (tid == 0) S->nv[k] = (unsigned char)(r + 1); __syncthreads(); } break; }
+                        { long long ti0 = DG_CLK(); I = dg_innerH(c, S->H, 16*th, 10, c.K->Fl[0]); DG_DEVT(if (tid == 0) S->dbg[0] += DG_CLK() - ti0);
+                            (void)ti0; }
                         DG_TRACE(c, 32, I, 0);
                         if ((int)I > Ihmax) Ihmax = (int)I;
                         if (I > 6) {
@@ -834,7 +850,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                                         }
                                         __syncthreads();
                                     }
-                                    if (LDSPTS == 0 && coopK > 0 && tid == 0)        /* the helpers' bound of this pair follows (only this workgroup writes it) */
+                                    /* the helpers' bound of this pair follows (only this workgroup writes it) */
+                                    if (LDSPTS == 0 && coopK > 0 && tid == 0)
                                         __hip_atomic_store(&cb->tau_bits, (unsigned long long)__double_as_longlong(tau_new < 0 ? 0.0 : tau_new), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                     {
                                         const int capr = (int)((sizeof(dg_lsq_scratch) / DG_NW) & ~(size_t)15);
@@ -958,7 +975,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             __syncthreads();
         }
         if (!done) {
-            if (deep) { chunk_s[cur] = cn3; pend_draws = cn3 > 0; gpar ^= 1; }     /* its draws: next iteration, waves 6 and 7, into the slot this chunk leaves */
+            /* its draws: next iteration, waves 6 and 7, into the slot this chunk leaves */
+            if (deep) { chunk_s[cur] = cn3; pend_draws = cn3 > 0; gpar ^= 1; }
             cur = nxt;
             presolved = pre_cnt;
             if (pre_cnt > 0) { mtab ^= 1; if (tid == 0) S->K.gmodels = (double *)(ws + A.wl.off_models + (size_t)mtab * DG_MTAB_BYTES); }
@@ -980,7 +998,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         {
             int dgn = 0;
             if (pr.degen) {
-                if (tid < 7) { dg_pt q = dg_ldpt<LDSPTS>(P, S->samidxBest[tid]); S->u7[tid][0] = q.x1; S->u7[tid][1] = q.y1; S->u7[tid][2] = q.x2; S->u7[tid][3] = q.y2; }
+                if (tid < 7) { dg_pt q = dg_ldpt<LDSPTS>(P, S->samidxBest[tid]); S->u7[tid][0] = q.x1; S->u7[tid][1] = q.y1; S->u7[tid][2] = q.x2;
+                    S->u7[tid][3] = q.y2; }
                 __syncthreads();
                 dgn = dg_checksample(c, S->FBest, S->u7, 3*th, S->H);
             }
@@ -1109,16 +1128,20 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         st[0] = no_sam; st[1] = iter_cnt; st[2] = S->n_lafrej; st[3] = (int)maxS.I; st[4] = c.n_fds + c.n_exfds;
         st[5] = degen_cnt; st[6] = Ihmax; st[7] = best_sample; st[8] = c.n_fds; st[9] = c.n_exfds;
         st[10] = c.n_hds; st[11] = c.n_aux; st[12] = (int)(t_best - t_start); st[13] = (int)(t_end - t_start);
-        st[14] = A.variant_threads; st[15] = A.mode | (resume ? 256 : 0) | (strm == 2 ? 512 : 0);      /* bit 8: the pair was set aside and resumed; bit 9: its chunks came from a producer workgroup */
+        /* bit 8: the pair was set aside and resumed; bit 9: its chunks came from a producer workgroup */
+        st[14] = A.variant_threads; st[15] = A.mode | (resume ? 256 : 0) | (strm == 2 ? 512 : 0);
     }
     if (fan) {
-        if (tid == 0) __hip_atomic_store(&scb->stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       /* the workers leave: nothing of theirs is read any more */
+        /* the workers leave: nothing of theirs is read any more */
+        if (tid == 0) __hip_atomic_store(&scb->stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (scb && strm >= 1) {
         /* take the request back, or tell the producer to stop and wait until it has left */
         __syncthreads();
         int gone = 0;
         if (tid == 0) {
-            int e = DG_ST_REQ; gone = __hip_atomic_compare_exchange_strong(&scb->state, &e, DG_ST_IDLE, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0; S->itmp[30] = gone;
+            int e = DG_ST_REQ;
+                gone = __hip_atomic_compare_exchange_strong(&scb->state, &e, DG_ST_IDLE, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+                S->itmp[30] = gone;
             if (gone) __hip_atomic_fetch_add(A.done_pairs + 1, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();

@@ -261,7 +261,8 @@ struct dg_hrep_sc { double *Z, *V, *D, *A1, *A2; dg_eig_ws &ews; };     /* scrat
 #define DG_HPUB_BYTES ((size_t)DG_RAN_REP * 8 * sizeof(unsigned long long))
 #define DG_HREP_HDR_BYTES ((DG_HPUB_OFF + DG_HPUB_BYTES + 255) & ~(size_t)255)
 __device__ __forceinline__ size_t dg_hrep_logs_bytes() { return DG_HREP_HDR_BYTES; }
-__device__ __forceinline__ size_t dg_hrep_wave_bytes(int n_max) { return ((size_t)n_max * (2 * sizeof(int) + sizeof(double) + 2 * sizeof(dg_pt)) + 255) & ~(size_t)255; }
+__device__ __forceinline__ size_t dg_hrep_wave_bytes(int n_max) { return ((size_t)n_max * (2 * sizeof(int) + sizeof(double) + 2 * sizeof(dg_pt)) + 255) & ~(size_t)255;
+    }
 
 #define DG_AS1(T) __attribute__((address_space(1))) T
 #define DG_AS3(T) __attribute__((address_space(3))) T
@@ -320,7 +321,8 @@ __device__ __forceinline__ void dg_lsq_wave_stream(const dg_pt *P, const int *li
                 for (int u = 0; u < 4; u++) { const int j = base + 512 + 64 * u + lane; idn[u] = j < len ? list[j] : -1; }
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) if (base + 64 * u + lane < len) { DG_AS1(double) *o = stage + 4 * (size_t)(base + 64 * u + lane); o[0] = q[u].x1; o[1] = q[u].y1; o[2] = q[u].x2; o[3] = q[u].y2; }
+            for (int u = 0; u < 4; u++) if (base + 64 * u + lane < len) { DG_AS1(double) *o = stage + 4 * (size_t)(base + 64 * u + lane); o[0] = q[u].x1;
+                o[1] = q[u].y1; o[2] = q[u].x2; o[3] = q[u].y2; }
 #pragma unroll
             for (int f = 0; f < 2; f++) {            /* 128 points per fill, one array per coordinate */
                 const int cnt = len - base - 128 * f < 128 ? len - base - 128 * f : 128;
@@ -437,7 +439,8 @@ __device__ __noinline__ void dg_u2h_wave(CTX &c, dg_wave_ws *w, double *lt, cons
     dg_hrep_sc sc = {lt, w->V, w->D, w->A1, w->A2, w->ews};
     DG_WSYNC();
     if (len <= 12) {
-        if (lane < len) { const dg_pt q = dg_ldpt<LDSPTS>(P, list[lane]); w->px[4*lane] = q.x1; w->px[4*lane+1] = q.y1; w->px[4*lane+2] = q.x2; w->px[4*lane+3] = q.y2; }
+        if (lane < len) { const dg_pt q = dg_ldpt<LDSPTS>(P, list[lane]); w->px[4*lane] = q.x1; w->px[4*lane+1] = q.y1; w->px[4*lane+2] = q.x2;
+            w->px[4*lane+3] = q.y2; }
         DG_WSYNC();
         if (len == 4) { if (lane == 0) dg_u2h_4pt_mv(lt, lt + 81, w->px, Hout); DG_WSYNC(); }
         else if (len > 4) dg_u2h_norm_w(&sc, w->px, len, Hout, lane);
@@ -564,7 +567,8 @@ __device__ __forceinline__ bool dg_hpub_seen(unsigned long long *pub, int j, uns
             const unsigned long long kk = w & ~(DG_HPUB_VALID | DG_HPUB_KNOWN);
             if (w & DG_HPUB_KNOWN) break;                                       /* ended at a set of an earlier local optimisation */
             if (__ballot(inserted && r != k && key == kk) != 0ull) break;       /* cut by a lower repetition's set: it inserts nothing from here on */
-            if (lane == src) inserted = true;                                   /* (a set it visited itself before is in the table already: marking it twice is harmless) */
+            /* (a set it visited itself before is in the table already: marking it twice is harmless) */
+            if (lane == src) inserted = true;
         }
     }
     const unsigned long long mine = ((unsigned long long)(unsigned)I << 32) | hash;
@@ -590,7 +594,8 @@ __device__ __noinline__ void dg_hrep_wave(CTX &c, int kind, dg_hrep_log *lg, int
     DG_HW(0);
     if (lane == 0) { lg->I0 = (int)r0.I; lg->J0 = r0.J; lg->nit = 0; lg->last_short = 0; lg->has_fin = 0; }
     /* the status word goes out when the repetition ends, behind its iteration words (the wave's stores are drained first) */
-    auto finish = [&](int nit_) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) dg_hpub_store(pub + 8 * rep + 7, DG_HPUB_VALID | (unsigned long long)nit_); };
+    auto finish = [&](int nit_) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) dg_hpub_store(pub + 8 * rep + 7, DG_HPUB_VALID | (unsigned long long)nit_); };
     /* the real table takes at most DG_HT_CAP entries and drops the rest: near that limit "inserted" is no longer certain */
     const bool share = *c.ht.count + 4 * DG_RAN_REP * DG_ILSQ_ITERS < DG_HT_CAP;
     if (r0.I < 4) { finish(0); return; }
@@ -642,7 +647,8 @@ __device__ __forceinline__ int dg_hjob_claim(dg_hjob_cb *cb, int g, int *lds_nex
         const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&cb->next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         if ((v >> 8) != g || (v & 255) >= DG_RAN_REP) return -1;
         int ok = 0;
-        if (lane == 0) { int e = v; ok = __hip_atomic_compare_exchange_strong(&cb->next, &e, v + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0; }
+        if (lane == 0) { int e = v;
+            ok = __hip_atomic_compare_exchange_strong(&cb->next, &e, v + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0; }
         if (__builtin_amdgcn_readfirstlane(ok)) return v & 255;
     }
 }
@@ -704,7 +710,8 @@ __device__ __forceinline__ dg_score dg_inHranic_waves(CTX &c, int kind, int ninl
         if (__builtin_amdgcn_readfirstlane(wave) == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) { __hip_atomic_store(&cb->gen, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_fetch_add(c.A->done_pairs + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (lane == 0) { __hip_atomic_store(&cb->gen, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(c.A->done_pairs + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         }
         __syncthreads();
     }
@@ -715,7 +722,8 @@ __device__ __forceinline__ dg_score dg_inHranic_waves(CTX &c, int kind, int ninl
         if (__builtin_amdgcn_readfirstlane(wave) == 0) {
             dg_wait_count(*c.A, &cb->done, DG_RAN_REP, 2, 4);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (lane == 0) { __hip_atomic_store(&cb->gen, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_fetch_add(c.A->done_pairs + 2, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (lane == 0) { __hip_atomic_store(&cb->gen, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(c.A->done_pairs + 2, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         }
         __syncthreads();
     }
@@ -790,7 +798,8 @@ __device__ __forceinline__ int dg_hjob_find(const dg_args &A, int *bc /* LDS */)
                     const int j = (int)((blockIdx.x + (unsigned)(q + lane)) % (unsigned)A.n_res);
                     if (q + lane < A.n_res && found < 0) {
                         const int g = __hip_atomic_load(&A.hjob[j].gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (g > 0) { const int v = __hip_atomic_load(&A.hjob[j].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if ((v >> 8) == g && (v & 255) < DG_RAN_REP) found = j; }
+                        if (g > 0) { const int v = __hip_atomic_load(&A.hjob[j].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((v >> 8) == g && (v & 255) < DG_RAN_REP) found = j; }
                     }
                 }
                 const unsigned long long m = __ballot(found >= 0);
@@ -825,7 +834,8 @@ __device__ __forceinline__ void dg_h_help(const dg_args &A, dg_f_shared *S, doub
     const int g = S->itmp[24], n = S->itmp[25], kind = S->itmp[26], ssiz = S->itmp[27]; const double th = S->dtmp[31];
     __syncthreads();
     if (g <= 0) return;
-    if (n < 8 || n > A.wl.n_max || ssiz < 4 || ssiz > 12 || kind < 0 || kind > 4) {      /* never the case for an open job: refuse instead of reading wild memory */
+    /* never the case for an open job: refuse instead of reading wild memory */
+    if (n < 8 || n > A.wl.n_max || ssiz < 4 || ssiz > 12 || kind < 0 || kind > 4) {
         if (tid == 0) __hip_atomic_store(A.err_flag, 16 + (n < 8 || n > A.wl.n_max ? 1 : 0) + (ssiz < 4 || ssiz > 12 ? 2 : 0) + (kind < 0 || kind > 4 ? 4 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
@@ -1033,7 +1043,8 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
     int best_sample = 0, accepted = 0, done = 0; long long t_best = t_start;
     double *e4 = S->FBest;                                   /* model behind errs[4] (last so-far-best sample) */
 
-    if (__builtin_amdgcn_readfirstlane(wave) == 0) { dg_srand_wave(&S->rng, A.seeds[pair], lane); const int v_ = dg_rand_block(&S->rng, 1, lane); if (lane == 0) S->itmp[31] = v_; }
+    if (__builtin_amdgcn_readfirstlane(wave) == 0) { dg_srand_wave(&S->rng, A.seeds[pair], lane); const int v_ = dg_rand_block(&S->rng, 1, lane);
+        if (lane == 0) S->itmp[31] = v_; }
     __syncthreads();
     unsigned seed = (unsigned)S->itmp[31];
     __syncthreads();
@@ -1097,7 +1108,8 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
             if (wave == 0) {
                 if (chunk_s[nxt] > 0) dg_sample_pool<4, LDSPTS>(chunk_s[nxt], n, pool, S->draws3[nxt], S->alm3[nxt], pscr, lane, S->dbg);
             } else if (wave == 1) {
-                if (cn2 > 0) { unsigned sd = dg_sample_chain<4>(seed, cn2, S->seeds3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }   /* its draws: after the barrier */
+                /* its draws: after the barrier */
+                if (cn2 > 0) { unsigned sd = dg_sample_chain<4>(seed, cn2, S->seeds3[nx2], lane, S->dbg); if (lane == 0) S->itmp[31] = (int)sd; }
             }
             /* static round-robin over the scoring waves: waves 2.. when there are more than two, else both waves after their sampler stage */
             /* Screen (Sampson metric): once a local optimisation has run, a sample past the 50th only matters if its J beats
@@ -1208,7 +1220,8 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
                 __syncthreads();
                 iter_cnt++;
                 DG_PHH(2);
-                if (dg_h_lo(c, kind, e4, th, maxS, &iterID, &p1_inliers, no_sam, iter_cnt - 1)) { new_max = 1; accepted = 1; best_sample = no_sam; t_best = wall_clock64(); }
+                if (dg_h_lo(c, kind, e4, th, maxS, &iterID, &p1_inliers, no_sam, iter_cnt - 1)) { new_max = 1; accepted = 1; best_sample = no_sam;
+                    t_best = wall_clock64(); }
                 DG_PHH(3);
             }
             if (new_max) {
@@ -1225,11 +1238,13 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
     /* ---- "If there were no LOs, do at least one NOW!"  exp_ranH.c:759-862 ---- */
     if (iter_cnt == 0) {
         __syncthreads();
-        if (__builtin_amdgcn_readfirstlane(wave) == 0 && no_sam > 0) { int li = no_sam - 1 - chunk_base; if (li < 0) li = 0; dg_srand_wave(&S->rng, c.seeds[li], lane); dg_rand_skip(&S->rng, 5, lane); }
+        if (__builtin_amdgcn_readfirstlane(wave) == 0 && no_sam > 0) { int li = no_sam - 1 - chunk_base; if (li < 0) li = 0;
+            dg_srand_wave(&S->rng, c.seeds[li], lane); dg_rand_skip(&S->rng, 5, lane); }
         __syncthreads();
         iter_cnt++;
         DG_PHH(2);
-        if (dg_h_lo(c, kind, maxSs.J > 0 ? e4 : (const double *)0 /* errs[4] never written */, th, maxS, &iterID, &p1_inliers, no_sam, iter_cnt - 1)) { accepted = 1; best_sample = no_sam; t_best = wall_clock64(); }
+        if (dg_h_lo(c, kind, maxSs.J > 0 ? e4 : (const double *)0 /* errs[4] never written */, th, maxS, &iterID, &p1_inliers, no_sam, iter_cnt - 1)) { accepted = 1;
+            best_sample = no_sam; t_best = wall_clock64(); }
         DG_PHH(3);
     }
 

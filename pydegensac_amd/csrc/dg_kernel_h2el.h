@@ -135,7 +135,8 @@ __device__ __noinline__ int dg_h2_A2toRH(const double *ua, const double *ub, dou
         dg_h2_Znd(Z + 2*7*9 + 2*7*3 + 7, D2, N2);
     }
     DG_WSYNC();
-    for (int e = lane; e < 225; e += 64) { const int i = e / 15, j = e - 15 * i; ZT[e] = i < 14 ? Z[j*14 + i] : 0.0; }   /* mattr(ZT, Z, 15, 14), last row zero */
+    /* mattr(ZT, Z, 15, 14), last row zero */
+    for (int e = lane; e < 225; e += 64) { const int i = e / 15, j = e - 15 * i; ZT[e] = i < 14 ? Z[j*14 + i] : 0.0; }
     DG_WSYNC();
     const int nullsize = dg_nullspace_wave(ZT, U, 15, nb, lane);
     if (lane == 0) {
@@ -304,7 +305,8 @@ __device__ __forceinline__ void dg_h2_pair(const dg_args &A, dg_f_shared *S, con
     if (tid < 9) { S->F[tid] = 0; S->Hx[tid] = 0; }
     if (tid < 36) S->bufF[tid / 9][tid % 9] = 0;
     __syncthreads();
-    double *scr = (double *)&S->lsq;                               /* 3 * 225 doubles + 30 ints of LDS for the elimination (the least-squares scratch is idle then) */
+    /* 3 * 225 doubles + 30 ints of LDS for the elimination (the least-squares scratch is idle then) */
+    double *scr = (double *)&S->lsq;
     static_assert(sizeof(dg_lsq_scratch) >= 3 * 225 * sizeof(double) + 30 * sizeof(int), "elimination scratch does not fit");
     const unsigned inlLimit = pr.h2_inl_limit == 0 ? 0x7fffffffu : (unsigned)pr.h2_inl_limit;
     const int do_lo = pr.h2_do_lo;

@@ -86,7 +86,8 @@ DG_STEQR_FN int dg_steqr9(DG_STEQR_PTR d, DG_STEQR_PTR e, DG_STEQR_PTR z, const 
                 if (m == l) { l++; if (l <= lend) continue; break; }
                 if (m == l + 1) {
                     dg_laev2(d[l], e[l], d[l+1], &rt1, &rt2, &c, &s);
-                    if (c != 1. || s != 0.) { const double t = z[(l+1)*zs], u = z[l*zs]; DG_STEQR_STZ(z[(l+1)*zs], c*t - s*u); DG_STEQR_STZ(z[l*zs], s*t + c*u); }
+                    if (c != 1. || s != 0.) { const double t = z[(l+1)*zs], u = z[l*zs]; DG_STEQR_STZ(z[(l+1)*zs], c*t - s*u); DG_STEQR_STZ(z[l*zs], s*t + c*u);
+                        }
                     DG_STEQR_ST(d[l], rt1); DG_STEQR_ST(d[l+1], rt2); DG_STEQR_ST(e[l], 0.);
                     l += 2; if (l <= lend) continue; break;
                 }
@@ -131,7 +132,8 @@ _Pragma("unroll 2")      /* two rotations per trip: half the loop-carried regist
                 if (m == l) { l--; if (l >= lend) continue; break; }
                 if (m == l - 1) {
                     dg_laev2(d[l-1], e[l-1], d[l], &rt1, &rt2, &c, &s);
-                    if (c != 1. || s != 0.) { const double t = z[l*zs], u = z[(l-1)*zs]; DG_STEQR_STZ(z[l*zs], c*t - s*u); DG_STEQR_STZ(z[(l-1)*zs], s*t + c*u); }
+                    if (c != 1. || s != 0.) { const double t = z[l*zs], u = z[(l-1)*zs]; DG_STEQR_STZ(z[l*zs], c*t - s*u); DG_STEQR_STZ(z[(l-1)*zs], s*t + c*u);
+                        }
                     DG_STEQR_ST(d[l-1], rt1); DG_STEQR_ST(d[l], rt2); DG_STEQR_ST(e[l-1], 0.);
                     l -= 2; if (l >= lend) continue; break;
                 }

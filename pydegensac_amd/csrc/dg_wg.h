@@ -242,7 +242,8 @@ __device__ __forceinline__ dg_pass_res dg_pass(dg_red *r, const dg_pass_cfg &c, 
             for (int u = 0; u < DG_PU; u++) { bL[u] = __ballot(in[u]); bJ[u] = __ballot(nz[u]); bL2[u] = c.list2 ? __ballot(in2[u]) : 0ull; }
             if (lane == 0) {
 #pragma unroll
-                for (int u = 0; u < DG_PU; u++) { r->u[par][wave][3*u] = (unsigned)__popcll(bL[u]); r->u[par][wave][3*u+1] = (unsigned)__popcll(bJ[u]); r->u[par][wave][3*u+2] = (unsigned)__popcll(bL2[u]); }
+                for (int u = 0; u < DG_PU; u++) { r->u[par][wave][3*u] = (unsigned)__popcll(bL[u]); r->u[par][wave][3*u+1] = (unsigned)__popcll(bJ[u]);
+                    r->u[par][wave][3*u+2] = (unsigned)__popcll(bL2[u]); }
             }
             __syncthreads();
 #pragma unroll

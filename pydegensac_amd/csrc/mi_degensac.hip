@@ -114,7 +114,8 @@ extern "C" int mi_degensac_screen_counts(const double *pts1, const double *pts2,
         ext[0] = fmax(ext[0], fabs(q.x1)); ext[1] = fmax(ext[1], fabs(q.y1)); ext[2] = fmax(ext[2], fabs(q.x2)); ext[3] = fmax(ext[3], fabs(q.y2));
     }
     DevBuf<dg_pt> dp; DevBuf<double> dm; DevBuf<uint32_t> d1, d2;
-    if (dp.alloc(n) || dm.alloc((size_t)n_models * 9) || d1.alloc(n_models) || d2.alloc(n_models)) { set_err("device allocation failed"); return MI_DEGENSAC_ENOMEM; }
+    if (dp.alloc(n) || dm.alloc((size_t)n_models * 9) || d1.alloc(n_models) || d2.alloc(n_models)) { set_err("device allocation failed");
+        return MI_DEGENSAC_ENOMEM; }
     HIPCHK(hipMemcpy(dp.p, hp.data(), (size_t)n * sizeof(dg_pt), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dm.p, models, (size_t)n_models * 72, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(dg_screen_counts_kernel, dim3((n_models + 63) / 64), dim3(64), 0, 0, dp.p, n, dm.p, n_models, kind, th, ext[0], ext[1], ext[2], ext[3], d1.p, d2.p);
@@ -145,10 +146,12 @@ extern "C" int mi_degensac_screen_counts_h(const double *pts1, const double *pts
     DG_UNIT_ENTER(device);
     if (n <= 0 || n_models <= 0 || (dim != 2 && dim != 6) || !cnt) { set_err("bad argument"); return MI_DEGENSAC_EINVAL; }
     std::vector<dg_pt> hp((size_t)n); std::vector<double> hm((size_t)n_models * 18, 0.0);
-    for (int i = 0; i < n; i++) { dg_pt q; q.x1 = pts1[(size_t)i * dim]; q.y1 = pts1[(size_t)i * dim + 1]; q.x2 = pts2[(size_t)i * dim]; q.y2 = pts2[(size_t)i * dim + 1]; hp[i] = q; }
+    for (int i = 0; i < n; i++) { dg_pt q; q.x1 = pts1[(size_t)i * dim]; q.y1 = pts1[(size_t)i * dim + 1]; q.x2 = pts2[(size_t)i * dim];
+        q.y2 = pts2[(size_t)i * dim + 1]; hp[i] = q; }
     for (int m = 0; m < n_models; m++) for (int j = 0; j < 9; j++) hm[(size_t)m * 18 + j] = models[(size_t)m * 9 + j];
     DevBuf<dg_pt> dp; DevBuf<double> dm; DevBuf<uint32_t> dc; DevBuf<uint8_t> dk;
-    if (dp.alloc(n) || dm.alloc((size_t)n_models * 18) || dc.alloc(n_models) || (cand && dk.alloc((size_t)n_models * n))) { set_err("device allocation failed"); return MI_DEGENSAC_ENOMEM; }
+    if (dp.alloc(n) || dm.alloc((size_t)n_models * 18) || dc.alloc(n_models) || (cand && dk.alloc((size_t)n_models * n))) { set_err("device allocation failed");
+        return MI_DEGENSAC_ENOMEM; }
     HIPCHK(hipMemcpy(dp.p, hp.data(), (size_t)n * sizeof(dg_pt), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dm.p, hm.data(), hm.size() * 8, hipMemcpyHostToDevice));
     const double tb = (th * 9 / 4) * (1.0 + 1e-6);            /* the kernel's own bound (dg_kernel_h.h, main loop) */
@@ -187,7 +190,8 @@ __global__ void dg_sample_stream_kernel(unsigned seed0, int n, int ssz, int iter
 {
     /* the main kernels' sampler (dg_sample_chunk), chunk by chunk, run by one wave: with the pool in LDS (n <= 4096:
      * the parallel pool stage) or in global memory (the sequential one) */
-    __shared__ unsigned seeds[DG_CHUNK]; __shared__ int draws[DG_CHUNK][8]; __shared__ dg_rng g; __shared__ unsigned sd0; __shared__ unsigned long long alm[DG_CHUNK / 64];
+    __shared__ unsigned seeds[DG_CHUNK]; __shared__ int draws[DG_CHUNK][8]; __shared__ dg_rng g; __shared__ unsigned sd0;
+        __shared__ unsigned long long alm[DG_CHUNK / 64];
     __shared__ int pool_l[4096]; __shared__ int scratch[2 * DG_CHUNK * 7];
     const int lane = threadIdx.x;
     const bool lds = n <= 4096;
@@ -242,7 +246,8 @@ __global__ void dg_solve7_kernel(const double *p1, const double *p2, int dim, co
     __shared__ double wscr[81];                  /* one wave per block: the general elimination, one lane at a time */
     for (unsigned long long need = __ballot(!ok); need; need &= need - 1) {
         if ((int)(threadIdx.x & 63) != __ffsll((long long)need) - 1) continue;
-        for (int i = 0; i < 7; i++) { double a[3] = {sp[i].x1, sp[i].y1, 1.0}, b[3] = {sp[i].x2, sp[i].y2, 1.0}; for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) wscr[9*i+3*k+l] = b[k] * a[l]; }
+        for (int i = 0; i < 7; i++) { double a[3] = {sp[i].x1, sp[i].y1, 1.0}, b[3] = {sp[i].x2, sp[i].y2, 1.0};
+            for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) wscr[9*i+3*k+l] = b[k] * a[l]; }
         if (dg_null9<7, 2>(wscr, wscr + 63) == 2) { for (int i = 0; i < 9; i++) { f1[i] = wscr[63+i]; f2[i] = wscr[72+i]; } ok = 1; }
     }
     if (ok) {

@@ -111,7 +111,8 @@ __global__ void mt_merge_kernel(const mt_best *part, int splits, int n1, int l2,
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n1) return;
     mt_best m = part[i];
-    for (int s = 1; s < splits; s++) { const mt_best c = part[(size_t)s * n1 + i]; if (c.i0 >= 0) mt_push(m, c.d0, c.i0); if (c.i1 >= 0) mt_push(m, c.d1, c.i1); }
+    for (int s = 1; s < splits; s++) { const mt_best c = part[(size_t)s * n1 + i]; if (c.i0 >= 0) mt_push(m, c.d0, c.i0); if (c.i1 >= 0) mt_push(m, c.d1, c.i1);
+        }
     idx[2 * i] = m.i0; idx[2 * i + 1] = m.i1;
     dist[2 * i] = l2 ? sqrtf(m.d0) : m.d0; dist[2 * i + 1] = l2 ? sqrtf(m.d1) : m.d1;
 }
@@ -149,7 +150,8 @@ struct MtDevGuard {
     int enter(int device)
     {
         int n = 0;
-        if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { (void)hipGetLastError(); snprintf(mt_err, sizeof mt_err, "no HIP device: this library has no CPU path"); return MI_DEGENSAC_ENODEV; }
+        if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { (void)hipGetLastError();
+            snprintf(mt_err, sizeof mt_err, "no HIP device: this library has no CPU path"); return MI_DEGENSAC_ENODEV; }
         if (device < 0 || device >= n) { snprintf(mt_err, sizeof mt_err, "device index out of range"); return MI_DEGENSAC_ENODEV; }
         if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
         if (prev != device) { MTCHK(hipSetDevice(device)); armed = prev >= 0; }
@@ -167,7 +169,8 @@ static int mt_words(int norm, int dim)
 extern "C" int mi_degensac_match_knn2_dev(int norm, const void *d_desc1, int n1, const void *d_desc2, int n2, int dim, int device,
                                           void *stream, int32_t *d_idx, float *d_dist)
 {
-    if ((norm != MI_DEGENSAC_NORM_L2 && norm != MI_DEGENSAC_NORM_HAMMING) || n1 < 0 || n2 < 0 || dim <= 0) { snprintf(mt_err, sizeof mt_err, "bad argument"); return MI_DEGENSAC_EINVAL; }
+    if ((norm != MI_DEGENSAC_NORM_L2 && norm != MI_DEGENSAC_NORM_HAMMING) || n1 < 0 || n2 < 0 || dim <= 0) { snprintf(mt_err, sizeof mt_err, "bad argument");
+        return MI_DEGENSAC_EINVAL; }
     const int words = mt_words(norm, dim);
     if (words < 0) { snprintf(mt_err, sizeof mt_err, "Hamming descriptors must be padded to a multiple of 4 bytes"); return MI_DEGENSAC_EINVAL; }
     MtDevGuard g; int rc = g.enter(device); if (rc) return rc;
@@ -214,7 +217,8 @@ extern "C" int mi_degensac_match(int norm, const void *desc1, int n1, const void
     const size_t esz = norm == MI_DEGENSAC_NORM_L2 ? 4 : 1, b1 = (size_t)n1 * dim * esz, b2 = (size_t)n2 * dim * esz;
     char *d1 = nullptr, *d2 = nullptr; int32_t *di = nullptr, *dbi = nullptr; float *dd = nullptr, *dbd = nullptr; uint8_t *dk = nullptr;
     struct Free { char *&a, *&b; int32_t *&c, *&d; float *&e, *&f; uint8_t *&g;
-                  ~Free() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); (void)hipFree(d); (void)hipFree(e); (void)hipFree(f); (void)hipFree(g); } } fr{d1, d2, di, dbi, dd, dbd, dk};
+                  ~Free() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); (void)hipFree(d); (void)hipFree(e); (void)hipFree(f); (void)hipFree(g);
+                      } } fr{d1, d2, di, dbi, dd, dbd, dk};
     MTCHK(hipMalloc((void **)&d1, b1 ? b1 : 4)); MTCHK(hipMalloc((void **)&d2, b2 ? b2 : 4));
     MTCHK(hipMalloc((void **)&di, (size_t)n1 * 8)); MTCHK(hipMalloc((void **)&dd, (size_t)n1 * 8));
     MTCHK(hipMemcpy(d1, desc1, b1, hipMemcpyHostToDevice)); MTCHK(hipMemcpy(d2, desc2, b2, hipMemcpyHostToDevice));

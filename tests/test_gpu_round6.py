@@ -147,7 +147,9 @@ def test_fan_mode_equals_the_cooperative_mode_and_the_oracle(oracle_port):
     symmetric-epipolar metric and a plane-dominated scene (DEGENSAC branch: a bound that can fall); a worker that never answers
     (wait limit 0) ends in discard + re-run, not in wrong numbers."""
     cases = [dict(n=9000, ir=0.3, iters=6000, et="sampson", plane=0.0), dict(n=12000, ir=0.15, iters=10001, et="sampson", plane=0.0),
-             dict(n=8500, ir=0.35, iters=4000, et="symm_epipolar", plane=0.0), dict(n=9000, ir=0.4, iters=5000, et="sampson", plane=0.7)]
+             dict(n=8500, ir=0.35, iters=4000, et="symm_epipolar", plane=0.0), dict(n=9000, ir=0.4, iters=5000, et="sampson", plane=0.7),
+             dict(n=9000, ir=0.5, iters=100, et="sampson", plane=0.0), dict(n=9000, ir=0.5, iters=300, et="sampson", plane=0.0),       # budgets of one and two chunks
+             dict(n=9000, ir=0.5, iters=513, et="sampson", plane=0.0)]
     for cs in cases:
         A, B = [], []
         for i in range(2):
