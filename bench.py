@@ -624,8 +624,8 @@ def main():
                 sp = {"workload": f"C4 literal through ONE process: mi_degensac_find_fundamental_batch_multi, devices [0..{world - 1}], host buffers (PCIe staging timed), no collective",
                       "n_gpus": world, "pairs_per_gpu": 4096 // world, "ms_per_step": r1["dt"] / 3 * 1e3, "models_per_s": int(r1["st"][:, 4].sum()) * 3 / r1["dt"],
                       "pairs_per_s": 4096 * 3 / r1["dt"], "parity_checked": r1["n_checked"]}
-            except Exception as e:        # a parity mismatch is a SystemExit and still ends the bench
-                sp = {"workload": "C4 literal through one process", "error": str(e)[:300]}
+            except BaseException as e:    # reported, never fatal here: the other ranks wait at the barrier below (the headline's own parity checks above are fatal)
+                sp = {"workload": "C4 literal through one process", "error": f"{type(e).__name__}: {str(e)[:300]}"}
         dist.barrier()
 
     if rank == 0 and args.dump_results:
