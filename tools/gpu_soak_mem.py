@@ -13,12 +13,15 @@ rng = np.random.default_rng(0)
 F = [syn.two_view_fundamental(int(n), 0.4, 0.3, seed=i)[:2] for i, n in enumerate(rng.choice([100, 500, 2000], 64))]
 H = [syn.homography_pairs(int(n), 0.4, 0.5, seed=i)[:2] for i, n in enumerate(rng.choice([100, 1000, 5000], 64))]
 E = [syn.ellipse_pairs(int(n), 0.3, 1.0, i)[0] for i, n in enumerate(rng.choice([50, 500, 3000], 32))]
+BIG = [syn.two_view_fundamental(22000 + 1000 * i, 0.3, 0.1, seed=70 + i)[:2] for i in range(3)]       # one large pair per call: cooperative + fan mode (round 6)
 free = lambda: torch.cuda.mem_get_info(0)[0] / 2**20
 def work(tid, rounds, log):
     r = np.random.default_rng(tid)
     for it in range(rounds):
         k = int(r.integers(0, 3)); P = int(r.choice([1, 3, 40, 600]))
-        if k == 0:
+        if it % 17 == 5:
+            b = BIG[int(r.integers(0, len(BIG)))]; pd.findFundamentalMatrixBatch([b[0]], [b[1]], 0.5, 0.9999, 4000, seeds=[it])
+        elif k == 0:
             ids = r.integers(0, len(F), P); pd.findFundamentalMatrixBatch([F[i][0] for i in ids], [F[i][1] for i in ids], 0.5, 0.9999, 3000, seeds=list(range(P)))
         elif k == 1:
             ids = r.integers(0, len(H), P); pd.findHomographyBatch([H[i][0] for i in ids], [H[i][1] for i in ids], 1.0, 0.999, 2000, seeds=list(range(P)))
