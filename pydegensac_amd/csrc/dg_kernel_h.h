@@ -255,6 +255,17 @@ __device__ __forceinline__ dg_score dg_inHranic(CTX &c, int kind, int ninl, doub
  * table, the comparisons and the buffer rotation in repetition order.  Same arithmetic per repetition, same decisions in
  * the same order; a repetition the reference would have cut short is simply computed further than needed. */
 #define DG_HLT 640                /* doubles of LDS per wave: the long-list fit's table (dg_lsq_seq_par), the 12-point fit's design matrix */
+/* This kernel's static LDS is dg_f_shared + the argument block + DG_HLT doubles per wave.  At 256 threads that is 48 bytes more than half
+ * a CU's LDS, so there the LAST wave's table lives in members of dg_f_shared that only the fundamental-matrix kernel uses (wpad, the
+ * checksample tables and the union behind them are contiguous): two workgroups per CU. */
+#define DG_HLT_STATIC_WAVES (DG_T == 256 ? DG_NW - 1 : DG_NW)
+static_assert(DG_T != 256 || offsetof(dg_f_shared, n_ahead) - offsetof(dg_f_shared, wpad) >= DG_HLT * sizeof(double), "no room for the last wave's table");
+template <class C_>
+__device__ __forceinline__ double *dg_hlt_wave(C_ &c, int wave)
+{
+    if (DG_T == 256 && wave == DG_NW - 1) return c.S->wpad;
+    return c.hlt + (size_t)DG_HLT * wave;
+}
 struct dg_hrep_sc { double *Z, *V, *D, *A1, *A2; dg_eig_ws &ews; };     /* scratch view with the member names the solvers use */
 /* behind the ten records: the published inlier sets of a local optimisation's repetitions (dg_hpub_*): per repetition eight 8-byte words */
 #define DG_HPUB_OFF   (((size_t)DG_RAN_REP * sizeof(dg_hrep_log) + 127) & ~(size_t)127)
@@ -659,7 +670,7 @@ __device__ __forceinline__ void dg_hjob_work(CTX &c, dg_hjob_cb *cb, int g, int 
     for (;;) {
         const int r = dg_hjob_claim(cb, g, lds_next, lane);
         if (r < 0) break;
-        dg_hrep_wave<LDSPTS>(c, kind, &logs[r], ssiz, th, c.hlt + (size_t)DG_HLT * wave, wb, lane, wave, (unsigned long long *)((char *)logs + DG_HPUB_OFF), r);
+        dg_hrep_wave<LDSPTS>(c, kind, &logs[r], ssiz, th, dg_hlt_wave(c, wave), wb, lane, wave, (unsigned long long *)((char *)logs + DG_HPUB_OFF), r);
         if (cb) {
             /* the record is in the owner's workspace: visible before the count goes up */
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1123,7 +1134,7 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
                 auto exact = [&](const int mi) {
                     /* this wave's pass (dg_hm_wpass: the next step's points in flight, J added tile by tile in point order) from this
                      * wave's block of the local optimisation's LDS tables, which are idle in the main loop */
-                    double *lt = c.hlt + (size_t)DG_HLT * wave, *Hm = lt + 64 * DG_PU, *z18 = Hm + 16;
+                    double *lt = dg_hlt_wave(c, wave), *Hm = lt + 64 * DG_PU, *z18 = Hm + 16;
                     const double *g = c.K->gmodels + (size_t)mi * 18;
                     DG_WSYNC();
                     if (lane < 9) Hm[lane] = g[lane];
@@ -1289,15 +1300,13 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
 }
 
 template <int T, int LDSPTS>
-/* at 256 threads this kernel's static LDS (dg_f_shared + the argument block + 5 KB per wave) is just above 80 KB: one workgroup per CU
- * whatever the register count, so it is compiled for one wave per SIMD there (the 512- and 128-thread variants are the ones the host picks) */
-#define DG_MINW_H (DG_T == 256 ? 1 : DG_MINW)
+#define DG_MINW_H DG_MINW
 __global__ __launch_bounds__(DG_T, DG_MINW_H) void dg_find_homography_kernel(dg_args A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
     __shared__ dg_f_shared Sh;
     __shared__ int next_pair;
-    __shared__ double Hlt[DG_NW][DG_HLT];       /* per-wave solver tables of the one-repetition-per-wave local optimisation */
+    __shared__ double Hlt[DG_HLT_STATIC_WAVES][DG_HLT];       /* per-wave solver tables of the one-repetition-per-wave local optimisation (dg_hlt_wave) */
     /* the device code reads the arguments through a pointer (dg_f_ctx::A, also inside non-inlined functions): give it an
      * LDS copy, so the by-value kernel argument's address is never taken (that would make the compiler keep a private
      * per-lane copy of the whole block in scratch memory and turn every uniform argument into a vector value) */

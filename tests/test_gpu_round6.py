@@ -1,5 +1,6 @@
 """GPU: round 6 — every hand-over wait is bounded and fault-injectable (homography helpers, cooperative large-n mode), ransacH2el's
-no-model mask equals the oracle's, the versioned diagnostics struct, per-call timing of the host-pointer path, bench.py's launch modes."""
+no-model mask equals the oracle's, the versioned diagnostics struct, per-call timing of the host-pointer path, bench.py's launch modes, the fan mode,
+per-context scheduling, the homography kernel at two workgroups per CU."""
 import ctypes as C
 import json
 import os
@@ -203,3 +204,23 @@ def test_scheduling_defaults_belong_to_a_context():
         assert L.mi_degensac_ctx_set_scheduling(a, -3, 0) != 0
     finally:
         L.mi_degensac_ctx_destroy(a); L.mi_degensac_ctx_destroy(b)
+
+
+def test_homography_batches_between_one_and_two_pairs_per_cu_run_two_workgroups_per_cu(oracle_port):
+    """The 256-thread homography kernel fits two workgroups per CU (its last wave's solver table lives in LDS members only the
+    fundamental-matrix kernel uses) and is the host's choice for batches of more than one and at most two pairs per CU: same results as the
+    512-thread kernel, and the oracle's."""
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    P = cus + 9
+    sets = [syn.homography_pairs(300 + 7 * (i % 5), 0.5, 0.5, seed=900 + i, laf=True)[:2] for i in range(P)]
+    A = [s_[0] for s_ in sets]; B = [s_[1] for s_ in sets]; seeds = [11 + i for i in range(P)]
+    H, k = pd.findHomographyBatch(A, B, 2.0, 0.999, 5000, 3.0, seeds=seeds); st = pd.last_stats()
+    assert {s_["threads"] for s_ in st} == {256}, {s_["threads"] for s_ in st}
+    H2, k2 = pd.findHomographyBatch(A, B, 2.0, 0.999, 5000, 3.0, seeds=seeds, tuning=_lib.TUNE_LATENCY); st2 = pd.last_stats()
+    assert {s_["threads"] for s_ in st2} == {512}
+    assert np.array_equal(np.asarray(H), np.asarray(H2)) and all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(k, k2))
+    for p in (0, 1, P // 2, P - 1):
+        Ho, mo, so = oracle_port.find_homography(A[p], B[p], 2.0, 0.999, 5000, 0, True, 3.0, seed=seeds[p])
+        assert (st[p]["samples"], st[p]["lo_runs"], st[p]["I"]) == (so["samples"], so["lo_runs"], so["I"]), p
+        assert np.array_equal(np.asarray(k[p]), mo), p

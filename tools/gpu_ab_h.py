@@ -25,17 +25,18 @@ def run(P, d, reps=3, tune=0):
         torch.cuda.synchronize(); ts.append((time.perf_counter() - t) * 1e3)
     st = d_st.cpu().numpy()
     return min(ts[1:]), float(np.mean(ts[1:])), int(st[0, 14]), int(st[0, 15]), float(st[:, 13].max() / 1e5), float(st[:, 13].mean() / 1e5), d_H.cpu().numpy(), d_mask.cpu().numpy()
-for P in (1024, 256):
+PS = [int(x) for x in os.environ.get('AB_H_PAIRS', '1024,256').split(',')]
+for P in PS:
     d = data(P); ref = None
     for tune in TUNES:
-      for mode in (1, 0):
+      for mode in ((1, 0) if 'AB_H_PAIRS' not in os.environ else (1,)):
         _lib.set_hjob_mode(mode)
         best, mean, thr, plc, longest, meanp, H, m = run(P, d, tune=tune)
         same = "" if ref is None else " identical: %s" % (np.array_equal(ref[0], H) and np.array_equal(ref[1], m))
         ref = ref or (H, m)
         print(f"C3 x {P:4d} helpers {mode}: best {best:6.2f} ms mean {mean:6.2f} ms  threads {thr} placement {plc}  longest pair {longest:5.1f} ms mean pair {meanp:5.2f} ms{same}", flush=True)
 p1, p2 = syn.homography_pairs(N, 0.4, 0.5, seed=0, laf=True)[:2]
-for mode in (1, 0):
+for mode in ((1, 0) if 'AB_H_PAIRS' not in os.environ else ()):
     _lib.set_hjob_mode(mode); ts = []
     for r in range(12):
         t = time.perf_counter(); pd.findHomography_(p1, p2, 2.0, 0.999, 50000, 0, True, 3.0, seed=r + 1); ts.append((time.perf_counter() - t) * 1e3)
