@@ -72,8 +72,10 @@ extern "C" {
 #define MI_DEGENSAC_FLAG_STREAM_ON   8u       /* fundamental matrix: stream mode on whatever the batch size                            */
 #define MI_DEGENSAC_FLAG_STREAM_TEST(b) (((uint32_t)(b) & 3u) << 8)   /* with STREAM_ON: bit 0 = the owner scores every chunk it takes from
                                                  the producer again, bit 1 = pairs ask for a producer even while unstarted pairs remain */
-#define MI_DEGENSAC_FLAG_STREAM_AUTO 64u      /* fundamental matrix: the library's automatic choice for this call, whatever the process-wide default says        */
-#define MI_DEGENSAC_FLAG_HJOB_ON     128u     /* homography: helper workgroups on for this call, whatever the process-wide default says                          */
+#define MI_DEGENSAC_FLAG_STREAM_AUTO 64u      /* fundamental matrix: the library's automatic choice for this call, whatever the process-wide default says \
+ */
+#define MI_DEGENSAC_FLAG_HJOB_ON     128u     /* homography: helper workgroups on for this call, whatever the process-wide default says \
+ */
 #define MI_DEGENSAC_FLAG_NO_HJOB     16u      /* homography: no helper workgroups for the local optimisations of this call             */
 
 /* tuning word (0 = let the library decide; results never depend on it, only speed does):

@@ -136,7 +136,8 @@ static void FDsSym(const double *u, const double *F, double *p, int len)  /* :14
 static void FDsSymidx(const double *mu, const double *F, double *p, int len, const int *idx, int siz)  /* :170-198 */
 {
     int mi; (void)len;
-    for (mi = 0; mi < siz; mi++) { int i = idx[mi]; const double *u = mu + 6*i; F_COMMON; double a = rxc*rxc + ryc*ryc, b = rx*rx + ry*ry; p[i] = r*r * (a+b)/(a*b); }
+    for (mi = 0; mi < siz; mi++) { int i = idx[mi]; const double *u = mu + 6*i; F_COMMON; double a = rxc*rxc + ryc*ryc, b = rx*rx + ry*ry;
+        p[i] = r*r * (a+b)/(a*b); }
 }
 static void exFDsSym(const double *u, const double *F, double *p, double *w, int len)   /* :228-250 */
 {
@@ -707,7 +708,8 @@ static dg_score exp_inFranicustom(dg_ctx *c, const double *u, int len, int *inli
 /* sym + LAF consistency of a candidate, shared shape of exp_ranF.c:1383-1411 / :1526-1556 / :1654-1682.
  * Returns 0 if the candidate must be rejected. */
 static int g_legacy_sym = 0;      /* exp_ransacFcustom's symmetric check: all points instead of the inliers (exp_ranF.c:943-953) */
-static __thread int g_laf_rej = 0;         /* candidates the LAF check turned down (`S.Ilafs < maxS.Ilafs`, exp_ranF.c:1410 / :1553 / :1681): stats[DG_ST_REJECTED] of the F driver */
+static __thread int g_laf_rej = 0;         /* candidates the LAF check turned down (`S.Ilafs < maxS.Ilafs`, exp_ranF.c:1410 / :1553 / :1681):
+   stats[DG_ST_REJECTED] of the F driver */
 static int f_checks(const double *u, const double *u_1, const double *u_2, int len, const double *f, const int *inliers,
                     dg_score *S, const dg_score *maxS, int doSymCheck, double SymCheck_th, int DO_LAF_CHECK,
                     double th_laf_check, fdsidx_fn FDS1idx, double *d_check, double *err_laf)
@@ -1520,7 +1522,8 @@ static dg_score ransacH2el(dg_ctx *c, const double *u10, int len, double th, dou
     unsigned seed;
     if (inlLimit == 0) inlLimit = 0x7fffffff;
     u6 = (double *)malloc(6 * (size_t)len * sizeof(double));
-    for (i = 0; i < len; ++i) { u6[i*6+0] = u10[i*10+0]; u6[i*6+1] = u10[i*10+1]; u6[i*6+2] = 1; u6[i*6+3] = u10[i*10+5]; u6[i*6+4] = u10[i*10+6]; u6[i*6+5] = 1; }
+    for (i = 0; i < len; ++i) { u6[i*6+0] = u10[i*10+0]; u6[i*6+1] = u10[i*10+1]; u6[i*6+2] = 1; u6[i*6+3] = u10[i*10+5]; u6[i*6+4] = u10[i*10+6];
+        u6[i*6+5] = 1; }
     pool = (int *)malloc(len * sizeof(int));
     for (i = 0; i < len; i++) pool[i] = i;
     samidx = pool + len - 2;

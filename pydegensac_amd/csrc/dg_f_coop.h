@@ -29,7 +29,8 @@ __device__ __forceinline__ dg_coop_ws dg_coop_views(const dg_args &A, int slot)
 }
 #define DG_COOP_GEN_MASK 0xfffff
 #ifndef DG_COOP_SPW
-#define DG_COOP_SPW 1            /* stage 1: point slices per claiming workgroup (C5: 85.4 ms with 3, 82.8 with 2, 80.4 with 1: a unit's claim and its release cost ~3 us) */
+#define DG_COOP_SPW 1            /* stage 1: point slices per claiming workgroup (C5: 85.4 ms with 3, 82.8 with 2, 80.4 with 1: a unit's claim and its release \
+   cost ~3 us) */
 #endif
 /* stage 4 (repetitions of a local optimisation as units): the job header + records (DG_LOJOB_BYTES behind the stage-3 staging),
  * and list k (0 .. 4 DG_RAN_REP - 1; repetition q: `inliers` = list 2q, the second list = 2q + 1, the slice-local staging of its
@@ -58,7 +59,8 @@ __device__ __forceinline__ void dg_coop_publish(dg_coop_cb *cb, int &coop_gen, i
             /* the device-wide best-score bound only rises while a pair runs (atomic max on the ordered bits of a double >= 0) */
             __hip_atomic_fetch_max(&cb->tau_bits, (unsigned long long)__double_as_longlong(tau < 0 ? 0.0 : tau), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&cb->done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&cb->next, (int)((((unsigned)(coop_gen + 1) & DG_COOP_GEN_MASK) << 12) | (unsigned)n_units), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&cb->next, (int)((((unsigned)(coop_gen + 1) & DG_COOP_GEN_MASK) << 12) | (unsigned)n_units), __ATOMIC_RELAXED,
+                __HIP_MEMORY_SCOPE_AGENT);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -151,7 +153,8 @@ __device__ __forceinline__ void dg_coop_unit_screen(dg_f_shared *S, const dg_coo
         DG_WSYNC();
         unsigned cq = 0;
         if (__ballot(need) != 0ull)
-            cq = l1 ? dg_l1_tile_counts<0>(v.P, lo, hi, (const float *)tab, nb, lane) : dg_l2_tile_counts<0>(v.P, lo, hi, (const double *)tab, nb, kind, t94b, lane);
+            cq = l1 ? dg_l1_tile_counts<0>(v.P, lo, hi, (const float *)tab, nb, lane) : dg_l2_tile_counts<0>(v.P, lo, hi, (const double *)tab, nb, kind, t94b,
+                lane);
         if (have && need && cq) __hip_atomic_fetch_add(v.cnt + mi, cq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         DG_WSYNC();
     }
@@ -196,7 +199,8 @@ __device__ __forceinline__ void dg_coop_unit_pass(dg_f_shared *S, const dg_coop_
  * workgroup passes over all n points (ordered MSAC terms in LDS + this workgroup's HBM buffer), the hash of a set on wave 1
  * while wave 0 draws and fits the next 8-subset.  The table is only looked up. */
 template <int T>
-__device__ __noinline__ void dg_lo_rep_wg(dg_f_shared *S, const dg_pt *P, const int n, const dg_ht &ht, dg_lo_log *lg, int *ib, int *alt, int *sA, int *sB, double *jbuf,
+__device__ __noinline__ void dg_lo_rep_wg(dg_f_shared *S, const dg_pt *P, const int n, const dg_ht &ht, dg_lo_log *lg, int *ib, int *alt, int *sA, int *sB,
+    double *jbuf,
                                           const int ssiz, const double th, const int mk_full, const int mk_ex, const int tid)
 {
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -214,7 +218,8 @@ __device__ __noinline__ void dg_lo_rep_wg(dg_f_shared *S, const dg_pt *P, const 
         const int lo = wv * sl < n ? wv * sl : n, hi = lo + sl < n ? lo + sl : n;
         unsigned *wc = (unsigned *)S->lsq.svw;
         __syncthreads();
-        const dg_pass_res r = dg_wpass_slice(P, lo, hi, [&](const dg_pt &q) { return dg_Ferr(kind, F, q); }, thJ, la ? sA + lo : (int *)0, thL, lb ? sB + lo : (int *)0, thL2,
+        const dg_pass_res r = dg_wpass_slice(P, lo, hi, [&](const dg_pt &q) { return dg_Ferr(kind, F, q); }, thJ, la ? sA + lo : (int *)0, thL,
+            lb ? sB + lo : (int *)0, thL2,
                                              wantJ ? jbuf + lo : (double *)0, lane);
         if (lane == 0) { wc[4 * wv] = r.I; wc[4 * wv + 1] = r.nL; wc[4 * wv + 2] = r.nL2; wc[4 * wv + 3] = r.nJ; }
         __syncthreads();
@@ -326,13 +331,16 @@ __device__ __forceinline__ void dg_coop_unit_rep(const dg_args &A, dg_f_shared *
     const dg_lo_job *job = (const dg_lo_job *)lj;
     char *ws = A.ws + (size_t)slot * A.wl.stride;
     dg_ht ht; ht.heads = (int *)(ws + A.wl.off_ht); ht.count = ht.heads + 64; ht.ent = ht.heads + 80;
-    dg_lo_rep_wg<T>(S, v.P, job->n, ht, (dg_lo_log *)(lj + 128 + (size_t)DG_LOJOB_STRIDE * u), dg_coop_lo_list(A, slot, 2 * u), dg_coop_lo_list(A, slot, 2 * u + 1),
-                    dg_coop_lo_list(A, slot, 2 * DG_RAN_REP + 2 * u), dg_coop_lo_list(A, slot, 2 * DG_RAN_REP + 2 * u + 1), jbuf, job->ssiz, job->th, job->mk_full, job->mk_ex, tid);
+    dg_lo_rep_wg<T>(S, v.P, job->n, ht, (dg_lo_log *)(lj + 128 + (size_t)DG_LOJOB_STRIDE * u), dg_coop_lo_list(A, slot, 2 * u), dg_coop_lo_list(A, slot,
+        2 * u + 1),
+                    dg_coop_lo_list(A, slot, 2 * DG_RAN_REP + 2 * u), dg_coop_lo_list(A, slot, 2 * DG_RAN_REP + 2 * u + 1), jbuf, job->ssiz, job->th,
+                        job->mk_full, job->mk_ex, tid);
 }
 
 /* Whole workgroup (owner or helper): work on generation G until it has no unclaimed unit left */
 template <int T>
-__device__ __forceinline__ void dg_coop_work(const dg_args &A, int slot, dg_f_shared *S, const dg_coop_ws &v, dg_coop_cb *cb, int G, double *jbuf, int *bc /* LDS */, int tid)
+__device__ __forceinline__ void dg_coop_work(const dg_args &A, int slot, dg_f_shared *S, const dg_coop_ws &v, dg_coop_cb *cb, int G, double *jbuf,
+    int *bc /* LDS */, int tid)
 {
     for (;;) {
         const int u = dg_coop_claim(cb, G, bc);
@@ -370,7 +378,8 @@ __device__ __forceinline__ void dg_f_helper(const dg_args &A, dg_f_shared *S, co
     for (;;) {
         if (wave0) {
             int g;
-            while ((g = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&cb->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) == last) __builtin_amdgcn_s_sleep(4);
+            while ((g = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&cb->gen, __ATOMIC_RELAXED,
+                __HIP_MEMORY_SCOPE_AGENT))) == last) __builtin_amdgcn_s_sleep(4);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             *bc = g;                                                         /* every lane stores the same value */
         }

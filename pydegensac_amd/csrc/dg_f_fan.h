@@ -76,7 +76,8 @@ __device__ __noinline__ void dg_f_fan_worker(const dg_args &A, dg_f_shared *S, c
                 if (cl < hd) {
                     int ok = 0;
                     if (lane == 0) { int e = cl;
-                        ok = __hip_atomic_compare_exchange_strong(&scb->claim, &e, cl + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0; }
+                        ok = __hip_atomic_compare_exchange_strong(&scb->claim, &e, cl + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0; }
                     if (__builtin_amdgcn_readfirstlane(ok)) { seq = cl; break; }
                     continue;
                 }

@@ -198,7 +198,8 @@ __device__ __noinline__ dg_score dg_inFrani_serial(CTX &c, int ninl, double th, 
                 int hit = -1;
                 for (int k = 0; k < S->n_ahead; k++) {
                     const int *a = (const int *)&S->rng, *b = (const int *)&S->ahead[k].before;
-                    const bool same = lane < 31 ? a[lane] == b[lane] : (lane == 31 ? S->rng.f == S->ahead[k].before.f : (lane == 32 ? S->rng.b == S->ahead[k].before.b : true));
+                    const bool same = lane < 31 ? a[lane] == b[lane] : (lane == 31 ? S->rng.f == S->ahead[k].before.f : (lane == 32
+                        ? S->rng.b == S->ahead[k].before.b : true));
                     if (hit < 0 && __ballot(!same) == 0ull) hit = k;
                 }
                 if (hit >= 0) {
@@ -274,7 +275,8 @@ __device__ __noinline__ dg_score dg_inFrani_serial(CTX &c, int ninl, double th, 
 /* one wave's pass of model Fm under metric `kind` over all n points: I = #(d <= thJ), J = the reference-order MSAC sum, the
  * ordered id lists at thL (la) and thL2 (lb, optional); `tile` = the wave's LDS tile for the MSAC terms (dg_wpass_impl) */
 template <int LDSPTS>
-__device__ __noinline__ dg_pass_res dg_f_wpass(const dg_pt *P, int n, int kind, const double *Fm /* LDS */, double thJ, int *la_, double thL, int *lb_, double thL2,
+__device__ __noinline__ dg_pass_res dg_f_wpass(const dg_pt *P, int n, int kind, const double *Fm /* LDS */, double thJ, int *la_, double thL, int *lb_,
+    double thL2,
                                                double *tile, int lane)
 {
     n = __builtin_amdgcn_readfirstlane(n); kind = __builtin_amdgcn_readfirstlane(kind);

@@ -53,7 +53,8 @@ __device__ __noinline__ unsigned dg_sample_chain(unsigned seed, int cn, unsigned
  * per-sample alias flag: two draws on the same position, or a draw inside the tail block, make the swaps of that sample
  * order-dependent -> replayed sequentially in stage 2.  The rounds of a chunk are independent: one wave each. */
 template <int NDRAW>
-__device__ __noinline__ void dg_sample_draws_round(int rd, int cn, int n, const unsigned *seeds, int (*draws)[8], unsigned long long *almask, int lane, long long *dbg = 0)
+__device__ __noinline__ void dg_sample_draws_round(int rd, int cn, int n, const unsigned *seeds, int (*draws)[8], unsigned long long *almask, int lane,
+    long long *dbg = 0)
 {
     long long ts1 = DG_CLK();
     const int k = rd * 64 + lane;
@@ -281,7 +282,8 @@ __device__ __forceinline__ int dg_sample_pool_seq_range(int k_lo, int k_hi, int 
 #define DG_PGT (DG_JBUF_LDS_BYTES >= 8192 ? 1024 : 512)   /* slots per collision table; the two tables live in the pool stage's LDS scratch */
 static_assert(2 * DG_PGT * sizeof(int) <= DG_JBUF_LDS_BYTES, "collision tables do not fit the pool-stage scratch");
 template <int NDRAW>
-__device__ __noinline__ void dg_sample_pool_grp(int cn, int n, int *vp_, int (*draws_)[8], const unsigned long long *almask_, int *pscratch /* LDS, 2 * DG_PGT ints */,
+__device__ __noinline__ void dg_sample_pool_grp(int cn, int n, int *vp_, int (*draws_)[8], const unsigned long long *almask_,
+    int *pscratch /* LDS, 2 * DG_PGT ints */,
                                                 int lane, long long *dbg)
 {
     long long ts2 = DG_CLK();

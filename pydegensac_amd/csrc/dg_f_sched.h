@@ -140,7 +140,8 @@ __device__ __forceinline__ int dg_stream_find(const dg_args &A, int *bc /* LDS *
                     int ok = 0;
                     if (threadIdx.x == 0) {
                         int e = DG_ST_REQ;
-                            ok = __hip_atomic_compare_exchange_strong(&A.scb[j].state, &e, DG_ST_ATTACHED, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+                            ok = __hip_atomic_compare_exchange_strong(&A.scb[j].state, &e, DG_ST_ATTACHED, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
                         if (ok) __hip_atomic_fetch_add(A.done_pairs + 1, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     if (__builtin_amdgcn_readfirstlane(ok)) { res = j; __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }

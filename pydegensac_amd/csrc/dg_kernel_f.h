@@ -169,7 +169,8 @@ struct dg_f_ctx {
     double *hlt;             /* homography kernel: [DG_NW][DG_HLT] doubles of LDS, one block per wave (one-repetition-per-wave LO) */
     int hjob_gen;            /* homography kernel: generation of this slot's last local-optimisation job (dg_hjob_cb) */
     int lo_assumed, lo_prev;
-        /* cooperative large-n mode: 8-subset draws the last committed repetition of a local optimisation consumed (the start states of the next ones assume it) */
+        /* cooperative large-n mode: 8-subset draws the last committed repetition of a local optimisation consumed (the start states of the next ones assume it)
+         */
 
     __device__ __forceinline__ dg_pt pt(int i) const { return P[i]; }
     /* LAF point sets u_1 (which=1: +a12,+a22) and u_2 (which=2: +a11,+a21): bindings.cpp:337-409 */
@@ -480,7 +481,8 @@ __device__ __noinline__ unsigned dg_innerH_serial(CTX &c, double *H /* LDS, in/o
  * go through `tile` (LDS, >= 64 * DG_PU doubles: the wave's solver scratch, idle during a pass) and are added, in point order,
  * before the next step, whose points are loaded before that. */
 template <int LDSPTS, class Err>
-__device__ __forceinline__ dg_pass_res dg_wpass_impl(const dg_pt *P, int n, Err err, double thJ, int *la_, double thL, int *lb_, double thL2, double *tile_, int lane)
+__device__ __forceinline__ dg_pass_res dg_wpass_impl(const dg_pt *P, int n, Err err, double thJ, int *la_, double thL, int *lb_, double thL2, double *tile_,
+    int lane)
 {
     __attribute__((address_space(1))) int *la = (__attribute__((address_space(1))) int *)la_, *lb = (__attribute__((address_space(1))) int *)lb_;
     __attribute__((address_space(3))) double *t = (__attribute__((address_space(3))) double *)tile_;
@@ -534,7 +536,8 @@ __device__ __forceinline__ dg_pass_res dg_wpass_impl(const dg_pt *P, int n, Err 
  * compacted in point order into slice-local outputs (la / lb / jout start at the slice's first slot); no sum: the caller adds the
  * slices' terms one after the other.  Returns I, nL, nL2, nJ of the slice. */
 template <class Err>
-__device__ __forceinline__ dg_pass_res dg_wpass_slice(const dg_pt *P, int lo, int hi, Err err, double thJ, int *la_, double thL, int *lb_, double thL2, double *jout_, int lane)
+__device__ __forceinline__ dg_pass_res dg_wpass_slice(const dg_pt *P, int lo, int hi, Err err, double thJ, int *la_, double thL, int *lb_, double thL2,
+    double *jout_, int lane)
 {
     __attribute__((address_space(1))) int *la = (__attribute__((address_space(1))) int *)la_, *lb = (__attribute__((address_space(1))) int *)lb_;
     __attribute__((address_space(1))) double *jo = (__attribute__((address_space(1))) double *)jout_;
@@ -571,7 +574,8 @@ __device__ __forceinline__ dg_pass_res dg_wpass_slice(const dg_pt *P, int lo, in
     return out;
 }
 static_assert(offsetof(dg_wave_ws, Z) == 0 && offsetof(dg_wave_ws, px) + sizeof(((dg_wave_ws *)0)->px) >= 64 * DG_PU * sizeof(double) &&
-              offsetof(dg_wave_ws, ews) >= offsetof(dg_wave_ws, px) + sizeof(((dg_wave_ws *)0)->px), "a wave pass's MSAC-term tile spans dg_wave_ws::Z .. ::px");
+              offsetof(dg_wave_ws, ews) >= offsetof(dg_wave_ws, px) + sizeof(((dg_wave_ws *)0)->px),
+                  "a wave pass's MSAC-term tile spans dg_wave_ws::Z .. ::px");
 
 /* one wave's pass of homography Hm (metric HDs): I, J at thJ, the ordered id list at thL */
 template <int LDSPTS>
@@ -900,7 +904,8 @@ __device__ __noinline__ void dg_innerFH(CTX &c, const int *idxH, unsigned lenH, 
         if (lane < 9) S->fhF2[rep][lane] = S->fhF[rep][lane];
         DG_WSYNC();
         double thf;
-        unsigned cnt = dg_u2Fit_wave<LDSPTS>(&S->ww[wave], P, n, S->fhF2[rep], th, th*3, 4, c.K->wlist + (size_t)wave * c.K->n_max, c.K->wstage + (size_t)wave * c.K->n_max, c.K->n_max, lane, &thf, &aux_local);
+        unsigned cnt = dg_u2Fit_wave<LDSPTS>(&S->ww[wave], P, n, S->fhF2[rep], th, th*3, 4, c.K->wlist + (size_t)wave * c.K->n_max,
+            c.K->wstage + (size_t)wave * c.K->n_max, c.K->n_max, lane, &thf, &aux_local);
         if (lane == 0) { S->fhCnt2[rep] = (int)cnt; S->fhTh[rep] = thf; S->itmp[8 + wave] = aux_local; }
         DG_WSYNC();
     }
@@ -966,7 +971,8 @@ __device__ __noinline__ unsigned dg_rFtH(CTX &c, const unsigned char *hinl, doub
     unsigned nhinlCount, hinlCount;
     {
         dg_pass_cfg cfg = dg_cfg0(n); cfg.list = idxN; cfg.thL = 0.5; cfg.flags = nhinl; cfg.thF = 0.5;
-        dg_pass_res r = dg_pass(&S->red, cfg, [&](int pid, int) { dg_pt p = dg_ldpt<LDSPTS>(P, pid); return dg_HDs(Hr, p.x1, p.y1, p.x2, p.y2) > 100*th ? 0.0 : 1.0; }, tid);
+        dg_pass_res r = dg_pass(&S->red, cfg, [&](int pid, int) { dg_pt p = dg_ldpt<LDSPTS>(P, pid); return dg_HDs(Hr, p.x1, p.y1, p.x2,
+            p.y2) > 100*th ? 0.0 : 1.0; }, tid);
         c.n_hds++;
         nhinlCount = r.nL;
         dg_pass_cfg cfg2 = dg_cfg0(n); cfg2.list = idxH; cfg2.thL = 0.5;

@@ -199,7 +199,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     };
     while (!done && no_sam < max_sam) {
         int coop_no_ev = 0;          /* cooperative mode: the screen left no survivor: no model of this chunk can be an event of the commit */
-        /* cooperative mode: samples of the next chunk solved during this one's scoring; size of the chunk whose seed chain runs in this iteration (deep pipeline) */
+        /* cooperative mode: samples of the next chunk solved during this one's scoring; size of the chunk whose seed chain runs in this iteration (deep
+           pipeline) */
         int pre_cnt = 0, cn3 = 0;
         int ff = 0, tail_p = 0;      /* producer: the owner is already past this chunk: sampler stages only; the owner's position */
         int seq = no_sam / DG_CHUNK;
@@ -236,7 +237,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                 __hip_atomic_store(&scb->max_sam, max_sam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&scb->tail, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (strm < 2 && !legacy_sym && no_sam >= A.stream_min_sam && max_sam - no_sam >= A.stream_min_left && (strm == 1 || (seq & 3) == 0 || no_sam < 1024)) {
+            if (strm < 2 && !legacy_sym && no_sam >= A.stream_min_sam && max_sam - no_sam >= A.stream_min_left && (strm == 1 || (seq & 3) == 0 ||
+                no_sam < 1024)) {
                 /* ask for a producer (or renew an unanswered request with a fresh image; or see whether the producer has caught up) */
                 __syncthreads();
                 if (tid == 0) {
@@ -244,14 +246,16 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                     if (strm == 0) {
                         if ((A.stream_test & 2) || A.stream_early || __hip_atomic_load(A.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= A.n_pairs) {
                             int e = DG_ST_IDLE;
-                            if (__hip_atomic_compare_exchange_strong(&scb->state, &e, DG_ST_BUSY, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) act = 1;
+                            if (__hip_atomic_compare_exchange_strong(&scb->state, &e, DG_ST_BUSY, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                __HIP_MEMORY_SCOPE_AGENT)) act = 1;
                         }
                     } else {
                         const int st_ = __hip_atomic_load(&scb->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (st_ == DG_ST_REQ) {
                             if (no_sam - img_sam >= 8192) {
                                 int e = DG_ST_REQ;
-                                if (__hip_atomic_compare_exchange_strong(&scb->state, &e, DG_ST_BUSY, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                                if (__hip_atomic_compare_exchange_strong(&scb->state, &e, DG_ST_BUSY, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT)) {
                                     act = 1; __hip_atomic_fetch_add(A.done_pairs + 1, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 }
                             }
@@ -265,7 +269,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                 if (act == 1) {
                     if (tid == 0) {
                         const double tau_ = maxS.J < maxSs.J ? maxS.J : maxSs.J;
-                        __hip_atomic_store(&scb->tau_bits, (unsigned long long)__double_as_longlong(tau_ < 0 ? 0.0 : tau_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&scb->tau_bits, (unsigned long long)__double_as_longlong(tau_ < 0 ? 0.0 : tau_), __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(&scb->max_sam, max_sam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(&scb->tail, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(&scb->head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -341,7 +346,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             if (nw >= 0) {
                 D.n_fds = c.n_fds; D.n_exfds = c.n_exfds; D.n_hds = c.n_hds; D.n_aux = c.n_aux; D.t_parked = wall_clock64();
                 /* development build (tools/gpu_tail.py): what is known about the pair when it is set aside */
-                DG_DEVT(if (A.phase_out && tid == 0) { long long *o_ = A.phase_out + ((size_t)A.n_pairs + 4096 + pair) * 16; o_[0] = max_sam - no_sam; o_[1] = iter_cnt; o_[2] = degen_cnt; o_[3] = D.t_parked - t_start; o_[4] = (long long)maxS.I; });
+                DG_DEVT(if (A.phase_out && tid == 0) { long long *o_ = A.phase_out + ((size_t)A.n_pairs + 4096 + pair) * 16; o_[0] = max_sam - no_sam;
+                    o_[1] = iter_cnt; o_[2] = degen_cnt; o_[3] = D.t_parked - t_start; o_[4] = (long long)maxS.I; });
                 if (tid == 0) S->park = D;
                 __syncthreads();
                 char *pk = ws + A.wl.off_park;
@@ -356,7 +362,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                     idx = __builtin_amdgcn_readfirstlane(idx);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (tid == 0) __hip_atomic_store(A.park_q + (size_t)q * A.park_cap + idx, ((long long)pair << 32) | (long long)(unsigned)wsid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid == 0) __hip_atomic_store(A.park_q + (size_t)q * A.park_cap + idx, ((long long)pair << 32) | (long long)(unsigned)wsid,
+                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 return nw;
             }
@@ -518,7 +525,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         }
 
         DG_PH(1);
-        /* ====== score chunk c (waves 2.., one wave per model, points streamed from LDS)  ||  pool swaps of chunk c+1 (wave 0)  ||  seeds + draws of chunk c+2 (wave 1) ====== */
+        /* ====== score chunk c (waves 2.., one wave per model, points streamed from LDS)  ||  pool swaps of chunk c+1 (wave 0)  ||  seeds + draws of chunk c+2
+           (wave 1) ====== */
         nxt = cur == 2 ? 0 : cur + 1; const int nx2 = nxt == 2 ? 0 : nxt + 1;
         {
             if (deep) {
@@ -539,7 +547,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
             else if (wave == 0) {
                 const int ps = deep ? nx2 : nxt;
                 if (deep && pend_draws) {          /* the draws of that chunk come from waves 6 and 7 (below) */
-                    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&S->itmp[23], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < 2) __builtin_amdgcn_s_sleep(1);
+                    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&S->itmp[23], __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_WORKGROUP)) < 2) __builtin_amdgcn_s_sleep(1);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 }
                 if (chunk_s[ps] > 0) dg_sample_pool<7, LDSPTS>(chunk_s[ps], n, pool, S->draws3[ps], S->alm3[ps], pscr, lane, S->dbg);
@@ -583,7 +592,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                     int nv_ = 0, nb_ = 0; unsigned rx = 0, incl = 0; const int k_ = wsi * 64 + lane;
                     if (wsi < NB) {
                         if (k_ < chunk) {
-                            const int r_ = dg_solve7_lane(P, c.draws[k_], c.K->gmodels + (size_t)k_ * 27, &rx, (double *)((char *)&S->lsq + (size_t)wsi * capw));
+                            const int r_ = dg_solve7_lane(P, c.draws[k_], c.K->gmodels + (size_t)k_ * 27, &rx,
+                                (double *)((char *)&S->lsq + (size_t)wsi * capw));
                             if (r_ < 0) nb_ = 1; else nv_ = r_;
                         }
                         incl = (unsigned)nv_;
@@ -593,7 +603,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         if (lane == 0) __hip_atomic_fetch_add(&S->itmp[21], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
-                    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&S->itmp[21], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < NB) __builtin_amdgcn_s_sleep(1);
+                    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&S->itmp[21], __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_WORKGROUP)) < NB) __builtin_amdgcn_s_sleep(1);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     unsigned tot = 0, wbase = 0;
 #pragma unroll
@@ -613,7 +624,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         if (lane == 0) __hip_atomic_fetch_add(&S->itmp[22], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
-                    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&S->itmp[22], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < NB) __builtin_amdgcn_s_sleep(1);
+                    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&S->itmp[22], __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_WORKGROUP)) < NB) __builtin_amdgcn_s_sleep(1);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     Ms = (int)__builtin_amdgcn_readfirstlane(tot);
                 }
@@ -667,7 +679,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
         /* the draws of chunk c+2 (its seeds are complete now): the rounds of 64 samples are independent, one wave each; nothing
          * reads them before the pool stage of the next iteration, which sits behind the barriers of the commit */
         if (cn2 > 0 && wave < DG_CHUNK / 64) {
-            for (int rd = wave; rd < DG_CHUNK / 64; rd += DG_NW) dg_sample_draws_round<7>(rd, cn2, n, S->seeds3[nx2], S->draws3[nx2], S->alm3[nx2], lane, S->dbg);
+            for (int rd = wave; rd < DG_CHUNK / 64; rd += DG_NW) dg_sample_draws_round<7>(rd, cn2, n, S->seeds3[nx2], S->draws3[nx2], S->alm3[nx2], lane,
+                S->dbg);
         }
         DG_PH(2);
         if (producer) {
@@ -852,7 +865,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                                     }
                                     /* the helpers' bound of this pair follows (only this workgroup writes it) */
                                     if (LDSPTS == 0 && coopK > 0 && tid == 0)
-                                        __hip_atomic_store(&cb->tau_bits, (unsigned long long)__double_as_longlong(tau_new < 0 ? 0.0 : tau_new), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        __hip_atomic_store(&cb->tau_bits, (unsigned long long)__double_as_longlong(tau_new < 0 ? 0.0 : tau_new),
+                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                     {
                                         const int capr = (int)((sizeof(dg_lsq_scratch) / DG_NW) & ~(size_t)15);
                                         /* only what the commit has not consumed yet: this sample's remaining roots and the later samples (the slots of
@@ -860,7 +874,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                                          * look at these models is not counted in scnt */
                                         dg_score_chunk_F<LDSPTS>(P, n, c.K->gmodels, S->mslot, Mtot, wave, DG_NW, mk_full, th, tau_new, S->ext,
                                                                  (char *)&S->lsq + (size_t)wave * capr, capr,
-                                                                 (double *)(c.K->wstage + (size_t)wave * c.K->n_max), c.K->res_I, c.K->res_J, lane, (unsigned *)0,
+                                                                 (double *)(c.K->wstage + (size_t)wave * c.K->n_max), c.K->res_I, c.K->res_J, lane,
+                                                                     (unsigned *)0,
                                                                  (int)S->moff[k] + r + 1);
                                     }
                                     __syncthreads();
@@ -936,7 +951,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
                 }
                 if (scb && strm >= 1 && tid == 0) {
                     const double tau_ = maxS.J < maxSs.J ? maxS.J : maxSs.J;
-                    __hip_atomic_store(&scb->tau_bits, (unsigned long long)__double_as_longlong(tau_ < 0 ? 0.0 : tau_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&scb->tau_bits, (unsigned long long)__double_as_longlong(tau_ < 0 ? 0.0 : tau_), __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&scb->max_sam, max_sam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 DG_PH(4);
@@ -1163,7 +1179,8 @@ __device__ __forceinline__ int dg_f_pair(const dg_args &A, dg_f_shared *S, unsig
     if (A.phase_out && tid == 0) { for (int i = 0; i < 16; i++) A.phase_out[(size_t)pair * 16 + i] = S->lt[i]; }
     if (0)
 #endif
-    DG_DEVT(if (A.phase_out && tid == 0) { S->ph[7] = DG_CLK() - t_start; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + i] = S->ph[i]; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + 8 + i] = S->dbg[i]; A.phase_out[(size_t)pair * 16 + 15] = DG_CLK(); });
+    DG_DEVT(if (A.phase_out && tid == 0) { S->ph[7] = DG_CLK() - t_start; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + i] = S->ph[i];
+        for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + 8 + i] = S->dbg[i]; A.phase_out[(size_t)pair * 16 + 15] = DG_CLK(); });
 #undef DG_PH
     return -1;
 }

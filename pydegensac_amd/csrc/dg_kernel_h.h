@@ -18,7 +18,8 @@
 
 /* u2h (Htools.c:115-131) over a list of ids, reference summation order (see dg_lsq_seq) */
 template <class PtFn>
-__device__ __forceinline__ void dg_u2h_big(dg_red *r, dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, double *Hout /* LDS */, dg_pt *stage, int stage_cap,
+__device__ __forceinline__ void dg_u2h_big(dg_red *r, dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, double *Hout /* LDS */, dg_pt *stage,
+    int stage_cap,
                                            double *ltab)
 {
     (void)r;
@@ -83,7 +84,8 @@ __device__ __forceinline__ int dg_h_checks(CTX &c, int kind, const double *h /* 
     const dg_pt *P = c.P;
     if (pr.sym_th > 0) {
         dg_pass_cfg cfg = dg_cfg0(cnt); cfg.src = list; cfg.wantC = 1; cfg.thC = pr.sym_th;
-        dg_pass_res r = dg_pass(&Sh->red, cfg, [&](int pid, int) { dg_pt p = dg_ldpt<LDSPTS>(P, pid); return dg_Hsym(Hinv, H1, p.x1, p.y1, p.x2, p.y2, 2, 1); }, c.tid);
+        dg_pass_res r = dg_pass(&Sh->red, cfg, [&](int pid, int) { dg_pt p = dg_ldpt<LDSPTS>(P, pid); return dg_Hsym(Hinv, H1, p.x1, p.y1, p.x2, p.y2, 2, 1); },
+            c.tid);
         S.Is = r.C;
         if (S.Is < maxS.Is) return 0;
     }
@@ -272,7 +274,8 @@ struct dg_hrep_sc { double *Z, *V, *D, *A1, *A2; dg_eig_ws &ews; };     /* scrat
 #define DG_HPUB_BYTES ((size_t)DG_RAN_REP * 8 * sizeof(unsigned long long))
 #define DG_HREP_HDR_BYTES ((DG_HPUB_OFF + DG_HPUB_BYTES + 255) & ~(size_t)255)
 __device__ __forceinline__ size_t dg_hrep_logs_bytes() { return DG_HREP_HDR_BYTES; }
-__device__ __forceinline__ size_t dg_hrep_wave_bytes(int n_max) { return ((size_t)n_max * (2 * sizeof(int) + sizeof(double) + 2 * sizeof(dg_pt)) + 255) & ~(size_t)255;
+__device__ __forceinline__ size_t dg_hrep_wave_bytes(int n_max) { return ((size_t)n_max * (2 * sizeof(int) + sizeof(double) + 2 * sizeof(dg_pt)) + 255) &
+    ~(size_t)255;
     }
 
 #define DG_AS1(T) __attribute__((address_space(1))) T
@@ -307,7 +310,8 @@ __device__ __forceinline__ void dg_stage_ld4(const DG_AS1(double) *stage, int ba
     }
 }
 template <int LDSPTS, int ROWS2>
-__device__ __forceinline__ void dg_lsq_wave_stream(const dg_pt *P, const int *list_, int len, dg_pt *stage_, double *lt_, double *V, double *A1o, double *A2o, int lane)
+__device__ __forceinline__ void dg_lsq_wave_stream(const dg_pt *P, const int *list_, int len, dg_pt *stage_, double *lt_, double *V, double *A1o, double *A2o,
+    int lane)
 {
     const DG_AS1(int) *list = (const DG_AS1(int) *)list_;
     DG_AS1(double) *stage = (DG_AS1(double) *)(double *)stage_;
@@ -420,8 +424,10 @@ __device__ __forceinline__ void dg_lsq_wave_stream(const dg_pt *P, const int *li
                     if (!ROWS2) {
                         for (; p + 8 <= cnt; p += 8) {
                             const DG_AS3(double) *w = t + 10 * p;
-                            const double u0 = w[x0], v0 = w[y0], u1 = w[10 + x0], v1 = w[10 + y0], u2 = w[20 + x0], v2 = w[20 + y0], u3 = w[30 + x0], v3 = w[30 + y0];
-                            const double u4 = w[40 + x0], v4 = w[40 + y0], u5 = w[50 + x0], v5 = w[50 + y0], u6 = w[60 + x0], v6 = w[60 + y0], u7 = w[70 + x0], v7 = w[70 + y0];
+                            const double u0 = w[x0], v0 = w[y0], u1 = w[10 + x0], v1 = w[10 + y0], u2 = w[20 + x0], v2 = w[20 + y0], u3 = w[30 + x0],
+                                v3 = w[30 + y0];
+                            const double u4 = w[40 + x0], v4 = w[40 + y0], u5 = w[50 + x0], v5 = w[50 + y0], u6 = w[60 + x0], v6 = w[60 + y0], u7 = w[70 + x0],
+                                v7 = w[70 + y0];
                             val += u0 * v0; val += u1 * v1; val += u2 * v2; val += u3 * v3; val += u4 * v4; val += u5 * v5; val += u6 * v6; val += u7 * v7;
                         }
                         for (; p < cnt; p++) { const DG_AS3(double) *w = t + 10 * p; val += w[x0] * w[y0]; }
@@ -429,7 +435,8 @@ __device__ __forceinline__ void dg_lsq_wave_stream(const dg_pt *P, const int *li
                         for (; p + 4 <= cnt; p += 4) {
                             const DG_AS3(double) *w = t + 10 * p;
                             const double u0 = w[x0], v0 = w[y0], p0 = w[x1], q0 = w[y1], u1 = w[10 + x0], v1 = w[10 + y0], p1 = w[10 + x1], q1 = w[10 + y1];
-                            const double u2 = w[20 + x0], v2 = w[20 + y0], p2 = w[20 + x1], q2 = w[20 + y1], u3 = w[30 + x0], v3 = w[30 + y0], p3 = w[30 + x1], q3 = w[30 + y1];
+                            const double u2 = w[20 + x0], v2 = w[20 + y0], p2 = w[20 + x1], q2 = w[20 + y1], u3 = w[30 + x0], v3 = w[30 + y0], p3 = w[30 + x1],
+                                q3 = w[30 + y1];
                             val += u0 * v0; val += p0 * q0; val += u1 * v1; val += p1 * q1; val += u2 * v2; val += p2 * q2; val += u3 * v3; val += p3 * q3;
                         }
                         for (; p < cnt; p++) { const DG_AS3(double) *w = t + 10 * p; val += w[x0] * w[y0]; val += w[x1] * w[y1]; }
@@ -573,7 +580,8 @@ __device__ __forceinline__ bool dg_hpub_seen(unsigned long long *pub, int j, uns
         /* a finished repetition's iteration count is in its status word; the unfinished one (k == p) counts as far as its words go */
         for (int i = 0; i < DG_ILSQ_ITERS; i++) {
             const int src = 6 * k + i;
-            const unsigned long long w = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), src) << 32) | (unsigned)__builtin_amdgcn_readlane((int)v, src);
+            const unsigned long long w = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32),
+                src) << 32) | (unsigned)__builtin_amdgcn_readlane((int)v, src);
             if (!(w & DG_HPUB_VALID)) break;                                    /* not (yet) reached */
             const unsigned long long kk = w & ~(DG_HPUB_VALID | DG_HPUB_KNOWN);
             if (w & DG_HPUB_KNOWN) break;                                       /* ended at a set of an earlier local optimisation */
@@ -665,7 +673,8 @@ __device__ __forceinline__ int dg_hjob_claim(dg_hjob_cb *cb, int g, int *lds_nex
 }
 /* one wave: work on job g until no repetition is left to claim */
 template <int LDSPTS>
-__device__ __forceinline__ void dg_hjob_work(CTX &c, dg_hjob_cb *cb, int g, int *lds_next, int kind, dg_hrep_log *logs, int ssiz, double th, char *wb, int lane, int wave)
+__device__ __forceinline__ void dg_hjob_work(CTX &c, dg_hjob_cb *cb, int g, int *lds_next, int kind, dg_hrep_log *logs, int ssiz, double th, char *wb, int lane,
+    int wave)
 {
     for (;;) {
         const int r = dg_hjob_claim(cb, g, lds_next, lane);
@@ -847,7 +856,8 @@ __device__ __forceinline__ void dg_h_help(const dg_args &A, dg_f_shared *S, doub
     if (g <= 0) return;
     /* never the case for an open job: refuse instead of reading wild memory */
     if (n < 8 || n > A.wl.n_max || ssiz < 4 || ssiz > 12 || kind < 0 || kind > 4) {
-        if (tid == 0) __hip_atomic_store(A.err_flag, 16 + (n < 8 || n > A.wl.n_max ? 1 : 0) + (ssiz < 4 || ssiz > 12 ? 2 : 0) + (kind < 0 || kind > 4 ? 4 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(A.err_flag, 16 + (n < 8 || n > A.wl.n_max ? 1 : 0) + (ssiz < 4 || ssiz > 12 ? 2 : 0) + (kind < 0 || kind > 4 ? 4 : 0),
+            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     /* (the parameters belong to generation g as long as a claim of generation g succeeds: the owner does not open the next job
@@ -867,7 +877,8 @@ __device__ __forceinline__ void dg_h_help(const dg_args &A, dg_f_shared *S, doub
 
 /* one LO run of the driver (exp_ranH.c:678-747 / :795-861).  e4 = model behind errs[4].  Returns 1 if accepted. */
 template <int LDSPTS>
-__device__ __noinline__ int dg_h_lo(CTX &c, int kind, const double *e4, double th, dg_score &maxS, int *iterID, int *p1_inliers, int no_sam, int lo_run /* 0-based */)
+__device__ __noinline__ int dg_h_lo(CTX &c, int kind, const double *e4, double th, dg_score &maxS, int *iterID, int *p1_inliers, int no_sam,
+    int lo_run /* 0-based */)
 {
     dg_f_shared *S = c.S; const int n = c.n, tid = c.tid;
     dg_hbufs B; B.pe[0] = 0; B.pe[1] = 1; B.pe[2] = 2;
@@ -940,7 +951,8 @@ __device__ __noinline__ int dg_h_lo(CTX &c, int kind, const double *e4, double t
 
 /* One 4-point problem per lane (own register allocation): orientation test, 8x9 null vector, near-singularity
  * test and, for the symmetric metrics, H1 = inverse of the transposed H.  Returns 1 when the sample yields a model. */
-__device__ __noinline__ int dg_solve4_lane(const dg_pt *P, const int *ids, int kind, double *hm, double *H1m, double *wscr /* LDS, this wave's, >= 81 doubles */)
+__device__ __noinline__ int dg_solve4_lane(const dg_pt *P, const int *ids, int kind, double *hm, double *H1m,
+    double *wscr /* LDS, this wave's, >= 81 doubles */)
 {
     dg_pt sp[4];
 #pragma unroll
@@ -1127,7 +1139,8 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
              * tau = min(maxS.J, maxSs.J) (the commit below), and J <= #(d < 9/4 th) <= the division-free candidate count of
              * dg_HDs_maybe_below: a model whose count does not exceed tau gets J = 0 without the exact pass (pinvJ: eight divisions
              * per point).  Every model still counts as scored (n_hds), as in the fundamental-matrix kernel. */
-            const double tau_s = (kind == 0 && iter_cnt > 0 && no_sam >= DG_ITER_SAM && th != 0 && !c.rrun && !A.trace) ? (maxS.J < maxSs.J ? maxS.J : maxSs.J) : 0.0;
+            const double tau_s = (kind == 0 && iter_cnt > 0 && no_sam >= DG_ITER_SAM && th != 0 && !c.rrun && !A.trace) ? (maxS.J < maxSs.J ? maxS.J : maxSs.J)
+                : 0.0;
             if (wave >= DG_SW0) {
                 constexpr int STR = DG_NW - DG_SW0;
                 /* exact score of model mi: I, and J as the reference's sequential sum over the nonzero terms in point order */
@@ -1167,7 +1180,8 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
         __syncthreads();
         if (cn2 > 0) seed = (unsigned)S->itmp[31];
         if (cn2 > 0 && wave < DG_CHUNK / 64) {               /* the draws of chunk c+2, one wave per 64 samples (see the F kernel) */
-            for (int rd = wave; rd < DG_CHUNK / 64; rd += DG_NW) dg_sample_draws_round<4>(rd, cn2, n, S->seeds3[nx2], S->draws3[nx2], S->alm3[nx2], lane, S->dbg);
+            for (int rd = wave; rd < DG_CHUNK / 64; rd += DG_NW) dg_sample_draws_round<4>(rd, cn2, n, S->seeds3[nx2], S->draws3[nx2], S->alm3[nx2], lane,
+                S->dbg);
         }
         DG_PHH(1);
 
@@ -1254,7 +1268,8 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
         __syncthreads();
         iter_cnt++;
         DG_PHH(2);
-        if (dg_h_lo(c, kind, maxSs.J > 0 ? e4 : (const double *)0 /* errs[4] never written */, th, maxS, &iterID, &p1_inliers, no_sam, iter_cnt - 1)) { accepted = 1;
+        if (dg_h_lo(c, kind, maxSs.J > 0 ? e4 : (const double *)0 /* errs[4] never written */, th, maxS, &iterID, &p1_inliers, no_sam,
+            iter_cnt - 1)) { accepted = 1;
             best_sample = no_sam; t_best = wall_clock64(); }
         DG_PHH(3);
     }
@@ -1295,7 +1310,8 @@ __device__ __forceinline__ void dg_h_pair(const dg_args &A, dg_f_shared *S, unsi
     hjob_gen = c.hjob_gen;
     if (A.done_pairs && tid == 0) __hip_atomic_fetch_add(A.done_pairs, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     DG_PHH(6);
-    DG_DEVT(if (A.phase_out && tid == 0) { S->ph[7] = DG_CLK() - t_start; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + i] = S->ph[i]; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + 8 + i] = S->dbg[i]; });
+    DG_DEVT(if (A.phase_out && tid == 0) { S->ph[7] = DG_CLK() - t_start; for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + i] = S->ph[i];
+        for (int i = 0; i < 8; i++) A.phase_out[(size_t)pair * 16 + 8 + i] = S->dbg[i]; });
 #undef DG_PHH
 }
 

@@ -403,8 +403,10 @@ __device__ __forceinline__ void dg_lsq_seq_par(SC *s, dg_pt *stage, int len, int
                 if (!rows2) {
                     for (; p + 8 <= cnt; p += 8) {
                         const double *t = ltab + 10 * p;
-                        const double u0 = t[x0], v0 = t[y0], u1 = t[10 + x0], v1 = t[10 + y0], u2 = t[20 + x0], v2 = t[20 + y0], u3 = t[30 + x0], v3 = t[30 + y0];
-                        const double u4 = t[40 + x0], v4 = t[40 + y0], u5 = t[50 + x0], v5 = t[50 + y0], u6 = t[60 + x0], v6 = t[60 + y0], u7 = t[70 + x0], v7 = t[70 + y0];
+                        const double u0 = t[x0], v0 = t[y0], u1 = t[10 + x0], v1 = t[10 + y0], u2 = t[20 + x0], v2 = t[20 + y0], u3 = t[30 + x0],
+                            v3 = t[30 + y0];
+                        const double u4 = t[40 + x0], v4 = t[40 + y0], u5 = t[50 + x0], v5 = t[50 + y0], u6 = t[60 + x0], v6 = t[60 + y0], u7 = t[70 + x0],
+                            v7 = t[70 + y0];
                         val += u0 * v0; val += u1 * v1; val += u2 * v2; val += u3 * v3; val += u4 * v4; val += u5 * v5; val += u6 * v6; val += u7 * v7;
                     }
                     for (; p < cnt; p++) { const double *t = ltab + 10 * p; val += t[x0] * t[y0]; }
@@ -412,7 +414,8 @@ __device__ __forceinline__ void dg_lsq_seq_par(SC *s, dg_pt *stage, int len, int
                     for (; p + 4 <= cnt; p += 4) {
                         const double *t = ltab + 10 * p;
                         const double u0 = t[x0], v0 = t[y0], p0 = t[x1], q0 = t[y1], u1 = t[10 + x0], v1 = t[10 + y0], p1 = t[10 + x1], q1 = t[10 + y1];
-                        const double u2 = t[20 + x0], v2 = t[20 + y0], p2 = t[20 + x1], q2 = t[20 + y1], u3 = t[30 + x0], v3 = t[30 + y0], p3 = t[30 + x1], q3 = t[30 + y1];
+                        const double u2 = t[20 + x0], v2 = t[20 + y0], p2 = t[20 + x1], q2 = t[20 + y1], u3 = t[30 + x0], v3 = t[30 + y0], p3 = t[30 + x1],
+                            q3 = t[30 + y1];
                         val += u0 * v0; val += p0 * q0; val += u1 * v1; val += p1 * q1; val += u2 * v2; val += p2 * q2; val += u3 * v3; val += p3 * q3;
                     }
                     for (; p < cnt; p++) { const double *t = ltab + 10 * p; val += t[x0] * t[y0]; val += t[x1] * t[y1]; }
@@ -455,7 +458,8 @@ __device__ __forceinline__ void dg_lsq_seq_par(SC *s, dg_pt *stage, int len, int
 }
 
 template <class PtFn>
-__device__ __forceinline__ void dg_lsq_seq(dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, int rows2, double *A1o, double *A2o, dg_pt *stage, int stage_cap,
+__device__ __forceinline__ void dg_lsq_seq(dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, int rows2, double *A1o, double *A2o, dg_pt *stage,
+    int stage_cap,
                                            double *ltab = (double *)0)
 {
     /* gather the listed correspondences into a contiguous staging array (all lanes), so that the sequential
@@ -469,7 +473,8 @@ __device__ __forceinline__ void dg_lsq_seq(dg_lsq_scratch *s, PtFn pt, const int
 }
 
 template <class PtFn>
-__device__ __forceinline__ void dg_u2f_big(dg_red *r, dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, double *Fout /* LDS */, dg_pt *stage, int stage_cap,
+__device__ __forceinline__ void dg_u2f_big(dg_red *r, dg_lsq_scratch *s, PtFn pt, const int *list, int len, int tid, double *Fout /* LDS */, dg_pt *stage,
+    int stage_cap,
                                            double *ltab = (double *)0)
 {
     (void)r;

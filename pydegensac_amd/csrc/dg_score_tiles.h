@@ -93,8 +93,10 @@ __device__ __forceinline__ unsigned dg_l1_tile_counts(const dg_pt *P, int p_lo, 
             const dg_f2 f4 = dg_splat2(c1.x), f5 = dg_splat2(c1.y), f6 = dg_splat2(c1.z), f7 = dg_splat2(c1.w), f8 = dg_splat2(c2.x);
             const float thr = c2.y;
             /* r = x1 (f0 x2 + f3 y2 + f6) + y1 (f1 x2 + f4 y2 + f7) + (f2 x2 + f5 y2 + f8), 4 nested FMAs per element */
-            const dg_f2 ra = dg_fma2(X1a, dg_fma2(f0, X2a, dg_fma2(f3, Y2a, f6)), dg_fma2(Y1a, dg_fma2(f1, X2a, dg_fma2(f4, Y2a, f7)), dg_fma2(f2, X2a, dg_fma2(f5, Y2a, f8))));
-            const dg_f2 rb = dg_fma2(X1b, dg_fma2(f0, X2b, dg_fma2(f3, Y2b, f6)), dg_fma2(Y1b, dg_fma2(f1, X2b, dg_fma2(f4, Y2b, f7)), dg_fma2(f2, X2b, dg_fma2(f5, Y2b, f8))));
+            const dg_f2 ra = dg_fma2(X1a, dg_fma2(f0, X2a, dg_fma2(f3, Y2a, f6)), dg_fma2(Y1a, dg_fma2(f1, X2a, dg_fma2(f4, Y2a, f7)), dg_fma2(f2, X2a,
+                dg_fma2(f5, Y2a, f8))));
+            const dg_f2 rb = dg_fma2(X1b, dg_fma2(f0, X2b, dg_fma2(f3, Y2b, f6)), dg_fma2(Y1b, dg_fma2(f1, X2b, dg_fma2(f4, Y2b, f7)), dg_fma2(f2, X2b,
+                dg_fma2(f5, Y2b, f8))));
             const unsigned c = (unsigned)__popcll(__ballot(!(fabsf(ra.x) >= thr)) & on[0]) + (unsigned)__popcll(__ballot(!(fabsf(ra.y) >= thr)) & on[1]) +
                                (unsigned)__popcll(__ballot(!(fabsf(rb.x) >= thr)) & on[2]) + (unsigned)__popcll(__ballot(!(fabsf(rb.y) >= thr)) & on[3]);
             cnt += lane == j ? c : 0u;

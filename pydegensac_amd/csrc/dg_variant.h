@@ -14,7 +14,8 @@ enum { DG_MODE_HBM = 0, DG_MODE_LDS = 1, DG_MODE_POOL_LDS = 2 };
  * reports the static LDS bytes of the F / H kernels.  resident: workgroups of that kernel one CU keeps resident with
  * `dyn` bytes of dynamic LDS.  launch: enqueues `grid` persistent workgroups (they pull pairs from A.ticket). */
 #define DG_VARIANT_DECL(T_) \
-    hipError_t dg_variant_##T_##_init(const unsigned C[8][32], const unsigned Ct[32][8], const unsigned G[32], const unsigned T[31][32], int max_lds, int static_lds[2]); \
+    hipError_t dg_variant_##T_##_init(const unsigned C[8][32], const unsigned Ct[32][8], const unsigned G[32], const unsigned T[31][32], int max_lds, \
+        int static_lds[2]); \
     hipError_t dg_variant_##T_##_resident(int homography, int mode, size_t dyn, int *blocks_per_cu); \
     hipError_t dg_variant_##T_##_launch(int homography, int mode, int grid, size_t dyn, hipStream_t stream, const dg_args &A);
 DG_VARIANT_DECL(512)

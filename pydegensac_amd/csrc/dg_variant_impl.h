@@ -3,7 +3,8 @@
 #define DG_VCAT(a, b, c) DG_VCAT2(a, b, c)
 #include "dg_variant.h"
 
-hipError_t DG_VCAT(dg_variant_, DG_T, _init)(const unsigned C[8][32], const unsigned Ct[32][8], const unsigned G[32], const unsigned T[31][32], int max_lds, int static_lds[2])
+hipError_t DG_VCAT(dg_variant_, DG_T, _init)(const unsigned C[8][32], const unsigned Ct[32][8], const unsigned G[32], const unsigned T[31][32], int max_lds,
+    int static_lds[2])
 {
     hipError_t e;
     if ((e = hipMemcpyToSymbol(HIP_SYMBOL(dg_rng_T), T, sizeof(unsigned) * 31 * 32)) != hipSuccess) return e;

@@ -26,7 +26,8 @@ template <class T> struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
     int alloc(size_t n) { if (hipMalloc((void **)&p, (n ? n : 1) * sizeof(T)) == hipSuccess) return 0; (void)hipGetLastError(); return MI_DEGENSAC_ENOMEM; }
 };
-#define DG_UNIT_ENTER(device) DevGuard g_; { int rc_ = (mi_degensac_device_count() == 0) ? (set_err("no HIP device: this library has no CPU path"), MI_DEGENSAC_ENODEV) : g_.enter(device); if (rc_) return rc_; rc_ = dev_init(device); if (rc_) return rc_; }
+#define DG_UNIT_ENTER(device) DevGuard g_; { int rc_ = (mi_degensac_device_count() == 0) ? (set_err("no HIP device: this library has no CPU path"), \
+    MI_DEGENSAC_ENODEV) : g_.enter(device); if (rc_) return rc_; rc_ = dev_init(device); if (rc_) return rc_; }
 
 /* ---- unit-level kernels --------------------------------------------------------------------------- */
 __global__ void dg_score_models_kernel(const double *p1, const double *p2, int n, int dim, const double *models, int n_models,
@@ -70,7 +71,8 @@ extern "C" int mi_degensac_score_models(const double *pts1, const double *pts2, 
     HIPCHK(hipMemcpy(d1.p, pts1, (size_t)n * dim * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d2.p, pts2, (size_t)n * dim * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dm.p, models, (size_t)n_models * 72, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(dg_score_models_kernel, dim3((n_models + 3) / 4), dim3(256), 0, 0, d1.p, d2.p, n, dim, dm.p, n_models, kind, th, dI.p, dJ.p, resid ? dr.p : nullptr);
+    hipLaunchKernelGGL(dg_score_models_kernel, dim3((n_models + 3) / 4), dim3(256), 0, 0, d1.p, d2.p, n, dim, dm.p, n_models, kind, th, dI.p, dJ.p,
+        resid ? dr.p : nullptr);
     HIPCHK(hipGetLastError()); HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(I, dI.p, (size_t)n_models * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(J, dJ.p, (size_t)n_models * 8, hipMemcpyDeviceToHost));
@@ -118,7 +120,8 @@ extern "C" int mi_degensac_screen_counts(const double *pts1, const double *pts2,
         return MI_DEGENSAC_ENOMEM; }
     HIPCHK(hipMemcpy(dp.p, hp.data(), (size_t)n * sizeof(dg_pt), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dm.p, models, (size_t)n_models * 72, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(dg_screen_counts_kernel, dim3((n_models + 63) / 64), dim3(64), 0, 0, dp.p, n, dm.p, n_models, kind, th, ext[0], ext[1], ext[2], ext[3], d1.p, d2.p);
+    hipLaunchKernelGGL(dg_screen_counts_kernel, dim3((n_models + 63) / 64), dim3(64), 0, 0, dp.p, n, dm.p, n_models, kind, th, ext[0], ext[1], ext[2], ext[3],
+        d1.p, d2.p);
     HIPCHK(hipGetLastError()); HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(c1, d1.p, (size_t)n_models * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(c2, d2.p, (size_t)n_models * 4, hipMemcpyDeviceToHost));
@@ -203,8 +206,10 @@ __global__ void dg_sample_stream_kernel(unsigned seed0, int n, int ssz, int iter
     unsigned seed = sd0;
     for (int base = 0; base < iters; base += DG_CHUNK) {
         int chunk = iters - base; if (chunk > DG_CHUNK) chunk = DG_CHUNK;
-        if (lds) seed = ssz == 7 ? dg_sample_chunk<7, 2>(seed, chunk, n, pool, seeds, draws, alm, pscr, lane) : dg_sample_chunk<4, 2>(seed, chunk, n, pool, seeds, draws, alm, pscr, lane);
-        else     seed = ssz == 7 ? dg_sample_chunk<7, 0>(seed, chunk, n, pool, seeds, draws, alm, 0, lane) : dg_sample_chunk<4, 0>(seed, chunk, n, pool, seeds, draws, alm, 0, lane);
+        if (lds) seed = ssz == 7 ? dg_sample_chunk<7, 2>(seed, chunk, n, pool, seeds, draws, alm, pscr, lane) : dg_sample_chunk<4, 2>(seed, chunk, n, pool,
+            seeds, draws, alm, pscr, lane);
+        else     seed = ssz == 7 ? dg_sample_chunk<7, 0>(seed, chunk, n, pool, seeds, draws, alm, 0, lane) : dg_sample_chunk<4, 0>(seed, chunk, n, pool, seeds,
+            draws, alm, 0, lane);
         __syncthreads();
         for (int k = lane; k < chunk; k += 64) for (int i = 0; i < ssz; i++) out[(size_t)(base + k) * ssz + i] = draws[k][i];
         __syncthreads();
@@ -270,7 +275,8 @@ extern "C" int mi_degensac_solve7(const double *pts1, const double *pts2, int n,
 {
     DG_UNIT_ENTER(device);
     DevBuf<double> d1, d2, dm; DevBuf<int> ds, dn, dr;
-    if (d1.alloc((size_t)n * dim) || d2.alloc((size_t)n * dim) || dm.alloc((size_t)n_samples * 27) || ds.alloc((size_t)n_samples * 7) || dn.alloc(n_samples) || dr.alloc((size_t)n_samples * 3))
+    if (d1.alloc((size_t)n * dim) || d2.alloc((size_t)n * dim) || dm.alloc((size_t)n_samples * 27) || ds.alloc((size_t)n_samples * 7) || dn.alloc(n_samples) ||
+        dr.alloc((size_t)n_samples * 3))
     { set_err("device allocation failed"); return MI_DEGENSAC_ENOMEM; }
     HIPCHK(hipMemcpy(d1.p, pts1, (size_t)n * dim * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d2.p, pts2, (size_t)n * dim * 8, hipMemcpyHostToDevice));

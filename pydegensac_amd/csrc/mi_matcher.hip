@@ -40,7 +40,8 @@ __device__ __forceinline__ void mt_push(mt_best &b, float d, int i)
  * (distance, index) order, so the result does not depend on the split count.  With one split the kernel writes the final
  * answer itself. */
 template <int NORM>
-__global__ __launch_bounds__(256) void mt_knn2_kernel(const uint32_t *q, int n1, const uint32_t *t, int n2, int words, int t_chunk /* train rows per split, multiple of 64 */,
+__global__ __launch_bounds__(256) void mt_knn2_kernel(const uint32_t *q, int n1, const uint32_t *t, int n2, int words,
+    int t_chunk /* train rows per split, multiple of 64 */,
                                                       int32_t *idx /* [n1,2] */, float *dist /* [n1,2] */, mt_best *part /* [splits][n1] or null */)
 {
     __shared__ uint32_t qs[MT_DC][MT_Q + 1], ts[MT_DC][MT_T + 1];
@@ -143,7 +144,8 @@ __global__ void mt_kpts_to_xyA_kernel(const float *kp, int n, double *out)
 
 static thread_local char mt_err[256] = "";
 extern "C" const char *mi_degensac_match_last_error(void) { return mt_err; }
-#define MTCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(mt_err, sizeof mt_err, "%s failed: %s", #x, hipGetErrorString(e_)); (void)hipGetLastError(); return MI_DEGENSAC_EHIP; } } while (0)
+#define MTCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(mt_err, sizeof mt_err, "%s failed: %s", #x, hipGetErrorString(e_)); \
+    (void)hipGetLastError(); return MI_DEGENSAC_EHIP; } } while (0)
 
 struct MtDevGuard {
     int prev = -1; bool armed = false;
@@ -184,11 +186,14 @@ extern "C" int mi_degensac_match_knn2_dev(int norm, const void *d_desc1, int n1,
     mt_best *part = nullptr;
     if (splits > 1) MTCHK(hipMallocAsync((void **)&part, (size_t)splits * n1 * sizeof(mt_best), (hipStream_t)stream));
     const dim3 grid(qtiles, splits), block(256);
-    if (norm == MI_DEGENSAC_NORM_L2) hipLaunchKernelGGL(mt_knn2_kernel<0>, grid, block, 0, (hipStream_t)stream, (const uint32_t *)d_desc1, n1, (const uint32_t *)d_desc2, n2, words, n2 > 0 ? t_chunk : MT_T, d_idx, d_dist, part);
-    else                             hipLaunchKernelGGL(mt_knn2_kernel<1>, grid, block, 0, (hipStream_t)stream, (const uint32_t *)d_desc1, n1, (const uint32_t *)d_desc2, n2, words, n2 > 0 ? t_chunk : MT_T, d_idx, d_dist, part);
+    if (norm == MI_DEGENSAC_NORM_L2) hipLaunchKernelGGL(mt_knn2_kernel<0>, grid, block, 0, (hipStream_t)stream, (const uint32_t *)d_desc1, n1,
+        (const uint32_t *)d_desc2, n2, words, n2 > 0 ? t_chunk : MT_T, d_idx, d_dist, part);
+    else                             hipLaunchKernelGGL(mt_knn2_kernel<1>, grid, block, 0, (hipStream_t)stream, (const uint32_t *)d_desc1, n1,
+        (const uint32_t *)d_desc2, n2, words, n2 > 0 ? t_chunk : MT_T, d_idx, d_dist, part);
     hipError_t le = hipGetLastError();
     if (le == hipSuccess && part) {
-        hipLaunchKernelGGL(mt_merge_kernel, dim3((n1 + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, splits, n1, norm == MI_DEGENSAC_NORM_L2 ? 1 : 0, d_idx, d_dist);
+        hipLaunchKernelGGL(mt_merge_kernel, dim3((n1 + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, splits, n1, norm == MI_DEGENSAC_NORM_L2 ? 1 : 0,
+            d_idx, d_dist);
         le = hipGetLastError();
     }
     if (part) (void)hipFreeAsync(part, (hipStream_t)stream);

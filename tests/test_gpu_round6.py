@@ -224,3 +224,21 @@ def test_homography_batches_between_one_and_two_pairs_per_cu_run_two_workgroups_
         Ho, mo, so = oracle_port.find_homography(A[p], B[p], 2.0, 0.999, 5000, 0, True, 3.0, seed=seeds[p])
         assert (st[p]["samples"], st[p]["lo_runs"], st[p]["I"]) == (so["samples"], so["lo_runs"], so["I"]), p
         assert np.array_equal(np.asarray(k[p]), mo), p
+
+
+def test_fundamental_batches_of_more_than_two_pairs_per_cu_take_the_256_thread_kernel(oracle_port):
+    """The variant crossover of the fundamental-matrix kernel: up to two pairs per CU the 512-thread kernel (with producers), past that the
+    256-thread kernel at two workgroups per CU; results do not depend on the choice."""
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    base = [syn.two_view_fundamental(200 + 9 * i, 0.5, 0.1, seed=700 + i)[:2] for i in range(8)]
+    for P, want in ((2 * cus, 512), (2 * cus + 8, 256)):
+        A = [base[i % 8][0] for i in range(P)]; B = [base[i % 8][1] for i in range(P)]; seeds = [21 + i for i in range(P)]
+        F, k = pd.findFundamentalMatrixBatch(A, B, 0.5, 0.999, 3000, seeds=seeds); st = pd.last_stats()
+        assert {s_["threads"] for s_ in st} == {want}, (P, {s_["threads"] for s_ in st})
+        F2, k2 = pd.findFundamentalMatrixBatch(A, B, 0.5, 0.999, 3000, seeds=seeds, tuning=_lib.TUNE_THROUGHPUT4); st2 = pd.last_stats()
+        assert np.array_equal(np.asarray(F), np.asarray(F2)) and all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(k, k2))
+        for p in (0, P - 1):
+            Fo, mo, so = oracle_port.find_fundamental(A[p], B[p], 0.5, 0.999, 3000, 0, True, 0.0, True, seed=seeds[p])
+            assert (st[p]["samples"], st[p]["lo_runs"], st[p]["I"]) == (so["samples"], so["lo_runs"], so["I"]), p
+            assert np.array_equal(np.asarray(k[p]), mo), p

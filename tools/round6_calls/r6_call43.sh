@@ -1,0 +1,5 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/c43; rm -rf $O; mkdir -p $O
+timeout 1800 python -m pytest tests -m gpu -x -q > $O/t_gpu.log 2>&1; echo "gpu rc $?" >> $O/t_gpu.log; tail -3 $O/t_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+python bench.py --steps 3 --warmup 1 > $O/bench.log 2>&1; tail -1 $O/bench.log | cut -c1-400
