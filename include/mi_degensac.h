@@ -377,7 +377,10 @@ int mi_degensac_solve7(const double *pts1, const double *pts2, int n, int dim,
  * op 4 = the real roots of a cubic as the 7-point solver takes them (Ftools.c:251-298; in 4 coefficients, out 3, flag =
  * the number of roots): the one routine of the path that calls the math library (pow / acos / cos).  The device takes their
  * correctly rounded values (dg_crmath.h), which the host's libm returns in all but ~0.1-0.2 % of its calls: the one place
- * where the device can differ from a host run of the reference in the last bits. */
+ * where the device can differ from a host run of the reference in the last bits.
+ * op 5 = op 3 with TWO problems per wave (dg_eig2.h: problem 2t in lanes 0..31 of wave t, 2t + 1 in lanes 32..63), same output.
+ * op 6 / 7 = timing of op 3 / op 5: every wave solves its problem(s) flag[0] times (on entry) and leaves the 100 MHz ticks that took
+ * in out[wave]. */
 int mi_degensac_mat3(int op, const double *in, int count, int device, double *out, int32_t *flag);
 /* the screening counts of the scoring phase (dg_score_tiles.h) for given fundamental-matrix models over a point set:
  * c1[m] = level-1 count (single precision, loosest denominator, rounding-widened threshold), c2[m] = level-2 count

@@ -736,4 +736,6 @@ DG_FN double dg_truncQuad(double epsilon, double thr)
     return 1 - (epsilon / (thr*9/4));
 }
 
+#include "dg_eig2.h"
+
 #endif /* DG_DEV_SMALL_H */

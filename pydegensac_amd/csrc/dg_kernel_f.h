@@ -346,6 +346,7 @@ __device__ __noinline__ int dg_checksample(CTX &c, const double *F /* LDS */, co
 {
     dg_f_shared *S = c.S; const int tid = c.tid, lane = tid & 63, wave = tid >> 6;
     __syncthreads();
+#if DG_NW >= 5
     for (int tr = wave; tr < 5; tr += DG_NW) {
         dg_wave_ws *w = &S->ww[wave];
         const unsigned char IDXS[5][3] = {{0,1,2}, {3,4,5}, {0,1,6}, {3,4,6}, {2,5,6}};
@@ -369,6 +370,38 @@ __device__ __noinline__ int dg_checksample(CTX &c, const double *F /* LDS */, co
         }
         DG_WSYNC();
     }
+#else
+    /* fewer waves than triplets: a wave takes two triplets at a time, one per half-wave (dg_fit_norm_w2: both eigen-solves in one pass), the
+     * second one's scratch in the workgroup's least-squares block, which is idle here.  Four waves: one round instead of two. */
+    static_assert(sizeof(dg_lsq_scratch) >= (size_t)DG_NW * DG_X2_DOUBLES * sizeof(double), "second-problem scratch");
+    for (int base = wave; base < 5; base += 2 * DG_NW) {
+        dg_wave_ws *w = &S->ww[wave];
+        double *x2 = (double *)&S->lsq + (size_t)wave * DG_X2_DOUBLES;
+        const bool uph = lane >= 32, two = base + DG_NW < 5, mine = (lane & 31) == 0 && (!uph || two);
+        const int tr = uph ? base + DG_NW : base;
+        double *Hh = uph ? x2 + DG_X2_USER : w->H, *Ds = uph ? x2 + DG_X2_USER + 9 : w->Ds, *sDs = uph ? x2 + DG_X2_USER + 16 : w->sDs;
+        int *idx = uph ? (int *)(x2 + DG_X2_USER + 23) : w->idx;
+        double *cpx = uph ? x2 + DG_X2_USER + 27 : w->cpx;
+        const unsigned char IDXS[5][3] = {{0,1,2}, {3,4,5}, {0,1,6}, {3,4,6}, {2,5,6}};
+        if (mine) {
+            dg_Hdetect(F, u7, IDXS[tr], Hh);
+            for (int j = 0; j < 7; j++) { Ds[j] = dg_HDs(Hh, u7[j][0], u7[j][1], u7[j][2], u7[j][3]); sDs[j] = Ds[j]; idx[j] = j; }
+            for (int a = 0; a < 7; ++a)                                  /* sortDs, DegUtils.c:164-183 */
+                for (int b = a + 1; b < 7; ++b)
+                    if (sDs[b] < sDs[a]) { double t = sDs[b]; sDs[b] = sDs[a]; sDs[a] = t; int ti = idx[b]; idx[b] = idx[a]; idx[a] = ti; }
+            for (int j = 0; j < 5; ++j) { const double *q = u7[idx[j]]; cpx[4*j] = q[0]; cpx[4*j+1] = q[1]; cpx[4*j+2] = q[2]; cpx[4*j+3] = q[3]; }
+        }
+        DG_WSYNC();
+        dg_fit_norm_w2<true>(w, x2, w->cpx, x2 + DG_X2_USER + 27, 5, w->H, two ? x2 + DG_X2_USER : (double *)0, lane);
+        if (mine) {
+            int inlCount = 0;
+            for (int j = 0; j < 7; ++j) if (dg_HDs(Hh, u7[j][0], u7[j][1], u7[j][2], u7[j][3]) < th) ++inlCount;
+            S->csRes[tr] = inlCount > 4;
+            for (int j = 0; j < 9; j++) S->csH[tr][j] = Hh[j];
+        }
+        DG_WSYNC();
+    }
+#endif
     __syncthreads();
     int win = -1;
     for (int i = 4; i >= 0; i--) if (S->csRes[i]) win = i;
@@ -878,6 +911,7 @@ __device__ __noinline__ void dg_innerFH(CTX &c, const int *idxH, unsigned lenH, 
         for (int i = 0; i < 4; i++) S->fhIds[rep][6+i] = idxO[pick[6+i]];
     }
     __syncthreads();
+#if DG_NW >= 8
     /* 10-point model + its consensus, one wave per repetition */
     for (unsigned rep = wave; rep < repCount; rep += DG_NW) {
         dg_wave_ws *w = &S->ww[wave];
@@ -892,6 +926,31 @@ __device__ __noinline__ void dg_innerFH(CTX &c, const int *idxH, unsigned lenH, 
         if (lane == 0) { S->fhCnt[rep] = (int)cnt; S->fhCnt2[rep] = -1; }
         DG_WSYNC();
     }
+#else
+    /* 10-point model + its consensus: a wave takes two repetitions at a time, one fit per half-wave (dg_fit_norm_w2), then their two
+     * counting passes.  Fifteen repetitions on four waves: two rounds of fits instead of four. */
+    static_assert(sizeof(dg_lsq_scratch) >= (size_t)DG_NW * DG_X2_DOUBLES * sizeof(double), "second-problem scratch");
+    for (unsigned base = wave; base < repCount; base += 2 * DG_NW) {
+        dg_wave_ws *w = &S->ww[wave];
+        double *x2 = (double *)&S->lsq + (size_t)wave * DG_X2_DOUBLES, *pxB = w->Z + 80;
+        const unsigned repB = base + DG_NW; const bool two = repB < repCount;
+        if (lane < 10) { dg_pt q = dg_ldpt<LDSPTS>(P, S->fhIds[base][lane]); w->px[4*lane] = q.x1; w->px[4*lane+1] = q.y1; w->px[4*lane+2] = q.x2;
+            w->px[4*lane+3] = q.y2; }
+        else if (two && lane >= 32 && lane < 42) { const int hl = lane - 32; dg_pt q = dg_ldpt<LDSPTS>(P, S->fhIds[repB][hl]); pxB[4*hl] = q.x1;
+            pxB[4*hl+1] = q.y1; pxB[4*hl+2] = q.x2; pxB[4*hl+3] = q.y2; }
+        DG_WSYNC();
+        dg_fit_norm_w2<false>(w, x2, w->px, pxB, 10, S->fhF[base], two ? S->fhF[repB] : (double *)0, lane);
+        for (int h = 0; h < (two ? 2 : 1); h++) {
+            const unsigned rep = h ? repB : base;
+            double Fr[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) Fr[i] = S->fhF[rep][i];
+            unsigned cnt = dg_wave_count_lt<LDSPTS>(P, n, Fr, th, lane);
+            if (lane == 0) { S->fhCnt[rep] = (int)cnt; S->fhCnt2[rep] = -1; }
+            DG_WSYNC();
+        }
+    }
+#endif
     c.n_aux += (int)repCount;
     __syncthreads();
     /* repetitions that set a new record of the pre-refinement count get u2Fit (DegUtils.c:562-566) */

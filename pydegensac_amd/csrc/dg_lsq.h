@@ -220,6 +220,81 @@ __device__ __forceinline__ void dg_u2h_norm_wave_noz(dg_wave_ws *s, const double
     DG_WSYNC();
 }
 
+/* ---- two small normalised fits side by side in one wave (dg_eig2.h) --------------------------------------------------------------
+ * Problem A in lanes 0..31 with the wave's own scratch (w->V, D, A1, A2, ews), problem B in lanes 32..63 with the block x2
+ * (DG_X2_* doubles: V, D, A1, A2, the eigen-solver's work vectors, then room for the caller's per-problem scalars).  The design matrix
+ * is not stored: the 45 normal-matrix entries (two passes of 32 lanes per problem) form its entries on the fly from the normalised
+ * coordinates (w->Z: A at 0, B at 40) — the products and sums of lin_fmN / lin_hgN + cov_mat in their order (Ftools.c:300-328, Htools.c:60-99,
+ * utools.c:170-184), i.e. the bits of dg_u2f_norm_w / dg_u2h_norm_w.  outB = null: one problem (the upper half repeats it in x2).
+ * len <= 10, no weights.  All 64 lanes. */
+#define DG_X2_V 0
+#define DG_X2_D 81
+#define DG_X2_A1 90
+#define DG_X2_A2 93
+#define DG_X2_EWS 96
+#define DG_X2_USER 141               /* first double a caller may use for its own second-problem data */
+#define DG_X2_DOUBLES 188            /* per wave (checksample: + H, Ds, sDs, idx, five gathered points) */
+static_assert(sizeof(dg_eig_ws) == (DG_X2_USER - DG_X2_EWS) * sizeof(double), "x2 layout");
+template <bool HOMOG>
+__device__ __noinline__ void dg_fit_norm_w2(dg_wave_ws *w, double *x2, const double *pA, const double *pB, int len, double *outA, double *outB, int lane_w)
+{
+    const bool uph = lane_w >= 32, two = outB != (double *)0;
+    const int hl = lane_w & 31;
+    const double *p = (uph && two) ? pB : pA;
+    double *V = uph ? x2 + DG_X2_V : w->V, *D = uph ? x2 + DG_X2_D : w->D, *A1s = uph ? x2 + DG_X2_A1 : w->A1, *A2s = uph ? x2 + DG_X2_A2 : w->A2;
+    double *nz = w->Z + (uph ? 40 : 0);
+    double A1[3], A2[3];
+    dg_normu_small(p, len, A1, A2);
+    if (hl < len) {
+        nz[4*hl] = p[4*hl] * A1[0] + A1[1]; nz[4*hl+1] = p[4*hl+1] * A1[0] + A1[2];
+        nz[4*hl+2] = p[4*hl+2] * A2[0] + A2[1]; nz[4*hl+3] = p[4*hl+3] * A2[0] + A2[2];
+    }
+    if (hl == 0) for (int i = 0; i < 3; i++) { A1s[i] = A1[i]; A2s[i] = A2[i]; }
+    DG_WSYNC();
+    for (int en = hl; en < 45; en += 32) {
+        int ie = 0; while ((ie+1)*(ie+2)/2 <= en) ie++;
+        const int je = en - ie*(ie+1)/2;
+        double val = 0;
+        if (HOMOG) {
+            /* entry c of DLT row r (0: the x row, 1: the y row) of a point: (b_j, 0, -a0 b_j) resp. (0, b_j, -a1 b_j), j = c / 3 */
+            auto zent = [](int r, int c, double a0, double a1, double b0, double b1) {
+                const int j = c / 3, m = c - 3 * j;
+                const double bj = j == 0 ? b0 : (j == 1 ? b1 : 1.0);
+                if (m == 2) return -(r == 0 ? a0 : a1) * bj;
+                return m == r ? bj : 0.0;
+            };
+            for (int k = 0; k < len; k++) {
+                const double a0 = nz[4*k], a1 = nz[4*k+1], b0 = nz[4*k+2], b1 = nz[4*k+3];
+                val += zent(0, ie, a0, a1, b0, b1) * zent(0, je, a0, a1, b0, b1);
+                val += zent(1, ie, a0, a1, b0, b1) * zent(1, je, a0, a1, b0, b1);
+            }
+        } else {
+            /* entry c = 3 k + l of a point's row: a[l] * b[k] with a = (a0, a1, 1), b = (b0, b1, 1) */
+            const int li = ie % 3, ki = ie / 3, lj = je % 3, kj = je / 3;
+            for (int k = 0; k < len; k++) {
+                const double a0 = nz[4*k], a1 = nz[4*k+1], b0 = nz[4*k+2], b1 = nz[4*k+3];
+                const double zi = (li == 0 ? a0 : (li == 1 ? a1 : 1.0)) * (ki == 0 ? b0 : (ki == 1 ? b1 : 1.0));
+                const double zj = (lj == 0 ? a0 : (lj == 1 ? a1 : 1.0)) * (kj == 0 ? b0 : (kj == 1 ? b1 : 1.0));
+                val += zi * zj;
+            }
+        }
+        V[9*ie+je] = val; V[ie+9*je] = val;
+    }
+    DG_WSYNC();
+    dg_eig_sym_wave2(w->V, w->D, &w->ews, x2 + DG_X2_V, x2 + DG_X2_D, (dg_eig_ws *)(x2 + DG_X2_EWS), lane_w);
+    if (hl == 0 && (!uph || two)) {
+        double *out = uph ? outB : outA;
+        if (HOMOG) { for (int i = 0; i < 9; i++) out[i] = V[i]; dg_denormH(out, A1s, A2s); }
+        else {
+            int j = 0; for (int i = 1; i < 9; i++) if (D[i] < D[j]) j = i;
+            for (int i = 0; i < 9; i++) out[i] = V[j*9 + i];
+            dg_singulF(out);
+            dg_denormF(out, A1s, A2s);
+        }
+    }
+    DG_WSYNC();
+}
+
 __device__ __noinline__ void dg_u2h_small_w(dg_lsq_scratch *s, const double *p, int len, double *H, int lane)
 {
     if (len < 4) return;

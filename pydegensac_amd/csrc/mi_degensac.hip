@@ -343,15 +343,51 @@ __global__ void dg_eig9_kernel(const double *in, int count, double *out, int *fl
     if (lane == 0) flag[t] = info;
 }
 
+/* op 5: two problems per wave (dg_eig2.h dg_eig_sym_wave2): block t solves problems 2t (lanes 0..31) and 2t + 1 (lanes 32..63; the last
+ * block of an odd count solves its one problem twice).  Output layout as op 3.
+ * op 6 / 7: timing of op 3 / op 5 — every block solves its problem(s) `reps` (= flag[0] on entry, via `count`'s high bits: see the host
+ * side) times from fresh copies and writes the ticks of the 100 MHz clock it took to out[t] */
+__global__ void dg_eig9x2_kernel(const double *in, int count, double *out, int *flag, int reps /* 0 = results, else timing */, int two)
+{
+    __shared__ double a[2][81], w[2][9]; __shared__ dg_eig_ws ews[2];
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int p0 = two ? 2 * t : t, p1 = two ? (2 * t + 1 < count ? 2 * t + 1 : 2 * t) : t;
+    if (p0 >= count) return;
+    int info = 0;
+    const long long t0 = wall_clock64();
+    for (int r = 0; r < (reps > 0 ? reps : 1); r++) {
+        for (int i = lane; i < 81; i += 64) { a[0][i] = in[(size_t)p0 * 81 + i]; a[1][i] = in[(size_t)p1 * 81 + i]; }
+        DG_WSYNC();
+        if (two) info = dg_eig_sym_wave2(a[0], w[0], &ews[0], a[1], w[1], &ews[1], lane);
+        else info = dg_eig_sym_wave(a[0], w[0], lane, &ews[0]);
+        DG_WSYNC();
+    }
+    const long long t1 = wall_clock64();
+    if (reps > 0) { if (lane == 0) out[t] = (double)(t1 - t0); return; }
+    for (int h = 0; h < (two ? 2 : 1); h++) {
+        const int p = h ? p1 : p0;
+        if (lane < 9) out[(size_t)p * 90 + lane] = w[h][lane];
+        for (int i = lane; i < 81; i += 64) out[(size_t)p * 90 + 9 + i] = a[h][i];
+    }
+    if (lane == 0) flag[p0] = info;
+    if (lane == 32 && two) flag[p1] = info;
+}
+
 extern "C" int mi_degensac_mat3(int op, const double *in, int count, int device, double *out, int32_t *flag)
 {
     DG_UNIT_ENTER(device);
-    if (op < 0 || op > 4 || count < 0) { set_err("bad op"); return MI_DEGENSAC_EINVAL; }
-    const size_t ni = op == 4 ? 4 : op == 3 ? 81 : op == 2 ? 40 : 9, no = op == 4 ? 3 : op == 3 ? 90 : op == 1 ? 12 : 9;
+    if (op < 0 || op > 7 || count < 0) { set_err("bad op"); return MI_DEGENSAC_EINVAL; }
+    const int reps = op >= 6 ? (flag[0] > 0 ? flag[0] : 1) : 0;            /* ops 6 / 7: repetitions per block, passed in flag[0] */
+    const size_t ni = op == 4 ? 4 : (op == 3 || op >= 5) ? 81 : op == 2 ? 40 : 9, no = op == 4 ? 3 : (op == 3 || op >= 5) ? 90 : op == 1 ? 12 : 9;
     DevBuf<double> di, dout; DevBuf<int> df;
     if (di.alloc(count * ni) || dout.alloc(count * no) || df.alloc(count)) { set_err("device allocation failed"); return MI_DEGENSAC_ENOMEM; }
     HIPCHK(hipMemcpy(di.p, in, count * ni * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(df.p, 0, (size_t)count * sizeof(int)));
     if (count && op == 3) hipLaunchKernelGGL(dg_eig9_kernel, dim3(count), dim3(64), 0, 0, di.p, count, dout.p, df.p);
+    else if (count && op >= 5) {
+        const int two = (op == 5 || op == 7) ? 1 : 0;
+        hipLaunchKernelGGL(dg_eig9x2_kernel, dim3(two ? (count + 1) / 2 : count), dim3(64), 0, 0, di.p, count, dout.p, df.p, reps, two);
+    }
     else if (count) hipLaunchKernelGGL(dg_mat3_kernel, dim3((count + 63) / 64), dim3(64), 0, 0, op, di.p, count, dout.p, df.p);
     HIPCHK(hipGetLastError()); HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, dout.p, count * no * 8, hipMemcpyDeviceToHost));

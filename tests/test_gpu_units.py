@@ -262,6 +262,40 @@ def test_wave_eigensolver_equals_oracle_dsyev():
     assert not bad, (len(bad), bad[:10], flag[bad[:10]])
 
 
+def test_two_eigenproblems_per_wave_equal_one_per_wave():
+    """mi_degensac_mat3 op 5 (dg_eig2.h: problem 2t in lanes 0..31 of wave t, problem 2t + 1 in lanes 32..63, dsteqr's decisions per half-wave)
+    against op 3 on the same matrices, bit for bit — every output number, the info word — in neighbouring and in random pairings (the two
+    halves then take different QL / QR paths and sweep counts), odd counts included."""
+    L = _lib.lib()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    rng = np.random.default_rng(35)
+    N = 1501; A = np.zeros((N, 9, 9))
+    for t in range(N):
+        k = t % 5
+        if k == 0:
+            m = rng.normal(size=(rng.integers(8, 60), 9)); a = m.T @ m
+        elif k == 1:
+            x1 = rng.normal(size=(10, 2)) * np.sqrt(2) / 2; x2 = x1 + rng.normal(size=(10, 2)) * 0.05
+            m = np.stack([np.r_[b[0] * np.r_[a_, 1.0], b[1] * np.r_[a_, 1.0], np.r_[a_, 1.0]] for a_, b in zip(x1, x2)]); a = m.T @ m
+        elif k == 2:
+            a = rng.normal(size=(9, 9)) * 10.0 ** rng.integers(-5, 6); a = a + a.T
+        elif k == 3:
+            m = rng.normal(size=(6, 9)); a = m.T @ m                       # rank 6
+        else:
+            a = np.diag(rng.normal(size=9)) + 1e-9 * rng.normal(size=(9, 9)); a = (a + a.T) / 2
+        A[t] = (a + a.T) / 2
+
+    def run(op, M):
+        out = np.zeros((len(M), 90)); flag = np.zeros(len(M), np.int32)
+        _lib.check(L.mi_degensac_mat3(op, dp(np.ascontiguousarray(M)), len(M), 0, dp(out), flag.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out, flag
+    for trial in range(3):
+        M = A if trial == 0 else A[rng.permutation(N)]
+        o1, f1 = run(3, M); o2, f2 = run(5, M)
+        assert np.array_equal(f1, f2), trial
+        assert np.array_equal(o1, o2, equal_nan=True), (trial, np.flatnonzero((o1 != o2).any(axis=1))[:10])
+
+
 def test_screening_counts_are_supersets_of_the_exact_band():
     """Level 1 (fp32, loosest denominator) and level 2 (fp64, own denominator) of the scoring phase's screens must never
     count fewer points than lie inside the 9/4 th band of the exact residuals, for random models, for models fitted to the
