@@ -154,6 +154,13 @@ static __device__ __forceinline__ double dg_rdl_d(double v, int l)
 }
 #define DG_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+/* The same for data that travels through LDS only: the fences name the local address space, so the compiler waits for the wave's LDS
+ * operations and leaves its global loads and stores in flight.  DG_WSYNC's fences cover every address space, i.e. s_waitcnt vmcnt(0): inside
+ * a loop that keeps the NEXT step's points (or terms) in flight that wait is a full L2 round trip per step (round 6: the passes of the
+ * local optimisations, the streamed least squares, the LDS-fed sums).  Use only where nothing written to global memory before the
+ * barrier is read behind it before a full DG_WSYNC. */
+#define DG_WSYNC_LDS() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); __builtin_amdgcn_wave_barrier(); \
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local"); } while (0)
 
 #ifdef DG_EIG_TIMING
 static __device__ long long dg_eig_ticks[4];

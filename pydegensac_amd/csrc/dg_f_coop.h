@@ -232,10 +232,11 @@ __device__ __noinline__ void dg_lo_rep_wg(dg_f_shared *S, const dg_pt *P, const 
         }
         if (la) for (int k = lane; k < (int)r.nL; k += 64) la[offA + k] = sA[lo + k];
         if (lb) for (int k = lane; k < (int)r.nL2; k += 64) lb[offB + k] = sB[lo + k];
-        if (wantJ && tid == T - 64) {
+        if (wantJ && tid >= T - 64) {       /* the last wave: the slices' terms one slice after the other, fed through LDS (the fits' design-matrix block) */
             double J = 0.0;
-            for (int w = 0; w < NWt; w++) { const int l_ = w * sl < n ? w * sl : n; J = dg_seq_sum_from<1>(jbuf + l_, (int)wc[4 * w + 3], J); }
-            S->red.bc[0] = J;
+            for (int w = 0; w < NWt; w++) { const int l_ = w * sl < n ? w * sl : n; J = dg_seq_sum_wave_g(jbuf + l_, (int)wc[4 * w + 3], J, S->lsq.Z, 192,
+                lane); }
+            if (lane == 0) S->red.bc[0] = J;
         }
         __syncthreads();
         if (wantJ) out.J = S->red.bc[0];
@@ -429,10 +430,10 @@ __device__ __noinline__ dg_pass_res dg_coop_pass(CTX &c, const double *Fm /* LDS
         }
         out.I += rc.I; out.nL += rc.nL; out.nL2 += rc.nL2; out.nJ += rc.nJ;
     }
-    if (cfg.wantJ && tid == DG_T - 64) {
+    if (cfg.wantJ && tid >= DG_T - 64) {    /* the last wave, the units' terms fed through LDS (dg_seq_sum_wave_g) */
         double J = 0.0;
-        for (int u = 0; u < n_units; u++) J = dg_seq_sum_from<1>(v.stg_j + (size_t)u * slice, (int)v.rec[u].nJ, J);
-        S->red.bc[0] = J;
+        for (int u = 0; u < n_units; u++) J = dg_seq_sum_wave_g(v.stg_j + (size_t)u * slice, (int)v.rec[u].nJ, J, S->lsq.Z, 192, tid & 63);
+        if ((tid & 63) == 0) S->red.bc[0] = J;
     }
     __syncthreads();
     if (cfg.wantJ) out.J = S->red.bc[0];

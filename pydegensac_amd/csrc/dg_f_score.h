@@ -3,6 +3,7 @@
  * Part of the fundamental-matrix kernel: included by dg_kernel_f_main.h, in this order, after dg_kernel_f.h and dg_score_tiles.h. */
 #ifndef DG_F_SCORE_H
 #define DG_F_SCORE_H
+#define DG_AS3L(T) __attribute__((address_space(3))) T
 
 /* ---------------------------------------------------------------------------------------------- */
 /* Scoring phase of one wave (own register allocation).  The chunk's models are dealt round-robin to the NS scoring
@@ -106,7 +107,14 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
             double Fe[9];
 #pragma unroll
             for (int j = 0; j < 9; j++) Fe[j] = dg_readlane_d(F[j], l);
-            unsigned cI = 0, cnt = 0;
+            /* J: the nonzero terms of a step go, in point order, through this wave's LDS table (the batch's screens are done with it) and are
+             * added before the next step, as in the local optimisation's passes (dg_wpass_impl) — they used to be written to the wave's
+             * global buffer and read back by lane 0 sixteen at a time, one L2 round trip per sixteen dependent adds.  A table too small for
+             * a whole step (the six scoring waves of the 512-thread kernel share the block) is flushed after every G tiles. */
+            unsigned cI = 0, sJ = 0;
+            double J = 0.0;
+            DG_AS3L(double) *tl = (DG_AS3L(double) *)(double *)tab;
+            const int G = __builtin_amdgcn_readfirstlane(tab_bytes / (64 * (int)sizeof(double)) < DG_PU ? tab_bytes / (64 * (int)sizeof(double)) : DG_PU);
             for (int base = 0; base < n; base += 64 * DG_PU) {
                 dg_pt qq[DG_PU]; double dd[DG_PU];
 #pragma unroll
@@ -120,13 +128,19 @@ __device__ __noinline__ void dg_score_chunk_F(const dg_pt *P, int n, const doubl
                     cI += (act && d <= th) ? 1u : 0u;
                     const bool nz = !(term == 0.0);
                     const unsigned long long bJ = __ballot(nz);
-                    if (nz) ((__attribute__((address_space(1))) double *)jbuf)[cnt + (unsigned)__popcll(bJ & lt_mask)] = term;
-                    cnt += (unsigned)__popcll(bJ);
+                    if (G > 0) { if (nz) tl[sJ + (unsigned)__popcll(bJ & lt_mask)] = term; }
+                    else if (nz) ((__attribute__((address_space(1))) double *)jbuf)[sJ + (unsigned)__popcll(bJ & lt_mask)] = term;
+                    sJ += (unsigned)__popcll(bJ);
+                    if (G > 0 && ((u + 1) % G == 0 || u == DG_PU - 1)) {
+                        DG_WSYNC_LDS();
+                        if (sJ) J = dg_seq_sum_impl<3>((const double *)tab, (int)sJ, J);
+                        sJ = 0;
+                        DG_WSYNC_LDS();
+                    }
                 }
             }
             DG_WSYNC();
-            double J = 0.0; if (lane == 0) J = dg_seq_sum(jbuf, (int)cnt);
-            J = __shfl(J, 0, 64);
+            if (G == 0) { if (lane == 0) J = dg_seq_sum(jbuf, (int)sJ); J = __shfl(J, 0, 64); }
             const unsigned I = dg_wave_sum_u(cI);
             DG_WSYNC();
             if (lane == 0) { res_I[mie] = I; res_J[mie] = J; }

@@ -556,10 +556,10 @@ __device__ __forceinline__ dg_pass_res dg_wpass_impl(const dg_pt *P, int n, Err 
 #pragma unroll
             for (int u = 0; u < DG_PU; u++) { const int j = base + DG_PU * 64 + u * 64 + lane; if (j < n) qn[u] = dg_ldpt<LDSPTS>(P, j); }
         }
-        DG_WSYNC();
-        if (sJ) J = dg_seq_sum_from<3>((const double *)tile_, (int)sJ, J);
+        DG_WSYNC_LDS();                  /* (the terms are in LDS; the id lists, global, are read after the pass) */
+        if (sJ) J = dg_seq_sum_impl<3>((const double *)tile_, (int)sJ, J);
         nJ += sJ;
-        DG_WSYNC();
+        DG_WSYNC_LDS();
     }
     out.I = dg_wave_sum_u(cI); out.J = J; out.nL = nA; out.nL2 = nB; out.nJ = nJ;
     DG_WSYNC();
@@ -836,8 +836,11 @@ __device__ __noinline__ unsigned dg_u2Fit_wave(dg_wave_ws *w, const dg_pt *P, in
             for (int j = lane; j < (int)cnt; j += 64) stage[j] = dg_ldpt<LDSPTS>(P, list[j]);
             DG_WSYNC();
             /* the normal matrix from shared design-matrix entries, twelve points per fill of this wave's Z (idle in the long form) */
-            if (stage_cap >= 2 * (int)cnt) dg_lsq_seq_par(w, stage, (int)cnt, lane, 64, 0, w->A1, w->A2, [] { DG_WSYNC(); }, w->Z, 12);
-            else dg_lsq_seq_core(w, stage, (int)cnt, lane, 0, w->A1, w->A2);
+            /* (with an LDS table the fit needs no scratch behind the staged points: any list length) */
+            /* the table: Z and V of this wave's scratch, 200 doubles (V is written when the sums are done) */
+            static_assert(offsetof(dg_wave_ws, V) == offsetof(dg_wave_ws, Z) + sizeof(((dg_wave_ws *)0)->Z) && sizeof(((dg_wave_ws *)0)->Z) +
+                          sizeof(((dg_wave_ws *)0)->V) >= 200 * sizeof(double), "table of the long-list fit");
+            dg_lsq_seq_par(w, stage, (int)cnt, lane, 64, 0, w->A1, w->A2, [] { DG_WSYNC(); }, w->Z, 20);
             DG_WSYNC();
             dg_eig_sym_wave(w->V, w->D, lane, &w->ews);
             if (lane == 0) {

@@ -344,12 +344,13 @@ __device__ __forceinline__ void dg_lsq_wave_stream(const dg_pt *P, const int *li
                 if (cnt <= 0) break;
                 t[lane] = q[2*f].x1; t[128 + lane] = q[2*f].y1; t[256 + lane] = q[2*f].x2; t[384 + lane] = q[2*f].y2;
                 t[64 + lane] = q[2*f+1].x1; t[192 + lane] = q[2*f+1].y1; t[320 + lane] = q[2*f+1].x2; t[448 + lane] = q[2*f+1].y2;
-                DG_WSYNC();
-                if (lane < 4) acc = dg_seq_sum_from<3>(lt_ + 128 * lane, cnt, acc);
-                DG_WSYNC();
+                DG_WSYNC_LDS();
+                if (lane < 4) acc = dg_seq_sum_impl<3>(lt_ + 128 * lane, cnt, acc);
+                DG_WSYNC_LDS();
             }
         }
     }
+    DG_WSYNC();                      /* `stage` (global) is complete: the two sweeps below read it */
     if (len > 0) acc /= len;
     const double m1x = dg_readlane_d(acc, 0), m1y = dg_readlane_d(acc, 1), m2x = dg_readlane_d(acc, 2), m2y = dg_readlane_d(acc, 3);
     double dsum = 0;
@@ -368,9 +369,9 @@ __device__ __forceinline__ void dg_lsq_wave_stream(const dg_pt *P, const int *li
                 double a = q[u].x1 - m1x, b = q[u].y1 - m1y; t[64 * u + lane] = sqrt(a*a + b*b);
                 a = q[u].x2 - m2x; b = q[u].y2 - m2y; t[256 + 64 * u + lane] = sqrt(a*a + b*b);
             }
-            DG_WSYNC();
-            if (lane < 2) dsum = dg_seq_sum_from<3>(lt_ + 256 * lane, cnt, dsum);
-            DG_WSYNC();
+            DG_WSYNC_LDS();
+            if (lane < 2) dsum = dg_seq_sum_impl<3>(lt_ + 256 * lane, cnt, dsum);
+            DG_WSYNC_LDS();
         }
     }
     double A1[3], A2[3];
@@ -418,7 +419,7 @@ __device__ __forceinline__ void dg_lsq_wave_stream(const dg_pt *P, const int *li
                     }
                     w[9] = 0.0;
                 }
-                DG_WSYNC();
+                DG_WSYNC_LDS();
                 if (lane < 45) {
                     int p = 0;
                     if (!ROWS2) {
@@ -442,7 +443,7 @@ __device__ __forceinline__ void dg_lsq_wave_stream(const dg_pt *P, const int *li
                         for (; p < cnt; p++) { const DG_AS3(double) *w = t + 10 * p; val += w[x0] * w[y0]; val += w[x1] * w[y1]; }
                     }
                 }
-                DG_WSYNC();
+                DG_WSYNC_LDS();
             }
         }
     }
@@ -522,10 +523,10 @@ __device__ __noinline__ dg_pass_res dg_hm_wpass(const dg_pt *P, int n, int kind,
 #pragma unroll
             for (int u = 0; u < DG_PU; u++) { const int j = base + DG_PU * 64 + u * 64 + lane; if (j < n) qn[u] = dg_ldpt<LDSPTS>(P, j); }
         }
-        DG_WSYNC();
-        J = dg_seq_sum_from<3>((const double *)lt_, (int)sJ, J);
+        DG_WSYNC_LDS();                  /* (the terms are in LDS; the id lists, global, are read after the pass) */
+        J = dg_seq_sum_impl<3>((const double *)lt_, (int)sJ, J);
         nJ += sJ;
-        DG_WSYNC();
+        DG_WSYNC_LDS();
     }
     out.I = dg_wave_sum_u(cI);
     out.J = J;

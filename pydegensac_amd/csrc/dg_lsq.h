@@ -395,11 +395,148 @@ __device__ __forceinline__ void dg_lsq_seq_core(SC *s, const dg_pt *stage, int l
  * Needs 32 B of scratch per point behind the staged points: stage must hold 2 * len entries.
  * `sync` separates the phases (__syncthreads for a workgroup, a wave barrier for one wave); tid < 64 is the wave that
  * runs the serial parts. */
+/* dg_lsq_seq_par by ONE wave with every sequential sum fed from LDS (ltab: 10 * ltab_pts doubles).
+ * The staged points are read from global memory once per phase, 64 at a time with the next block's load in flight; a phase's terms —
+ * the four coordinates (centroids), the two centroid distances, the design-matrix entries — go through the LDS table in sub-blocks and are
+ * added from there, in list order, by the lanes that own the sums.  (Round 6: the sums used to read their terms back from global memory
+ * sixteen at a time, two batches in flight — one L2 round trip per sixteen dependent adds: 63 of the 140 us of a u2Fit iteration.)
+ * Same terms, same adds, same order as dg_lsq_seq_core / the reference (utools.c:7-51, :170-184); `stage` is left as it was. */
+template <class SC>
+__device__ __forceinline__ void dg_lsq_seq_wave(SC *s, const dg_pt *stage, int len, int lane, int rows2, double *A1o, double *A2o, double *ltab,
+                                                const int ltab_pts)
+{
+    const int tabd = 10 * ltab_pts;
+    /* sub-block sizes: multiples of eight (the sums take their terms eight at a time), at most one load block */
+    const int BA = ((tabd / 4) & ~7) < 64 ? ((tabd / 4) & ~7) : 64, BB = ((tabd / 2) & ~7) < 64 ? ((tabd / 2) & ~7) : 64;
+    const int fpts = ltab_pts >= 8 ? (ltab_pts & ~7) : ltab_pts;
+    /* ---- centroids: lane l in 0..3 sums coordinate l */
+    double acc = 0;
+    {
+        dg_pt qn = stage[lane < len ? lane : 0];
+        for (int blk = 0; blk < len; blk += 64) {
+            const dg_pt q = qn;
+            if (blk + 64 < len) qn = stage[blk + 64 + lane < len ? blk + 64 + lane : blk];
+            const int bc = len - blk < 64 ? len - blk : 64;
+            for (int f0 = 0; f0 < bc; f0 += BA) {
+                const int cnt = bc - f0 < BA ? bc - f0 : BA;
+                if (lane >= f0 && lane < f0 + cnt) { const int r = lane - f0; ltab[r] = q.x1; ltab[BA + r] = q.y1; ltab[2*BA + r] = q.x2;
+                    ltab[3*BA + r] = q.y2; }
+                DG_WSYNC_LDS();
+                if (lane < 4) acc = dg_seq_sum_impl<3>(ltab + BA * lane, cnt, acc);
+                DG_WSYNC_LDS();
+            }
+        }
+    }
+    if (len > 0) acc /= len;
+    if (lane < 4) s->D[lane] = acc;
+    DG_WSYNC_LDS();
+    const double m1x = s->D[0], m1y = s->D[1], m2x = s->D[2], m2y = s->D[3];
+    /* ---- mean distances to the centroids: lane 0 image 1, lane 1 image 2 */
+    double dsum = 0;
+    {
+        dg_pt qn = stage[lane < len ? lane : 0];
+        for (int blk = 0; blk < len; blk += 64) {
+            const dg_pt q = qn;
+            if (blk + 64 < len) qn = stage[blk + 64 + lane < len ? blk + 64 + lane : blk];
+            double a = q.x1 - m1x, b = q.y1 - m1y; const double d1 = sqrt(a*a + b*b);
+            a = q.x2 - m2x; b = q.y2 - m2y; const double d2 = sqrt(a*a + b*b);
+            const int bc = len - blk < 64 ? len - blk : 64;
+            for (int f0 = 0; f0 < bc; f0 += BB) {
+                const int cnt = bc - f0 < BB ? bc - f0 : BB;
+                if (lane >= f0 && lane < f0 + cnt) { const int r = lane - f0; ltab[r] = d1; ltab[BB + r] = d2; }
+                DG_WSYNC_LDS();
+                if (lane < 2) dsum = dg_seq_sum_impl<3>(ltab + BB * lane, cnt, dsum);
+                DG_WSYNC_LDS();
+            }
+        }
+    }
+    double A1[3], A2[3];
+    A1[0] = __shfl(dsum, 0, 64); A2[0] = __shfl(dsum, 1, 64);
+    if (A1[0] != 0) A1[0] = len * sqrt(2.0) / A1[0];
+    if (A2[0] != 0) A2[0] = len * sqrt(2.0) / A2[0];
+    A1[1] = m1x * -A1[0]; A1[2] = m1y * -A1[0];
+    A2[1] = m2x * -A2[0]; A2[2] = m2y * -A2[0];
+    if (lane == 0) { for (int i = 0; i < 3; i++) { A1o[i] = A1[i]; A2o[i] = A2[i]; } }
+    DG_WSYNC_LDS();
+    /* ---- normal matrix with the per-point work shared: every lane forms the nine (F: z[3k+l] = a_l b_k, lin_fmN) or ten (H: b_q, -a0 b_q,
+     * -a1 b_q and a structural zero, lin_hgN) design-matrix entries of its own point, normalised on the fly, in registers; a fill is
+     * ltab_pts consecutive lanes writing theirs to the table, from which every accumulating lane reads its two (F) or four (H) factors per
+     * point: same factors, same multiplies, same adds in list order. */
+    {
+        const double s1 = A1[0], t1x = A1[1], t1y = A1[2], s2 = A2[0], t2x = A2[1], t2y = A2[2];
+        int ie = 0, je = 0;
+        { int e = 0; for (int i = 0; i < 9; i++) for (int q = 0; q <= i; q++) { if (e == lane) { ie = i; je = q; } e++; } }
+        const int ki = ie / 3, li = ie % 3, kj = je / 3, lj = je % 3;
+        const int x0 = !rows2 ? ie : (li == 0 ? ki : li == 1 ? 9 : 3 + ki), y0 = !rows2 ? je : (lj == 0 ? kj : lj == 1 ? 9 : 3 + kj);
+        const int x1 = li == 0 ? 9 : li == 1 ? ki : 6 + ki, y1 = lj == 0 ? 9 : lj == 1 ? kj : 6 + kj;
+        double val = 0;
+        dg_pt qn = stage[lane < len ? lane : 0];
+        for (int blk = 0; blk < len; blk += 64) {
+            const dg_pt p = qn; dg_pt q;
+            if (blk + 64 < len) qn = stage[blk + 64 + lane < len ? blk + 64 + lane : blk];
+            q.x1 = p.x1 * s1 + t1x; q.y1 = p.y1 * s1 + t1y; q.x2 = p.x2 * s2 + t2x; q.y2 = p.y2 * s2 + t2y;
+            double z[9];
+            if (!rows2) {
+                const double a[3] = {q.x1, q.y1, 1.0}, b[3] = {q.x2, q.y2, 1.0};
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+#pragma unroll
+                    for (int l = 0; l < 3; l++) z[3*k + l] = a[l] * b[k];
+            } else {
+                const double b[3] = {q.x2, q.y2, 1.0};
+#pragma unroll
+                for (int k = 0; k < 3; k++) { z[k] = b[k]; z[3 + k] = -q.x1 * b[k]; z[6 + k] = -q.y1 * b[k]; }
+            }
+            const int bc = len - blk < 64 ? len - blk : 64;
+            for (int f0 = 0; f0 < bc; f0 += fpts) {
+                const int cnt = bc - f0 < fpts ? bc - f0 : fpts;
+                if (lane >= f0 && lane < f0 + cnt) {
+                    double *t = ltab + 10 * (lane - f0);
+#pragma unroll
+                    for (int k = 0; k < 9; k++) t[k] = z[k];
+                    t[9] = 0.0;
+                }
+                DG_WSYNC_LDS();
+                if (lane < 45) {
+                    int p = 0;
+                    if (!rows2) {
+                        for (; p + 8 <= cnt; p += 8) {
+                            const double *t = ltab + 10 * p;
+                            const double u0 = t[x0], v0 = t[y0], u1 = t[10 + x0], v1 = t[10 + y0], u2 = t[20 + x0], v2 = t[20 + y0], u3 = t[30 + x0],
+                                v3 = t[30 + y0];
+                            const double u4 = t[40 + x0], v4 = t[40 + y0], u5 = t[50 + x0], v5 = t[50 + y0], u6 = t[60 + x0], v6 = t[60 + y0], u7 = t[70 + x0],
+                                v7 = t[70 + y0];
+                            val += u0 * v0; val += u1 * v1; val += u2 * v2; val += u3 * v3; val += u4 * v4; val += u5 * v5; val += u6 * v6; val += u7 * v7;
+                        }
+                        for (; p < cnt; p++) { const double *t = ltab + 10 * p; val += t[x0] * t[y0]; }
+                    } else {
+                        for (; p + 4 <= cnt; p += 4) {
+                            const double *t = ltab + 10 * p;
+                            const double u0 = t[x0], v0 = t[y0], p0 = t[x1], q0 = t[y1], u1 = t[10 + x0], v1 = t[10 + y0], p1 = t[10 + x1], q1 = t[10 + y1];
+                            const double u2 = t[20 + x0], v2 = t[20 + y0], p2 = t[20 + x1], q2 = t[20 + y1], u3 = t[30 + x0], v3 = t[30 + y0], p3 = t[30 + x1],
+                                q3 = t[30 + y1];
+                            val += u0 * v0; val += p0 * q0; val += u1 * v1; val += p1 * q1; val += u2 * v2; val += p2 * q2; val += u3 * v3; val += p3 * q3;
+                        }
+                        for (; p < cnt; p++) { const double *t = ltab + 10 * p; val += t[x0] * t[y0]; val += t[x1] * t[y1]; }
+                    }
+                }
+                DG_WSYNC_LDS();
+            }
+        }
+        if (lane < 45) { s->V[9*ie + je] = val; s->V[ie + 9*je] = val; }
+    }
+}
+
 template <class SC, class Sync>
 __device__ __forceinline__ void dg_lsq_seq_par(SC *s, dg_pt *stage, int len, int tid, int nthr, int rows2, double *A1o, double *A2o, Sync sync,
                                                double *ltab = (double *)0 /* optional LDS scratch, 10 doubles per point of a fill, used by wave 0 only */,
                                                const int ltab_pts = 64 /* points per fill of ltab (<= 64) */)
 {
+    if (ltab) {          /* an LDS table: the whole fit by the first wave, every sum fed from LDS (dg_lsq_seq_wave) */
+        if (tid < 64) dg_lsq_seq_wave(s, stage, len, tid & 63, rows2, A1o, A2o, ltab, ltab_pts);
+        sync();
+        return;
+    }
     /* [4][len] coordinates, then [2][len] centroid distances; stored and loaded as global memory (not flat) */
     __attribute__((address_space(1))) double *aux = (__attribute__((address_space(1))) double *)(double *)(stage + len);
     const int lane = tid & 63; const bool w0 = tid < 64;
@@ -443,64 +580,6 @@ __device__ __forceinline__ void dg_lsq_seq_par(SC *s, dg_pt *stage, int len, int
         }
     }
     sync();
-    if (w0 && ltab) {
-        /* Normal matrix with the per-point work shared: the wave first forms, 64 points at a time and one point per lane,
-         * the nine (F: z[3k+l] = a_l b_k, lin_fmN) or ten (H: b_q, -a0 b_q, -a1 b_q and a structural zero, lin_hgN)
-         * design-matrix entries of each point in LDS — the same products the lanes used to form for themselves behind
-         * run-time selects — and then every accumulating lane reads its two (F) or four (H) factors per point from there:
-         * same factors, same multiplies, same adds in list order. */
-        int ie = 0, je = 0;
-        { int e = 0; for (int i = 0; i < 9; i++) for (int q = 0; q <= i; q++) { if (e == lane) { ie = i; je = q; } e++; } }
-        const int ki = ie / 3, li = ie % 3, kj = je / 3, lj = je % 3;
-        const int x0 = !rows2 ? ie : (li == 0 ? ki : li == 1 ? 9 : 3 + ki), y0 = !rows2 ? je : (lj == 0 ? kj : lj == 1 ? 9 : 3 + kj);
-        const int x1 = li == 0 ? 9 : li == 1 ? ki : 6 + ki, y1 = lj == 0 ? 9 : lj == 1 ? kj : 6 + kj;
-        double val = 0;
-        for (int base = 0; base < len; base += ltab_pts) {
-            const int cnt = len - base < ltab_pts ? len - base : ltab_pts;
-            if (lane < cnt) {
-                const dg_pt q = stage[base + lane]; double *t = ltab + 10 * lane;
-                if (!rows2) {
-                    const double a[3] = {q.x1, q.y1, 1.0}, b[3] = {q.x2, q.y2, 1.0};
-#pragma unroll
-                    for (int k = 0; k < 3; k++)
-#pragma unroll
-                        for (int l = 0; l < 3; l++) t[3*k + l] = a[l] * b[k];
-                } else {
-                    const double b[3] = {q.x2, q.y2, 1.0};
-#pragma unroll
-                    for (int k = 0; k < 3; k++) { t[k] = b[k]; t[3 + k] = -q.x1 * b[k]; t[6 + k] = -q.y1 * b[k]; }
-                }
-                t[9] = 0.0;
-            }
-            DG_WSYNC();
-            if (lane < 45) {
-                int p = 0;
-                if (!rows2) {
-                    for (; p + 8 <= cnt; p += 8) {
-                        const double *t = ltab + 10 * p;
-                        const double u0 = t[x0], v0 = t[y0], u1 = t[10 + x0], v1 = t[10 + y0], u2 = t[20 + x0], v2 = t[20 + y0], u3 = t[30 + x0],
-                            v3 = t[30 + y0];
-                        const double u4 = t[40 + x0], v4 = t[40 + y0], u5 = t[50 + x0], v5 = t[50 + y0], u6 = t[60 + x0], v6 = t[60 + y0], u7 = t[70 + x0],
-                            v7 = t[70 + y0];
-                        val += u0 * v0; val += u1 * v1; val += u2 * v2; val += u3 * v3; val += u4 * v4; val += u5 * v5; val += u6 * v6; val += u7 * v7;
-                    }
-                    for (; p < cnt; p++) { const double *t = ltab + 10 * p; val += t[x0] * t[y0]; }
-                } else {
-                    for (; p + 4 <= cnt; p += 4) {
-                        const double *t = ltab + 10 * p;
-                        const double u0 = t[x0], v0 = t[y0], p0 = t[x1], q0 = t[y1], u1 = t[10 + x0], v1 = t[10 + y0], p1 = t[10 + x1], q1 = t[10 + y1];
-                        const double u2 = t[20 + x0], v2 = t[20 + y0], p2 = t[20 + x1], q2 = t[20 + y1], u3 = t[30 + x0], v3 = t[30 + y0], p3 = t[30 + x1],
-                            q3 = t[30 + y1];
-                        val += u0 * v0; val += p0 * q0; val += u1 * v1; val += p1 * q1; val += u2 * v2; val += p2 * q2; val += u3 * v3; val += p3 * q3;
-                    }
-                    for (; p < cnt; p++) { const double *t = ltab + 10 * p; val += t[x0] * t[y0]; val += t[x1] * t[y1]; }
-                }
-            }
-            DG_WSYNC();
-        }
-        if (lane < 45) { s->V[9*ie + je] = val; s->V[ie + 9*je] = val; }
-        return;
-    }
     if (w0 && lane < 45) {                                        /* normal matrix: lane e owns entry (ie, je), je <= ie */
         int ie = 0, je = 0;
         { int e = 0; for (int i = 0; i < 9; i++) for (int q = 0; q <= i; q++) { if (e == lane) { ie = i; je = q; } e++; } }
@@ -542,7 +621,7 @@ __device__ __forceinline__ void dg_lsq_seq(dg_lsq_scratch *s, PtFn pt, const int
     __syncthreads();
     for (int j = tid; j < len; j += DG_T) stage[j] = pt(list[j]);
     __syncthreads();
-    if (stage_cap >= 2 * len) dg_lsq_seq_par(s, stage, len, tid, DG_T, rows2, A1o, A2o, [] { __syncthreads(); }, ltab);
+    if (ltab || stage_cap >= 2 * len) dg_lsq_seq_par(s, stage, len, tid, DG_T, rows2, A1o, A2o, [] { __syncthreads(); }, ltab);
     else if (tid < 64) dg_lsq_seq_core(s, stage, len, tid, rows2, A1o, A2o);
     __syncthreads();
 }

@@ -87,7 +87,7 @@ __device__ __forceinline__ double dg_wave_sum_d(double v) { return dg_tile_sum(v
  * global_load, not flat), so a batch's latency is covered by the previous batch's adds.  Own register allocation: the
  * callers are inlined into the drivers dozens of times. */
 template <int AS>
-__device__ __noinline__ double dg_seq_sum_from(const double *t_, int cnt, double J)
+__device__ __forceinline__ double dg_seq_sum_impl(const double *t_, int cnt, double J)
 {
     const __attribute__((address_space(AS))) double *t = (const __attribute__((address_space(AS))) double *)t_;
     int k = 0;
@@ -112,11 +112,52 @@ __device__ __noinline__ double dg_seq_sum_from(const double *t_, int cnt, double
         k += DG_SEQ_AHEAD;
     }
 #undef DG_SEQ_AHEAD
-    for (; k + 8 <= cnt; k += 8) {
-        const double v0 = t[k], v1 = t[k+1], v2 = t[k+2], v3 = t[k+3], v4 = t[k+4], v5 = t[k+5], v6 = t[k+6], v7 = t[k+7];
-        J += v0; J += v1; J += v2; J += v3; J += v4; J += v5; J += v6; J += v7;
+    /* the last (fewer than 32) terms: every load first — one latency for all of them; they used to be taken eight at a time and then one
+     * at a time, a memory round trip per batch and per term (a pass's step, a fit's fill end in such a tail) — then the adds, the last
+     * partial group of eight under a select */
+    const int r = cnt - k;
+#define DG_SEQ_TAIL(NT) do { double v[NT]; \
+        _Pragma("unroll") for (int i = 0; i < NT; i++) v[i] = t[k + (i < r ? i : r - 1)]; \
+        _Pragma("unroll") for (int c = 0; c < NT / 8; c++) { const int rc = r - 8 * c; \
+            if (rc >= 8) { J += v[8*c]; J += v[8*c+1]; J += v[8*c+2]; J += v[8*c+3]; J += v[8*c+4]; J += v[8*c+5]; J += v[8*c+6]; J += v[8*c+7]; } \
+            else if (rc > 0) { _Pragma("unroll") for (int i = 0; i < 7; i++) J = i < rc ? J + v[8*c+i] : J; } } } while (0)
+    if (r > 16) DG_SEQ_TAIL(32); else if (r > 8) DG_SEQ_TAIL(16); else if (r > 0) DG_SEQ_TAIL(8);
+#undef DG_SEQ_TAIL
+    return J;
+}
+/* the same as a function of its own (own register allocation: the callers are inlined into the drivers dozens of times).  A call is also a
+ * wait for EVERY outstanding memory operation of the wave (the callee's prologue is s_waitcnt 0): where the caller keeps the next step's
+ * points or terms in flight across the sum — the passes of the local optimisations, the streamed least squares — it inlines
+ * dg_seq_sum_impl instead (round 6). */
+template <int AS>
+__device__ __noinline__ double dg_seq_sum_from(const double *t_, int cnt, double J) { return dg_seq_sum_impl<AS>(t_, cnt, J); }
+/* The same sum over terms in GLOBAL memory by a whole wave: 64 terms per coalesced load (the next block's load in flight), through an LDS
+ * tile of `cap` doubles (a multiple of 64, at most 256), from which every lane adds them in order (dg_seq_sum_from<3>).  One L2 round
+ * trip per `cap` terms instead of one per sixteen.  All 64 lanes of one wave call it together; every lane returns the sum. */
+__device__ __noinline__ double dg_seq_sum_wave_g(const double *g_, int cnt, double J, double *tile_, int cap, int lane)
+{
+    const __attribute__((address_space(1))) double *g = (const __attribute__((address_space(1))) double *)g_;
+    __attribute__((address_space(3))) double *t = (__attribute__((address_space(3))) double *)tile_;
+    cnt = __builtin_amdgcn_readfirstlane(cnt); cap = __builtin_amdgcn_readfirstlane(cap);
+    if (cap > 256) cap = 256;
+    const int nb = cap / 64;                                   /* terms per lane and block */
+    double nx[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int k = 64 * i + lane; nx[i] = (i < nb && k < cnt) ? g[k] : 0.0; }
+    for (int k0 = 0; k0 < cnt; k0 += cap) {
+        const int m = cnt - k0 < cap ? cnt - k0 : cap;
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (i < nb) t[64 * i + lane] = nx[i];
+        if (k0 + cap < cnt) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const int k = k0 + cap + 64 * i + lane; nx[i] = (i < nb && k < cnt) ? g[k] : 0.0; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        J = dg_seq_sum_impl<3>((const double *)tile_, m, J);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     }
-    for (; k < cnt; k++) J += t[k];
     return J;
 }
 /* terms in global memory (HBM workspace) */

@@ -1,0 +1,16 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/c53; rm -rf $O; mkdir -p $O
+timeout 1800 python -m pytest tests -m gpu -x -q > $O/t_gpu.log 2>&1; echo "gpu rc $?" >> $O/t_gpu.log; tail -3 $O/t_gpu.log
+timeout 600 python tools/gpu_fuzz.py 800 971 > $O/fuzz.log 2>&1; tail -1 $O/fuzz.log
+timeout 900 python tools/gpu_fuzz.py large 40 972 > $O/fuzz_large.log 2>&1; tail -1 $O/fuzz_large.log
+timeout 300 python tools/gpu_phases.py 256 2>&1 | grep -v amdgpu | cut -c1-330 | head -5
+for i in 1 2; do
+  MI_DEGENSAC_LIB=tools/libmi_degensac_prev.so timeout 400 python tools/gpu_ab5.py 4096,512 prev=0:0 2>&1 | grep -v amdgpu | cut -c1-210 >> $O/ab.log
+  timeout 400 python tools/gpu_ab5.py 4096,512 cur=0:0 2>&1 | grep -v amdgpu | cut -c1-210 >> $O/ab.log
+done
+cat $O/ab.log
+python bench.py --config c5 --steps 2 --warmup 1 --no-secondary --parity-pairs 1 --no-cpu-baseline 2>/dev/null | cut -c1-300
+MI_DEGENSAC_LIB=tools/libmi_degensac_prev.so python bench.py --config c5 --steps 2 --warmup 1 --no-secondary --parity-pairs 1 --no-cpu-baseline 2>/dev/null | cut -c1-300
+timeout 600 python tools/gpu_fuzz_h.py 400 973 > $O/fuzz_h.log 2>&1; tail -1 $O/fuzz_h.log
+MI_DEGENSAC_LIB=tools/libmi_degensac_prev.so timeout 300 python tools/gpu_ab_h.py 0 2>&1 | grep "C3 x 1024 helpers 1\|one C3 pair per call, helpers 1"
+timeout 300 python tools/gpu_ab_h.py 0 2>&1 | grep "C3 x 1024 helpers 1\|one C3 pair per call, helpers 1"
