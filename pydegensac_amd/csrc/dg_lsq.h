@@ -405,6 +405,7 @@ template <class SC>
 __device__ __forceinline__ void dg_lsq_seq_wave(SC *s, const dg_pt *stage, int len, int lane, int rows2, double *A1o, double *A2o, double *ltab,
                                                 const int ltab_pts)
 {
+    len = __builtin_amdgcn_readfirstlane(len);
     const int tabd = 10 * ltab_pts;
     /* sub-block sizes: multiples of eight (the sums take their terms eight at a time), at most one load block */
     const int BA = ((tabd / 4) & ~7) < 64 ? ((tabd / 4) & ~7) : 64, BB = ((tabd / 2) & ~7) < 64 ? ((tabd / 2) & ~7) : 64;

@@ -90,6 +90,8 @@ template <int AS>
 __device__ __forceinline__ double dg_seq_sum_impl(const double *t_, int cnt, double J)
 {
     const __attribute__((address_space(AS))) double *t = (const __attribute__((address_space(AS))) double *)t_;
+    /* every active lane gets the same count (the callers' lanes differ in WHERE their terms are, not in how many): scalar loop control */
+    cnt = __builtin_amdgcn_readfirstlane(cnt);
     int k = 0;
     /* DG_SEQ_AHEAD terms per batch, two batches in flight: at most 32 loads outstanding, well inside the 6-bit vmcnt
      * (64 outstanding global loads returned wrong sums on gfx950: the counter saturates at 63) */
