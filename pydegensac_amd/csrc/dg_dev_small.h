@@ -152,15 +152,19 @@ static __device__ __forceinline__ double dg_rdl_d(double v, int l)
     int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
-#define DG_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+/* The fences are compiler-level only (at wavefront scope the back end emits no wait: it relies on a wave's accesses to one memory reaching
+ * it in issue order).  That order does NOT hold between the two paths to LDS — a FLAT store through a generic pointer and a ds_read of the
+ * same address: the ds_read can overtake the store (round 6: dg_u2f_small_w read the null vector its callee had just written through a
+ * generic pointer, right behind the return) — so the barrier waits for the wave's outstanding memory operations explicitly. */
+#define DG_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+                        __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 /* The same for data that travels through LDS only: the fences name the local address space, so the compiler waits for the wave's LDS
  * operations and leaves its global loads and stores in flight.  DG_WSYNC's fences cover every address space, i.e. s_waitcnt vmcnt(0): inside
  * a loop that keeps the NEXT step's points (or terms) in flight that wait is a full L2 round trip per step (round 6: the passes of the
  * local optimisations, the streamed least squares, the LDS-fed sums).  Use only where nothing written to global memory before the
  * barrier is read behind it before a full DG_WSYNC. */
-#define DG_WSYNC_LDS() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); __builtin_amdgcn_wave_barrier(); \
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local"); } while (0)
+#define DG_WSYNC_LDS() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+                            __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local"); } while (0)
 
 #ifdef DG_EIG_TIMING
 static __device__ long long dg_eig_ticks[4];

@@ -410,6 +410,9 @@ __device__ __forceinline__ void dg_lsq_seq_wave(SC *s, const dg_pt *stage, int l
     /* sub-block sizes: multiples of eight (the sums take their terms eight at a time), at most one load block */
     const int BA = ((tabd / 4) & ~7) < 64 ? ((tabd / 4) & ~7) : 64, BB = ((tabd / 2) & ~7) < 64 ? ((tabd / 2) & ~7) : 64;
     const int fpts = ltab_pts >= 8 ? (ltab_pts & ~7) : ltab_pts;
+    /* the terms of the first two sweeps are READ with ds_read (dg_seq_sum_impl<3>): they are written with ds_write too — a FLAT store through
+     * the generic pointer and a ds_read of the same address are not ordered against each other */
+    __attribute__((address_space(3))) double *lt3 = (__attribute__((address_space(3))) double *)ltab;
     /* ---- centroids: lane l in 0..3 sums coordinate l */
     double acc = 0;
     {
@@ -420,8 +423,8 @@ __device__ __forceinline__ void dg_lsq_seq_wave(SC *s, const dg_pt *stage, int l
             const int bc = len - blk < 64 ? len - blk : 64;
             for (int f0 = 0; f0 < bc; f0 += BA) {
                 const int cnt = bc - f0 < BA ? bc - f0 : BA;
-                if (lane >= f0 && lane < f0 + cnt) { const int r = lane - f0; ltab[r] = q.x1; ltab[BA + r] = q.y1; ltab[2*BA + r] = q.x2;
-                    ltab[3*BA + r] = q.y2; }
+                if (lane >= f0 && lane < f0 + cnt) { const int r = lane - f0; lt3[r] = q.x1; lt3[BA + r] = q.y1; lt3[2*BA + r] = q.x2;
+                    lt3[3*BA + r] = q.y2; }
                 DG_WSYNC_LDS();
                 if (lane < 4) acc = dg_seq_sum_impl<3>(ltab + BA * lane, cnt, acc);
                 DG_WSYNC_LDS();
@@ -444,7 +447,7 @@ __device__ __forceinline__ void dg_lsq_seq_wave(SC *s, const dg_pt *stage, int l
             const int bc = len - blk < 64 ? len - blk : 64;
             for (int f0 = 0; f0 < bc; f0 += BB) {
                 const int cnt = bc - f0 < BB ? bc - f0 : BB;
-                if (lane >= f0 && lane < f0 + cnt) { const int r = lane - f0; ltab[r] = d1; ltab[BB + r] = d2; }
+                if (lane >= f0 && lane < f0 + cnt) { const int r = lane - f0; lt3[r] = d1; lt3[BB + r] = d2; }
                 DG_WSYNC_LDS();
                 if (lane < 2) dsum = dg_seq_sum_impl<3>(ltab + BB * lane, cnt, dsum);
                 DG_WSYNC_LDS();

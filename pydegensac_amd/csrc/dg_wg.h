@@ -154,11 +154,9 @@ __device__ __noinline__ double dg_seq_sum_wave_g(const double *g_, int cnt, doub
 #pragma unroll
             for (int i = 0; i < 4; i++) { const int k = k0 + cap + 64 * i + lane; nx[i] = (i < nb && k < cnt) ? g[k] : 0.0; }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        DG_WSYNC_LDS();
         J = dg_seq_sum_impl<3>((const double *)tile_, m, J);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        DG_WSYNC_LDS();
     }
     return J;
 }

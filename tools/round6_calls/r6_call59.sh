@@ -1,0 +1,14 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/c59; rm -rf $O; mkdir -p $O
+timeout 1800 python -m pytest tests -m gpu -x -q > $O/t_gpu.log 2>&1; echo "gpu rc $?" >> $O/t_gpu.log; tail -3 $O/t_gpu.log
+timeout 600 python tools/gpu_fuzz.py 800 1001 > $O/fuzz.log 2>&1; tail -1 $O/fuzz.log
+timeout 600 python tools/gpu_fuzz_h.py 400 1002 > $O/fuzz_h.log 2>&1; tail -1 $O/fuzz_h.log
+timeout 600 python tools/gpu_fuzz.py large 30 1003 > $O/fuzz_large.log 2>&1; tail -1 $O/fuzz_large.log
+timeout 300 python tools/gpu_phases.py 256 2>&1 | grep -v amdgpu | cut -c1-330 | grep "^mean\|^pair 161"
+for i in 1 2; do
+  MI_DEGENSAC_LIB=tools/libmi_degensac_prev.so timeout 400 python tools/gpu_ab5.py 4096,512 prev=0:0 2>&1 | grep -v amdgpu | cut -c1-210 >> $O/ab.log
+  timeout 400 python tools/gpu_ab5.py 4096,512 cur=0:0 2>&1 | grep -v amdgpu | cut -c1-210 >> $O/ab.log
+done
+cat $O/ab.log
+MI_DEGENSAC_LIB=tools/libmi_degensac_prev.so timeout 300 python tools/gpu_ab_h.py 0 2>&1 | grep "C3 x 1024 helpers 1\|one C3 pair per call, helpers 1"
+timeout 300 python tools/gpu_ab_h.py 0 2>&1 | grep "C3 x 1024 helpers 1\|one C3 pair per call, helpers 1"
