@@ -324,16 +324,16 @@ __device__ __noinline__ void dg_sample_pool_grp(int cn, int n, int *vp_, int (*d
             const unsigned h1 = (unsigned)s % DG_PGT, h2 = ((unsigned)s * 40503u >> 7) % DG_PGT;
             if (active) { __hip_atomic_fetch_max(tab + h1, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_max(tab + DG_PGT + h2, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-            DG_WSYNC();
+            DG_WSYNC_LDS();          /* (the tables are LDS, accessed through LDS-qualified pointers only; the gather above stays in flight) */
             if (active) {
                 const unsigned e1 = tab[h1], e2 = tab[DG_PGT + h2];
                 if ((e1 >> 6) == (unsigned)s) coll = (e1 & 63u) != (unsigned)lane;
                 else if ((e2 >> 6) == (unsigned)s) coll = (e2 & 63u) != (unsigned)lane;
                 else coll = true;
             }
-            DG_WSYNC();
+            DG_WSYNC_LDS();
             if (active) { tab[h1] = 0u; tab[DG_PGT + h2] = 0u; }
-            DG_WSYNC();
+            DG_WSYNC_LDS();
         }
         if (al || __ballot(active && coll) != 0ull) {
             t = dg_sample_pool_seq_range<NDRAW>(k0, k0 + g, n, vp, draws, almask_in, t, lane);
