@@ -479,7 +479,10 @@ DG_FN double dg_det3(const double *A)                      /* utools.c:196-202 *
     return r;
 }
 
-DG_FN void dg_denormF(double *F, const double *A1, const double *A2)   /* utools.c:53-70 */
+/* (pointer types are template parameters: a caller that knows its buffers are LDS passes address-space-qualified pointers and gets ds_
+ * instructions instead of FLAT ones) */
+template <class PF, class PA>
+DG_FN void dg_denormF(PF F, PA A1, PA A2)   /* utools.c:53-70 */
 {
     double r, x, y;
     r = A2[0]; x = A2[1]; y = A2[2];
@@ -630,7 +633,8 @@ DG_FN int dg_rroots3(const double *po, double *r)         /* Ftools.c:251-298 */
  * (Hestenes) Jacobi on the columns of F, which is accurate also for the tiny singular values
  * (CCMATH svduv is not: absolute 1e-15 deflation threshold).  F = sum_k a_k v_k^T after rotation;
  * drop the term with the smallest |a_k|. */
-static __device__ __forceinline__ void dg_singulF(double *F)
+template <class PF>
+static __device__ __forceinline__ void dg_singulF(PF F)
 {
     /* fully unrolled: A, V live in registers (static indices only) */
     double A[9], V[9] = {1,0,0, 0,1,0, 0,0,1};

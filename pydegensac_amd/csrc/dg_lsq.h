@@ -30,7 +30,8 @@ struct dg_wave_ws {
 };
 
 /* utools.c:7-51 normu over k gathered points p[4*i + {0,1,2,3}] = x1,y1,x2,y2 */
-__device__ __forceinline__ void dg_normu_small(const double *p, int len, double *A1, double *A2)
+template <class PC>
+__device__ __forceinline__ void dg_normu_small(PC p, int len, double *A1, double *A2)
 {
     int i, j; double a, b;
     for (j = 0; j < 3; j++) { A1[j] = 0; A2[j] = 0; }
@@ -71,7 +72,8 @@ __device__ __forceinline__ void dg_u2h_4pt(dg_lsq_scratch *s, const double *p, d
 /* ---- wave-cooperative variants of the small solvers (all 64 lanes of wave 0 call these) ----------------
  * Same arithmetic as the reference's u2f / u2h (Ftools.c:350-458, Htools.c:101-133); the design-matrix rows, the 45 normal-matrix entries and
  * the eigen-solver's inner loops are spread over lanes.  p (gathered coordinates) is in LDS. */
-__device__ __forceinline__ void dg_cov9_wave(double *Cv, const double *Z, int rows, int lane)
+template <class PV, class PZ>
+__device__ __forceinline__ void dg_cov9_wave(PV Cv, PZ Z, int rows, int lane)
 {
     if (lane < 45) {
         int i = 0; while ((i+1)*(i+2)/2 <= lane) i++;
@@ -83,8 +85,8 @@ __device__ __forceinline__ void dg_cov9_wave(double *Cv, const double *Z, int ro
 }
 
 /* long form (> 8 points, normalised LSQ) for any scratch type with members Z, V, D, A1, A2, ews */
-template <class SC>
-__device__ __forceinline__ void dg_u2f_norm_w(SC *s, const double *p, const double *wts, int len, double *F, int lane)
+template <class SC, class PP, class PF>
+__device__ __forceinline__ void dg_u2f_norm_w(SC *s, PP p, const double *wts, int len, PF F, int lane)
 {
     double A1[3], A2[3];
     dg_normu_small(p, len, A1, A2);
@@ -97,14 +99,14 @@ __device__ __forceinline__ void dg_u2f_norm_w(SC *s, const double *p, const doub
     }
     if (lane == 0) for (int i = 0; i < 3; i++) { s->A1[i] = A1[i]; s->A2[i] = A2[i]; }
     DG_WSYNC();
-    dg_cov9_wave(s->V, s->Z, len, lane);
+    dg_cov9_wave(&s->V[0], &s->Z[0], len, lane);
     DG_WSYNC();
-    dg_eig_sym_wave(s->V, s->D, lane, &s->ews);
+    dg_eig_sym_wave((double *)&s->V[0], (double *)&s->D[0], lane, (dg_eig_ws *)&s->ews);
     if (lane == 0) {
         int j = 0; for (int i = 1; i < 9; i++) if (s->D[i] < s->D[j]) j = i;
         for (int i = 0; i < 9; i++) F[i] = s->V[j*9 + i];
         dg_singulF(F);
-        dg_denormF(F, s->A1, s->A2);
+        dg_denormF(F, &s->A1[0], &s->A2[0]);
     }
     DG_WSYNC();
 }
@@ -135,8 +137,15 @@ __device__ __noinline__ void dg_u2f_small_w(dg_lsq_scratch *s, const double *p, 
 }
 
 /* dg_u2f_small_w on a wave's own scratch (dg_wave_ws: Z doubles as the 9 x 8 system, V as the left factor's column) */
-__device__ __noinline__ void dg_u2f_small_wave(dg_wave_ws *s, const double *p, const double *wts /* LDS or 0 */, int len, double *F, int lane)
+__device__ __noinline__ void dg_u2f_small_wave(dg_wave_ws *s_, const double *p_, const double *wts /* LDS or 0 */, int len, double *F_, int lane)
 {
+    /* the wave's scratch, the gathered points and the model are LDS on every call: address-space-qualified views, so that every access of
+     * this function and of the helpers inlined into it is a ds_ instruction (through the generic parameters they were all FLAT: 62 stores and
+     * 54 loads).  The callees below take generic pointers again; they begin (prologue) and end (DG_WSYNC) with a wait for the wave's memory
+     * operations, so the two paths never meet an unordered pair of accesses. */
+    __attribute__((address_space(3))) dg_wave_ws *s = (__attribute__((address_space(3))) dg_wave_ws *)s_;
+    const __attribute__((address_space(3))) double *p = (const __attribute__((address_space(3))) double *)p_;
+    __attribute__((address_space(3))) double *F = (__attribute__((address_space(3))) double *)F_;
     if (len > 8) {
         dg_u2f_norm_w(s, p, wts, len, F, lane);
     } else {
@@ -152,7 +161,7 @@ __device__ __noinline__ void dg_u2f_small_wave(dg_wave_ws *s, const double *p, c
             s->Z[e] = z;
         }
         DG_WSYNC();
-        dg_svd_lastcol_9x8_wave(s->Z, s->V, lane);
+        dg_svd_lastcol_9x8_wave((double *)&s->Z[0], (double *)&s->V[0], lane);
         if (lane == 0) { for (int i = 0; i < 9; i++) F[i] = s->V[i]; dg_singulF(F); }
         DG_WSYNC();
     }
