@@ -419,9 +419,11 @@ __device__ __forceinline__ void dg_lsq_seq_wave(SC *s, const dg_pt *stage, int l
     /* sub-block sizes: multiples of eight (the sums take their terms eight at a time), at most one load block */
     const int BA = ((tabd / 4) & ~7) < 64 ? ((tabd / 4) & ~7) : 64, BB = ((tabd / 2) & ~7) < 64 ? ((tabd / 2) & ~7) : 64;
     const int fpts = ltab_pts >= 8 ? (ltab_pts & ~7) : ltab_pts;
-    /* the terms of the first two sweeps are READ with ds_read (dg_seq_sum_impl<3>): they are written with ds_write too — a FLAT store through
-     * the generic pointer and a ds_read of the same address are not ordered against each other */
-    __attribute__((address_space(3))) double *lt3 = (__attribute__((address_space(3))) double *)ltab;
+    /* the terms of all three sweeps are READ with ds_read (dg_seq_sum_impl<3>, the table of the normal matrix): they are written with ds_write
+     * too — a FLAT store through the generic pointer and a ds_read of the same address are not ordered against each other.  (A FLAT read of
+     * the table also counts as a vector-memory operation: waiting for it waits for the next block's points, which are meant to stay in flight.) */
+    typedef __attribute__((address_space(3))) double dg_ldsd;
+    dg_ldsd *lt3 = (dg_ldsd *)ltab;
     /* ---- centroids: lane l in 0..3 sums coordinate l */
     double acc = 0;
     {
@@ -504,7 +506,7 @@ __device__ __forceinline__ void dg_lsq_seq_wave(SC *s, const dg_pt *stage, int l
             for (int f0 = 0; f0 < bc; f0 += fpts) {
                 const int cnt = bc - f0 < fpts ? bc - f0 : fpts;
                 if (lane >= f0 && lane < f0 + cnt) {
-                    double *t = ltab + 10 * (lane - f0);
+                    dg_ldsd *t = lt3 + 10 * (lane - f0);
 #pragma unroll
                     for (int k = 0; k < 9; k++) t[k] = z[k];
                     t[9] = 0.0;
@@ -514,23 +516,23 @@ __device__ __forceinline__ void dg_lsq_seq_wave(SC *s, const dg_pt *stage, int l
                     int p = 0;
                     if (!rows2) {
                         for (; p + 8 <= cnt; p += 8) {
-                            const double *t = ltab + 10 * p;
+                            const dg_ldsd *t = lt3 + 10 * p;
                             const double u0 = t[x0], v0 = t[y0], u1 = t[10 + x0], v1 = t[10 + y0], u2 = t[20 + x0], v2 = t[20 + y0], u3 = t[30 + x0],
                                 v3 = t[30 + y0];
                             const double u4 = t[40 + x0], v4 = t[40 + y0], u5 = t[50 + x0], v5 = t[50 + y0], u6 = t[60 + x0], v6 = t[60 + y0], u7 = t[70 + x0],
                                 v7 = t[70 + y0];
                             val += u0 * v0; val += u1 * v1; val += u2 * v2; val += u3 * v3; val += u4 * v4; val += u5 * v5; val += u6 * v6; val += u7 * v7;
                         }
-                        for (; p < cnt; p++) { const double *t = ltab + 10 * p; val += t[x0] * t[y0]; }
+                        for (; p < cnt; p++) { const dg_ldsd *t = lt3 + 10 * p; val += t[x0] * t[y0]; }
                     } else {
                         for (; p + 4 <= cnt; p += 4) {
-                            const double *t = ltab + 10 * p;
+                            const dg_ldsd *t = lt3 + 10 * p;
                             const double u0 = t[x0], v0 = t[y0], p0 = t[x1], q0 = t[y1], u1 = t[10 + x0], v1 = t[10 + y0], p1 = t[10 + x1], q1 = t[10 + y1];
                             const double u2 = t[20 + x0], v2 = t[20 + y0], p2 = t[20 + x1], q2 = t[20 + y1], u3 = t[30 + x0], v3 = t[30 + y0], p3 = t[30 + x1],
                                 q3 = t[30 + y1];
                             val += u0 * v0; val += p0 * q0; val += u1 * v1; val += p1 * q1; val += u2 * v2; val += p2 * q2; val += u3 * v3; val += p3 * q3;
                         }
-                        for (; p < cnt; p++) { const double *t = ltab + 10 * p; val += t[x0] * t[y0]; val += t[x1] * t[y1]; }
+                        for (; p < cnt; p++) { const dg_ldsd *t = lt3 + 10 * p; val += t[x0] * t[y0]; val += t[x1] * t[y1]; }
                     }
                 }
                 DG_WSYNC_LDS();
