@@ -355,8 +355,8 @@ __device__ __noinline__ void dg_lo_rep_wave(CTX &c, dg_lo_log *lg, int ssiz, dou
         if (lane == 0) { lg->it[it].hash = hash; lg->it[it].I = (int)r1.I; lg->it[it].drew = 0; lg->nit = it + 1; }
         /* a set an EARLIER round or local optimisation inserted ends the repetition here whatever the others of this round do
          * (the table is not written before the replay) */
-        { int known = 0; if (lane == 0) known = dg_ht_contains(c.ht, hash, (int)r1.I, -1) != -1; DG_RW(11);
-            if (__builtin_amdgcn_readfirstlane(known)) { ended = 2; break; } }
+        { const bool known = dg_ht_known_wave(c.ht, hash, (int)r1.I, lane); DG_RW(11);
+            if (known) { ended = 2; break; } }
         if (fit) {
             const int cnt = (int)nL2; int id;
             if (8 < cnt) {

@@ -393,6 +393,18 @@ __device__ __forceinline__ int dg_ht_contains(const dg_ht &h, unsigned hash, int
     while (e >= 0) { if ((unsigned)h.ent[4*e] == hash && h.ent[4*e+1] == length) return h.ent[4*e+2]; e = h.ent[4*e+3]; }
     return -1;
 }
+/* all 64 lanes of one wave: is the set (hash, length) in the table under ANY iterID?  The same answer as dg_ht_contains(.., -1) != -1 —
+ * every entry with this hash sits in the chain of bucket hash % 64, so looking at all entries finds exactly what the two chain walks find —
+ * from count / 64 independent loads per lane instead of a walk of dependent ones by one lane (an L2 round trip per step). */
+__device__ __forceinline__ bool dg_ht_known_wave(const dg_ht &h, unsigned hash, int length, int lane)
+{
+    typedef __attribute__((address_space(1))) int dg_gint;
+    const dg_gint *ent = (const dg_gint *)h.ent;
+    const int cnt = __builtin_amdgcn_readfirstlane(*(const dg_gint *)h.count);
+    bool hit = false;
+    for (int e = lane; e < cnt; e += 64) hit = hit || ((unsigned)ent[4*e] == hash && ent[4*e+1] == length);
+    return __ballot(hit) != 0ull;
+}
 __device__ __forceinline__ void dg_ht_insert(dg_ht &h, unsigned hash, int length, int iterID)
 {
     int e = *h.count;

@@ -632,8 +632,7 @@ __device__ __noinline__ void dg_hrep_wave(CTX &c, int kind, dg_hrep_log *lg, int
         if (lane == 0) { lg->it[it].J = r1.J; lg->it[it].hash = hash; lg->it[it].I = (int)r1.I; lg->nit = it + 1; }
         /* a set some EARLIER local optimisation already inserted ends the repetition here at the latest, whatever the other
          * repetitions of this one do (the table is not written before the replay) */
-        { int known = 0; if (lane == 0) known = dg_ht_contains(c.ht, hash, (int)r1.I, -1) != -1;
-          known = __builtin_amdgcn_readfirstlane(known);
+        { const bool known = dg_ht_known_wave(c.ht, hash, (int)r1.I, lane);
           if (lane == 0) dg_hpub_store(pub + 8 * rep + it, DG_HPUB_VALID | (known ? DG_HPUB_KNOWN : 0ull) | ((unsigned long long)(unsigned)r1.I << 32) | hash);
           if (known) { finish(it + 1); return; } }
         /* ... and so does a set that a repetition below this one has certainly inserted by now */
