@@ -1,0 +1,11 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/c75; rm -rf $O; mkdir -p $O
+python -c "import bench; print('sources', bench.source_id())" > $O/sources.log 2>&1
+timeout 1500 python tools/gpu_fuzz.py 10000 1901 > $O/fuzz_main.log 2>&1; tail -1 $O/fuzz_main.log
+timeout 900 python tools/gpu_fuzz_h.py 3000 1902 > $O/fuzz_h.log 2>&1; tail -1 $O/fuzz_h.log
+timeout 900 python tools/gpu_fuzz.py large 250 1903 > $O/fuzz_large.log 2>&1; tail -1 $O/fuzz_large.log
+timeout 900 python tools/gpu_fuzz.py batches 150 1904 > $O/fuzz_batches.log 2>&1; tail -1 $O/fuzz_batches.log
+timeout 600 python tools/gpu_fuzz.py edges 4000 1905 > $O/fuzz_edges.log 2>&1; tail -1 $O/fuzz_edges.log
+timeout 600 python tools/gpu_fuzz.py legacy 1000 1906 > $O/fuzz_legacy.log 2>&1; tail -1 $O/fuzz_legacy.log
+timeout 600 python tools/gpu_fuzz_h2el.py 60 1907 > $O/fuzz_h2el.log 2>&1; tail -1 $O/fuzz_h2el.log
+timeout 900 python tools/gpu_soak_mem.py 60 > $O/soak_mem.log 2>&1; tail -2 $O/soak_mem.log
