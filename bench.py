@@ -16,6 +16,7 @@ are resident in HBM before the timed region; the per-pair results are gathered o
                                                         fewer than N devices are visible)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
   python bench.py --gpus N --single-process             (ONE process, the C-ABI's device-list mode *_batch_multi, no collective)
+  ... --gpus N --c4-single-process                      (N ranks, and rank 0 also measures the literal C4 batch through one process: on request only)
 
 Prints ONE JSON line on rank 0 (contract of the driver) with `roofline` and `cpu_baseline` (the reference on one host
 core, the north-star denominator) plus `cpu_baseline_all_cores` (one reference process per host core).
@@ -567,6 +568,10 @@ def main():
     ap.add_argument("--dump-results", default="", help="rank 0 writes the gathered per-pair results of the last timed step to this .npz (tests)")
     ap.add_argument("--single-process", action="store_true",
                     help="drive the N GPUs from ONE process through the device-list entry points (*_batch_multi, no collective, host buffers)")
+    ap.add_argument("--c4-single-process", action="store_true",
+                    help="with N > 1 ranks: rank 0 also measures the literal C4 batch through ONE process over the same N GPUs (secondary.c4_literal_single_process) "
+                         "while the other ranks wait at a barrier; off by default: it opens every GPU from rank 0 next to the ranks' own processes, and the N-rank "
+                         "line must not depend on it")
     ap.add_argument("--dist-always", action="store_true",
                     help="initialise the RCCL process group and run the result all-gather even with one rank (tests the N > 1 code path on one GPU)")
     args = ap.parse_args()
@@ -616,7 +621,7 @@ def main():
     # ... and the same literal C4 batch driven from ONE process over the same N GPUs (device-list mode, no collective): rank 0 measures
     # it while the other ranks wait at a barrier with their GPUs idle
     sp = None
-    if c4 is not None:
+    if c4 is not None and args.c4_single_process:
         dist.barrier()
         if rank == 0:
             try:
