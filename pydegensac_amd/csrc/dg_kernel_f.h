@@ -802,6 +802,35 @@ __device__ __forceinline__ unsigned dg_wave_list_lt(const dg_pt *P, int n, const
     return off;
 }
 
+/* dg_wave_list_lt that also leaves the listed points themselves, in list order, in `stage` (global): stage[j] = P[list[j]].  The pass has every
+ * listed point in registers when it decides; gathering them again through the finished list costs an id load and a point load per 64 ids, one
+ * dependent pair of round trips after the other (round 6: 13 such steps per u2Fit iteration on 800 ids). */
+template <int LDSPTS>
+__device__ __forceinline__ unsigned dg_wave_list_lt_stage(const dg_pt *P, int n, const double *F, double thr, int *list, dg_pt *stage_, int lane)
+{
+    typedef __attribute__((address_space(1))) double dg_gdbl;
+    dg_gdbl *stage = (dg_gdbl *)(double *)stage_;
+    unsigned off = 0;
+    for (int base = 0; base < n; base += 64 * DG_PU) {
+        dg_pt q[DG_PU]; bool in[DG_PU];
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) { const int p = base + 64 * u + lane; q[u] = dg_ldpt<LDSPTS>(P, p < n ? p : 0); }
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) in[u] = base + 64 * u + lane < n && dg_FDs(F, q[u].x1, q[u].y1, q[u].x2, q[u].y2) < thr;
+#pragma unroll
+        for (int u = 0; u < DG_PU; u++) {
+            const unsigned long long b = __ballot(in[u]);
+            if (in[u]) {
+                const unsigned pos = off + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+                list[pos] = base + 64 * u + lane;
+                dg_gdbl *o = stage + 4 * (size_t)pos; o[0] = q[u].x1; o[1] = q[u].y1; o[2] = q[u].x2; o[3] = q[u].y2;
+            }
+            off += (unsigned)__popcll(b);
+        }
+    }
+    return off;
+}
+
 /* ---- DegUtils.c:635-690 u2Fit, run by ONE wave on its own scratch -----------------------------------
  * F (LDS, 9) in/out.  Returns the count and *thf = the threshold the reference's `inl` flags correspond to
  * (th after the full schedule, the current ths on the "fewer than 8 inliers" early return). */
@@ -814,7 +843,7 @@ __device__ __noinline__ unsigned dg_u2Fit_wave(dg_wave_ws *w, const dg_pt *P, in
         double Fr[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) Fr[i] = F[i];
-        unsigned cnt = dg_wave_list_lt<LDSPTS>(P, n, Fr, ths, list, lane); (*n_aux)++;
+        unsigned cnt = dg_wave_list_lt_stage<LDSPTS>(P, n, Fr, ths, list, stage, lane); (*n_aux)++;
         if (cnt < 8) { *thf = ths; return cnt; }
         DG_WSYNC();
         if (cnt <= 14) {
@@ -833,8 +862,7 @@ __device__ __noinline__ unsigned dg_u2Fit_wave(dg_wave_ws *w, const dg_pt *P, in
                 DG_WSYNC();
             }
         } else {
-            for (int j = lane; j < (int)cnt; j += 64) stage[j] = dg_ldpt<LDSPTS>(P, list[j]);
-            DG_WSYNC();
+            /* (the listed points are in `stage` already: dg_wave_list_lt_stage; the DG_WSYNC above has drained its stores) */
             /* the normal matrix from shared design-matrix entries, twelve points per fill of this wave's Z (idle in the long form) */
             /* (with an LDS table the fit needs no scratch behind the staged points: any list length) */
             /* the table: Z and V of this wave's scratch, 200 doubles (V is written when the sums are done) */
